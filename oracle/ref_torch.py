@@ -1,0 +1,433 @@
+"""TEST INFRASTRUCTURE (oracle) -- never imported by the product path.
+
+CPU restatement of the reference hot path on torch-CPU, following the reference's
+*algorithm* (reverse-over-reverse autodiff on a dynamic graph): every derivative is one
+`torch.autograd.grad(y, xs, grad_outputs=ones, create_graph=True)` call, which is what
+`paddle.grad(y, xs, create_graph=True)` does with its implicit all-ones cotangent
+(ppsci/autodiff/ad.py:73-75).  Run it in float64 ("truth") or float32 ("reference-like").
+
+What it follows in /root/reference (file:line):
+  * ppsci/arch/base.py:78-148        concat_to_tensor / split_to_dict
+  * ppsci/arch/mlp.py:95-114         PeriodEmbedding
+  * ppsci/arch/mlp.py:281-315        MLP.forward_tensor / MLP.forward (incl. the skip quirk)
+  * ppsci/arch/activation.py:77-88   Silu = x * sigmoid(x)
+  * ppsci/autodiff/ad.py:30-341      _Jacobian / Jacobians / _Hessian / Hessians / clear
+  * ppsci/utils/symbolic.py:111-137  _cvt_to_key
+  * ppsci/utils/symbolic.py:184-267  OperatorNode (Add / Mul are left folds in sympy arg order)
+  * ppsci/utils/symbolic.py:310-333  DerivativeNode (odd order -> jacobian, pairs -> hessian)
+  * ppsci/utils/symbolic.py:507-534  _post_traverse, :791-806 subs(1.0, 1) + dedupe
+  * ppsci/equation/pde/laplace.py:40-55, allen_cahn.py:56-64, navier_stokes.py:70-151, poisson.py:40-53
+  * ppsci/loss/mse.py:82-105         MSELoss.forward
+  * ppsci/loss/mtl/sum.py:45-60      Sum aggregator
+  * ppsci/utils/expression.py:60-131 ExpressionSolver.train_forward
+  * ppsci/optimizer/optimizer.py:225-248 Adam (paddle.optimizer.Adam, beta1=.9 beta2=.999 eps=1e-8)
+
+parity unpinned for NN numerics: PaddlePaddle cannot be installed here; the pinned parts are the
+known-answer values checked in tests/test_oracle.py (MSELoss mse.py:46-68, NS strings
+equation/pde/base.py:99-111) and the geometry doctests (tests/test_geometry.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import sympy as sp
+import torch
+
+from oracle.taylor_np import NetSpec
+
+DETACH_FUNC_NAME = "detach"  # ppsci/equation/pde/base.py:27
+
+
+# ----------------------------------------------------------------------------- arch
+class MLP:
+    """Restatement of ppsci.arch.MLP on explicit weights (never default-initialised)."""
+
+    def __init__(self, input_keys, output_keys, net: NetSpec, dtype=torch.float64):
+        self.input_keys = tuple(input_keys)
+        self.output_keys = tuple(output_keys)
+        self.dtype = dtype
+        self.activation = net.activation
+        self.skip_connection = net.skip_connection
+        self.periods = {self.input_keys[j]: w for j, w in net.periods.items()}
+        self.weights = [torch.tensor(w, dtype=dtype, requires_grad=True) for w in net.weights]
+        self.biases = [torch.tensor(b, dtype=dtype, requires_grad=True) for b in net.biases]
+
+    def parameters(self) -> List[torch.Tensor]:
+        out = []
+        for w, b in zip(self.weights, self.biases):
+            out += [w, b]
+        return out
+
+    def _act(self, y):
+        if self.activation == "tanh":
+            return torch.tanh(y)
+        if self.activation == "silu":
+            return y * torch.sigmoid(y)  # activation.py:87-88
+        if self.activation == "sin":
+            return torch.sin(y)
+        raise ValueError(self.activation)
+
+    def forward_tensor(self, x):  # mlp.py:281-296
+        y = x
+        skip = None
+        n_hidden = len(self.weights) - 1
+        for i in range(n_hidden):
+            y = y @ self.weights[i] + self.biases[i]
+            if self.skip_connection and i % 2 == 0:
+                if skip is not None:
+                    skip = y
+                    y = y + skip
+                else:
+                    skip = y
+            y = self._act(y)
+        return y @ self.weights[-1] + self.biases[-1]
+
+    def __call__(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:  # mlp.py:298-315
+        if self.periods:
+            y = dict(x)
+            for k, w in self.periods.items():
+                y[k] = torch.cat([torch.cos(w * x[k]), torch.sin(w * x[k])], dim=-1)
+            x = y
+        t = torch.cat([x[k] for k in self.input_keys], dim=-1)  # base.py:109-112
+        t = self.forward_tensor(t)
+        outs = torch.split(t, 1, dim=-1)  # base.py:145-148
+        return {k: v for k, v in zip(self.output_keys, outs)}
+
+
+# ----------------------------------------------------------------------------- autodiff
+def _grad(y, xs, create_graph=True):
+    single = not isinstance(xs, (list, tuple))
+    xs_l = [xs] if single else list(xs)
+    g = torch.autograd.grad(
+        y, xs_l, grad_outputs=torch.ones_like(y), create_graph=create_graph, allow_unused=True
+    )
+    g = [torch.zeros_like(x) if gi is None else gi for gi, x in zip(g, xs_l)]
+    return g[0] if single else g
+
+
+class _Jacobian:  # ad.py:30-77
+    def __init__(self, ys, xs, J=None):
+        self.ys, self.xs = ys, xs
+        self.dim_y, self.dim_x = ys.shape[1], xs.shape[1]
+        self.J = {} if J is None else J
+
+    def __call__(self, i=0, j=None):
+        if not 0 <= i < self.dim_y:
+            raise ValueError(f"i({i}) should in range [0, {self.dim_y}).")
+        if j is not None and not 0 <= j < self.dim_x:
+            raise ValueError(f"j({j}) should in range [0, {self.dim_x}).")
+        if i not in self.J:
+            y = self.ys[:, i : i + 1] if self.dim_y > 1 else self.ys
+            self.J[i] = _grad(y, self.xs)
+        return self.J[i] if (j is None or self.dim_x == 1) else self.J[i][:, j : j + 1]
+
+
+class Jacobians:  # ad.py:80-165
+    def __init__(self):
+        self.Js = {}
+
+    def __call__(self, ys, xs, i=0, j=None):
+        if not isinstance(xs, (list, tuple)):
+            key = (id(ys), id(xs))
+            if key not in self.Js:
+                self.Js[key] = (_Jacobian(ys, xs), ys, xs)
+            return self.Js[key][0](i, j)
+        xs_require = [x for x in xs if (id(ys), id(x)) not in self.Js]
+        grads_require = _grad(ys, xs_require) if xs_require else []
+        idx, out = 0, []
+        for k, x in enumerate(xs):
+            key = (id(ys), id(x))
+            assert x.shape[-1] == 1
+            if key not in self.Js:
+                self.Js[key] = (_Jacobian(ys, x, {0: grads_require[idx]}), ys, x)
+                idx += 1
+            out.append(self.Js[key][0](i, j))
+        return out
+
+    def _clear(self):
+        self.Js = {}
+
+
+class Hessians:  # ad.py:181-308
+    def __init__(self, jac: Jacobians):
+        self.Hs = {}
+        self.jac = jac
+
+    def __call__(self, ys, xs, component=None, i=0, j=0):
+        key = (id(ys), id(xs), component)
+        if key not in self.Hs:
+            dim_y = ys.shape[1]
+            if dim_y > 1:
+                if component is None:
+                    raise ValueError("component can not be None when dim_y>1.")
+                if component >= dim_y:
+                    raise ValueError("component should be smaller than dim_y.")
+                comp = component
+            else:
+                if component is not None:
+                    raise ValueError("component should be set to None when dim_y=1.")
+                comp = 0
+            grad_y = self.jac(ys, xs, i=comp, j=None)
+            self.Hs[key] = (_Jacobian(grad_y, xs), ys, xs)
+        return self.Hs[key][0](i, j)
+
+    def _clear(self):
+        self.Hs = {}
+
+
+jacobian = Jacobians()
+hessian = Hessians(jacobian)
+
+
+def clear():  # ad.py:326-341
+    jacobian._clear()
+    hessian._clear()
+
+
+# ----------------------------------------------------------------------------- symbolic
+def cvt_to_key(expr) -> str:  # symbolic.py:111-137
+    if isinstance(expr, sp.Function) and str(expr.func) == DETACH_FUNC_NAME:
+        return f"{cvt_to_key(expr.args[0])}_{DETACH_FUNC_NAME}"
+    if isinstance(expr, (sp.Symbol, sp.core.function.UndefinedFunction, sp.Function)):
+        return expr.name if hasattr(expr, "name") else str(expr)
+    if isinstance(expr, sp.Derivative):
+        s = expr.args[0].name
+        for symbol, order in expr.args[1:]:
+            s += f"__{symbol}" * order
+        return s
+    return str(expr)
+
+
+def post_traverse(cur, nodes):  # symbolic.py:507-534
+    if isinstance(cur, sp.Function):
+        for a in cur.args:
+            nodes = post_traverse(a, nodes)
+        nodes.append(cur)
+    elif isinstance(cur, sp.Derivative):
+        nodes = post_traverse(cur.args[0], nodes)
+        nodes.append(cur)
+    elif isinstance(cur, sp.Symbol):
+        nodes.append(cur)
+    elif isinstance(cur, sp.Number):
+        nodes.append(cur)
+    else:
+        for a in cur.args:
+            nodes = post_traverse(a, nodes)
+        nodes.append(cur)
+    return nodes
+
+
+_UNARY = {
+    sp.sin: torch.sin, sp.cos: torch.cos, sp.exp: torch.exp, sp.tanh: torch.tanh,
+    sp.log: torch.log, sp.sqrt: torch.sqrt, sp.Abs: torch.abs, sp.sinh: torch.sinh,
+    sp.cosh: torch.cosh, sp.tan: torch.tan,
+}
+
+
+def lambdify(expr: sp.Basic, model: MLP, dtype=None) -> Callable[[Dict[str, torch.Tensor]], torch.Tensor]:
+    """symbolic.py:681-981 without derivative fusion (fusion does not change values,
+    test/utils/test_symbolic.py:93-149)."""
+    dtype = dtype or model.dtype
+    expr = expr.subs(1.0, 1)  # symbolic.py:791
+    nodes = post_traverse(expr, [])
+    nodes = [n for n in nodes if not n.is_Symbol]  # symbolic.py:799-803 (no extra parameters)
+    nodes = list(dict.fromkeys(nodes))  # symbolic.py:806
+
+    def run(data: Dict[str, torch.Tensor]) -> torch.Tensor:
+        for n in nodes:
+            key = cvt_to_key(n)
+            if key in data:
+                continue
+            if isinstance(n, sp.Derivative):  # symbolic.py:310-333
+                val = data[cvt_to_key(n.args[0])]
+                for sym, order in n.args[1:]:
+                    order = int(order)
+                    x = data[cvt_to_key(sym)]
+                    if order & 1:
+                        val = jacobian(val, x)
+                        order -= 1
+                    for _ in range(0, order, 2):
+                        val = hessian(val, x)
+                data[key] = val
+            elif n.func == sp.Add:  # symbolic.py:225-229
+                val = data[cvt_to_key(n.args[0])]
+                for a in n.args[1:]:
+                    val = val + data[cvt_to_key(a)]
+                data[key] = val
+            elif n.func == sp.Mul:  # symbolic.py:231-235
+                val = data[cvt_to_key(n.args[0])]
+                for a in n.args[1:]:
+                    val = val * data[cvt_to_key(a)]
+                data[key] = val
+            elif n.func == sp.Pow:
+                data[key] = torch.pow(data[cvt_to_key(n.args[0])], data[cvt_to_key(n.args[1])])
+            elif isinstance(n, sp.Function) and str(n.func) == DETACH_FUNC_NAME:
+                data[key] = data[cvt_to_key(n.args[0])].detach()
+            elif isinstance(n, sp.Function) and n.func in _UNARY:
+                data[key] = _UNARY[n.func](data[cvt_to_key(n.args[0])])
+            elif isinstance(n, sp.Function):  # LayerNode symbolic.py:406-430
+                if str(n.func) in model.output_keys:
+                    data.update(model(data))
+                elif str(n.func) != "sdf":
+                    raise ValueError(f"Node {n} can not match any model")
+            elif n.is_Number or n.is_NumberSymbol:  # ConstantNode symbolic.py:433-468: 0-D fp32 tensor
+                data[key] = torch.tensor(float(n), dtype=torch.float32).to(dtype)
+            else:
+                raise NotImplementedError(f"The node {n} is not supported in lambdify.")
+        return data[cvt_to_key(nodes[-1])]
+
+    return run
+
+
+# ----------------------------------------------------------------------------- equations
+def laplace_exprs(dim: int) -> Dict[str, sp.Basic]:  # laplace.py:40-55
+    invars = sp.symbols("x y z")[:dim]
+    u = sp.Function("u")(*invars)
+    lap = 0
+    for v in invars:
+        lap += u.diff(v, 2)
+    return {"laplace": lap}
+
+
+def poisson_exprs(dim: int) -> Dict[str, sp.Basic]:  # poisson.py:40-53
+    invars = sp.symbols("x y z")[:dim]
+    p = sp.Function("p")(*invars)
+    e = 0
+    for v in invars:
+        e += p.diff(v, 2)
+    return {"poisson": e}
+
+
+def navier_stokes_exprs(nu, rho, dim: int, time: bool) -> Dict[str, sp.Basic]:  # navier_stokes.py:70-151
+    t, x, y, z = sp.symbols("t x y z")
+    invars = (x, y)
+    if time:
+        invars = (t,) + invars
+    if dim == 3:
+        invars += (z,)
+    u = sp.Function("u")(*invars)
+    v = sp.Function("v")(*invars)
+    w = sp.Function("w")(*invars) if dim == 3 else sp.Number(0)
+    p = sp.Function("p")(*invars)
+    cont = u.diff(x) + v.diff(y) + w.diff(z)
+
+    def mom(k, xk):
+        return (
+            k.diff(t) + u * k.diff(x) + v * k.diff(y) + w * k.diff(z)
+            - ((nu * k.diff(x)).diff(x) + (nu * k.diff(y)).diff(y) + (nu * k.diff(z)).diff(z))
+            + 1 / rho * p.diff(xk)
+        )
+
+    eqs = {"continuity": cont, "momentum_x": mom(u, x), "momentum_y": mom(v, y)}
+    if dim == 3:
+        eqs["momentum_z"] = mom(w, z)
+    return eqs
+
+
+def allen_cahn_fn(eps: float):  # allen_cahn.py:56-64
+    def allen_cahn(out):
+        t, x = out["t"], out["x"]
+        u = out["u"]
+        u__t, u__x = jacobian(u, [t, x])
+        u__x__x = jacobian(u__x, x)
+        return u__t - (eps**2) * u__x__x + 5 * u * u * u - 5 * u
+
+    return allen_cahn
+
+
+# ----------------------------------------------------------------------------- loss
+def mse_loss(output_dict, label_dict, weight_dict=None, reduction="mean", weight=None):  # mse.py:82-105
+    losses = {}
+    for key in label_dict:
+        loss = (output_dict[key] - label_dict[key]) ** 2
+        if weight_dict and key in weight_dict:
+            loss = loss * weight_dict[key]
+        if "area" in output_dict:
+            loss = loss * output_dict["area"]
+        loss = loss.sum() if reduction == "sum" else loss.mean()
+        if isinstance(weight, (float, int)):
+            loss = loss * weight
+        elif isinstance(weight, dict) and key in weight:
+            loss = loss * weight[key]
+        losses[key] = loss
+    return losses
+
+
+def loss_sum(losses: Dict[str, torch.Tensor]):  # mtl/sum.py:45-60
+    total = 0.0
+    for i, k in enumerate(losses):
+        total = losses[k] if i == 0 else total + losses[k]
+    return total
+
+
+# ----------------------------------------------------------------------------- train forward
+def train_forward(
+    model: MLP,
+    constraints: Sequence[dict],
+):
+    """expression.py:60-131.  Each constraint is a dict with
+    input (name->np [N,1]), exprs (name->callable(data_dict)), label, weight (name->np [N,1] or None),
+    reduction, loss_weight.  Returns (losses_all, losses_constraint, outputs_per_constraint)."""
+    losses_all: Dict[str, torch.Tensor] = {}
+    losses_constraint: Dict[str, float] = {}
+    outputs = []
+    for ci, c in enumerate(constraints):
+        inp = {k: torch.tensor(np.asarray(v), dtype=model.dtype, requires_grad=True) for k, v in c["input"].items()}
+        output_dict = model(inp)
+        data = dict(inp)
+        data.update(output_dict)
+        for name, ex in c["exprs"].items():
+            output_dict[name] = ex(data)
+        clear()
+        label = {k: torch.tensor(np.asarray(v), dtype=model.dtype) for k, v in c["label"].items()}
+        wd = None
+        if c.get("weight"):
+            wd = {k: torch.tensor(np.asarray(v), dtype=model.dtype) for k, v in c["weight"].items()}
+        losses = mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
+        name = c.get("name", f"c{ci}")
+        losses_constraint[name] = 0.0
+        for k in losses:
+            losses_constraint[name] += float(losses[k].item())
+            losses_all[k] = losses_all[k] + losses[k] if k in losses_all else losses[k]
+        outputs.append(output_dict)
+    return losses_all, losses_constraint, outputs
+
+
+def loss_and_grads(model: MLP, constraints: Sequence[dict]):
+    """train.py:117-158: forward, aggregate, backward.  Returns (total, losses_all, flat grad np)."""
+    losses_all, losses_cst, outputs = train_forward(model, constraints)
+    total = loss_sum(losses_all)
+    params = model.parameters()
+    grads = torch.autograd.grad(total, params, allow_unused=True)
+    flat = np.concatenate(
+        [(torch.zeros_like(p) if g is None else g).detach().numpy().ravel() for g, p in zip(grads, params)]
+    )
+    return float(total.item()), {k: float(v.item()) for k, v in losses_all.items()}, flat, outputs
+
+
+# ----------------------------------------------------------------------------- optimizer
+class Adam:
+    """paddle.optimizer.Adam as wrapped by ppsci/optimizer/optimizer.py:225-248 (beta1=0.9, beta2=0.999,
+    epsilon=1e-8, no weight decay): p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps*sqrt(1-b2^t))."""
+
+    def __init__(self, n: int, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, dtype=np.float64):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = np.zeros(n, dtype)
+        self.v = np.zeros(n, dtype)
+        self.t = 0
+
+    def step(self, p: np.ndarray, g: np.ndarray, lr: Optional[float] = None) -> np.ndarray:
+        lr = self.lr if lr is None else lr
+        self.t += 1
+        self.m = self.b1 * self.m + (1 - self.b1) * g
+        self.v = self.b2 * self.v + (1 - self.b2) * g * g
+        c2 = math.sqrt(1 - self.b2**self.t)
+        lr_t = lr * c2 / (1 - self.b1**self.t)
+        return p - lr_t * (self.m / (np.sqrt(self.v) + self.eps * c2))
+
+
+def exponential_decay_lr(lr0: float, gamma: float, decay_steps: int, step: int, by_epoch=False) -> float:
+    """ppsci/optimizer/lr_scheduler.py:212-269: paddle ExponentialDecay with gamma**(1/decay_steps) per step."""
+    return lr0 * (gamma ** (1.0 / decay_steps)) ** step
