@@ -1,0 +1,159 @@
+/* ppsci_hip.h -- C ABI of libppsci_hip.so, the MI355X (gfx950) hot path behind the
+ * ppsci.arch / ppsci.autodiff / ppsci.equation / ppsci.loss / ppsci.optimizer Python surface.
+ *
+ * The reference (PaddleScience) has NO native boundary for this path: every call below replaces a
+ * chain of `paddle.*` eager ops issued from Python.  Each entry point cites the
+ * reference code whose arithmetic it takes over.  All pointers are DEVICE pointers unless the
+ * name says `host`; the caller owns every buffer (the Python host allocates them as torch
+ * tensors); `stream` is a hipStream_t passed as void* (NULL = default stream).  Every function
+ * returns 0 on success or a negative PPSCI_E_* code, with a message in ppsci_last_error().
+ * Thread-compatible (no hidden global state except the last-error string, which is thread-local).
+ *
+ * Data layout in HBM (fp32 everywhere):
+ *   params  : ONE flat buffer in `model.parameters()` order  W0[d0,H] b0[H] W1[H,H] b1[H] ...
+ *             W_last[H,m] b_last[m]; W is row-major [in,out] exactly like paddle nn.Linear
+ *             (/root/reference/ppsci/arch/mlp.py:246,274).  d0 = d_raw + #period-embedded inputs.
+ *   inputs  : one [N] array per named variable (the reference's [N,1] tensors), SoA.
+ *   streams : U[(c*S + s)*N + p]  for network output c, stream s, point p.  Streams are ordered
+ *             (value, d/d dir_0 .. d/d dir_{n1-1}, d2/d dir_0^2 .. d2/d dir_{n2-1}^2), S = 1+n1+n2.
+ *   stash   : pre-activation streams of every hidden layer, tile-major, written by
+ *             ppsci_taylor_fwd and consumed by ppsci_taylor_bwd (opaque; size from ppsci_stash_bytes).
+ */
+#ifndef PPSCI_HIP_H
+#define PPSCI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPSCI_MAX_IN 8      /* raw input variables (x, y, z, t, ...) */
+#define PPSCI_MAX_DIRS 4    /* first-order derivative directions carried through the net */
+#define PPSCI_MAX_OUT 8     /* network outputs */
+#define PPSCI_MAX_HIDDEN 16 /* hidden layers */
+#define PPSCI_MAX_PROG 128  /* epilogue program length */
+#define PPSCI_MAX_RES 8     /* residual/loss terms per epilogue */
+#define PPSCI_MAX_AUX 16    /* auxiliary per-point arrays (labels, weights, sdf, ...) */
+
+enum { PPSCI_OK = 0, PPSCI_E_INVALID = -1, PPSCI_E_UNSUPPORTED = -2, PPSCI_E_LAUNCH = -3 };
+enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2 };
+enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1 };
+
+/* ppsci.arch.MLP (mlp.py:179-315) + the derivative set ppsci.autodiff would be asked for
+ * (ad.py:95-160, 254-303).  Derivatives are *directional*: dirs[i][j] is the component of
+ * direction i along raw input j, so d/dx is a unit vector and a mixed u_xy is obtained by
+ * polarisation with an extra direction (x+y). */
+typedef struct ppsci_mlp_desc {
+  int32_t d_raw;                 /* number of raw input variables (len(input_keys))          */
+  int32_t n_hidden;              /* number of hidden layers L (mlp.py: len(self.linears))    */
+  int32_t width;                 /* hidden width H, identical for all hidden layers          */
+  int32_t d_out;                 /* m = len(output_keys)                                     */
+  int32_t activation;            /* PPSCI_ACT_* (activation.py:139-154)                      */
+  int32_t skip_connection;       /* mlp.py:286-291 quirk: pre-activation doubled on even i>=2 */
+  int32_t n1;                    /* first-order directions                                   */
+  int32_t n2;                    /* second-order streams, along dirs[0..n2-1]; n2 <= n1      */
+  int32_t embed[PPSCI_MAX_IN];   /* PPSCI_EMBED_* per raw input (PeriodEmbedding mlp.py:95-114) */
+  float omega[PPSCI_MAX_IN];     /* 2*pi/period for PERIOD inputs                            */
+  float dirs[PPSCI_MAX_DIRS][PPSCI_MAX_IN];
+} ppsci_mlp_desc;
+
+/* Epilogue program: the pointwise part of a constraint -- the sympy operator tree that
+ * ppsci.lambdify turns into OperatorNode/ConstantNode/DetachNode lists (symbolic.py:184-267,
+ * 433-468, 165-181), or the closure body of AllenCahn (allen_cahn.py:56-64) -- in SSA form:
+ * instruction i defines value i.  `a`,`b` index earlier values (or an input / stream / aux array
+ * for the LD_* ops); `c` is an fp32 immediate (ConstantNode keeps constants in fp32). */
+enum {
+  PPSCI_OP_LD_IN = 0, /* a = raw input index          */
+  PPSCI_OP_LD_U,      /* a = stream index c*S + s     */
+  PPSCI_OP_LD_AUX,    /* a = aux array index          */
+  PPSCI_OP_CONST,     /* c                            */
+  PPSCI_OP_ADD, PPSCI_OP_SUB, PPSCI_OP_MUL, PPSCI_OP_DIV,
+  PPSCI_OP_NEG, PPSCI_OP_POW, /* v[a] ** v[b] */
+  PPSCI_OP_SIN, PPSCI_OP_COS, PPSCI_OP_TANH, PPSCI_OP_EXP, PPSCI_OP_LOG, PPSCI_OP_SQRT,
+  PPSCI_OP_ABS, PPSCI_OP_SINH, PPSCI_OP_COSH, PPSCI_OP_TAN,
+  PPSCI_OP_MAX, PPSCI_OP_MIN, PPSCI_OP_SIGN, PPSCI_OP_HEAVISIDE,
+  PPSCI_OP_DETACH,    /* identity forward, blocks the adjoint (DetachNode) */
+  PPSCI_OP_COUNT
+};
+
+typedef struct ppsci_instr {
+  int32_t op, a, b;
+  float c;
+} ppsci_instr;
+
+/* One loss term = one key of ppsci.loss.MSELoss.forward (mse.py:82-105):
+ *   loss_k = scale * sum_p  w_k[p] * area[p] * (v[value][p] - label_k[p])^2
+ * with scale = MSELoss.weight (or 1) for reduction="sum", and that / N_global for "mean". */
+typedef struct ppsci_residual {
+  int32_t value;   /* program value index holding the residual                  */
+  int32_t label;   /* aux index of the label array, or -1 for label == 0        */
+  int32_t weight;  /* aux index of the per-point weight array, or -1 for 1      */
+  int32_t area;    /* aux index of the "area" array (mse.py:92-93), or -1       */
+  float scale;
+} ppsci_residual;
+
+typedef struct ppsci_epilogue_desc {
+  int32_t n_instr;
+  int32_t n_res;
+  int32_t n_streams; /* m*S : number of rows of U / Ubar */
+  int32_t n_in;
+  int32_t n_aux;
+  ppsci_instr prog[PPSCI_MAX_PROG];
+  ppsci_residual res[PPSCI_MAX_RES];
+} ppsci_epilogue_desc;
+
+const char* ppsci_last_error(void);
+/* Tuning/testing knob: cap the number of workgroups of the tile kernels (0 = automatic, the default).
+ * Results do not depend on it beyond fp32 summation order. */
+void ppsci_set_max_grid(int max_blocks);
+/* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
+int ppsci_is_device_build(void);
+
+/* Number of fp32 parameters of the MLP (W and b of every linear). */
+int64_t ppsci_param_count(const ppsci_mlp_desc* d);
+/* Bytes of stash ppsci_taylor_fwd writes for N points (0 is never returned for N > 0). */
+int64_t ppsci_stash_bytes(const ppsci_mlp_desc* d, int64_t n_points);
+/* Rows ([rows, P] fp32) of gradient partials ppsci_taylor_bwd writes for N points. */
+int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_points);
+/* Rows ([rows, n_res] fp32) of loss partials ppsci_epilogue writes for N points. */
+int64_t ppsci_epilogue_partial_rows(int64_t n_points);
+
+/* MLP forward with Taylor-mode derivative streams, fused per 16-point tile (replaces
+ * MLP.forward mlp.py:298-315 + every jacobian()/hessian() sweep ad.py:56-77,181-236 the
+ * expression asks for).  inputs_host: host array of d_raw device pointers, each [N].
+ * U: [m*S, N].  stash: NULL (inference) or ppsci_stash_bytes() bytes. */
+int ppsci_taylor_fwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                     const float* const* inputs_host, float* U, void* stash, void* stream);
+
+/* Pointwise epilogue + fused MSE (OperatorNode chain symbolic.py:225-267 + MSELoss mse.py:82-105
+ * + the seed of backward()).  residual_out: NULL or [n_res, N]; Ubar: NULL (eval) or [m*S, N]
+ * receiving d(sum_k loss_k)/dU; loss_partials: [ppsci_epilogue_partial_rows(N), n_res]. */
+int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                   const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                   float* loss_partials, void* stream);
+
+/* Reverse sweep through the Taylor-mode forward: dL/dparams from dL/dU (replaces
+ * total_loss.backward() train.py:158 through the double-backward graph).  grad_partials:
+ * [ppsci_bwd_partial_rows(N), P], fully overwritten. */
+int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                     const float* const* inputs_host, const float* Ubar, const void* stash,
+                     float* grad_partials, void* stream);
+
+/* out[j] (+)= sum_r partials[r, j], fixed summation order (deterministic).  Used for the
+ * gradient (cols = P) and for the loss terms (cols = n_res; mtl/sum.py:45-60 adds them). */
+int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t cols, float* out, int accumulate,
+                      void* stream);
+
+/* paddle.optimizer.Adam step as configured by ppsci/optimizer/optimizer.py:225-248
+ * (no weight decay, no amsgrad):  g' = grad_scale*g;  m,v update;  p -= lr*sqrt(1-b2^t)/(1-b1^t) *
+ * m / (sqrt(v) + eps*sqrt(1-b2^t)).  step_t is the 1-based step count. */
+int ppsci_adam_step(int64_t n, float* params, const float* grad, float* m, float* v, float lr,
+                    float beta1, float beta2, float eps, int64_t step_t, float grad_scale,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPSCI_HIP_H */

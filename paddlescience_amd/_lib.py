@@ -1,0 +1,142 @@
+"""ctypes binding of libppsci_hip.so (C ABI: include/ppsci_hip.h).
+
+The product path has NO CPU fallback: `lib()` raises if the gfx950 library is missing, and it
+refuses a non-device build (`ppsci_is_device_build() == 0`, the CPU SIMT emulator that
+tests/ uses to execute the kernel source in a GPU-less container) unless a test injected that
+library explicitly through `_inject_for_tests`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16, 128, 8, 16
+
+ACT = {"tanh": 0, "silu": 1, "sin": 2}
+EMBED_NONE, EMBED_PERIOD = 0, 1
+
+(OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
+ OP_TANH, OP_EXP, OP_LOG, OP_SQRT, OP_ABS, OP_SINH, OP_COSH, OP_TAN, OP_MAX, OP_MIN, OP_SIGN, OP_HEAVISIDE,
+ OP_DETACH, OP_COUNT) = range(26)
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("d_raw", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32), ("d_out", C.c_int32),
+        ("activation", C.c_int32), ("skip_connection", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+        ("embed", C.c_int32 * MAX_IN), ("omega", C.c_float * MAX_IN), ("dirs", (C.c_float * MAX_IN) * MAX_DIRS),
+    ]
+
+
+class Instr(C.Structure):
+    _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_float)]
+
+
+class Residual(C.Structure):
+    _fields_ = [("value", C.c_int32), ("label", C.c_int32), ("weight", C.c_int32), ("area", C.c_int32),
+                ("scale", C.c_float)]
+
+
+class EpilogueDesc(C.Structure):
+    _fields_ = [
+        ("n_instr", C.c_int32), ("n_res", C.c_int32), ("n_streams", C.c_int32), ("n_in", C.c_int32),
+        ("n_aux", C.c_int32), ("prog", Instr * MAX_PROG), ("res", Residual * MAX_RES),
+    ]
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libppsci_hip.so")
+_lib: Optional[C.CDLL] = None
+_injected = False
+
+_SYMBOLS = {
+    "ppsci_last_error": (C.c_char_p, []),
+    "ppsci_is_device_build": (C.c_int, []),
+    "ppsci_set_max_grid": (None, [C.c_int]),
+    "ppsci_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
+    "ppsci_stash_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
+    "ppsci_bwd_partial_rows": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
+    "ppsci_epilogue_partial_rows": (C.c_int64, [C.c_int64]),
+    "ppsci_taylor_fwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "ppsci_epilogue": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
+                                 C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_taylor_bwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SYMBOLS)
+
+
+def _bind(path: str) -> C.CDLL:
+    lib_ = C.CDLL(path)
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(lib_, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib_
+
+
+def lib() -> C.CDLL:
+    """The loaded gfx950 library.  Raises loudly when it is missing -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(DEFAULT_LIB):
+            raise RuntimeError(
+                f"{DEFAULT_LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). paddlescience_amd has no CPU fallback."
+            )
+        l = _bind(DEFAULT_LIB)
+        if l.ppsci_is_device_build() != 1:
+            raise RuntimeError(f"{DEFAULT_LIB} is not a gfx950 device build")
+        _lib = l
+    return _lib
+
+
+def _inject_for_tests(path: Optional[str]) -> None:
+    """tests/ only: run the kernel source under the CPU SIMT emulator build."""
+    global _lib, _injected
+    _lib = _bind(path) if path else None
+    _injected = path is not None
+
+
+def is_emulated() -> bool:
+    return _injected
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().ppsci_last_error()
+        raise RuntimeError(f"libppsci_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr_array(ptrs: Sequence[int]):
+    arr = (C.c_void_p * max(1, len(ptrs)))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+def make_mlp_desc(d_raw: int, n_hidden: int, width: int, d_out: int, activation: str, skip_connection: bool,
+                  dirs: Sequence[Sequence[float]], n2: int, embed: Optional[Sequence[int]] = None,
+                  omega: Optional[Sequence[float]] = None) -> MlpDesc:
+    d = MlpDesc()
+    d.d_raw, d.n_hidden, d.width, d.d_out = d_raw, n_hidden, width, d_out
+    if activation not in ACT:
+        raise NotImplementedError(f"activation {activation!r} has no HIP kernel (supported: {sorted(ACT)})")
+    d.activation = ACT[activation]
+    d.skip_connection = 1 if skip_connection else 0
+    d.n1, d.n2 = len(dirs), n2
+    if len(dirs) > MAX_DIRS:
+        raise NotImplementedError(f"at most {MAX_DIRS} derivative directions per launch, got {len(dirs)}")
+    for i, row in enumerate(dirs):
+        for j, v in enumerate(row):
+            d.dirs[i][j] = float(v)
+    for j in range(d_raw):
+        d.embed[j] = int(embed[j]) if embed is not None else 0
+        d.omega[j] = float(omega[j]) if omega is not None else 0.0
+    return d

@@ -1,0 +1,331 @@
+// epilogue_optim.hip -- pointwise epilogue VM (+ fused MSE and its adjoint), row reduction, Adam.
+//
+// Epilogue: replaces the chain of tiny elementwise kernels the reference launches for
+//   OperatorNode / ConstantNode / DetachNode   /root/reference/ppsci/utils/symbolic.py:184-267,433-468,165-181
+//   AllenCahn closure body                     /root/reference/ppsci/equation/pde/allen_cahn.py:62
+//   MSELoss.forward                            /root/reference/ppsci/loss/mse.py:82-105
+// and the seed of total_loss.backward() (train.py:158) for the pointwise part.
+// One lane = one collocation point; all HBM traffic is coalesced SoA ([row][N] arrays).  The
+// program is uniform across lanes (no divergence); values live in a per-lane array.
+// Adam: paddle.optimizer.Adam as configured by /root/reference/ppsci/optimizer/optimizer.py:225-248.
+#include "ppsci_common.h"
+
+#ifndef PPSCI_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#define EPI_BLOCK 256
+
+struct EpiArgs {
+  ppsci_epilogue_desc e;
+  const float* x[PPSCI_MAX_IN];
+  const float* aux[PPSCI_MAX_AUX];
+  const float* U;
+  float* resid;     // may be null: [n_res, N]
+  float* Ubar;      // may be null: [n_streams, N]
+  float* partials;  // [gridDim.x, n_res]
+  long long N;
+  int iters;
+};
+
+__global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
+  PPSCI_DYN_SMEM(red);  // [EPI_BLOCK]
+  const int tid = threadIdx.x;
+  const int n = a.e.n_instr;
+  float lsum[PPSCI_MAX_RES];
+  for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
+
+  for (int it = 0; it < a.iters; ++it) {
+    const long long p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
+    const bool valid = p < a.N;
+    const long long pp = valid ? p : 0;
+    float v[PPSCI_MAX_PROG];
+    float adj[PPSCI_MAX_PROG];
+    // ---- forward
+    for (int i = 0; i < n; ++i) {
+      const ppsci_instr ins = a.e.prog[i];
+      float r;
+      switch (ins.op) {
+        case PPSCI_OP_LD_IN: r = a.x[ins.a][pp]; break;
+        case PPSCI_OP_LD_U: r = a.U[(long long)ins.a * a.N + pp]; break;
+        case PPSCI_OP_LD_AUX: r = a.aux[ins.a][pp]; break;
+        case PPSCI_OP_CONST: r = ins.c; break;
+        case PPSCI_OP_ADD: r = v[ins.a] + v[ins.b]; break;
+        case PPSCI_OP_SUB: r = v[ins.a] - v[ins.b]; break;
+        case PPSCI_OP_MUL: r = v[ins.a] * v[ins.b]; break;
+        case PPSCI_OP_DIV: r = v[ins.a] / v[ins.b]; break;
+        case PPSCI_OP_NEG: r = -v[ins.a]; break;
+        case PPSCI_OP_POW: r = powf(v[ins.a], v[ins.b]); break;
+        case PPSCI_OP_SIN: r = sinf(v[ins.a]); break;
+        case PPSCI_OP_COS: r = cosf(v[ins.a]); break;
+        case PPSCI_OP_TANH: r = tanhf(v[ins.a]); break;
+        case PPSCI_OP_EXP: r = expf(v[ins.a]); break;
+        case PPSCI_OP_LOG: r = logf(v[ins.a]); break;
+        case PPSCI_OP_SQRT: r = sqrtf(v[ins.a]); break;
+        case PPSCI_OP_ABS: r = fabsf(v[ins.a]); break;
+        case PPSCI_OP_SINH: r = sinhf(v[ins.a]); break;
+        case PPSCI_OP_COSH: r = coshf(v[ins.a]); break;
+        case PPSCI_OP_TAN: r = tanf(v[ins.a]); break;
+        case PPSCI_OP_MAX: r = fmaxf(v[ins.a], v[ins.b]); break;
+        case PPSCI_OP_MIN: r = fminf(v[ins.a], v[ins.b]); break;
+        case PPSCI_OP_SIGN: r = (v[ins.a] > 0.f) ? 1.f : ((v[ins.a] < 0.f) ? -1.f : 0.f); break;
+        case PPSCI_OP_HEAVISIDE: r = (v[ins.a] > 0.f) ? 1.f : 0.f; break;  // heaviside(x, y=0)
+        case PPSCI_OP_DETACH: r = v[ins.a]; break;
+        default: r = 0.f; break;
+      }
+      v[i] = r;
+      adj[i] = 0.f;
+    }
+    // ---- residuals, loss terms and their seeds
+    for (int k = 0; k < a.e.n_res; ++k) {
+      const ppsci_residual rs = a.e.res[k];
+      const float rv = v[rs.value];
+      if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
+      const float lab = (rs.label >= 0) ? a.aux[rs.label][pp] : 0.f;
+      float w = rs.scale;
+      if (rs.weight >= 0) w *= a.aux[rs.weight][pp];
+      if (rs.area >= 0) w *= a.aux[rs.area][pp];
+      const float diff = rv - lab;
+      if (valid) {
+        lsum[k] += w * diff * diff;
+        adj[rs.value] += 2.f * w * diff;
+      }
+    }
+    // ---- reverse
+    if (a.Ubar != nullptr) {
+      for (int i = n - 1; i >= 0; --i) {
+        const ppsci_instr ins = a.e.prog[i];
+        const float g = adj[i];
+        switch (ins.op) {
+          case PPSCI_OP_LD_U:
+            if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
+            break;
+          case PPSCI_OP_ADD: adj[ins.a] += g; adj[ins.b] += g; break;
+          case PPSCI_OP_SUB: adj[ins.a] += g; adj[ins.b] -= g; break;
+          case PPSCI_OP_MUL: adj[ins.a] += g * v[ins.b]; adj[ins.b] += g * v[ins.a]; break;
+          case PPSCI_OP_DIV: {
+            const float inv = 1.f / v[ins.b];
+            adj[ins.a] += g * inv;
+            adj[ins.b] -= g * v[i] * inv;
+          } break;
+          case PPSCI_OP_NEG: adj[ins.a] -= g; break;
+          case PPSCI_OP_POW: {
+            const float x = v[ins.a], y = v[ins.b];
+            adj[ins.a] += g * y * powf(x, y - 1.f);
+            if (x > 0.f) adj[ins.b] += g * v[i] * logf(x);
+          } break;
+          case PPSCI_OP_SIN: adj[ins.a] += g * cosf(v[ins.a]); break;
+          case PPSCI_OP_COS: adj[ins.a] -= g * sinf(v[ins.a]); break;
+          case PPSCI_OP_TANH: adj[ins.a] += g * (1.f - v[i] * v[i]); break;
+          case PPSCI_OP_EXP: adj[ins.a] += g * v[i]; break;
+          case PPSCI_OP_LOG: adj[ins.a] += g / v[ins.a]; break;
+          case PPSCI_OP_SQRT: adj[ins.a] += g * 0.5f / v[i]; break;
+          case PPSCI_OP_ABS: adj[ins.a] += g * ((v[ins.a] > 0.f) ? 1.f : ((v[ins.a] < 0.f) ? -1.f : 0.f)); break;
+          case PPSCI_OP_SINH: adj[ins.a] += g * coshf(v[ins.a]); break;
+          case PPSCI_OP_COSH: adj[ins.a] += g * sinhf(v[ins.a]); break;
+          case PPSCI_OP_TAN: adj[ins.a] += g * (1.f + v[i] * v[i]); break;
+          case PPSCI_OP_MAX:
+            if (v[ins.a] >= v[ins.b]) adj[ins.a] += g; else adj[ins.b] += g;
+            break;
+          case PPSCI_OP_MIN:
+            if (v[ins.a] <= v[ins.b]) adj[ins.a] += g; else adj[ins.b] += g;
+            break;
+          default: break;  // LD_IN, LD_AUX, CONST, SIGN, HEAVISIDE, DETACH: no adjoint flows
+        }
+      }
+    }
+  }
+
+  // ---- block reduction of the loss terms (fixed tree order => deterministic)
+  for (int k = 0; k < a.e.n_res; ++k) {
+    __syncthreads();
+    red[tid] = lsum[k];
+    __syncthreads();
+    for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) a.partials[(long long)blockIdx.x * a.e.n_res + k] = red[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------- reduce / Adam
+struct ReduceArgs {
+  const float* partials;
+  float* out;
+  long long rows, cols;
+  int accumulate;
+};
+
+__global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.cols) return;
+  float s = 0.f;
+  for (long long r = 0; r < a.rows; ++r) s += a.partials[r * a.cols + j];
+  a.out[j] = a.accumulate ? a.out[j] + s : s;
+}
+
+struct AdamArgs {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long n;
+  float lr_t, beta1, beta2, eps_t, grad_scale;
+};
+
+__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.n) return;
+  const float g = a.grad_scale * a.g[j];
+  const float m = a.beta1 * a.m[j] + (1.f - a.beta1) * g;
+  const float v = a.beta2 * a.v[j] + (1.f - a.beta2) * g * g;
+  a.m[j] = m;
+  a.v[j] = v;
+  a.p[j] = a.p[j] - a.lr_t * (m / (sqrtf(v) + a.eps_t));
+}
+
+// ------------------------------------------------------------------------------------ host side
+static thread_local char g_err[512] = "";
+
+extern "C" void ppsci_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ppsci_last_error(void) { return g_err; }
+
+static int g_max_grid = 0;
+extern "C" void ppsci_set_max_grid(int max_blocks) { g_max_grid = max_blocks > 0 ? max_blocks : 0; }
+extern "C" int ppsci_get_max_grid(void) { return g_max_grid; }
+
+extern "C" int ppsci_is_device_build(void) {
+#ifdef PPSCI_EMU
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+extern "C" int64_t ppsci_param_count(const ppsci_mlp_desc* d) {
+  ppsci_derived q;
+  if (!d || ppsci_derive(d, &q) != PPSCI_OK) return -1;
+  return q.P;
+}
+
+extern "C" int64_t ppsci_stash_bytes(const ppsci_mlp_desc* d, int64_t n_points) {
+  ppsci_derived q;
+  if (!d || n_points <= 0 || ppsci_derive(d, &q) != PPSCI_OK) return 0;
+  const int64_t ntiles = (n_points + PPSCI_TILE - 1) / PPSCI_TILE;
+  const int64_t S = 1 + d->n1 + d->n2;
+  return ntiles * d->n_hidden * S * q.NB * 64 * 16;
+}
+
+static int epi_grid(int64_t n_points, int* iters) {
+  int64_t blocks = (n_points + EPI_BLOCK - 1) / EPI_BLOCK;
+  int64_t grid = blocks < 2048 ? blocks : 2048;
+  if (grid < 1) grid = 1;
+  *iters = (int)((blocks + grid - 1) / grid);
+  return (int)grid;
+}
+
+extern "C" int64_t ppsci_epilogue_partial_rows(int64_t n_points) {
+  int iters;
+  return n_points > 0 ? epi_grid(n_points, &iters) : 0;
+}
+
+extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                              const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                              float* loss_partials, void* stream) {
+  if (!e || n_points <= 0 || !loss_partials || e->n_instr < 1 || e->n_instr > PPSCI_MAX_PROG || e->n_res < 0 ||
+      e->n_res > PPSCI_MAX_RES || e->n_in < 0 || e->n_in > PPSCI_MAX_IN || e->n_aux < 0 || e->n_aux > PPSCI_MAX_AUX) {
+    ppsci_set_error("epilogue: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  for (int i = 0; i < e->n_instr; ++i) {
+    const ppsci_instr& ins = e->prog[i];
+    bool ok = ins.op >= 0 && ins.op < PPSCI_OP_COUNT;
+    if (ok) {
+      if (ins.op == PPSCI_OP_LD_IN) ok = ins.a >= 0 && ins.a < e->n_in && inputs_host;
+      else if (ins.op == PPSCI_OP_LD_U) ok = ins.a >= 0 && ins.a < e->n_streams && U;
+      else if (ins.op == PPSCI_OP_LD_AUX) ok = ins.a >= 0 && ins.a < e->n_aux && aux_host;
+      else if (ins.op != PPSCI_OP_CONST) {
+        ok = ins.a >= 0 && ins.a < i;
+        const bool binary = ins.op == PPSCI_OP_ADD || ins.op == PPSCI_OP_SUB || ins.op == PPSCI_OP_MUL ||
+                            ins.op == PPSCI_OP_DIV || ins.op == PPSCI_OP_POW || ins.op == PPSCI_OP_MAX ||
+                            ins.op == PPSCI_OP_MIN;
+        if (binary) ok = ok && ins.b >= 0 && ins.b < i;
+      }
+    }
+    if (!ok) {
+      ppsci_set_error("epilogue: bad instruction %d (op %d a %d b %d)", i, ins.op, ins.a, ins.b);
+      return PPSCI_E_INVALID;
+    }
+  }
+  for (int k = 0; k < e->n_res; ++k) {
+    const ppsci_residual& r = e->res[k];
+    if (r.value < 0 || r.value >= e->n_instr || r.label >= e->n_aux || r.weight >= e->n_aux || r.area >= e->n_aux) {
+      ppsci_set_error("epilogue: bad residual %d", k);
+      return PPSCI_E_INVALID;
+    }
+  }
+  EpiArgs a;
+  memset(&a, 0, sizeof(a));
+  a.e = *e;
+  for (int j = 0; j < e->n_in; ++j) a.x[j] = inputs_host[j];
+  for (int j = 0; j < e->n_aux; ++j) a.aux[j] = aux_host[j];
+  a.U = U;
+  a.resid = residual_out;
+  a.Ubar = Ubar;
+  a.partials = loss_partials;
+  a.N = n_points;
+  const int grid = epi_grid(n_points, &a.iters);
+  PPSCI_LAUNCH(epilogue_kernel, EpiArgs, grid, EPI_BLOCK, EPI_BLOCK * sizeof(float), stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("epilogue: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t cols, float* out, int accumulate,
+                                 void* stream) {
+  if (!partials || !out || rows < 0 || cols <= 0) {
+    ppsci_set_error("reduce_rows: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  ReduceArgs a{partials, out, rows, cols, accumulate};
+  const int grid = (int)((cols + 255) / 256);
+  PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, 0, stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("reduce_rows: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_adam_step(int64_t n, float* params, const float* grad, float* m, float* v, float lr,
+                               float beta1, float beta2, float eps, int64_t step_t, float grad_scale,
+                               void* stream) {
+  if (!params || !grad || !m || !v || n <= 0 || step_t < 1) {
+    ppsci_set_error("adam_step: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  const double b1t = pow((double)beta1, (double)step_t), b2t = pow((double)beta2, (double)step_t);
+  const double c2 = sqrt(1.0 - b2t);
+  AdamArgs a{params, grad, m, v, n, (float)(lr * c2 / (1.0 - b1t)), beta1, beta2, (float)(eps * c2), grad_scale};
+  const int grid = (int)((n + 255) / 256);
+  PPSCI_LAUNCH(adam_kernel, AdamArgs, grid, 256, 0, stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("adam_step: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

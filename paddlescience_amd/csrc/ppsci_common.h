@@ -1,0 +1,78 @@
+// ppsci_common.h -- shared between the gfx950 build (hipcc) and the test-only CPU SIMT emulator
+// build (clang++ -DPPSCI_EMU, tests/emu/hip_emu.h).  The kernels are written once against the
+// handful of primitives defined here.
+#pragma once
+
+#include "ppsci_hip.h"
+
+#ifdef PPSCI_EMU
+#include "hip_emu.h"
+#define PPSCI_LAUNCH(KERNEL, ARGT, grid, block, lds, stream, args)                                   \
+  do {                                                                                               \
+    ARGT _a = (args);                                                                                \
+    emu::launch(emu_dim3{(unsigned)(grid)}, emu_dim3{(unsigned)(block)}, (size_t)(lds),              \
+                [](void* p) { KERNEL(*(ARGT*)p); }, &_a);                                            \
+  } while (0)
+#define PPSCI_SET_MAX_LDS(KERNEL, bytes) (0)
+#define PPSCI_LAST_LAUNCH_ERROR() (0)
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define PPSCI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define PPSCI_LAUNCH(KERNEL, ARGT, grid, block, lds, stream, args)                                   \
+  hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), (lds), (hipStream_t)(stream), (args))
+#define PPSCI_SET_MAX_LDS(KERNEL, bytes)                                                             \
+  ((int)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+#define PPSCI_LAST_LAUNCH_ERROR() ((int)hipGetLastError())
+// Orders this wave's LDS traffic: LDS ops of one wave execute in order, so a wavefront-scope
+// fence (compiler ordering) is all that is needed for the per-wave scratch transposes.
+__device__ __forceinline__ void ppsci_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#endif
+
+extern "C" int ppsci_get_max_grid(void);
+
+#define PPSCI_WAVES_PER_BLOCK 4
+#define PPSCI_BLOCK (64 * PPSCI_WAVES_PER_BLOCK)
+#define PPSCI_TILE 16            // collocation points per wave tile (= MFMA N)
+#define PPSCI_SCR_LD 20          // row stride (floats) of the per-wave 16x16 transpose scratch
+#define PPSCI_SCR_FLOATS (16 * PPSCI_SCR_LD)
+#define PPSCI_LDS_LIMIT_BYTES (160 * 1024)
+
+// Everything the kernels need that is derived from ppsci_mlp_desc (filled on the host).
+struct ppsci_derived {
+  int32_t d0;   // embedded input width
+  int32_t HP;   // hidden width padded to a multiple of 16
+  int32_t NB;   // HP / 16
+  int32_t P;    // parameter count
+  int32_t offW[PPSCI_MAX_HIDDEN + 1];
+  int32_t offB[PPSCI_MAX_HIDDEN + 1];
+};
+
+static inline int ppsci_derive(const ppsci_mlp_desc* d, ppsci_derived* q) {
+  if (d->d_raw < 1 || d->d_raw > PPSCI_MAX_IN) return PPSCI_E_INVALID;
+  if (d->n_hidden < 1 || d->n_hidden > PPSCI_MAX_HIDDEN) return PPSCI_E_INVALID;
+  if (d->width < 1 || d->d_out < 1 || d->d_out > PPSCI_MAX_OUT) return PPSCI_E_INVALID;
+  if (d->n1 < 0 || d->n1 > PPSCI_MAX_DIRS || d->n2 < 0 || d->n2 > d->n1) return PPSCI_E_INVALID;
+  int d0 = 0;
+  for (int j = 0; j < d->d_raw; ++j) d0 += (d->embed[j] == PPSCI_EMBED_PERIOD) ? 2 : 1;
+  q->d0 = d0;
+  // the kernels are instantiated for NB in {2, 4, 8}: round the padded width up
+  int nb = (d->width + 15) / 16;
+  q->NB = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 8 ? 8 : nb));
+  q->HP = q->NB * 16;
+  int off = 0, fin = d0;
+  for (int l = 0; l <= d->n_hidden; ++l) {
+    int fout = (l == d->n_hidden) ? d->d_out : d->width;
+    q->offW[l] = off;
+    off += fin * fout;
+    q->offB[l] = off;
+    off += fout;
+    fin = fout;
+  }
+  q->P = off;
+  return PPSCI_OK;
+}

@@ -1,0 +1,210 @@
+"""Thin host wrappers over the C ABI (include/ppsci_hip.h).  torch tensors are used ONLY as
+device-memory handles (`.data_ptr()`), never for arithmetic on the hot path.
+
+The functions here are what `ExpressionSolver.train_forward` / `Solver` (paddlescience_amd/solver)
+call instead of the reference's chain of eager paddle ops
+(/root/reference/ppsci/utils/expression.py:60-131, ppsci/solver/train.py:112-184).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _stream_ptr(t: torch.Tensor):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise ValueError("hot-path buffers must be contiguous float32 tensors")
+
+
+def _require_device(t: torch.Tensor):
+    """The product path runs on the GPU only; CPU tensors are accepted solely under the emulator."""
+    if not t.is_cuda and not L.is_emulated():
+        raise RuntimeError("paddlescience_amd hot path needs CUDA(HIP) tensors; there is no CPU fallback")
+
+
+@dataclass
+class StreamSpec:
+    """Which derivative streams the kernels carry: first-order along dirs[i] (vectors in raw-input
+    space) and pure second-order along dirs[:n2]."""
+
+    dirs: List[List[float]]
+    n2: int
+
+    @property
+    def S(self) -> int:
+        return 1 + len(self.dirs) + self.n2
+
+
+@dataclass
+class NetLayout:
+    """Shape of a ppsci.arch.MLP as the kernels see it (mlp.py:179-279)."""
+
+    d_raw: int
+    n_hidden: int
+    width: int
+    d_out: int
+    activation: str = "tanh"
+    skip_connection: bool = False
+    embed: Optional[List[int]] = None
+    omega: Optional[List[float]] = None
+
+    def desc(self, streams: StreamSpec) -> L.MlpDesc:
+        return L.make_mlp_desc(self.d_raw, self.n_hidden, self.width, self.d_out, self.activation,
+                               self.skip_connection, streams.dirs, streams.n2, self.embed, self.omega)
+
+    @property
+    def d0(self) -> int:
+        return self.d_raw + (sum(1 for e in self.embed if e == L.EMBED_PERIOD) if self.embed else 0)
+
+    def param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out, fin = [], self.d0
+        for l in range(self.n_hidden):
+            out += [(f"linears.{l}.weight", (fin, self.width)), (f"linears.{l}.bias", (self.width,))]
+            fin = self.width
+        out += [("last_fc.weight", (fin, self.d_out)), ("last_fc.bias", (self.d_out,))]
+        return out
+
+    @property
+    def n_params(self) -> int:
+        n = 0
+        for _, shp in self.param_shapes():
+            k = 1
+            for s in shp:
+                k *= s
+            n += k
+        return n
+
+
+def stash_bytes(desc: L.MlpDesc, n: int) -> int:
+    return int(L.lib().ppsci_stash_bytes(C.byref(desc), n))
+
+
+def bwd_partial_rows(desc: L.MlpDesc, n: int) -> int:
+    return int(L.lib().ppsci_bwd_partial_rows(C.byref(desc), n))
+
+
+def epilogue_partial_rows(n: int) -> int:
+    return int(L.lib().ppsci_epilogue_partial_rows(n))
+
+
+def taylor_fwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], U: torch.Tensor,
+               stash: Optional[torch.Tensor]) -> None:
+    n = inputs[0].numel()
+    _require_device(params)
+    _chk_f32(params, U, *inputs)
+    assert U.numel() == desc.d_out * (1 + desc.n1 + desc.n2) * n
+    ptrs = L.ptr_array([t.data_ptr() for t in inputs])
+    L.check(L.lib().ppsci_taylor_fwd(C.byref(desc), _p(params), n, ptrs, _p(U), _p(stash), _stream_ptr(params)))
+
+
+def epilogue(edesc: L.EpilogueDesc, n: int, inputs: Sequence[torch.Tensor], U: Optional[torch.Tensor],
+             aux: Sequence[torch.Tensor], resid: Optional[torch.Tensor], Ubar: Optional[torch.Tensor],
+             loss_partials: torch.Tensor) -> None:
+    _require_device(loss_partials)
+    _chk_f32(U, resid, Ubar, loss_partials, *inputs, *aux)
+    ip = L.ptr_array([t.data_ptr() for t in inputs])
+    ap = L.ptr_array([t.data_ptr() for t in aux])
+    L.check(L.lib().ppsci_epilogue(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar), _p(loss_partials),
+                                   _stream_ptr(loss_partials)))
+
+
+def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], Ubar: torch.Tensor,
+               stash: torch.Tensor, grad_partials: torch.Tensor) -> None:
+    n = inputs[0].numel()
+    _require_device(params)
+    _chk_f32(params, Ubar, grad_partials, *inputs)
+    ptrs = L.ptr_array([t.data_ptr() for t in inputs])
+    L.check(L.lib().ppsci_taylor_bwd(C.byref(desc), _p(params), n, ptrs, _p(Ubar), _p(stash), _p(grad_partials),
+                                     _stream_ptr(params)))
+
+
+def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor, accumulate: bool) -> None:
+    _require_device(out)
+    _chk_f32(partials, out)
+    L.check(L.lib().ppsci_reduce_rows(_p(partials), rows, cols, _p(out), 1 if accumulate else 0, _stream_ptr(out)))
+
+
+def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step_t: int,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
+    _require_device(params)
+    _chk_f32(params, grad, m, v)
+    L.check(L.lib().ppsci_adam_step(params.numel(), _p(params), _p(grad), _p(m), _p(v), lr, beta1, beta2, eps,
+                                    step_t, grad_scale, _stream_ptr(params)))
+
+
+# ----------------------------------------------------------------------------- epilogue builder
+class Program:
+    """Builds a ppsci_epilogue_desc in SSA form with common-subexpression reuse for loads/consts."""
+
+    def __init__(self, n_streams: int, n_in: int):
+        self.instrs: List[Tuple[int, int, int, float]] = []
+        self.res: List[Tuple[int, int, int, int, float]] = []
+        self.n_streams, self.n_in = n_streams, n_in
+        self.n_aux = 0
+        self._memo: Dict[Tuple, int] = {}
+
+    def _emit(self, op, a=0, b=0, c=0.0, memo=True) -> int:
+        key = (op, a, b, float(c))
+        if memo and key in self._memo:
+            return self._memo[key]
+        if len(self.instrs) >= L.MAX_PROG:
+            raise NotImplementedError(f"epilogue program longer than {L.MAX_PROG} instructions")
+        self.instrs.append((op, a, b, float(c)))
+        idx = len(self.instrs) - 1
+        if memo:
+            self._memo[key] = idx
+        return idx
+
+    def ld_in(self, j: int) -> int:
+        return self._emit(L.OP_LD_IN, j)
+
+    def ld_u(self, q: int) -> int:
+        return self._emit(L.OP_LD_U, q)
+
+    def ld_aux(self, k: int) -> int:
+        self.n_aux = max(self.n_aux, k + 1)
+        return self._emit(L.OP_LD_AUX, k)
+
+    def const(self, c: float) -> int:
+        import numpy as np
+
+        return self._emit(L.OP_CONST, 0, 0, float(np.float32(c)))
+
+    def op(self, op: int, a: int, b: int = 0) -> int:
+        return self._emit(op, a, b, 0.0)
+
+    def residual(self, value: int, label: int = -1, weight: int = -1, area: int = -1, scale: float = 1.0) -> int:
+        if len(self.res) >= L.MAX_RES:
+            raise NotImplementedError(f"more than {L.MAX_RES} loss terms in one epilogue")
+        for k in (label, weight, area):
+            if k >= 0:
+                self.n_aux = max(self.n_aux, k + 1)
+        self.res.append((value, label, weight, area, float(scale)))
+        return len(self.res) - 1
+
+    def build(self) -> L.EpilogueDesc:
+        e = L.EpilogueDesc()
+        e.n_instr, e.n_res = len(self.instrs), len(self.res)
+        e.n_streams, e.n_in, e.n_aux = self.n_streams, self.n_in, self.n_aux
+        for i, (op, a, b, c) in enumerate(self.instrs):
+            e.prog[i].op, e.prog[i].a, e.prog[i].b, e.prog[i].c = op, a, b, c
+        for k, (v, lab, w, ar, sc) in enumerate(self.res):
+            r = e.res[k]
+            r.value, r.label, r.weight, r.area, r.scale = v, lab, w, ar, sc
+        return e

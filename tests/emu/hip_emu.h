@@ -1,0 +1,240 @@
+// hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A tiny CPU SIMT emulator so that the *same* kernel
+// source that hipcc compiles for gfx950 (paddlescience_amd/csrc/*.hip) can be compiled for the
+// host (clang++ -DPPSCI_EMU) and executed lane-by-lane in this GPU-less container.  Every lane of
+// a workgroup is a ucontext fiber; __syncthreads / wave collectives (MFMA, shuffles) are fiber
+// barriers.  The product never loads the emulator build: paddlescience_amd/_lib.py only accepts
+// a library whose ppsci_is_device_build() returns 1 unless a test injects one explicitly.
+//
+// Emulated gfx950 semantics (from /opt/skills/guides/cdna_hip_programming.md section 3):
+//   v_mfma_f32_16x16x4_f32 : lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D/C
+//   register r of lane l is element (row = 4*(l>>4) + r, col = l&15); the result is a k-ordered
+//   fmaf chain (bitwise the same as the hardware, per the guide).
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct emu_dim3 {
+  unsigned x = 1, y = 1, z = 1;
+};
+
+namespace emu {
+
+constexpr int kWave = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct Barrier {
+  int n = 0, count = 0, gen = 0;
+};
+
+struct Wave {
+  Barrier bar;
+  float xa[2][kWave];
+  float xb[2][kWave];
+  unsigned op = 0;  // collective counter (same in every lane of the wave)
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  unsigned tid = 0;
+  unsigned wave_op = 0;
+};
+
+struct State {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  Barrier block_bar;
+  int cur = -1;
+  emu_dim3 blockIdx, blockDim, gridDim;
+  std::vector<float> smem;
+  void (*entry)(void*) = nullptr;
+  void* args = nullptr;
+};
+
+inline State& st() {
+  static State s;
+  return s;
+}
+
+inline void yield() {
+  State& s = st();
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline void barrier_wait(Barrier& b) {
+  int g = b.gen;
+  if (++b.count == b.n) {
+    b.count = 0;
+    b.gen++;
+  } else {
+    while (b.gen == g) yield();
+  }
+}
+
+inline void trampoline() {
+  State& s = st();
+  s.entry(s.args);
+  s.fibers[s.cur].done = true;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+// Runs `entry(args)` for every thread of every block of the grid (blocks sequentially).
+inline void launch(emu_dim3 grid, emu_dim3 block, size_t dyn_lds_bytes, void (*entry)(void*), void* args) {
+  State& s = st();
+  unsigned nthreads = block.x;
+  if (nthreads % kWave != 0) {
+    fprintf(stderr, "emu: block size must be a multiple of 64\n");
+    abort();
+  }
+  s.entry = entry;
+  s.args = args;
+  s.blockDim = block;
+  s.gridDim = grid;
+  s.smem.assign(dyn_lds_bytes / sizeof(float) + 16, 0.f);
+  if (s.fibers.size() < nthreads) {
+    size_t old = s.fibers.size();
+    s.fibers.resize(nthreads);
+    for (size_t i = old; i < nthreads; ++i) s.fibers[i].stack = (char*)malloc(kStack);
+  }
+  s.waves.assign(nthreads / kWave, Wave());
+  for (unsigned b = 0; b < grid.x; ++b) {
+    s.blockIdx.x = b;
+    // poison LDS between blocks: real LDS is not zero-initialised
+    for (auto& v : s.smem) v = std::nanf("");
+    s.block_bar = Barrier();
+    s.block_bar.n = (int)nthreads;
+    for (auto& w : s.waves) {
+      w = Wave();
+      w.bar.n = kWave;
+    }
+    for (unsigned t = 0; t < nthreads; ++t) {
+      Fiber& f = s.fibers[t];
+      f.done = false;
+      f.tid = t;
+      f.wave_op = 0;
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = kStack;
+      f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    unsigned remaining = nthreads;
+    while (remaining) {
+      for (unsigned t = 0; t < nthreads; ++t) {
+        if (s.fibers[t].done) continue;
+        s.cur = (int)t;
+        swapcontext(&s.sched, &s.fibers[t].ctx);
+        if (s.fibers[t].done) --remaining;
+      }
+    }
+  }
+  s.cur = -1;
+}
+
+struct TidProxy {
+  struct X {
+    operator unsigned() const { return st().fibers[st().cur].tid; }
+  } x;
+};
+struct BidProxy {
+  struct X {
+    operator unsigned() const { return st().blockIdx.x; }
+  } x;
+};
+struct BdimProxy {
+  struct X {
+    operator unsigned() const { return st().blockDim.x; }
+  } x;
+};
+struct GdimProxy {
+  struct X {
+    operator unsigned() const { return st().gridDim.x; }
+  } x;
+};
+
+inline Wave& my_wave() {
+  State& s = st();
+  return s.waves[s.fibers[s.cur].tid / kWave];
+}
+inline unsigned my_lane() { return st().fibers[st().cur].tid % kWave; }
+
+// Exchange one float per lane through the wave; returns pointer to the published buffer.
+inline const float* wave_publish(float v, float** other = nullptr, float v2 = 0.f) {
+  Wave& w = my_wave();
+  Fiber& f = st().fibers[st().cur];
+  unsigned buf = f.wave_op & 1u;
+  f.wave_op++;
+  w.xa[buf][my_lane()] = v;
+  w.xb[buf][my_lane()] = v2;
+  barrier_wait(w.bar);
+  if (other) *other = w.xb[buf];
+  return w.xa[buf];
+}
+
+}  // namespace emu
+
+static emu::TidProxy threadIdx;
+static emu::BidProxy blockIdx;
+static emu::BdimProxy blockDim;
+static emu::GdimProxy gridDim;
+
+#define PPSCI_DYN_SMEM(name) float* name = emu::st().smem.data()
+
+inline void __syncthreads() { emu::barrier_wait(emu::st().block_bar); }
+inline void ppsci_wave_sync() { emu::barrier_wait(emu::my_wave().bar); }
+
+inline float __shfl_xor(float v, int mask, int width = 64) {
+  const float* buf = emu::wave_publish(v);
+  unsigned l = emu::my_lane();
+  unsigned src = l ^ (unsigned)mask;
+  // width semantics: stay inside the aligned `width` segment (masks used here never leave it)
+  if ((src / width) != (l / width)) src = l;
+  return buf[src];
+}
+
+inline float __shfl(float v, int src_lane, int width = 64) {
+  const float* buf = emu::wave_publish(v);
+  unsigned l = emu::my_lane();
+  unsigned src = (l / width) * width + ((unsigned)src_lane % width);
+  return buf[src];
+}
+
+inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+  float* bb = nullptr;
+  const float* aa = emu::wave_publish(a, &bb, b);
+  unsigned l = emu::my_lane();
+  unsigned g = l >> 4, col = l & 15;
+  f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    unsigned row = 4 * g + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = std::fmaf(aa[16 * k + row], bb[16 * k + col], acc);
+    d[r] = acc;
+  }
+  return d;
+}
+
+inline float atomicAdd(float* p, float v) {
+  float old = *p;
+  *p = old + v;
+  return old;
+}
+
+typedef void* hipStream_t;
