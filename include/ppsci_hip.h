@@ -117,6 +117,8 @@ int64_t ppsci_param_count(const ppsci_mlp_desc* d);
 int64_t ppsci_stash_bytes(const ppsci_mlp_desc* d, int64_t n_points);
 /* Rows ([rows, P] fp32) of gradient partials ppsci_taylor_bwd writes for N points. */
 int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_points);
+/* Bytes of scratch ppsci_taylor_bwd needs for N points (per-tile hidden-weight gradient blocks). */
+int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points);
 /* Rows ([rows, n_res] fp32) of loss partials ppsci_epilogue writes for N points. */
 int64_t ppsci_epilogue_partial_rows(int64_t n_points);
 
@@ -135,11 +137,12 @@ int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* 
                    float* loss_partials, void* stream);
 
 /* Reverse sweep through the Taylor-mode forward: dL/dparams from dL/dU (replaces
- * total_loss.backward() train.py:158 through the double-backward graph).  grad_partials:
- * [ppsci_bwd_partial_rows(N), P], fully overwritten. */
+ * total_loss.backward() train.py:158 through the double-backward graph).  workspace:
+ * ppsci_bwd_workspace_bytes() bytes of scratch.  grad_partials: [ppsci_bwd_partial_rows(N), P],
+ * fully overwritten; the caller sums its rows with ppsci_reduce_rows. */
 int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
                      const float* const* inputs_host, const float* Ubar, const void* stash,
-                     float* grad_partials, void* stream);
+                     void* workspace, float* grad_partials, void* stream);
 
 /* out[j] (+)= sum_r partials[r, j], fixed summation order (deterministic).  Used for the
  * gradient (cols = P) and for the loss terms (cols = n_res; mtl/sum.py:45-60 adds them). */

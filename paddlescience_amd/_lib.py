@@ -57,13 +57,14 @@ _SYMBOLS = {
     "ppsci_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
     "ppsci_stash_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
     "ppsci_bwd_partial_rows": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
+    "ppsci_bwd_workspace_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
     "ppsci_epilogue_partial_rows": (C.c_int64, [C.c_int64]),
     "ppsci_taylor_fwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "ppsci_epilogue": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_taylor_bwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),

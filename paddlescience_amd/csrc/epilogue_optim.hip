@@ -160,12 +160,24 @@ struct ReduceArgs {
   int accumulate;
 };
 
+// 256 threads = 32 columns x 8 row groups; each thread sums rows r = rg, rg+8, ... of its column in a
+// fixed order, the 8 group sums are combined in a fixed order through LDS (deterministic).
+#define RED_COLS 32
+#define RED_GROUPS 8
 __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.cols) return;
+  PPSCI_DYN_SMEM(red);  // [RED_GROUPS][RED_COLS]
+  const int tc = threadIdx.x % RED_COLS, rg = threadIdx.x / RED_COLS;
+  const long long j = (long long)blockIdx.x * RED_COLS + tc;
   float s = 0.f;
-  for (long long r = 0; r < a.rows; ++r) s += a.partials[r * a.cols + j];
-  a.out[j] = a.accumulate ? a.out[j] + s : s;
+  if (j < a.cols)
+    for (long long r = rg; r < a.rows; r += RED_GROUPS) s += a.partials[r * a.cols + j];
+  red[rg * RED_COLS + tc] = s;
+  __syncthreads();
+  if (rg == 0 && j < a.cols) {
+    float t = red[tc];
+    for (int k = 1; k < RED_GROUPS; ++k) t += red[k * RED_COLS + tc];
+    a.out[j] = a.accumulate ? a.out[j] + t : t;
+  }
 }
 
 struct AdamArgs {
@@ -300,8 +312,8 @@ extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t co
     return PPSCI_E_INVALID;
   }
   ReduceArgs a{partials, out, rows, cols, accumulate};
-  const int grid = (int)((cols + 255) / 256);
-  PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, 0, stream, a);
+  const int grid = (int)((cols + RED_COLS - 1) / RED_COLS);
+  PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, RED_GROUPS * RED_COLS * sizeof(float), stream, a);
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("reduce_rows: launch failed (hip error %d)", err);

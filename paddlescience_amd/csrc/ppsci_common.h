@@ -15,6 +15,8 @@
   } while (0)
 #define PPSCI_SET_MAX_LDS(KERNEL, bytes) (0)
 #define PPSCI_LAST_LAUNCH_ERROR() (0)
+#define PPSCI_OCCUPANCY(KERNEL, block, lds, out) (*(out) = 2, 0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -24,6 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PPSCI_SET_MAX_LDS(KERNEL, bytes)                                                             \
   ((int)hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
 #define PPSCI_LAST_LAUNCH_ERROR() ((int)hipGetLastError())
+#define PPSCI_OCCUPANCY(KERNEL, block, lds, out)                                                     \
+  ((int)hipOccupancyMaxActiveBlocksPerMultiprocessor((out), (const void*)KERNEL, (block), (size_t)(lds)))
 // Orders this wave's LDS traffic: LDS ops of one wave execute in order, so a wavefront-scope
 // fence (compiler ordering) is all that is needed for the per-wave scratch transposes.
 __device__ __forceinline__ void ppsci_wave_sync() {
@@ -35,8 +39,13 @@ __device__ __forceinline__ void ppsci_wave_sync() {
 
 extern "C" int ppsci_get_max_grid(void);
 
-#define PPSCI_WAVES_PER_BLOCK 4
-#define PPSCI_BLOCK (64 * PPSCI_WAVES_PER_BLOCK)
+#ifndef PPSCI_FWD_WAVES
+#define PPSCI_FWD_WAVES 4   // waves (16-point tiles in flight) per forward workgroup
+#endif
+#ifndef PPSCI_BWD_WAVES
+#define PPSCI_BWD_WAVES 4   // waves per reverse-sweep workgroup
+#endif
+#define PPSCI_NUM_CU 256
 #define PPSCI_TILE 16            // collocation points per wave tile (= MFMA N)
 #define PPSCI_SCR_LD 20          // row stride (floats) of the per-wave 16x16 transpose scratch
 #define PPSCI_SCR_FLOATS (16 * PPSCI_SCR_LD)

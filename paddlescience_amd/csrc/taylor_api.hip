@@ -1,0 +1,99 @@
+// taylor_api.hip -- C ABI entry points of the Taylor-mode forward / reverse kernels: argument
+// checks, derived sizes, and dispatch to the per-activation translation units.
+#include "taylor_tile.h"
+
+#include <string.h>
+
+static int fill_fwd(FwdArgs& a, const ppsci_mlp_desc* d, int64_t n_points) {
+  memset(&a, 0, sizeof(a));
+  if (!d || ppsci_derive(d, &a.q) != PPSCI_OK) return PPSCI_E_INVALID;
+  a.d = *d;
+  a.N = n_points;
+  a.ntiles = (int)((n_points + PPSCI_TILE - 1) / PPSCI_TILE);
+  return PPSCI_OK;
+}
+
+static int fill_bwd(BwdArgs& a, const ppsci_mlp_desc* d, int64_t n_points) {
+  memset(&a, 0, sizeof(a));
+  if (!d || ppsci_derive(d, &a.q) != PPSCI_OK) return PPSCI_E_INVALID;
+  a.d = *d;
+  a.N = n_points;
+  a.ntiles = (int)((n_points + PPSCI_TILE - 1) / PPSCI_TILE);
+  return PPSCI_OK;
+}
+
+static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
+  switch (a.d.activation) {
+    case PPSCI_ACT_TANH: return ppsci_fwd_run_tanh(a, stream, launch, grid);
+    case PPSCI_ACT_SILU: return ppsci_fwd_run_silu(a, stream, launch, grid);
+    case PPSCI_ACT_SIN: return ppsci_fwd_run_sin(a, stream, launch, grid);
+    default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
+  }
+}
+
+static int run_bwd_act(BwdArgs& a, void* stream, int launch, int* grid) {
+  switch (a.d.activation) {
+    case PPSCI_ACT_TANH: return ppsci_bwd_run_tanh(a, stream, launch, grid);
+    case PPSCI_ACT_SILU: return ppsci_bwd_run_silu(a, stream, launch, grid);
+    case PPSCI_ACT_SIN: return ppsci_bwd_run_sin(a, stream, launch, grid);
+    default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_points) {
+  BwdArgs a;
+  if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
+  int grid = 0;
+  if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
+  // one row per workgroup (+ one row for the reduced per-tile hidden-layer weight gradients)
+  return grid + (a.q.NB <= PPSCI_BWD_DUMP_MAX_NB ? 1 : 0);
+}
+
+static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.n_hidden - 1) * a.q.HP * a.q.HP; }
+
+extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points) {
+  BwdArgs a;
+  if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
+  if (a.q.NB > PPSCI_BWD_DUMP_MAX_NB) return 16;
+  const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
+  const long long fl = ((long long)a.ntiles + chunks) * bwd_per_tile_floats(a);
+  return fl * 4 + 16;
+}
+
+extern "C" int ppsci_taylor_fwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                                const float* const* inputs_host, float* U, void* stash, void* stream) {
+  FwdArgs a;
+  if (!params || !inputs_host || !U || n_points < 0 || fill_fwd(a, d, n_points) != PPSCI_OK) {
+    ppsci_set_error("taylor_fwd: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  if (n_points == 0) return PPSCI_OK;
+  a.params = params;
+  for (int j = 0; j < d->d_raw; ++j) a.x[j] = inputs_host[j];
+  a.U = U;
+  a.stash = (f32x4*)stash;
+  return run_fwd_act(a, stream, 1, nullptr);
+}
+
+extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                                const float* const* inputs_host, const float* Ubar, const void* stash,
+                                void* workspace, float* grad_partials, void* stream) {
+  BwdArgs a;
+  if (!params || !inputs_host || !Ubar || !stash || !workspace || !grad_partials || n_points <= 0 ||
+      fill_bwd(a, d, n_points) != PPSCI_OK) {
+    ppsci_set_error("taylor_bwd: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  a.params = params;
+  for (int j = 0; j < d->d_raw; ++j) a.x[j] = inputs_host[j];
+  a.Ubar = Ubar;
+  a.stash = (const f32x4*)stash;
+  a.partials = grad_partials;
+  a.wpart = (f32x4*)workspace;
+  int grid = 0;
+  int rc = run_bwd_act(a, stream, 1, &grid);
+  if (rc != PPSCI_OK || a.q.NB > PPSCI_BWD_DUMP_MAX_NB) return rc;
+  float* wpart = (float*)workspace;
+  float* tmp = wpart + (long long)a.ntiles * bwd_per_tile_floats(a);
+  return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, grad_partials + (long long)grid * a.q.P, stream);
+}

@@ -1,0 +1,4 @@
+// taylor_bwd_tanh.hip -- instantiates the reverse-sweep kernels for activation "tanh".
+#define PPSCI_ACT_ID PPSCI_ACT_TANH
+#define PPSCI_BWD_RUN_NAME ppsci_bwd_run_tanh
+#include "taylor_bwd.inc"

@@ -10,7 +10,7 @@
 //   feed the next layer's MFMAs without any data movement: Z^T = W^T-fragments x H^T.
 //   "N layout" (needed for the weight-gradient GEMM, whose contraction runs over points):
 //       component `step` of lane (g,c) holds X[feature = 16*blk + c][point = 4*g + step].
-//   T -> N goes through a 1.25 KiB per-wave LDS scratch.
+//   T -> N goes through a per-wave LDS scratch (one 16x16 slot per stream).
 #pragma once
 #include "ppsci_common.h"
 
@@ -20,13 +20,14 @@
 
 // value and first three derivatives of the activation (SURVEY.md Appendix A;
 // /root/reference/ppsci/arch/activation.py:77-88 Silu = x*sigmoid(x), :139-154 tanh / sin)
-__device__ __forceinline__ void ppsci_act_eval(int act, float z, float& s, float& d1, float& d2, float& d3) {
-  if (act == PPSCI_ACT_TANH) {
+template <int ACT>
+__device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, float& d2, float& d3) {
+  if (ACT == PPSCI_ACT_TANH) {
     s = tanhf(z);
     d1 = 1.f - s * s;
     d2 = -2.f * s * d1;
     d3 = d1 * (6.f * s * s - 2.f);
-  } else if (act == PPSCI_ACT_SILU) {
+  } else if (ACT == PPSCI_ACT_SILU) {
     float g = 1.f / (1.f + expf(-z));
     float g1 = g * (1.f - g);
     float t = 1.f - 2.f * g;
@@ -48,12 +49,19 @@ __device__ __forceinline__ float ppsci_zscale(const ppsci_mlp_desc& d, int layer
   return (d.skip_connection && (layer & 1) == 0 && layer >= 2) ? 2.f : 1.f;
 }
 
-// sum over the 16 lanes that share g (i.e. over the 16 points of the tile); every lane gets it.
-__device__ __forceinline__ float ppsci_row_sum16(float v) {
-  v += __shfl_xor(v, 1, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 8, 16);
+// Sum over the 16 lanes of a DPP row (= over the 16 points of the tile, lanes sharing g).
+// The total is valid in the LAST lane of the row (c == 15); VALU-rate (4 DPP adds), no LDS.
+__device__ __forceinline__ float ppsci_row_sum16_last(float v) {
+#ifdef PPSCI_ABL_NOROWSUM
+  return v;
+#endif
+#define PPSCI_DPP_ADD(ctrl)                                                                            \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  PPSCI_DPP_ADD(0x111);  // row_shr:1
+  PPSCI_DPP_ADD(0x112);  // row_shr:2
+  PPSCI_DPP_ADD(0x114);  // row_shr:4
+  PPSCI_DPP_ADD(0x118);  // row_shr:8
+#undef PPSCI_DPP_ADD
   return v;
 }
 
@@ -64,15 +72,22 @@ __device__ __forceinline__ float ppsci_group_sum4(float v) {
   return v;
 }
 
-// T layout -> N layout of one 16x16 block through the wave-private scratch.
-__device__ __forceinline__ f32x4 ppsci_t2n(f32x4 v, float* scr, int g, int c) {
-  *(f32x4*)&scr[c * PPSCI_SCR_LD + 4 * g] = v;  // scr[point][feature]
-  ppsci_wave_sync();
-  f32x4 o;
+// T layout -> N layout of NS 16x16 blocks at once through the wave-private scratch (NS slots).
+template <int NS>
+__device__ __forceinline__ void ppsci_t2n(const f32x4 (&v)[NS], f32x4 (&o)[NS], float* scr, int g, int c) {
+#ifdef PPSCI_ABL_NOT2N
 #pragma unroll
-  for (int step = 0; step < 4; ++step) o[step] = scr[(4 * g + step) * PPSCI_SCR_LD + c];
+  for (int s = 0; s < NS; ++s) o[s] = v[s];
+  return;
+#endif
+#pragma unroll
+  for (int s = 0; s < NS; ++s) *(f32x4*)&scr[s * PPSCI_SCR_FLOATS + c * PPSCI_SCR_LD + 4 * g] = v[s];  // scr[point][feature]
   ppsci_wave_sync();
-  return o;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int step = 0; step < 4; ++step) o[s][step] = scr[s * PPSCI_SCR_FLOATS + (4 * g + step) * PPSCI_SCR_LD + c];
+  ppsci_wave_sync();
 }
 
 // ---- LDS staging of weights --------------------------------------------------------------
@@ -98,4 +113,68 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
     int ib = in >> 4, c = in & 15, kb = out >> 4, g = (out & 15) >> 2, r = out & 3;
     dst[((ib * NB + kb) * 64 + 16 * g + c) * 4 + r] = v;
   }
+}
+
+// Tile owned by (iteration, block, wave): consecutive tiles go to different workgroups first, so a
+// partially filled last round is spread over many CUs instead of filling a few of them.
+__device__ __forceinline__ int ppsci_tile_index(int it, int waves) {
+  return (it * waves + (int)(threadIdx.x >> 6)) * (int)gridDim.x + (int)blockIdx.x;
+}
+
+// ---- kernel argument blocks ------------------------------------------------------------------
+struct FwdArgs {
+  ppsci_mlp_desc d;
+  ppsci_derived q;
+  const float* params;
+  const float* x[PPSCI_MAX_IN];
+  float* U;
+  f32x4* stash;  // may be null
+  long long N;
+  int ntiles;
+  int iters;     // tile iterations per wave (uniform over the grid)
+  int resident;  // 1: all hidden-layer fragments stay in LDS; 0: re-staged per layer (lock-step)
+};
+
+struct BwdArgs {
+  ppsci_mlp_desc d;
+  ppsci_derived q;
+  const float* params;
+  const float* x[PPSCI_MAX_IN];
+  const float* Ubar;
+  const f32x4* stash;
+  float* partials;  // [gridDim.x + 1, P]
+  f32x4* wpart;     // [ntiles][L-1][NB*NB][64] float4: per-tile hidden-weight gradient blocks
+  long long N;
+  int ntiles;
+  int iters;
+  int resident;
+};
+
+// Two-stage, fixed-order reduction of the per-tile hidden-weight gradient partials (wgrad_reduce.hip):
+// stage 1 sums chunks of tiles, stage 2 sums the chunks and scatters into the canonical layout of
+// one row of grad_partials (every other entry of that row is set to 0).
+#define PPSCI_WRED_CHUNKS 64
+#define PPSCI_BWD_DUMP_MAX_NB 4  // padded width <= 64: per-tile partials; wider: LDS atomics
+int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
+                       float* row, void* stream);
+
+// per-activation entry points (one translation unit each, so they compile in parallel).
+// launch == 0: only plan (fills a.resident / a.iters and *grid_out); launch == 1: plan + launch.
+int ppsci_fwd_run_tanh(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_silu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_sin(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_tanh(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_silu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
+extern "C" void ppsci_set_error(const char* fmt, ...);
+
+// LDS carve sizes (floats)
+static inline int ppsci_fwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q) {
+  // W0s[d0*HP] + Bs[L*HP] + WLs[m*HP] + BLs[4*ceil(m/4)]
+  return (q.d0 + d.n_hidden + d.d_out) * q.HP + ((d.d_out + 3) / 4) * 4;
+}
+static inline int ppsci_bwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q, int S) {
+  // WLs[m*HP] gW0[d0*HP] gB[L*HP] gWL[m*HP] gBL[4*ceil(m/4)] scratch[WAVES*S*SCR]
+  return (2 * d.d_out + q.d0 + d.n_hidden) * q.HP + ((d.d_out + 3) / 4) * 4 +
+         PPSCI_BWD_WAVES * S * PPSCI_SCR_FLOATS;
 }

@@ -1,0 +1,80 @@
+// wgrad_reduce.hip -- fixed-order tree reduction of the per-tile hidden-weight gradient blocks that
+// taylor_bwd streams to HBM (see taylor_bwd.inc).  Purely HBM-bound: reads ntiles*(L-1)*HP^2 floats
+// once with float4 loads, coalesced.
+#include "taylor_tile.h"
+
+struct WRedArgs {
+  const float* wpart;  // [ntiles][per_tile]
+  float* tmp;          // [nchunks][per_tile]
+  float* row;          // [P]
+  ppsci_derived q;
+  int L, H, ntiles, nchunks, nb4;  // nb4 = workgroups per chunk (each covers 256 float4)
+  long long per_tile;              // (L-1)*HP*HP floats
+};
+
+// stage 1: tmp[chunk][j] = sum_{tile in chunk} wpart[tile][j]
+__global__ void __launch_bounds__(256) wgrad_reduce1_kernel(WRedArgs a) {
+  const int chunk = blockIdx.x / a.nb4;
+  const long long j4 = (long long)(blockIdx.x - chunk * a.nb4) * 256 + threadIdx.x;
+  if (j4 * 4 >= a.per_tile) return;
+  const int t0 = (int)((long long)a.ntiles * chunk / a.nchunks);
+  const int t1 = (int)((long long)a.ntiles * (chunk + 1) / a.nchunks);
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4* src = (const f32x4*)a.wpart + j4;
+  const long long stride4 = a.per_tile / 4;
+  for (int t = t0; t < t1; ++t) s += src[(long long)t * stride4];
+  ((f32x4*)a.tmp)[(long long)chunk * stride4 + j4] = s;
+}
+
+// stage 2: one thread per parameter of the row
+__global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.q.P) return;
+  float v = 0.f;
+  // is idx inside a hidden-to-hidden weight matrix?
+  for (int l = 1; l < a.L; ++l) {
+    const int off = a.q.offW[l];
+    if (idx >= off && idx < off + a.H * a.H) {
+      const int e = idx - off;
+      const int in = e / a.H, out = e - in * a.H;
+      const int NB = a.q.NB, HP = a.q.HP;
+      // block (ib, ob), lane 16g + c, component r  <->  (in = 16ib + 4g + r, out = 16ob + c)
+      const long long j = (long long)(l - 1) * HP * HP +
+                          ((long long)((in >> 4) * NB + (out >> 4)) * 64 + 16 * ((in & 15) >> 2) + (out & 15)) * 4 + (in & 3);
+      for (int c = 0; c < a.nchunks; ++c) v += a.tmp[(long long)c * a.per_tile + j];
+    }
+  }
+  a.row[idx] = v;
+}
+
+int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
+                       float* row, void* stream) {
+  WRedArgs a;
+  a.wpart = wpart;
+  a.tmp = tmp;
+  a.row = row;
+  a.q = q;
+  a.L = d.n_hidden;
+  a.H = d.width;
+  a.ntiles = ntiles;
+  a.nchunks = ntiles < PPSCI_WRED_CHUNKS ? ntiles : PPSCI_WRED_CHUNKS;
+  a.per_tile = (long long)(d.n_hidden - 1) * q.HP * q.HP;
+  if (a.per_tile > 0) {
+    a.nb4 = (int)((a.per_tile / 4 + 255) / 256);
+    PPSCI_LAUNCH(wgrad_reduce1_kernel, WRedArgs, a.nchunks * a.nb4, 256, 0, stream, a);
+    int e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) {
+      ppsci_set_error("wgrad_reduce1: launch failed (hip error %d)", e);
+      return PPSCI_E_LAUNCH;
+    }
+  } else {
+    a.nb4 = 0;
+  }
+  PPSCI_LAUNCH(wgrad_reduce2_kernel, WRedArgs, (q.P + 255) / 256, 256, 0, stream, a);
+  int e = PPSCI_LAST_LAUNCH_ERROR();
+  if (e != 0) {
+    ppsci_set_error("wgrad_reduce2: launch failed (hip error %d)", e);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

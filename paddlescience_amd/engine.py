@@ -1,0 +1,106 @@
+"""Execution engine of the hot path: owns the flat parameter / gradient / Adam-moment buffers and
+the per-constraint device buffers, and issues the five kernels of one training step.
+
+One step == `train_epoch_func` body of the reference (/root/reference/ppsci/solver/train.py:82-184):
+  for every constraint: model forward + expression forward + loss   (expression.py:89-126)
+  total_loss.backward()                                             (train.py:158)
+  fused_allreduce_gradients                                         (train.py:168-171)
+  optimizer.step(); clear_grad()                                    (train.py:175-180)
+Here: taylor_fwd -> epilogue -> taylor_bwd per constraint, one reduce_rows into the flat gradient,
+one RCCL all-reduce (torch.distributed, SUM) of that flat buffer when world_size > 1, one fused Adam.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import hotpath as hp
+
+
+class FusedConstraint:
+    """Device-resident state of one constraint batch: inputs, aux arrays, streams, stash, partials."""
+
+    def __init__(self, name: str, layout: hp.NetLayout, streams: hp.StreamSpec, edesc: L.EpilogueDesc,
+                 inputs: Sequence[torch.Tensor], aux: Sequence[torch.Tensor], loss_keys: Sequence[str],
+                 want_residual: bool = False):
+        self.name = name
+        self.layout, self.streams, self.edesc = layout, streams, edesc
+        self.desc = layout.desc(streams)
+        self.inputs = [t.contiguous().view(-1) for t in inputs]
+        self.aux = [t.contiguous().view(-1) for t in aux]
+        self.n = self.inputs[0].numel()
+        self.loss_keys = list(loss_keys)
+        dev = self.inputs[0].device
+        q = layout.d_out * streams.S
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.U = torch.zeros((q, self.n), **f32)
+        self.Ubar = torch.zeros((q, self.n), **f32)  # rows never loaded by the program stay 0
+        self.stash = torch.empty(hp.stash_bytes(self.desc, self.n) // 4, **f32)
+        self.loss_rows = hp.epilogue_partial_rows(self.n)
+        self.loss_partials = torch.zeros((self.loss_rows, max(1, edesc.n_res)), **f32)
+        self.loss_terms = torch.zeros(max(1, edesc.n_res), **f32)
+        self.grad_rows = hp.bwd_partial_rows(self.desc, self.n)
+        if self.grad_rows <= 0:
+            raise NotImplementedError(
+                f"network {layout.n_hidden}x{layout.width} with {streams.S} streams has no HIP reverse kernel")
+        self.grad_partials = torch.empty((self.grad_rows, layout.n_params), **f32)
+        self.workspace = torch.empty(max(4, hp.bwd_workspace_bytes(self.desc, self.n) // 4), **f32)
+        self.resid = torch.zeros((max(1, edesc.n_res), self.n), **f32) if want_residual else None
+
+    def set_inputs(self, inputs: Sequence[torch.Tensor], aux: Optional[Sequence[torch.Tensor]] = None) -> None:
+        """New batch of the same size (ContinuousNamedArrayDataset, array_dataset.py:208-228)."""
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src.view(-1))
+        if aux is not None:
+            for dst, src in zip(self.aux, aux):
+                dst.copy_(src.view(-1))
+
+    def forward(self, params: torch.Tensor, train: bool) -> None:
+        hp.taylor_fwd(self.desc, params, self.inputs, self.U, self.stash if train else None)
+        hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
+                    self.loss_partials)
+        hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)
+
+    def backward(self, params: torch.Tensor) -> None:
+        hp.taylor_bwd(self.desc, params, self.inputs, self.Ubar, self.stash, self.workspace, self.grad_partials)
+
+    def losses(self) -> Dict[str, float]:
+        vals = self.loss_terms.detach().cpu().tolist()  # one device->host sync, only when logging
+        return {k: vals[i] for i, k in enumerate(self.loss_keys)}
+
+
+class Engine:
+    def __init__(self, layout: hp.NetLayout, params: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8,
+                 dp_reduce: str = "sum"):
+        assert params.numel() == layout.n_params
+        self.layout = layout
+        self.params = params
+        self.grad = torch.zeros_like(params)
+        self.m = torch.zeros_like(params)
+        self.v = torch.zeros_like(params)
+        self.t = 0
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.dp_reduce = dp_reduce
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    def forward_backward(self, constraints: Sequence[FusedConstraint]) -> None:
+        for i, c in enumerate(constraints):
+            c.forward(self.params, True)
+            c.backward(self.params)
+            hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+
+    def allreduce(self) -> None:
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+
+    def optimizer_step(self, lr: float) -> None:
+        self.t += 1
+        scale = (1.0 / self.world) if (self.dp_reduce == "mean" and self.world > 1) else 1.0
+        hp.adam_step(self.params, self.grad, self.m, self.v, lr, self.t, self.beta1, self.beta2, self.eps, scale)
+
+    def train_step(self, constraints: Sequence[FusedConstraint], lr: float) -> None:
+        self.forward_backward(constraints)
+        self.allreduce()
+        self.optimizer_step(lr)

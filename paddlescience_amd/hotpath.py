@@ -99,6 +99,10 @@ def bwd_partial_rows(desc: L.MlpDesc, n: int) -> int:
     return int(L.lib().ppsci_bwd_partial_rows(C.byref(desc), n))
 
 
+def bwd_workspace_bytes(desc: L.MlpDesc, n: int) -> int:
+    return int(L.lib().ppsci_bwd_workspace_bytes(C.byref(desc), n))
+
+
 def epilogue_partial_rows(n: int) -> int:
     return int(L.lib().ppsci_epilogue_partial_rows(n))
 
@@ -125,13 +129,13 @@ def epilogue(edesc: L.EpilogueDesc, n: int, inputs: Sequence[torch.Tensor], U: O
 
 
 def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], Ubar: torch.Tensor,
-               stash: torch.Tensor, grad_partials: torch.Tensor) -> None:
+               stash: torch.Tensor, workspace: torch.Tensor, grad_partials: torch.Tensor) -> None:
     n = inputs[0].numel()
     _require_device(params)
     _chk_f32(params, Ubar, grad_partials, *inputs)
     ptrs = L.ptr_array([t.data_ptr() for t in inputs])
-    L.check(L.lib().ppsci_taylor_bwd(C.byref(desc), _p(params), n, ptrs, _p(Ubar), _p(stash), _p(grad_partials),
-                                     _stream_ptr(params)))
+    L.check(L.lib().ppsci_taylor_bwd(C.byref(desc), _p(params), n, ptrs, _p(Ubar), _p(stash), _p(workspace),
+                                     _p(grad_partials), _stream_ptr(params)))
 
 
 def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor, accumulate: bool) -> None:

@@ -8,8 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "paddlescience_amd", "csrc")
 OUT = os.path.join(ROOT, "tests", "_emu_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["taylor_fwd.hip", "taylor_bwd.hip", "epilogue_optim.hip"]
-HEADERS = ["ppsci_common.h", "taylor_tile.h"]
+SOURCES = ["taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_bwd_tanh.hip",
+           "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_api.hip", "wgrad_reduce.hip", "epilogue_optim.hip"]
+HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc"]
 
 
 def _newer(dst, srcs):
@@ -34,7 +35,7 @@ def build() -> str:
             subprocess.check_call([CLANG] + flags + ["-c", s, "-o", obj])
         return obj
 
-    with ThreadPoolExecutor(3) as ex:
+    with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(one, SOURCES))
     if not _newer(lib, objs):
         subprocess.check_call([CLANG, "-shared", "-o", lib] + objs)

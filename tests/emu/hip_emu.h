@@ -231,6 +231,25 @@ inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int
   return d;
 }
 
+// DPP row_shr:n (ctrl 0x110+n) with bound_ctrl: lane i of each 16-lane row reads lane i-n, 0 if outside.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  float f;
+  std::memcpy(&f, &src, 4);
+  const float* buf = emu::wave_publish(f);
+  unsigned l = emu::my_lane();
+  if (ctrl > 0x110 && ctrl <= 0x11f && row_mask == 0xf && bank_mask == 0xf) {
+    int n = ctrl - 0x110;
+    int i = (int)(l & 15) - n;
+    if (i < 0) return bound_ctrl ? 0 : old;
+    float r = buf[(l & ~15u) + (unsigned)i];
+    int ri;
+    std::memcpy(&ri, &r, 4);
+    return ri;
+  }
+  fprintf(stderr, "emu: unsupported DPP ctrl 0x%x\n", ctrl);
+  abort();
+}
+
 inline float atomicAdd(float* p, float v) {
   float old = *p;
   *p = old + v;

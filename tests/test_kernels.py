@@ -109,7 +109,8 @@ def _run_bwd(net, X, dirs, n2, Ubar):
     P = params.numel()
     partials = _full((rows, P), float("nan"))
     ub = _t(Ubar.reshape(-1, N))
-    hp.taylor_bwd(desc, params, inputs, ub, st, partials)
+    ws = _full((max(4, hp.bwd_workspace_bytes(desc, N) // 4),), float("nan"))
+    hp.taylor_bwd(desc, params, inputs, ub, st, ws, partials)
     grad = _full((P,), float("nan"))
     hp.reduce_rows(partials, rows, P, grad, False)
     return grad.cpu().numpy().astype(np.float64)
@@ -124,6 +125,8 @@ def _run_bwd(net, X, dirs, n2, Ubar):
         ([24, 24, 24], 2, np.eye(2), 0, "sin", 5),
         ([16], 1, np.zeros((0, 2)), 0, "tanh", 33),
         ([40, 40, 40], 1, np.eye(2), 2, "tanh", 19),     # NB = 4 (H=40 padded to 64)
+        ([64, 64, 64, 64], 1, [[0, 1], [1, 0]], 1, "tanh", 40),  # bench shape: register-accumulator path
+        ([20, 20, 20, 20, 20], 1, np.eye(2), 2, "tanh", 25),     # reference laplace2d.yaml depth (5x20)
     ],
 )
 def test_bwd_param_grads_match_oracle(hidden, dout, dirs, n2, act, N):

@@ -1,0 +1,43 @@
+"""Builds ablation / tuning variants of libppsci_hip.so into build/variants/<name>.so (tanh kernels only
+matter for the timing script, but every TU is built so the library links)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+VARIANTS = {
+    "base": [],
+    "occ2": ["-DPPSCI_BWD_MIN_WAVES=2"],
+    "fwd8": ["-DPPSCI_FWD_WAVES=8"],
+    "nostash": ["-DPPSCI_ABL_NOSTASH"],
+    "noatomic": ["-DPPSCI_ABL_NOATOMIC"],
+    "not2n": ["-DPPSCI_ABL_NOT2N"],
+    "norowsum": ["-DPPSCI_ABL_NOROWSUM"],
+}
+
+
+def build_variant(name, extra):
+    out = os.path.join(ROOT, "build", "variants", name)
+    os.makedirs(out, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(out, src.replace(".hip", ".o"))
+        subprocess.check_call([G.HIPCC] + G.FLAGS + extra + ["-c", os.path.join(G.CSRC, src), "-o", obj],
+                              stderr=subprocess.DEVNULL)
+        return obj
+
+    with ThreadPoolExecutor(8) as ex:
+        objs = list(ex.map(one, G.SOURCES))
+    lib = os.path.join(ROOT, "build", "variants", name + ".so")
+    subprocess.check_call([G.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(VARIANTS)
+    for n in names:
+        print(n, build_variant(n, VARIANTS[n]), flush=True)

@@ -12,4 +12,5 @@ for path in sys.argv[1:]:
         for k, pat in KEYS:
             m = re.search(pat + r": (\S+)", b)
             vals.append(f"{k}={m.group(1) if m else '?'}")
-        print(f"{name[:60]:62s} " + " ".join(vals))
+        short = name.split(" ")[0][:58]
+        print(f"{short:60s} " + " ".join(vals))
