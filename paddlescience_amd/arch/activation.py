@@ -1,0 +1,15 @@
+"""Activation registry (/root/reference/ppsci/arch/activation.py:139-154).  Only the activations
+with a fused HIP implementation are accepted on the hot path: tanh, silu (= x*sigmoid(x), :77-88)
+and sin.  Asking for another one raises at model-construction time."""
+HIP_ACTIVATIONS = ("tanh", "silu", "sin")
+REFERENCE_ACTIVATIONS = ("elu", "relu", "selu", "gelu", "leaky_relu", "sigmoid", "silu", "sin", "cos", "swish",
+                         "tanh", "identity", "siren", "stan")
+
+
+def get_activation(name: str) -> str:
+    low = name.lower()
+    if low not in REFERENCE_ACTIVATIONS:
+        raise ValueError(f"Act name must be in {REFERENCE_ACTIVATIONS}, but got {name}")
+    if low not in HIP_ACTIVATIONS:
+        raise NotImplementedError(f"activation {name!r} has no fused HIP kernel yet (available: {HIP_ACTIVATIONS})")
+    return low

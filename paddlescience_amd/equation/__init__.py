@@ -1,0 +1,18 @@
+"""ppsci.equation (/root/reference/ppsci/equation/__init__.py:55-76)."""
+import copy
+
+from .pde import PDE, AllenCahn, Laplace, NavierStokes, Poisson  # noqa: F401
+
+__all__ = ["PDE", "AllenCahn", "Laplace", "NavierStokes", "Poisson", "build_equation"]
+
+
+def build_equation(cfg):
+    if cfg is None:
+        return None
+    cfg = copy.deepcopy(cfg)
+    eq_dict = {}
+    for item in cfg:
+        cls = next(iter(item.keys()))
+        kwargs = item[cls]
+        eq_dict[cls] = globals()[cls](**kwargs)
+    return eq_dict

@@ -1,0 +1,5 @@
+from .allen_cahn import AllenCahn  # noqa: F401
+from .base import PDE  # noqa: F401
+from .laplace import Laplace  # noqa: F401
+from .navier_stokes import NavierStokes  # noqa: F401
+from .poisson import Poisson  # noqa: F401

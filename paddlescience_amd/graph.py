@@ -1,0 +1,386 @@
+"""Symbolic per-point expression graph: the front-end that lowers a constraint's expressions to
+(derivative stream set, epilogue program) for the fused HIP kernels.
+
+Why it exists: the reference evaluates `model(x)`, `jacobian(u, x)`, `hessian(u, x)` and the
+operator tree eagerly on paddle tensors with a dynamic autograd graph
+(/root/reference/ppsci/autodiff/ad.py, ppsci/utils/symbolic.py:184-504, expression.py:96-102).
+Here the same Python calls are made ONCE on proxy tensors (`Sym`); the recorded graph is then
+compiled into
+  * the set of network derivatives the Taylor-mode kernel must carry (hotpath.StreamSpec), and
+  * a postfix program for the epilogue VM (hotpath.Program), incl. the MSE terms of
+    ppsci/loss/mse.py:82-105.
+Derivatives of arbitrary recorded expressions are obtained by symbolic differentiation down to the
+network-output leaves (`net` -> `der`), which is what repeated `paddle.grad(..., create_graph=True)`
+computes numerically (ad.py:73-75).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib as L
+from . import hotpath as hp
+
+Number = Union[int, float]
+
+_UNARY_OPS = {
+    "sin": L.OP_SIN, "cos": L.OP_COS, "tanh": L.OP_TANH, "exp": L.OP_EXP, "log": L.OP_LOG, "sqrt": L.OP_SQRT,
+    "abs": L.OP_ABS, "sinh": L.OP_SINH, "cosh": L.OP_COSH, "tan": L.OP_TAN, "neg": L.OP_NEG, "sign": L.OP_SIGN,
+    "heaviside": L.OP_HEAVISIDE, "detach": L.OP_DETACH,
+}
+_BINARY_OPS = {"add": L.OP_ADD, "sub": L.OP_SUB, "mul": L.OP_MUL, "div": L.OP_DIV, "pow": L.OP_POW,
+               "max": L.OP_MAX, "min": L.OP_MIN}
+
+
+class Sym:
+    """A per-point scalar field ([N, 1] in the reference).  Immutable; hash-consed by structure."""
+
+    __slots__ = ("kind", "name", "value", "model", "comp", "dirs", "op", "args", "_key")
+    _cache: Dict[tuple, "Sym"] = {}
+
+    def __new__(cls, kind, name=None, value=None, model=None, comp=None, dirs=(), op=None, args=()):
+        key = (kind, name, None if value is None else float(np.float32(value)), id(model) if model is not None else None,
+               comp, tuple(dirs), op, tuple(id(a) for a in args))
+        hit = cls._cache.get(key)
+        if hit is not None:
+            return hit
+        self = object.__new__(cls)
+        self.kind, self.name, self.model, self.comp = kind, name, model, comp
+        self.value = None if value is None else float(np.float32(value))  # ConstantNode: fp32 (symbolic.py:448-454)
+        self.dirs, self.op, self.args = tuple(dirs), op, tuple(args)
+        self._key = key
+        cls._cache[key] = self
+        return self
+
+    # ---- constructors
+    @staticmethod
+    def input(name: str) -> "Sym":
+        return Sym("in", name=name)
+
+    @staticmethod
+    def aux(name: str) -> "Sym":
+        return Sym("aux", name=name)
+
+    @staticmethod
+    def const(v: Number) -> "Sym":
+        return Sym("const", value=float(v))
+
+    @staticmethod
+    def net(model, comp: int, dirs: Sequence[str] = ()) -> "Sym":
+        return Sym("net", model=model, comp=comp, dirs=tuple(sorted(dirs)))
+
+    # ---- reference-tensor look-alike surface
+    @property
+    def shape(self):
+        return [-1, 1]
+
+    def detach(self) -> "Sym":
+        return apply("detach", self)
+
+    def __repr__(self):
+        if self.kind == "in":
+            return self.name
+        if self.kind == "aux":
+            return f"aux:{self.name}"
+        if self.kind == "const":
+            return repr(self.value)
+        if self.kind == "net":
+            k = self.model.output_keys[self.comp]
+            return k + "".join(f"__{d}" for d in self.dirs)
+        return f"{self.op}({', '.join(map(repr, self.args))})"
+
+    # ---- arithmetic
+    def __add__(self, o): return apply("add", self, _lift(o))
+    def __radd__(self, o): return apply("add", _lift(o), self)
+    def __sub__(self, o): return apply("sub", self, _lift(o))
+    def __rsub__(self, o): return apply("sub", _lift(o), self)
+    def __mul__(self, o): return apply("mul", self, _lift(o))
+    def __rmul__(self, o): return apply("mul", _lift(o), self)
+    def __truediv__(self, o): return apply("div", self, _lift(o))
+    def __rtruediv__(self, o): return apply("div", _lift(o), self)
+    def __pow__(self, o): return apply("pow", self, _lift(o))
+    def __rpow__(self, o): return apply("pow", _lift(o), self)
+    def __neg__(self): return apply("neg", self)
+    def __pos__(self): return self
+
+    def __bool__(self):
+        raise TypeError("a traced expression has no truth value: data-dependent Python control flow cannot be "
+                        "lowered to the fused HIP path")
+
+    def sin(self): return apply("sin", self)
+    def cos(self): return apply("cos", self)
+    def tanh(self): return apply("tanh", self)
+    def exp(self): return apply("exp", self)
+    def log(self): return apply("log", self)
+    def sqrt(self): return apply("sqrt", self)
+    def abs(self): return apply("abs", self)
+    def pow(self, o): return apply("pow", self, _lift(o))
+
+
+def _lift(v) -> Sym:
+    if isinstance(v, Sym):
+        return v
+    if isinstance(v, (int, float, np.floating, np.integer)):
+        return Sym.const(float(v))
+    if isinstance(v, np.ndarray) and v.size == 1:
+        return Sym.const(float(v.reshape(-1)[0]))
+    raise TypeError(f"cannot mix a traced expression with {type(v)}")
+
+
+def is_const(s: Sym, v: Optional[float] = None) -> bool:
+    return s.kind == "const" and (v is None or s.value == v)
+
+
+def apply(op: str, *args: Sym) -> Sym:
+    """Builds an op node.  Only exact algebraic identities with 0/1 are folded (they do not change the
+    fp32 result), so the reference's operation order is preserved."""
+    if op in _BINARY_OPS:
+        a, b = args
+        if op == "add":
+            if is_const(a, 0.0):
+                return b
+            if is_const(b, 0.0):
+                return a
+        elif op == "sub":
+            if is_const(b, 0.0):
+                return a
+        elif op == "mul":
+            if is_const(a, 0.0) or is_const(b, 0.0):
+                return Sym.const(0.0)
+            if is_const(a, 1.0):
+                return b
+            if is_const(b, 1.0):
+                return a
+        elif op == "div":
+            if is_const(b, 1.0):
+                return a
+        elif op == "pow":
+            if is_const(b, 1.0):
+                return a
+        if a.kind == "const" and b.kind == "const" and op in ("add", "sub", "mul"):
+            f = {"add": np.add, "sub": np.subtract, "mul": np.multiply}[op]
+            return Sym.const(float(f(np.float32(a.value), np.float32(b.value))))
+        return Sym("op", op=op, args=(a, b))
+    if op in _UNARY_OPS:
+        (a,) = args
+        if op == "neg" and a.kind == "const":
+            return Sym.const(-a.value)
+        return Sym("op", op=op, args=(a,))
+    raise NotImplementedError(f"operation {op!r} is not supported by the epilogue VM")
+
+
+# ----------------------------------------------------------------------------- differentiation
+def diff(e: Sym, var: str) -> Sym:
+    """d e / d var, symbolically (what jacobian() obtains numerically in the reference)."""
+    k = e.kind
+    if k == "in":
+        return Sym.const(1.0 if e.name == var else 0.0)
+    if k in ("aux", "const"):
+        return Sym.const(0.0)
+    if k == "net":
+        if var not in e.model.input_keys:
+            return Sym.const(0.0)
+        if len(e.dirs) >= 2:
+            raise NotImplementedError(
+                f"derivative order {len(e.dirs) + 1} of a network output ({e!r} w.r.t. {var}) is beyond the fused "
+                "HIP kernels (orders 0..2)")
+        return Sym.net(e.model, e.comp, e.dirs + (var,))
+    op, a = e.op, e.args
+    if op == "detach":
+        return Sym.const(0.0)
+    if op == "add":
+        return diff(a[0], var) + diff(a[1], var)
+    if op == "sub":
+        return diff(a[0], var) - diff(a[1], var)
+    if op == "mul":
+        return diff(a[0], var) * a[1] + a[0] * diff(a[1], var)
+    if op == "div":
+        return diff(a[0], var) / a[1] - e * diff(a[1], var) / a[1]
+    if op == "neg":
+        return -diff(a[0], var)
+    if op == "pow":
+        da, db = diff(a[0], var), diff(a[1], var)
+        out = Sym.const(0.0)
+        if not is_const(da, 0.0):
+            out = out + a[1] * apply("pow", a[0], a[1] - 1.0) * da
+        if not is_const(db, 0.0):
+            out = out + e * apply("log", a[0]) * db
+        return out
+    d = diff(a[0], var)
+    if is_const(d, 0.0):
+        return d
+    if op == "sin":
+        return apply("cos", a[0]) * d
+    if op == "cos":
+        return -(apply("sin", a[0]) * d)
+    if op == "tanh":
+        return (1.0 - e * e) * d
+    if op == "exp":
+        return e * d
+    if op == "log":
+        return d / a[0]
+    if op == "sqrt":
+        return d / (2.0 * e)
+    if op == "abs":
+        return apply("sign", a[0]) * d
+    if op == "sinh":
+        return apply("cosh", a[0]) * d
+    if op == "cosh":
+        return apply("sinh", a[0]) * d
+    if op == "tan":
+        return (1.0 + e * e) * d
+    if op in ("sign", "heaviside"):
+        return Sym.const(0.0)
+    raise NotImplementedError(f"derivative of {op!r}")
+
+
+# ----------------------------------------------------------------------------- lowering
+def _walk(roots: Iterable[Sym]) -> List[Sym]:
+    seen, order = set(), []
+
+    def rec(n: Sym):
+        if id(n) in seen:
+            return
+        seen.add(id(n))
+        for a in n.args:
+            rec(a)
+        order.append(n)
+
+    for r in roots:
+        rec(r)
+    return order
+
+
+# (n1, n2) combinations the kernels are instantiated for (taylor_fwd.inc / taylor_bwd.inc)
+_INSTANTIATED = [(0, 0), (1, 1), (2, 0), (2, 1), (2, 2), (3, 3)]
+
+
+class Lowered:
+    """Result of lowering: everything engine.FusedConstraint needs except the device arrays."""
+
+    def __init__(self, model, streams: hp.StreamSpec, program: hp.Program, input_names: List[str],
+                 aux_names: List[str], loss_keys: List[str], value_index: Dict[str, int]):
+        self.model, self.streams, self.program = model, streams, program
+        self.input_names, self.aux_names, self.loss_keys = input_names, aux_names, loss_keys
+        self.value_index = value_index  # output name -> program value index
+
+
+def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = ()) -> Lowered:
+    """outputs: name -> traced expression.  losses: dicts with keys
+         key (output name), label (aux name or None), weight (aux name or None), area (aux name or None), scale.
+       Residual row k of the epilogue corresponds to losses[k]; `extra_outputs` are appended as
+       scale-0 residual rows so that eval / predict can read their values."""
+    roots = list(outputs.values())
+    nodes = _walk(roots)
+    models = {id(n.model): n.model for n in nodes if n.kind == "net"}
+    if len(models) > 1:
+        raise NotImplementedError("one constraint may reference a single network on the fused HIP path")
+    model = next(iter(models.values())) if models else None
+
+    # ---- derivative set -> stream specification
+    firsts, seconds, mixed = set(), set(), set()
+    for n in nodes:
+        if n.kind != "net":
+            continue
+        if len(n.dirs) == 1:
+            firsts.add(n.dirs[0])
+        elif len(n.dirs) == 2:
+            a, b = n.dirs
+            if a == b:
+                seconds.add(a)
+            else:
+                mixed.add((a, b))
+                seconds.update((a, b))
+    in_keys = list(model.input_keys) if model is not None else []
+    order_second = [v for v in in_keys if v in seconds]
+    order_first = [v for v in in_keys if v in firsts and v not in seconds]
+    dir_names: List[object] = list(order_second) + sorted(mixed) + order_first
+    n2 = len(order_second) + len(mixed)
+    n1 = len(dir_names)
+    choice = None
+    for (a, b) in _INSTANTIATED:
+        if a >= n1 and b >= n2 and (choice is None or (a, b) < choice):
+            choice = (a, b)
+    if choice is None:
+        raise NotImplementedError(f"derivative set with {n1} directions / {n2} second-order streams exceeds the "
+                                  f"instantiated kernels {_INSTANTIATED}")
+    # second-order streams are the first n2 directions: keep that prefix, pad with zero directions after it
+    dirs_vec: List[List[float]] = []
+    for d in dir_names:
+        v = [0.0] * len(in_keys)
+        if isinstance(d, tuple):
+            v[in_keys.index(d[0])] = 1.0
+            v[in_keys.index(d[1])] = 1.0
+        else:
+            v[in_keys.index(d)] = 1.0
+        dirs_vec.append(v)
+    n1p, n2p = choice
+    if n2p > n2:
+        # more second-order streams requested than needed: they must come from the FIRST directions, so
+        # move first-order-only directions in front of the zero padding (their second streams are unused)
+        pass
+    while len(dirs_vec) < n1p:
+        dirs_vec.append([0.0] * len(in_keys))
+    streams = hp.StreamSpec(dirs_vec, n2p)
+    S = streams.S
+    dir_index = {d: i for i, d in enumerate(dir_names)}
+
+    n_out = len(model.output_keys) if model is not None else 0
+    prog = hp.Program(n_out * S, len(in_keys))
+    # inputs that are not network inputs (e.g. parameters of a boundary function) are shipped as aux arrays
+    input_names = list(in_keys)
+    aux_names: List[str] = []
+
+    def aux_index(name: str) -> int:
+        if name not in aux_names:
+            aux_names.append(name)
+        return aux_names.index(name)
+
+    val: Dict[int, int] = {}
+    for n in nodes:
+        if n.kind == "in":
+            if n.name in input_names:
+                val[id(n)] = prog.ld_in(input_names.index(n.name))
+            else:
+                val[id(n)] = prog.ld_aux(aux_index(n.name))
+        elif n.kind == "aux":
+            val[id(n)] = prog.ld_aux(aux_index(n.name))
+        elif n.kind == "const":
+            val[id(n)] = prog.const(n.value)
+        elif n.kind == "net":
+            c = n.comp
+            if len(n.dirs) == 0:
+                val[id(n)] = prog.ld_u(c * S)
+            elif len(n.dirs) == 1:
+                val[id(n)] = prog.ld_u(c * S + 1 + dir_index[n.dirs[0]])
+            else:
+                a, b = n.dirs
+                if a == b:
+                    val[id(n)] = prog.ld_u(c * S + 1 + n1p + dir_index[a])
+                else:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
+                    sab = prog.ld_u(c * S + 1 + n1p + dir_index[(a, b)])
+                    sa = prog.ld_u(c * S + 1 + n1p + dir_index[a])
+                    sb = prog.ld_u(c * S + 1 + n1p + dir_index[b])
+                    t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, sab, sa), sb)
+                    val[id(n)] = prog.op(L.OP_MUL, prog.const(0.5), t)
+        else:
+            if n.op in _BINARY_OPS:
+                val[id(n)] = prog.op(_BINARY_OPS[n.op], val[id(n.args[0])], val[id(n.args[1])])
+            else:
+                val[id(n)] = prog.op(_UNARY_OPS[n.op], val[id(n.args[0])])
+
+    loss_keys = []
+    for ls in losses:
+        key = ls["key"]
+        lab = aux_index(ls["label"]) if ls.get("label") else -1
+        w = aux_index(ls["weight"]) if ls.get("weight") else -1
+        ar = aux_index(ls["area"]) if ls.get("area") else -1
+        prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0))
+        loss_keys.append(key)
+    for name in extra_outputs:
+        prog.residual(val[id(outputs[name])], -1, -1, -1, 0.0)
+        loss_keys.append(name)
+    value_index = {k: val[id(v)] for k, v in outputs.items()}
+    return Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)

@@ -1,0 +1,35 @@
+"""Generates tests/golden/geometry.npz by running the REFERENCE geometry code (numpy only, PaddlePaddle
+stubbed by tests/golden/_ref_import.py) in this container:
+
+    python tests/golden/make_geometry_golden.py
+
+The calls are listed in tests/golden/geometry_cases.py; tests/test_geometry.py replays them against
+paddlescience_amd.geometry and requires bit-identical arrays."""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+import geometry_cases  # noqa: E402
+
+
+def main():
+    _ref_import.install()
+    g1 = _ref_import.ref_module("ppsci.geometry.geometry_1d")
+    gnd = _ref_import.ref_module("ppsci.geometry.geometry_nd")
+    g2 = _ref_import.ref_module("ppsci.geometry.geometry_2d")
+    g3 = _ref_import.ref_module("ppsci.geometry.geometry_3d")
+    td = _ref_import.ref_module("ppsci.geometry.timedomain")
+    ns = types.SimpleNamespace(Interval=g1.Interval, Rectangle=g2.Rectangle, Cuboid=g3.Cuboid, Hypercube=gnd.Hypercube,
+                               TimeDomain=td.TimeDomain, TimeXGeometry=td.TimeXGeometry)
+    cases = geometry_cases.run(ns)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **cases)
+    print(f"wrote {len(cases)} arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""Geometry sampling is host numpy and must be BIT-EXACT with the reference.
+
+* tests/golden/geometry.npz was produced by the reference's own geometry code
+  (tests/golden/make_geometry_golden.py); every array must match exactly, dtype included.
+* The doctest known answers of /root/reference/ppsci/geometry/geometry.py:157-183, 257-281, 361-376
+  (np.random.seed(42)) are checked literally as well."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import geometry_cases  # noqa: E402
+
+from paddlescience_amd import geometry as G  # noqa: E402
+
+
+def test_matches_reference_generated_fixtures():
+    gold = np.load(os.path.join(HERE, "golden", "geometry.npz"))
+    mine = geometry_cases.run(G)
+    assert set(mine) == set(gold.files)
+    for k in gold.files:
+        a, b = mine[k], gold[k]
+        assert a.dtype == b.dtype, (k, a.dtype, b.dtype)
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        assert np.array_equal(a, b), k
+
+
+def test_reference_doctest_known_answers():
+    np.random.seed(42)
+    iv = G.Interval(0, 1).sample_interior(2)
+    np.testing.assert_array_equal(iv["x"], np.array([[0.37454012], [0.9507143]], dtype=np.float32))
+    np.testing.assert_array_equal(iv["sdf"], np.array([[0.37454012], [0.04928571]], dtype=np.float32))
+    r = G.Rectangle((0, 0), (1, 1)).sample_interior(2, "pseudo", None, False, True)
+    np.testing.assert_array_equal(r["x"], np.array([[0.7319939], [0.15601864]], dtype=np.float32))
+    np.testing.assert_array_equal(r["y"], np.array([[0.5986585], [0.15599452]], dtype=np.float32))
+    np.testing.assert_array_equal(r["sdf"], np.array([[0.2680061], [0.15599453]], dtype=np.float32))
+    np.testing.assert_allclose(r["sdf__x"], np.array([[-1.0001659], [0.25868416]], dtype=np.float32), rtol=1e-6)
+    np.testing.assert_allclose(r["sdf__y"], np.array([[-0.0], [0.74118376]], dtype=np.float32), rtol=1e-6)
+    c = G.Cuboid((0, 0, 0), (1, 1, 1)).sample_interior(2, "pseudo", None, True, True)
+    np.testing.assert_array_equal(c["z"], np.array([[0.0], [1.0]], dtype=np.float32))
+    np.testing.assert_allclose(c["sdf__z"], np.array([[0.50008297], [-0.49948692]], dtype=np.float32), rtol=1e-6)
+
+    np.random.seed(42)
+    b = G.Interval(0, 1).sample_boundary(2)
+    np.testing.assert_array_equal(b["x"], np.array([[0.0], [1.0]], dtype=np.float32))
+    np.testing.assert_array_equal(b["normal_x"], np.array([[-1.0], [1.0]], dtype=np.float32))
+    rb = G.Rectangle((0, 0), (1, 1)).sample_boundary(2)
+    np.testing.assert_array_equal(rb["x"], np.array([[1.0], [0.0]], dtype=np.float32))
+    np.testing.assert_array_equal(rb["y"], np.array([[0.49816048], [0.19714284]], dtype=np.float32))
+    np.testing.assert_array_equal(rb["normal_x"], np.array([[1.0], [-1.0]], dtype=np.float32))
+    cb = G.Cuboid((0, 0, 0), (1, 1, 1)).sample_boundary(2)
+    np.testing.assert_array_equal(cb["x"], np.array([[0.83244264], [0.18182497]], dtype=np.float32))
+    np.testing.assert_array_equal(cb["z"], np.array([[0.0], [1.0]], dtype=np.float32))
+
+
+def test_grids_of_the_baseline_configs():
+    """Laplace 101x101 on [0,1]^2 and LDC 99x99 on [-0.05,0.05]^2."""
+    x = G.Rectangle((0.0, 0.0), (1.0, 1.0)).uniform_points(10201)
+    assert x.shape == (10201, 2) and len(np.unique(x[:, 0])) == 101
+    y = G.Rectangle((-0.05, -0.05), (0.05, 0.05)).uniform_points(9801)
+    assert y.shape == (9801, 2) and len(np.unique(y[:, 1])) == 99
+
+
+def test_errors():
+    with pytest.raises(ValueError):
+        G.Hypercube((0, 0), (1,))
+    with pytest.raises(ValueError):
+        G.Rectangle((1, 0), (0, 1))
+    with pytest.raises(ValueError):
+        G.TimeXGeometry(G.TimeDomain(0, 1), G.Interval(0, 1)).random_points(5)
+    with pytest.raises(ValueError):
+        G.Rectangle((0, 0), (1, 1)).sample_interior(5, criteria=lambda x, y: x > 2)
+    with pytest.raises(NotImplementedError):
+        G.Rectangle((0, 0), (1, 1)).sample_interior(5, random="Halton")
