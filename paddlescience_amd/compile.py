@@ -1,0 +1,101 @@
+"""Constraint / validator compilation: trace the user's `output_expr` once on proxy tensors, lower it
+(graph.lower) and bind the device buffers (engine.FusedConstraint).
+
+This is the counterpart of `Solver.__init__`'s `convert_expr` (/root/reference/ppsci/solver/solver.py:
+496-535) + the per-iteration body of `ExpressionSolver.train_forward` (ppsci/utils/expression.py:89-126):
+what the reference re-executes op by op every iteration is decided here once."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import sympy as sp
+import torch
+
+from . import autodiff, graph
+from .engine import FusedConstraint
+from .graph import Sym
+
+LABEL_PREFIX, WEIGHT_PREFIX = "label:", "weight:"
+
+
+def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable]) -> Dict[str, Sym]:
+    """expression.py:96-102 on proxies: model forward, then every named expression on the data dict."""
+    data: Dict[str, object] = {}
+    for k in input_keys:
+        data[k] = Sym.input(k) if k in model.input_keys else Sym.aux(k)
+    missing = [k for k in model.input_keys if k not in data]
+    if missing:
+        raise KeyError(f"model input(s) {missing} are not provided by the dataset (has {list(input_keys)})")
+    output_dict = model(data)
+    data.update(output_dict)
+    out: Dict[str, Sym] = {}
+    for name, ex in exprs.items():
+        if isinstance(ex, sp.Basic):
+            from .utils.symbolic import lambdify
+
+            ex = lambdify(ex, model)
+        val = ex(data)
+        if not isinstance(val, Sym):
+            val = graph._lift(val)
+        out[name] = val
+    autodiff.clear()  # expression.py:109
+    return out
+
+
+def _to_dev(a, dev) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(dev).contiguous().view(-1)
+
+
+class CompiledConstraint:
+    """A constraint (or validator) bound to the fused kernels for a fixed batch size."""
+
+    def __init__(self, name: str, model, exprs: Dict[str, Callable], input_keys: Sequence[str],
+                 label_keys: Sequence[str], weight_keys: Sequence[str], loss, batch_size: int, n_global: int,
+                 device, train: bool = True, want_values: bool = False, extra_outputs: Sequence[str] = ()):
+        self.name, self.model, self.loss = name, model, loss
+        outputs = trace_exprs(model, input_keys, exprs)
+        for k in label_keys:
+            if k not in outputs:
+                # a label on a raw network output (expression.py: output_dict holds the model outputs too)
+                if k in model.output_keys:
+                    outputs[k] = Sym.net(model, model.output_keys.index(k))
+                else:
+                    raise KeyError(f"label key {k!r} is neither an expression nor a network output")
+        losses = []
+        for k in label_keys:
+            losses.append(dict(key=k, label=LABEL_PREFIX + k, weight=(WEIGHT_PREFIX + k) if k in weight_keys else None,
+                               area="area" if "area" in input_keys else None,
+                               scale=loss.term_scale(k, n_global) if loss is not None else 0.0))
+        self.low = graph.lower(outputs, losses, extra_outputs)
+        self.batch_size = batch_size
+        self.label_keys = list(label_keys)
+        dev = device
+        zeros = lambda: torch.zeros(batch_size, dtype=torch.float32, device=dev)  # noqa: E731
+        inputs = [zeros() for _ in self.low.input_names]
+        aux = [zeros() for _ in self.low.aux_names]
+        self.fused = FusedConstraint(name, model.layout, self.low.streams, self.low.program.build(), inputs, aux,
+                                     self.low.loss_keys, want_residual=want_values)
+        self.train = train
+
+    def bind(self, input: Dict[str, object], label: Optional[Dict[str, object]], weight: Optional[Dict[str, object]]):
+        """Upload one batch (named [n,1] arrays) into the constraint's device buffers."""
+        f = self.fused
+        dev = f.inputs[0].device if f.inputs else f.U.device
+        for dst, name in zip(f.inputs, self.low.input_names):
+            dst.copy_(_to_dev(input[name], dev))
+        for dst, name in zip(f.aux, self.low.aux_names):
+            if name.startswith(LABEL_PREFIX):
+                src = label[name[len(LABEL_PREFIX):]]
+            elif name.startswith(WEIGHT_PREFIX):
+                src = weight[name[len(WEIGHT_PREFIX):]]
+            else:
+                src = input[name]
+            dst.copy_(_to_dev(src, dev))
+
+    def values(self) -> Dict[str, torch.Tensor]:
+        """Per-point values of every loss key / extra output ([n,1] tensors), after a forward."""
+        assert self.fused.resid is not None
+        return {k: self.fused.resid[i].view(-1, 1) for i, k in enumerate(self.low.loss_keys)}

@@ -1,0 +1,5 @@
+from .base import Constraint  # noqa: F401
+from .geometric import BoundaryConstraint, InitialConstraint, InteriorConstraint  # noqa: F401
+from .supervised import SupervisedConstraint  # noqa: F401
+
+__all__ = ["Constraint", "InteriorConstraint", "BoundaryConstraint", "InitialConstraint", "SupervisedConstraint"]

@@ -1,0 +1,15 @@
+import copy
+
+from .array_dataset import ContinuousNamedArrayDataset, IterableNamedArrayDataset, NamedArrayDataset  # noqa: F401
+
+__all__ = ["NamedArrayDataset", "IterableNamedArrayDataset", "ContinuousNamedArrayDataset", "build_dataset"]
+
+
+def build_dataset(cfg):
+    """ppsci/data/dataset/__init__.py: cfg = {"name": ClassName, **kwargs}."""
+    cfg = dict(cfg)
+    cls = cfg.pop("name")
+    if cls not in __all__[:-1]:
+        raise NotImplementedError(f"dataset {cls!r} (file-backed data-driven datasets are out of scope of the PINN hot path)")
+    cfg.pop("transforms", None) if cfg.get("transforms") is None else None
+    return globals()[cls](**cfg)

@@ -1,0 +1,11 @@
+from . import mtl  # noqa: F401
+from .base import Loss  # noqa: F401
+from .mse import MSELoss  # noqa: F401
+
+__all__ = ["Loss", "MSELoss", "mtl", "build_loss"]
+
+
+def build_loss(cfg):
+    cfg = dict(cfg)
+    cls = cfg.pop("name")
+    return {"MSELoss": MSELoss}[cls](**cfg)

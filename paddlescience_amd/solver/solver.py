@@ -1,0 +1,352 @@
+"""ppsci.solver.Solver (/root/reference/ppsci/solver/solver.py:128-1116, train.py:58-213, eval.py,
+printer.py) re-implemented over the fused HIP engine.
+
+Constructor signature and the public methods (train / eval / predict / export stubs) follow the reference.
+What differs by design: every constraint is compiled ONCE into (Taylor-mode stream set, epilogue
+program) and a training iteration is a fixed sequence of kernel launches (engine.Engine); loss values
+are only read back (one device->host sync) every `log_freq` iterations, whereas the reference syncs on
+`.item()` for every loss term of every iteration (expression.py:122, train.py:145).
+Not supported (raise): AMP, update_freq > 1, L-BFGS, loss aggregators other than Sum, to_static,
+visualizers."""
+from __future__ import annotations
+
+import datetime
+import os
+import time
+from typing import Any, Callable, Dict, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import autodiff
+from ..compile import CompiledConstraint
+from ..device import get_device
+from ..engine import Engine
+from ..loss import mtl
+from ..utils import logger, misc, save_load
+
+
+def _is_full_static_batch(cst) -> bool:
+    ds = getattr(cst.data_loader, "dataset", cst.data_loader)
+    if getattr(ds, "is_iterable", False):
+        return type(ds).__name__ == "IterableNamedArrayDataset"
+    return len(cst.data_loader) == 1 and not cst.data_loader.batch_sampler.shuffle
+
+
+class Solver:
+    def __init__(
+        self,
+        model,
+        constraint: Optional[Dict[str, Any]] = None,
+        output_dir: Optional[str] = "./output/",
+        optimizer=None,
+        lr_scheduler=None,
+        epochs: int = 5,
+        iters_per_epoch: int = 20,
+        update_freq: int = 1,
+        save_freq: int = 0,
+        log_freq: int = 10,
+        eval_during_train: bool = False,
+        start_eval_epoch: int = 1,
+        eval_freq: int = 1,
+        seed: int = 42,
+        use_vdl: bool = False,
+        use_wandb: bool = False,
+        use_tbd: bool = False,
+        wandb_config: Optional[Mapping] = None,
+        device: str = "gpu",
+        equation: Optional[Dict[str, Any]] = None,
+        geom: Optional[Dict[str, Any]] = None,
+        validator: Optional[Dict[str, Any]] = None,
+        visualizer: Optional[Dict[str, Any]] = None,
+        use_amp: bool = False,
+        amp_level: str = "O1",
+        pretrained_model_path: Optional[str] = None,
+        checkpoint_path: Optional[str] = None,
+        compute_metric_by_batch: bool = False,
+        eval_with_no_grad: bool = False,
+        to_static: bool = False,
+        loss_aggregator: Optional[mtl.LossAggregator] = None,
+        *,
+        cfg=None,
+        dp_reduce: str = "sum",
+    ):
+        if use_amp or to_static:
+            raise NotImplementedError("AMP / to_static are not available on the fused HIP path (fp32 only)")
+        if update_freq != 1:
+            raise NotImplementedError("gradient accumulation (update_freq > 1) is not implemented yet")
+        if loss_aggregator is not None and not isinstance(loss_aggregator, mtl.Sum):
+            raise NotImplementedError("only the Sum loss aggregator is fused; per-loss-gradient aggregators are not")
+        if visualizer:
+            raise NotImplementedError("visualizers are out of scope of the hot path")
+        self.cfg = cfg
+        self.model = model
+        self.constraint = constraint
+        self.output_dir = output_dir
+        self.optimizer = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.epochs = epochs
+        self.iters_per_epoch = iters_per_epoch
+        self.update_freq = update_freq
+        self.save_freq = save_freq
+        self.log_freq = log_freq
+        self.eval_during_train = eval_during_train
+        self.start_eval_epoch = start_eval_epoch
+        self.eval_freq = eval_freq
+        self.seed = seed
+        self.equation = equation
+        self.geom = geom
+        self.validator = validator
+        self.visualizer = visualizer
+        self.compute_metric_by_batch = compute_metric_by_batch
+        self.eval_with_no_grad = eval_with_no_grad
+        self.loss_aggregator = loss_aggregator or mtl.Sum()
+        self.vdl_writer = self.wandb_writer = self.tbd_writer = None
+        self.benchmark_flag = bool(os.getenv("BENCHMARK_ROOT", None))
+        self.device = get_device()
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.global_step = 0
+        self.best_metric = {"metric": float("inf"), "epoch": 0}
+        self.train_output_info: Dict[str, misc.AverageMeter] = {}
+        self.train_time_info = {"batch_cost": misc.AverageMeter("batch_cost", ".5f", postfix="s"),
+                                "reader_cost": misc.AverageMeter("reader_cost", ".5f", postfix="s")}
+        self.eval_output_info: Dict[str, misc.AverageMeter] = {}
+        self.eval_time_info = {"batch_cost": misc.AverageMeter("batch_cost", ".5f", postfix="s"),
+                               "reader_cost": misc.AverageMeter("reader_cost", ".5f", postfix="s")}
+
+        if pretrained_model_path is not None:
+            save_load.load_pretrain(self.model, pretrained_model_path, self.equation)
+        if checkpoint_path is not None:
+            self.best_metric = save_load.load_checkpoint(checkpoint_path, self.model, self.optimizer, self.equation)
+
+        if self.world_size > 1:
+            # DataParallel wrap of the reference (solver.py:388-412): replicate rank 0's parameters
+            dist.broadcast(self.model.flat_params, src=0)
+        self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
+        if self.optimizer is not None:
+            self.engine.m, self.engine.v = self.optimizer.m, self.optimizer.v
+            self.engine.beta1, self.engine.beta2, self.engine.eps = (self.optimizer.beta1, self.optimizer.beta2,
+                                                                    self.optimizer.epsilon)
+            self.engine.t = self.optimizer.t
+
+        # ---- compile constraints (convert_expr, solver.py:496-535)
+        self._compiled: Dict[str, CompiledConstraint] = {}
+        self._static: Dict[str, bool] = {}
+        self._device_data: Dict[str, Tuple[dict, dict, dict]] = {}
+        if self.constraint:
+            for name, cst in self.constraint.items():
+                self._compiled[name] = self._compile_constraint(name, cst)
+        self._compiled_val: Dict[str, CompiledConstraint] = {}
+        self._predict_cache: Dict[tuple, CompiledConstraint] = {}
+
+    # ------------------------------------------------------------------ compilation helpers
+    def _equation_exprs(self, exprs: Dict[str, Callable]) -> Dict[str, Callable]:
+        return dict(exprs)
+
+    def _compile_constraint(self, name: str, cst) -> CompiledConstraint:
+        ds = getattr(cst.data_loader, "dataset", cst.data_loader)
+        input_keys = list(ds.input_keys)
+        label_keys = list(ds.label_keys)
+        weight_keys = list((ds.weight or {}).keys()) if not callable(getattr(ds, "weight_fn", None)) else label_keys
+        if getattr(ds, "is_iterable", False):
+            inp, lab, w = next(iter(ds))
+            bsz = len(next(iter(inp.values())))
+        else:
+            bsz = cst.data_loader.batch_sampler.batch_size
+            if cst.data_loader.batch_sampler.drop_last is False and len(ds) % bsz != 0 and len(cst.data_loader) > 1:
+                raise NotImplementedError(f"constraint {name}: ragged last batch ({len(ds)} % {bsz} != 0); use drop_last")
+            if len(cst.data_loader) == 1:
+                bsz = cst.data_loader.batch_sampler.num_samples
+        cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
+                                bsz * self.world_size, self.device, train=True)
+        self._static[name] = _is_full_static_batch(cst)
+        if self._static[name]:
+            inp, lab, w = next(cst.data_iter)
+            cc.bind(inp, lab, w)
+        return cc
+
+    # ------------------------------------------------------------------ training
+    def train(self) -> None:
+        """solver.py:544-669 + train.py:58-213."""
+        if self.optimizer is None:
+            raise ValueError("Solver.train needs an optimizer")
+        self.global_step = self.best_metric["epoch"] * self.iters_per_epoch
+        start_epoch = self.best_metric["epoch"] + 1
+        csts = list(self._compiled.values())
+        total_batch_size = sum(c.batch_size for c in csts)
+        for epoch_id in range(start_epoch, self.epochs + 1):
+            batch_tic = time.perf_counter()
+            for iter_id in range(1, self.iters_per_epoch + 1):
+                reader_tic = time.perf_counter()
+                for name, cc in self._compiled.items():
+                    if not self._static[name]:
+                        inp, lab, w = next(self.constraint[name].data_iter)
+                        cc.bind(inp, lab, w)
+                reader_cost = time.perf_counter() - reader_tic
+                self.engine.forward_backward([c.fused for c in csts])
+                self.engine.allreduce()
+                self.optimizer.step(self.engine.grad,
+                                    (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0)
+                self.optimizer.clear_grad()
+                if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
+                    self.lr_scheduler.step()
+                self.global_step += 1
+                if self.benchmark_flag and torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                batch_cost = time.perf_counter() - batch_tic
+                self.train_time_info["reader_cost"].update(reader_cost)
+                self.train_time_info["batch_cost"].update(batch_cost)
+                if iter_id == 1 or iter_id % self.log_freq == 0:
+                    self._update_train_loss()
+                    self._log_train_info(total_batch_size, epoch_id, iter_id)
+                batch_tic = time.perf_counter()
+            if self.lr_scheduler is not None and getattr(self.lr_scheduler, "by_epoch", False):
+                self.lr_scheduler.step()
+            cur_metric = float("inf")
+            if self.eval_during_train and epoch_id % self.eval_freq == 0 and epoch_id >= self.start_eval_epoch:
+                cur_metric, metric_dict_group = self.eval(epoch_id)
+                if cur_metric < self.best_metric["metric"]:
+                    self.best_metric["metric"] = cur_metric
+                    self.best_metric["epoch"] = epoch_id
+                    save_load.save_checkpoint(self.model, self.optimizer, self.best_metric, None, self.output_dir,
+                                              "best_model", self.equation)
+                logger.info(f"[Eval][Epoch {epoch_id}][best metric: {self.best_metric['metric']}]")
+            if self.save_freq > 0 and epoch_id % self.save_freq == 0:
+                save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
+                                          self.output_dir, f"epoch_{epoch_id}", self.equation)
+            save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
+                                      self.output_dir, "latest", self.equation, print_log=(epoch_id == self.epochs))
+
+    def _update_train_loss(self):
+        """printer.update_train_loss: total `loss` = Sum aggregator over all terms (mtl/sum.py:45-60), plus one
+        entry per constraint = sum of its keys (expression.py:120-126)."""
+        losses_all: Dict[str, float] = {}
+        per_cst: Dict[str, float] = {}
+        for name, cc in self._compiled.items():
+            vals = cc.fused.losses()
+            per_cst[name] = 0.0
+            for k in cc.label_keys:
+                per_cst[name] += vals[k]
+                losses_all[k] = losses_all.get(k, 0.0) + vals[k]
+        total = float(self.loss_aggregator(losses_all, self.global_step))
+        self.last_losses = {"loss": total, **per_cst}
+        for k, v in self.last_losses.items():
+            if k not in self.train_output_info:
+                self.train_output_info[k] = misc.AverageMeter(k, "7.5f")
+            self.train_output_info[k].update(v, 1)
+
+    def _log_train_info(self, batch_size: int, epoch_id: int, iter_id: int):
+        lr_msg = f"lr: {self.optimizer.get_lr():.5f}"
+        metric_msg = ", ".join(f"{k}: {m.avg:.5f}" for k, m in self.train_output_info.items())
+        time_msg = ", ".join(m.mean for m in self.train_time_info.values())
+        avg = self.train_time_info["batch_cost"].avg
+        ips_msg = f"ips: {batch_size / avg:.2f}" + (" samples/s" if self.benchmark_flag else "")
+        eta = ((self.epochs - epoch_id + 1) * self.iters_per_epoch - iter_id) * avg
+        ew, iw = len(str(self.epochs)), len(str(self.iters_per_epoch))
+        logger.info(f"[Train][Epoch {epoch_id:>{ew}}/{self.epochs}][Iter {iter_id:>{iw}}/{self.iters_per_epoch}] {lr_msg}, "
+                    f"{metric_msg}, {time_msg}, {ips_msg}, eta: {str(datetime.timedelta(seconds=int(eta)))}")
+        for m in self.train_time_info.values():
+            m.reset()
+        for m in self.train_output_info.values():
+            m.reset()
+
+    # ------------------------------------------------------------------ evaluation
+    def eval(self, epoch_id: int = 0) -> Tuple[float, Dict[str, Dict[str, float]]]:
+        """solver.py:684-711 + eval.py (_eval_by_dataset): returns (target metric, {validator: {metric.key: value}})."""
+        if not self.validator:
+            raise ValueError("Solver.eval needs at least one validator")
+        target = float("inf")
+        group: Dict[str, Dict[str, float]] = {}
+        for vname, val in self.validator.items():
+            ds = getattr(val.data_loader, "dataset", val.data_loader)
+            outs: Dict[str, list] = {}
+            labs: Dict[str, list] = {}
+            loss_sum: Dict[str, float] = {}
+            nb = 0
+            for (inp, lab, w) in val.data_loader:
+                bsz = len(next(iter(inp.values())))
+                key = (vname, bsz)
+                if key not in self._compiled_val:
+                    self._compiled_val[key] = CompiledConstraint(
+                        vname, self.model, val.output_expr, list(ds.input_keys), list(ds.label_keys),
+                        list((ds.weight or {}).keys()), val.loss, bsz, bsz, self.device, train=False, want_values=True)
+                cc = self._compiled_val[key]
+                cc.bind(inp, lab, w)
+                cc.fused.forward(self.model.flat_params, False)
+                vals = cc.values()
+                lv = cc.fused.losses()
+                for k in cc.label_keys:
+                    outs.setdefault(k, []).append(vals[k].clone())
+                    labs.setdefault(k, []).append(torch.as_tensor(np.asarray(lab[k], dtype=np.float32)).to(self.device).view(-1, 1))
+                    loss_sum[k] = loss_sum.get(k, 0.0) + lv[k]
+                nb += 1
+            all_out = {k: misc.all_gather(torch.cat(v, 0)) for k, v in outs.items()}
+            all_lab = {k: misc.all_gather(torch.cat(v, 0)) for k, v in labs.items()}
+            group[vname] = {}
+            for mname, metric in (val.metric or {}).items():
+                res = metric(all_out, all_lab)
+                for k, v in res.items():
+                    group[vname][f"{mname}.{k}"] = float(v)
+            msg = ", ".join(f"{k}: {v:.5f}" for k, v in group[vname].items())
+            logger.info(f"[Eval][Epoch {epoch_id}][{vname}] loss: {sum(loss_sum.values()) / max(nb, 1):.5f}, {msg}")
+            if group[vname] and target == float("inf"):
+                target = float(next(iter(group[vname].values())))  # first metric of the first validator
+        return target, group
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, input_dict: Dict[str, Union[np.ndarray, torch.Tensor]], expr_dict: Optional[Dict[str, Callable]] = None,
+                batch_size: Optional[int] = 64, no_grad: bool = True, return_numpy: bool = False):
+        """solver.py:729-872.  With world_size > 1 the points are rank-strided (v[rank::world]) and the
+        gathered result is restored to the input order, like the reference (:793-797, :847-855)."""
+        n = len(next(iter(input_dict.values())))
+        batch_size = n if batch_size is None else batch_size
+        keys = list(input_dict.keys())
+        arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)).reshape(n, -1).astype(np.float32)
+                for k, v in input_dict.items()}
+        world, rank = self.world_size, self.rank
+        pad = (-n) % world
+        if pad:
+            arrs = {k: np.concatenate([v, np.repeat(v[-1:], pad, 0)], 0) for k, v in arrs.items()}
+        local = {k: v[rank::world] for k, v in arrs.items()} if world > 1 else arrs
+        nl = len(next(iter(local.values())))
+        exprs = expr_dict if expr_dict is not None else {k: (lambda out, k=k: out[k]) for k in self.model.output_keys}
+        out_keys = list(exprs.keys())
+        results = {k: [] for k in out_keys}
+        for s in range(0, nl, batch_size):
+            chunk = {k: v[s:s + batch_size] for k, v in local.items()}
+            bsz = len(next(iter(chunk.values())))
+            ck = (id(expr_dict), tuple(keys), bsz)
+            if ck not in self._predict_cache:
+                self._predict_cache[ck] = CompiledConstraint("predict", self.model, exprs, keys, [], [], None, bsz, bsz,
+                                                            self.device, train=False, want_values=True,
+                                                            extra_outputs=out_keys)
+            cc = self._predict_cache[ck]
+            cc.bind(chunk, {}, {})
+            cc.fused.forward(self.model.flat_params, False)
+            vals = cc.values()
+            for k in out_keys:
+                results[k].append(vals[k].clone())
+        pred = {k: torch.cat(v, 0) for k, v in results.items()}
+        if world > 1:
+            gathered = {k: misc.all_gather(v, concat=False) for k, v in pred.items()}
+            pred = {}
+            for k, parts in gathered.items():
+                full = torch.empty((nl * world, 1), dtype=torch.float32, device=self.device)
+                for r, p in enumerate(parts):
+                    full[r::world] = p
+                pred[k] = full[:n]
+        if return_numpy:
+            return {k: v.detach().cpu().numpy() for k, v in pred.items()}
+        return pred
+
+    def visualize(self, epoch_id: int = 0):
+        raise NotImplementedError("visualizers are out of scope of the hot path")
+
+    def export(self, *args, **kwargs):
+        raise NotImplementedError("inference export (paddle.inference / ONNX) is out of scope")
+
+    def finetune(self, pretrained_model_path: str) -> None:
+        save_load.load_pretrain(self.model, pretrained_model_path, self.equation)
+        self.train()

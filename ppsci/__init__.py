@@ -1,0 +1,17 @@
+"""Drop-in alias: `import ppsci` resolves to the MI355X-native implementation (paddlescience_amd), so
+example scripts written against /root/reference/ppsci keep their import lines."""
+import sys
+
+import paddlescience_amd as _impl
+from paddlescience_amd import *  # noqa: F401,F403
+from paddlescience_amd import (arch, autodiff, constraint, data, equation, geometry, loss, metric, optimizer,  # noqa: F401
+                               solver, utils, validate)
+
+for _name in ("arch", "autodiff", "constraint", "data", "equation", "geometry", "loss", "metric", "optimizer", "solver",
+              "utils", "validate"):
+    sys.modules[f"ppsci.{_name}"] = getattr(_impl, _name)
+sys.modules["ppsci.loss.mtl"] = _impl.loss.mtl
+sys.modules["ppsci.optimizer.lr_scheduler"] = _impl.optimizer.lr_scheduler
+sys.modules["ppsci.utils.misc"] = _impl.utils.misc
+sys.modules["ppsci.utils.logger"] = _impl.utils.logger
+lambdify = _impl.lambdify
