@@ -1,0 +1,57 @@
+"""Worker of tests/test_distributed.py: one rank of a gloo data-parallel run on the CPU SIMT emulator."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_solver(outdir, world_batch, reduction, steps):
+    import ppsci
+    from oracle import taylor_np as T
+    from tests.common import set_model_weights
+
+    model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
+    set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
+    N = world_batch
+    X = np.random.default_rng(3).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    lab = np.random.default_rng(4).standard_normal((N, 1)).astype(np.float32) * 0.1
+    eq = ppsci.equation.AllenCahn(eps=0.01)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"t": X[:, :1], "x": X[:, 1:]},
+                       "label": {"allen_cahn": lab}},
+           "batch_size": N // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss(reduction), eq.equations, name="EQ")
+    opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
+
+
+def main():
+    outdir, reduction = sys.argv[1], sys.argv[2]
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    solver, model = build_solver(outdir, 64, reduction, 2)
+    solver.train()
+    pred = solver.predict({"t": np.linspace(0, 1, 11, dtype=np.float32).reshape(-1, 1),
+                           "x": np.linspace(-1, 1, 11, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
+                 loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""API-level parity for the other equation classes of the hot path:
+AllenCahn (Python closure calling jacobian, period embedding), NavierStokes 2-D steady (sympy, three
+outputs, per-point weights, detach_keys) and Poisson; plus symbolic-differentiation paths
+(output transform, mixed second derivative by polarisation).  Oracle: oracle/ref_torch.py in fp64."""
+import numpy as np
+import pytest
+import sympy as sp
+import torch
+
+import ppsci
+from oracle import ref_torch as R
+from oracle import taylor_np as T
+from ppsci.autodiff import hessian, jacobian
+from tests.common import make_dev_fixture, rel, set_model_weights
+
+dev = make_dev_fixture()
+
+
+def _solver(tmp_path, model, constraint, lr=1e-3):
+    opt = ppsci.optimizer.Adam(learning_rate=lr)(model)
+    return ppsci.solver.Solver(model, constraint, str(tmp_path), opt, epochs=1, iters_per_epoch=1, log_freq=1)
+
+
+def _sup_constraint(inputs, labels, exprs, loss, weights=None, name="EQ"):
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": inputs, "label": labels, "weight": weights}}
+    return ppsci.constraint.SupervisedConstraint(cfg, loss, exprs, name=name)
+
+
+def _run(solver):
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    return solver.engine.grad.cpu().numpy().astype(np.float64)
+
+
+def test_allen_cahn_closure_with_period_embedding(tmp_path):
+    w = float(np.float32(2 * np.pi / 2.0))
+    model = ppsci.arch.MLP(("t", "x"), ("u",), 3, 24, "tanh", periods={"x": (2.0, False)})
+    net = T.make_net(2, [24, 24, 24], 1, periods={1: w}, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 50
+    X = np.random.default_rng(42).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    eq = ppsci.equation.AllenCahn(eps=0.01)
+    cst = _sup_constraint({"t": X[:, :1], "x": X[:, 1:]}, {"allen_cahn": np.zeros((N, 1), np.float32)}, eq.equations,
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("t", "x"), ("u",), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"t": X[:, :1].astype(np.float64), "x": X[:, 1:].astype(np.float64)},
+              exprs={"allen_cahn": R.allen_cahn_fn(0.01)}, label={"allen_cahn": np.zeros((N, 1))}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert solver._compiled["EQ"].fused.losses()["allen_cahn"] == pytest.approx(total, rel=2e-5)
+    assert rel(g, gref) < 3e-5
+
+
+@pytest.mark.parametrize("detach_keys", [None, ("u", "v__y")])
+def test_navier_stokes_2d_sum_loss_with_weights(tmp_path, detach_keys):
+    model = ppsci.arch.MLP(("x", "y"), ("u", "v", "p"), 3, 20, "tanh")
+    net = T.make_net(2, [20, 20, 20], 3, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 40
+    X = np.random.default_rng(42).uniform(-0.05, 0.05, (N, 2)).astype(np.float32)
+    eq = ppsci.equation.NavierStokes(0.01, 1.0, 2, False, detach_keys=detach_keys)
+    keys = ("continuity", "momentum_x", "momentum_y")
+    lab = {k: np.zeros((N, 1), np.float32) for k in keys}
+    wts = {k: np.full((N, 1), 1e-4 * (i + 1), np.float32) for i, k in enumerate(keys)}
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, lab, eq.equations, ppsci.loss.MSELoss("sum"), wts)
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("x", "y"), ("u", "v", "p"), net.astype(np.float32).astype(np.float64))
+    oex = {k: R.lambdify(e, omodel) for k, e in eq.equations.items()}
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)}, exprs=oex,
+              label={k: v.astype(np.float64) for k, v in lab.items()}, weight={k: v.astype(np.float64) for k, v in wts.items()},
+              reduction="sum")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    mine = solver._compiled["EQ"].fused.losses()
+    for k in keys:
+        assert mine[k] == pytest.approx(losses[k], rel=3e-5), k
+    assert rel(g, gref) < 5e-5
+
+
+def test_ns_expression_strings_match_reference_doctest():
+    """equation/pde/base.py:99-111."""
+    ns = ppsci.equation.NavierStokes(1.0, 1.0, 2, False)
+    assert str(ns).splitlines()[1].strip() == "continuity: Derivative(u(x, y), x) + Derivative(v(x, y), y)"
+    ns = ppsci.equation.NavierStokes(1.0, 1.0, 2, False, detach_keys=("u", "v__y"))
+    lines = [l.strip() for l in str(ns).splitlines()]
+    assert lines[1] == "continuity: detach(Derivative(v(x, y), y)) + Derivative(u(x, y), x)"
+    assert lines[2] == ("momentum_x: detach(u(x, y))*Derivative(u(x, y), x) + v(x, y)*Derivative(u(x, y), y) + "
+                        "1.0*Derivative(p(x, y), x) - 1.0*Derivative(u(x, y), (x, 2)) - 1.0*Derivative(u(x, y), (y, 2))")
+
+
+def test_poisson_and_mixed_derivative_and_output_transform(tmp_path):
+    """Symbolic differentiation of a transformed output (hard boundary constraint u = x(1-x) * net) and a
+    mixed second derivative obtained by polarisation with the direction (x+y)."""
+    model = ppsci.arch.MLP(("x", "y"), ("p",), 2, 20, "silu")
+    net = T.make_net(2, [20, 20], 1, activation="silu", bias_scale=0.05)
+    set_model_weights(model, net)
+    model.register_output_transform(lambda inp, out: {"p": inp["x"] * (1.0 - inp["x"]) * out["p"]})
+    N = 33
+    X = np.random.default_rng(1).uniform(0, 1, (N, 2)).astype(np.float32)
+
+    def mixed(out):
+        return hessian(out["p"], out["x"]) + 2.0 * jacobian(jacobian(out["p"], out["x"]), out["y"]) + out["p"] * out["y"]
+
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"r": np.full((N, 1), 0.3, np.float32)}, {"r": mixed},
+                          ppsci.loss.MSELoss("mean", weight=2.5))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    # oracle with plain torch autograd
+    net32 = net.astype(np.float32).astype(np.float64)
+    omodel = R.MLP(("x", "y"), ("p",), net32)
+    x = torch.tensor(X[:, :1].astype(np.float64), requires_grad=True)
+    y = torch.tensor(X[:, 1:].astype(np.float64), requires_grad=True)
+    p = x * (1.0 - x) * omodel({"x": x, "y": y})["p"]
+    px = torch.autograd.grad(p.sum(), x, create_graph=True)[0]
+    pxx = torch.autograd.grad(px.sum(), x, create_graph=True)[0]
+    pxy = torch.autograd.grad(px.sum(), y, create_graph=True)[0]
+    r = pxx + 2.0 * pxy + p * y
+    loss = 2.5 * ((r - float(np.float32(0.3))) ** 2).mean()
+    gref = torch.autograd.grad(loss, omodel.parameters(), allow_unused=True)
+    gref = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gref, omodel.parameters())])
+    assert solver._compiled["EQ"].fused.losses()["r"] == pytest.approx(float(loss), rel=3e-5)
+    assert rel(g, gref) < 5e-5
+
+
+def test_autodiff_errors_follow_reference():
+    from paddlescience_amd.graph import Sym
+
+    model = ppsci.arch.MLP(("x",), ("u",), 1, 16)
+    out = model({"x": Sym.input("x")})
+    x = Sym.input("x")
+    with pytest.raises(ValueError):
+        jacobian(out["u"], x, i=1)
+    with pytest.raises(ValueError):
+        hessian(out["u"], x, component=0)
+    with pytest.raises(NotImplementedError):
+        jacobian(hessian(out["u"], x), x)  # third order
+    with pytest.raises(TypeError):
+        jacobian(out["u"], torch.zeros(3, 1))
+    ppsci.autodiff.clear()
+    assert ppsci.autodiff.hessian.Hs == {} and ppsci.autodiff.jacobian.Js == {}
