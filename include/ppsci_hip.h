@@ -108,6 +108,10 @@ const char* ppsci_last_error(void);
 /* Tuning/testing knob: cap the number of workgroups of the tile kernels (0 = automatic, the default).
  * Results do not depend on it beyond fp32 summation order. */
 void ppsci_set_max_grid(int max_blocks);
+/* Measurement knob (bench.py): when non-zero, ppsci_taylor_bwd launches ONLY its main kernel and skips the
+ * two small tree-reduction kernels, so that HIP events around the call time that one kernel.  The
+ * hidden-layer weight-gradient row is then left unwritten.  Default 0. */
+void ppsci_set_bwd_main_only(int on);
 /* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
 int ppsci_is_device_build(void);
 

@@ -214,6 +214,9 @@ extern "C" const char* ppsci_last_error(void) { return g_err; }
 static int g_max_grid = 0;
 extern "C" void ppsci_set_max_grid(int max_blocks) { g_max_grid = max_blocks > 0 ? max_blocks : 0; }
 extern "C" int ppsci_get_max_grid(void) { return g_max_grid; }
+static int g_bwd_main_only = 0;
+extern "C" void ppsci_set_bwd_main_only(int on) { g_bwd_main_only = on ? 1 : 0; }
+extern "C" int ppsci_get_bwd_main_only(void) { return g_bwd_main_only; }
 
 extern "C" int ppsci_is_device_build(void) {
 #ifdef PPSCI_EMU

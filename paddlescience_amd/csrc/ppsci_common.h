@@ -38,6 +38,7 @@ __device__ __forceinline__ void ppsci_wave_sync() {
 #endif
 
 extern "C" int ppsci_get_max_grid(void);
+extern "C" int ppsci_get_bwd_main_only(void);
 
 #ifndef PPSCI_FWD_WAVES
 #define PPSCI_FWD_WAVES 4   // waves (16-point tiles in flight) per forward workgroup

@@ -92,7 +92,7 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   a.wpart = (f32x4*)workspace;
   int grid = 0;
   int rc = run_bwd_act(a, stream, 1, &grid);
-  if (rc != PPSCI_OK || a.q.NB > PPSCI_BWD_DUMP_MAX_NB) return rc;
+  if (rc != PPSCI_OK || a.q.NB > PPSCI_BWD_DUMP_MAX_NB || ppsci_get_bwd_main_only()) return rc;
   float* wpart = (float*)workspace;
   float* tmp = wpart + (long long)a.ntiles * bwd_per_tile_floats(a);
   return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, grad_partials + (long long)grid * a.q.P, stream);
