@@ -150,6 +150,21 @@ def main():
     flops_fwd = 2.0 * p_mat * S * N_PER_GPU   # F_R
     ach = flops_bwd / t_bwd / 1e12
 
+    # HBM traffic of the dominant kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KiB) collected by
+    # tools/profile_bench.sh in separate rocprofv3 --pmc passes of this same command and condensed by
+    # tools/summarize_profile.py into profiles/*_pmc_summary.json (a live bench run cannot read PMCs itself)
+    traffic = None
+    try:
+        import glob
+
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_summary.json")))
+        if files:
+            for k, v in json.load(open(files[-1])).items():
+                if k.startswith("void taylor_bwd_kernel<4, 2, 1, 0"):
+                    traffic = v.get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        traffic = None
+
     if rank == 0:
         out = {
             "metric": "collocation-points/sec (PDE residual+grad)",
@@ -169,7 +184,7 @@ def main():
                        "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss},
             "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0, true>", "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": None, "kernel_ms": t_bwd * 1e3,
+                         "traffic": traffic, "kernel_ms": t_bwd * 1e3,
                          "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:
