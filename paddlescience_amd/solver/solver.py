@@ -149,7 +149,11 @@ class Solver:
         ds = getattr(cst.data_loader, "dataset", cst.data_loader)
         input_keys = list(ds.input_keys)
         label_keys = list(ds.label_keys)
-        weight_keys = list((ds.weight or {}).keys()) if not callable(getattr(ds, "weight_fn", None)) else label_keys
+        if hasattr(ds, "weight_fn"):  # ContinuousNamedArrayDataset
+            w0 = ds.weight_fn(ds.input_fn()) if callable(ds.weight_fn) else None
+            weight_keys = list(w0.keys()) if w0 else []
+        else:
+            weight_keys = list((ds.weight or {}).keys())
         if getattr(ds, "is_iterable", False):
             inp, lab, w = next(iter(ds))
             bsz = len(next(iter(inp.values())))
