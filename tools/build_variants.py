@@ -12,6 +12,7 @@ import __graft_entry__ as G  # noqa: E402
 VARIANTS = {
     "base": [],
     "occ2": ["-DPPSCI_BWD_MIN_WAVES=2"],
+    "bwd8occ2": ["-DPPSCI_BWD_MIN_WAVES=2", "-DPPSCI_BWD_WAVES=8"],
     "fwd8": ["-DPPSCI_FWD_WAVES=8"],
     "nostash": ["-DPPSCI_ABL_NOSTASH"],
     "noatomic": ["-DPPSCI_ABL_NOATOMIC"],
