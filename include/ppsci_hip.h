@@ -160,6 +160,23 @@ int ppsci_adam_step(int64_t n, float* params, const float* grad, float* m, float
                     float beta1, float beta2, float eps, int64_t step_t, float grad_scale,
                     void* stream);
 
+/* ---- FNO spectral convolution (BASELINE config 4) --------------------------------------------------
+ * Replaces the per-mode complex channel contraction of FactorizedSpectralConv.forward
+ * (ppsci/arch/fno_block.py:707-796) = _contract_dense_trick's four real einsums "abcd,becd->aecd"
+ * (fno_block.py:346-372), including the fftshift + centre-crop bookkeeping, on the UNSHIFTED rfft2
+ * spectrum.  x_ft / out_ft: complex64 as interleaved floats [B, C, H, Wf, 2] with Wf = W/2+1;
+ * w_re / w_im: [c_in, c_out, modes_x, modes_y] (modes_y = n_modes[1]//2+1).  Only the kept modes of
+ * out_ft / gx_ft are written: the caller provides zero-initialised spectra (paddle.zeros in the reference). */
+typedef struct ppsci_spectral_desc {
+  int32_t batch, c_in, c_out, h, wf, modes_x, modes_y;
+} ppsci_spectral_desc;
+
+int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                              float* out_ft, void* stream);
+/* gx_ft = gout . conj(w)^T on the kept modes (NULL to skip); gw = sum_b conj(x) gout (both NULL to skip). */
+int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                              const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,10 @@ class MlpDesc(C.Structure):
     ]
 
 
+class SpectralDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("batch", "c_in", "c_out", "h", "wf", "modes_x", "modes_y")]
+
+
 class Instr(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_float)]
 
@@ -67,6 +71,10 @@ _SYMBOLS = {
     "ppsci_taylor_bwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "ppsci_spectral_conv2d_fwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
+    "ppsci_spectral_conv2d_bwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
 }

@@ -1,7 +1,8 @@
 from .base import Arch  # noqa: F401
+from .fno import SpectralConv2d, spectral_contract  # noqa: F401
 from .mlp import MLP  # noqa: F401
 
-__all__ = ["Arch", "MLP", "build_model"]
+__all__ = ["Arch", "MLP", "SpectralConv2d", "spectral_contract", "build_model"]
 
 
 def build_model(cfg):

@@ -1,0 +1,212 @@
+// spectral_conv.hip -- FNO spectral convolution: per-mode complex channel contraction on MFMA.
+//
+// Replaces the four real einsums "abcd,becd->aecd" of
+//   _contract_dense_trick           /root/reference/ppsci/arch/fno_block.py:346-372
+// together with the mode slicing / fftshift bookkeeping of
+//   FactorizedSpectralConv.forward  /root/reference/ppsci/arch/fno_block.py:707-796
+// (rfftn -> fftshift(dim -2) -> centre-crop n_modes[0] rows x first n_modes[1]//2+1 columns -> contraction
+//  -> write into a zero spectrum -> fftshift -> irfftn).  The FFTs themselves stay in hipFFT (torch.fft).
+//
+// The shift + crop is folded into index arithmetic on the UNSHIFTED spectrum: weight row m of the kept block
+// sits at shifted row c0 + m, i.e. unshifted row r = (c0 + m + H/2) mod H (H even), and the reference's second
+// fftshift puts the result back to the same r.
+//
+// Per kept mode the complex product  out[b,o] = sum_i x[b,i] * w[i,o]  is one real GEMM
+//   [B x 2Ci] . [[wr, wi], [-wi, wr]]  ->  [B x 2Co]
+// done with v_mfma_f32_16x16x4_f32: one wave per (mode, 16-row batch tile, 16-column block of [out_r | out_i]).
+// At the BASELINE size (B=16, Ci=Co=32, 84 modes) this is 11 MFLOP against ~1.7 MB of operands: the kernel is
+// HBM/latency-bound; MFMA is used because the shape is a true dense contraction (north-star), not for speed.
+#include "ppsci_common.h"
+
+#ifndef PPSCI_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <string.h>
+
+extern "C" void ppsci_set_error(const char* fmt, ...);
+
+struct SpecArgs {
+  ppsci_spectral_desc d;
+  const float* x;   // [B, Cin, H, Wf, 2]   (Cin = c_in for fwd, c_out for bwd_x)
+  const float* wr;  // [Ci, Co, Mx, My]
+  const float* wi;
+  float* out;       // [B, Cout, H, Wf, 2]
+  int conj_t;       // 0: out = x . w            (forward)
+                    // 1: out = x . conj(w)^T    (gradient w.r.t. the input spectrum)
+  int c0, ntile_b, nblk_n, cin, cout;
+};
+
+__device__ __forceinline__ int spec_row(const ppsci_spectral_desc& d, int c0, int m) {
+  return (c0 + m + d.h / 2) % d.h;
+}
+
+// real-expanded weight element Wexp[kk][jj], kk in [0, 2*cin), jj in [0, 2*cout)
+__device__ __forceinline__ float spec_w(const SpecArgs& a, int kk, int jj, int mode_off) {
+  const int ci = a.d.c_in, co = a.d.c_out;
+  const long long ms = (long long)a.d.modes_x * a.d.modes_y;
+  if (!a.conj_t) {
+    // rows: [xr(i) | xi(i)], cols: [out_r(o) | out_i(o)]
+    const int i = kk < ci ? kk : kk - ci, o = jj < co ? jj : jj - co;
+    const long long idx = ((long long)i * co + o) * ms + mode_off;
+    if (kk < ci) return jj < co ? a.wr[idx] : a.wi[idx];
+    return jj < co ? -a.wi[idx] : a.wr[idx];
+  }
+  // rows: [gr(o) | gi(o)], cols: [gx_r(i) | gx_i(i)];  gx = g . conj(w)^T
+  const int o = kk < co ? kk : kk - co, i = jj < ci ? jj : jj - ci;
+  const long long idx = ((long long)i * co + o) * ms + mode_off;
+  if (kk < co) return jj < ci ? a.wr[idx] : -a.wi[idx];
+  return jj < ci ? a.wi[idx] : a.wr[idx];
+}
+
+__global__ void __launch_bounds__(64) spectral_contract_kernel(SpecArgs a) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  int id = blockIdx.x;
+  const int nb = id % a.nblk_n;
+  id /= a.nblk_n;
+  const int tb = id % a.ntile_b;
+  const int mode = id / a.ntile_b;
+  const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
+  const int r = spec_row(a.d, a.c0, mx);
+  const long long plane = (long long)a.d.h * a.d.wf * 2;
+  const long long pix = ((long long)r * a.d.wf + my) * 2;
+  const int K = 2 * a.cin;
+  const int brow = tb * 16 + c;       // A operand row (batch index) for this lane
+  const bool bok = brow < a.d.batch;
+  const int jj = nb * 16 + c;         // B operand column for this lane
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int kk = k0 + g;  // this lane's k index for A[i=c][k=g] and B[k=g][j=c]
+    float av = 0.f, bv = 0.f;
+    if (kk < K) {
+      const int ch = kk < a.cin ? kk : kk - a.cin, part = kk < a.cin ? 0 : 1;
+      if (bok) av = a.x[((long long)brow * a.cin + ch) * plane + pix + part];
+      if (jj < 2 * a.cout) bv = spec_w(a, kk, jj, mode);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  }
+  // D[row = 4g + rr][col = c]: batch row, expanded output column
+  if (jj < 2 * a.cout) {
+    const int ch = jj < a.cout ? jj : jj - a.cout, part = jj < a.cout ? 0 : 1;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int b = tb * 16 + 4 * g + rr;
+      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix + part] = acc[rr];
+    }
+  }
+}
+
+// gw[i,o,mode] = sum_b conj(x[b,i]) * g[b,o]:  gwr = sum xr*gr + xi*gi,  gwi = sum xr*gi - xi*gr
+struct SpecWArgs {
+  ppsci_spectral_desc d;
+  const float* x;
+  const float* g;
+  float* gwr;
+  float* gwi;
+  int c0;
+  long long total;
+};
+
+__global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.total) return;
+  const int ms = a.d.modes_x * a.d.modes_y;
+  const int mode = (int)(t % ms);
+  const long long io = t / ms;
+  const int o = (int)(io % a.d.c_out), i = (int)(io / a.d.c_out);
+  const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
+  const int r = spec_row(a.d, a.c0, mx);
+  const long long plane = (long long)a.d.h * a.d.wf * 2;
+  const long long pix = ((long long)r * a.d.wf + my) * 2;
+  float sr = 0.f, si = 0.f;
+  for (int b = 0; b < a.d.batch; ++b) {
+    const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix;
+    const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix;
+    const float xr = xp[0], xi = xp[1], gr = gp[0], gi = gp[1];
+    sr += xr * gr + xi * gi;
+    si += xr * gi - xi * gr;
+  }
+  a.gwr[t] = sr;
+  a.gwi[t] = si;
+}
+
+static int spec_check(const ppsci_spectral_desc* d, int* c0) {
+  if (!d || d->batch < 1 || d->c_in < 1 || d->c_out < 1 || d->h < 2 || d->wf < 1 || d->modes_x < 1 || d->modes_y < 1 ||
+      d->modes_x > d->h || d->modes_y > d->wf) {
+    ppsci_set_error("spectral_conv: invalid descriptor");
+    return PPSCI_E_INVALID;
+  }
+  if ((d->h & 1) || ((d->h - d->modes_x) & 1)) {
+    // odd sizes: the reference's centre-crop slices / double fftshift are not inverse to each other
+    ppsci_set_error("spectral_conv: H (%d) and H - modes_x (%d) must be even", d->h, d->h - d->modes_x);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  *c0 = (d->h - d->modes_x) / 2;
+  return PPSCI_OK;
+}
+
+static int launch_contract(const ppsci_spectral_desc* d, const float* x, const float* wr, const float* wi, float* out,
+                           int conj_t, void* stream) {
+  SpecArgs a;
+  memset(&a, 0, sizeof(a));
+  int rc = spec_check(d, &a.c0);
+  if (rc != PPSCI_OK) return rc;
+  a.d = *d;
+  a.x = x;
+  a.wr = wr;
+  a.wi = wi;
+  a.out = out;
+  a.conj_t = conj_t;
+  a.cin = conj_t ? d->c_out : d->c_in;
+  a.cout = conj_t ? d->c_in : d->c_out;
+  a.ntile_b = (d->batch + 15) / 16;
+  a.nblk_n = (2 * a.cout + 15) / 16;
+  const int grid = d->modes_x * d->modes_y * a.ntile_b * a.nblk_n;
+  PPSCI_LAUNCH(spectral_contract_kernel, SpecArgs, grid, 64, 0, stream, a);
+  int e = PPSCI_LAST_LAUNCH_ERROR();
+  if (e != 0) {
+    ppsci_set_error("spectral_conv: launch failed (hip error %d)", e);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                         const float* w_im, float* out_ft, void* stream) {
+  if (!x_ft || !w_re || !w_im || !out_ft) {
+    ppsci_set_error("spectral_conv2d_fwd: null pointer");
+    return PPSCI_E_INVALID;
+  }
+  return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream);
+}
+
+extern "C" int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                         const float* w_im, const float* gout_ft, float* gx_ft, float* gw_re,
+                                         float* gw_im, void* stream) {
+  if (!x_ft || !w_re || !w_im || !gout_ft) {
+    ppsci_set_error("spectral_conv2d_bwd: null pointer");
+    return PPSCI_E_INVALID;
+  }
+  if (gx_ft) {
+    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream);
+    if (rc != PPSCI_OK) return rc;
+  }
+  if (gw_re && gw_im) {
+    SpecWArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = spec_check(d, &a.c0);
+    if (rc != PPSCI_OK) return rc;
+    a.d = *d;
+    a.x = x_ft;
+    a.g = gout_ft;
+    a.gwr = gw_re;
+    a.gwi = gw_im;
+    a.total = (long long)d->c_in * d->c_out * d->modes_x * d->modes_y;
+    PPSCI_LAUNCH(spectral_wgrad_kernel, SpecWArgs, (int)((a.total + 255) / 256), 256, 0, stream, a);
+    int e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) {
+      ppsci_set_error("spectral_conv2d_bwd: launch failed (hip error %d)", e);
+      return PPSCI_E_LAUNCH;
+    }
+  }
+  return PPSCI_OK;
+}
