@@ -177,6 +177,40 @@ int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const float* x_ft, c
 int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                               const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, void* stream);
 
+/* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
+ * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it
+ * (ppsci/arch/spinn.py:83-104).  Parameters flat in parameters() order: embed_u.W[1,H] embed_u.b embed_v.W
+ * embed_v.b linears.l.W linears.l.b ... last_fc.W[H,R] last_fc.b[R].  F / Fbar: [3][N][R] = value, d/dx and
+ * d2/dx2 of the R = r*m outputs w.r.t. the net's single coordinate. */
+typedef struct ppsci_modmlp_desc {
+  int32_t n_hidden, width, d_out, activation;
+} ppsci_modmlp_desc;
+
+int64_t ppsci_modmlp_param_count(const ppsci_modmlp_desc* d);
+int64_t ppsci_modmlp_stash_floats(const ppsci_modmlp_desc* d, int64_t n_points);
+int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params, int64_t n_points, const float* x, float* F,
+                     float* stash /* NULL for inference */, void* stream);
+/* grad_partials: [n_points, P], fully overwritten (sum the rows with ppsci_reduce_rows). */
+int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params, int64_t n_points, const float* x,
+                     const float* Fbar, const float* stash, float* grad_partials, void* stream);
+
+/* Tensor-product grid: q(i,j,k) = sum_r fx[i,r] fy[j,r] fz[k,r] (SPINN.forward_tensor spinn.py:140-167) for
+ * q in {u, u_xx, u_yy, u_zz}; res = cu*u + cxx*u_xx + cyy*u_yy + czz*u_zz (Helmholtz helmholtz.py:78-93:
+ * cu = k^2, cxx = cyy = czz = 1; a boundary constraint on u: cu = 1, others 0);
+ * loss = scale * sum (res - label)^2 (MSELoss); gadj = d loss / d res. */
+typedef struct ppsci_spinn_grid_desc {
+  int32_t n[3];
+  int32_t rank;
+  float cu, cxx, cyy, czz, scale;
+} ppsci_spinn_grid_desc;
+
+int64_t ppsci_spinn_grid_partial_rows(const ppsci_spinn_grid_desc* d);
+int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
+                         const float* label /* [nx*ny*nz] or NULL */, float* resid /* or NULL */,
+                         float* gadj /* or NULL */, float* loss_partials, void* stream);
+int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
+                         const float* gadj, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,9 +22,14 @@ What it follows in /root/reference (file:line):
   * ppsci/utils/expression.py:60-131 ExpressionSolver.train_forward
   * ppsci/optimizer/optimizer.py:225-248 Adam (paddle.optimizer.Adam, beta1=.9 beta2=.999 eps=1e-8)
 
-parity unpinned for NN numerics: PaddlePaddle cannot be installed here; the pinned parts are the
-known-answer values checked in tests/test_oracle.py (MSELoss mse.py:46-68, NS strings
-equation/pde/base.py:99-111) and the geometry doctests (tests/test_geometry.py).
+Pinning status.  PaddlePaddle cannot be installed here, so the real reference cannot be run end to end.
+Pinned are: the stored known answers (MSELoss mse.py:46-68, NS strings equation/pde/base.py:99-111,
+tests/test_oracle.py), and -- for the NN / autodiff numerics -- tests/golden/hotpath.npz, which was produced
+by executing the reference's OWN Python files (arch/mlp.py, autodiff/ad.py, utils/symbolic.py with
+fuse_derivative=True, equation/pde/*.py, loss/mse.py) with `paddle` replaced by a torch-backed shim
+(tests/golden/_paddle_shim.py, tests/golden/make_hotpath_golden.py); this restatement reproduces those
+fixtures to 1e-10 (tests/test_golden_hotpath.py).  What remains unpinned is PaddlePaddle's own kernel
+arithmetic (covered by the fp32-vs-fp64 tolerance) and the SPINN / FNO restatements at the end of this file.
 """
 from __future__ import annotations
 
@@ -431,3 +436,55 @@ class Adam:
 def exponential_decay_lr(lr0: float, gamma: float, decay_steps: int, step: int, by_epoch=False) -> float:
     """ppsci/optimizer/lr_scheduler.py:212-269: paddle ExponentialDecay with gamma**(1/decay_steps) per step."""
     return lr0 * (gamma ** (1.0 / decay_steps)) ** step
+
+
+# ----------------------------------------------------------------------------- SPINN (config 5)
+class ModifiedMLP1:
+    """One-input ModifiedMLP branch (ppsci/arch/mlp.py:488-507) on explicit weights.
+    params: dict with wu,bu,wv,bv, w (list), b (list), wl, bl (numpy, [in,out] weights)."""
+
+    def __init__(self, params: dict, activation: str = "tanh", dtype=torch.float64):
+        self.act = activation
+        cv = lambda a: torch.tensor(np.asarray(a), dtype=dtype, requires_grad=True)  # noqa: E731
+        self.wu, self.bu, self.wv, self.bv = cv(params["wu"]), cv(params["bu"]), cv(params["wv"]), cv(params["bv"])
+        self.w = [cv(a) for a in params["w"]]
+        self.b = [cv(a) for a in params["b"]]
+        self.wl, self.bl = cv(params["wl"]), cv(params["bl"])
+
+    def parameters(self):
+        out = [self.wu, self.bu, self.wv, self.bv]
+        for w, b in zip(self.w, self.b):
+            out += [w, b]
+        return out + [self.wl, self.bl]
+
+    def _a(self, y):
+        return {"tanh": torch.tanh, "sin": torch.sin, "silu": lambda t: t * torch.sigmoid(t)}[self.act](y)
+
+    def forward_tensor(self, x):  # mlp.py:488-507
+        u = self._a(x @ self.wu + self.bu)
+        v = self._a(x @ self.wv + self.bv)
+        y = x
+        for w, b in zip(self.w, self.b):
+            y = self._a(y @ w + b)
+            y = y * u + (1 - y) * v
+        return y @ self.wl + self.bl
+
+
+def spinn_helmholtz(branches, xs, k: float = 1.0, coeffs=None):
+    """u and residual on the tensor-product grid (spinn.py:140-167, helmholtz.py:78-93).  The second derivatives
+    are taken per branch output column by double backward -- mathematically what hvp_revrev's nested jvp with
+    unit tangents returns per grid point.  Returns (u, res) as [nx,ny,nz] tensors."""
+    f, f2 = [], []
+    for net, x in zip(branches, xs):
+        out = net.forward_tensor(x)  # [n, R]
+        d2 = []
+        for r in range(out.shape[1]):
+            g = torch.autograd.grad(out[:, r].sum(), x, create_graph=True)[0]
+            d2.append(torch.autograd.grad(g.sum(), x, create_graph=True)[0])
+        f.append(out)
+        f2.append(torch.cat(d2, dim=1))
+    e = lambda a, b, c: torch.einsum("ir,jr,kr->ijk", a, b, c)  # noqa: E731
+    u = e(f[0], f[1], f[2])
+    uxx, uyy, uzz = e(f2[0], f[1], f[2]), e(f[0], f2[1], f[2]), e(f[0], f[1], f2[2])
+    c = coeffs if coeffs is not None else (k**2, 1.0, 1.0, 1.0)
+    return u, c[0] * u + c[1] * uxx + c[2] * uyy + c[3] * uzz

@@ -33,6 +33,15 @@ class SpectralDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "c_in", "c_out", "h", "wf", "modes_x", "modes_y")]
 
 
+class ModMlpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_hidden", "width", "d_out", "activation")]
+
+
+class SpinnGridDesc(C.Structure):
+    _fields_ = [("n", C.c_int32 * 3), ("rank", C.c_int32), ("cu", C.c_float), ("cxx", C.c_float), ("cyy", C.c_float),
+                ("czz", C.c_float), ("scale", C.c_float)]
+
+
 class Instr(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_float)]
 
@@ -75,6 +84,17 @@ _SYMBOLS = {
                                             C.c_void_p]),
     "ppsci_spectral_conv2d_bwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_modmlp_param_count": (C.c_int64, [C.POINTER(ModMlpDesc)]),
+    "ppsci_modmlp_stash_floats": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
+    "ppsci_modmlp_fwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "ppsci_modmlp_bwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "ppsci_spinn_grid_partial_rows": (C.c_int64, [C.POINTER(SpinnGridDesc)]),
+    "ppsci_spinn_grid_fwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_spinn_grid_bwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
 }

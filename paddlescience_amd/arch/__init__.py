@@ -1,8 +1,9 @@
 from .base import Arch  # noqa: F401
 from .fno import SpectralConv2d, spectral_contract  # noqa: F401
 from .mlp import MLP  # noqa: F401
+from .spinn import SPINN  # noqa: F401
 
-__all__ = ["Arch", "MLP", "SpectralConv2d", "spectral_contract", "build_model"]
+__all__ = ["Arch", "MLP", "SpectralConv2d", "spectral_contract", "SPINN", "build_model"]
 
 
 def build_model(cfg):
@@ -11,4 +12,4 @@ def build_model(cfg):
     if isinstance(cfg, (list, tuple)):
         raise NotImplementedError("ModelList is not supported on the fused HIP path yet")
     (name, kwargs), = cfg.items()
-    return {"MLP": MLP}[name](**kwargs)
+    return {"MLP": MLP, "SPINN": SPINN}[name](**kwargs)

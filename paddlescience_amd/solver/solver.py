@@ -124,8 +124,16 @@ class Solver:
         if self.world_size > 1:
             # DataParallel wrap of the reference (solver.py:388-412): replicate rank 0's parameters
             dist.broadcast(self.model.flat_params, src=0)
-        self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
-        if self.optimizer is not None:
+        from ..arch.spinn import SPINN
+
+        self._is_spinn = isinstance(self.model, SPINN)
+        if self._is_spinn:
+            from ..spinn_engine import SpinnEngine
+
+            self.engine = SpinnEngine(self.model)
+        else:
+            self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
+        if self.optimizer is not None and not self._is_spinn:
             self.engine.m, self.engine.v = self.optimizer.m, self.optimizer.v
             self.engine.beta1, self.engine.beta2, self.engine.eps = (self.optimizer.beta1, self.optimizer.beta2,
                                                                     self.optimizer.epsilon)
@@ -145,7 +153,32 @@ class Solver:
     def _equation_exprs(self, exprs: Dict[str, Callable]) -> Dict[str, Callable]:
         return dict(exprs)
 
+    def _compile_spinn_constraint(self, name: str, cst):
+        """Separable nets: the expression must be linear in {u, u_xx, u_yy, u_zz} (arch.spinn.GridLinear)."""
+        from ..arch.spinn import GridLinear
+        from ..graph import Sym
+        from ..spinn_engine import SpinnConstraint
+
+        ds = getattr(cst.data_loader, "dataset", cst.data_loader)
+        if len(ds.label_keys) != 1:
+            raise NotImplementedError("one label key per SPINN constraint")
+        key = ds.label_keys[0]
+        data = {k: Sym.input(k) for k in self.model.input_keys}
+        data.update(self.model(data))
+        val = cst.output_expr[key](data) if key in cst.output_expr else data[key]
+        if not isinstance(val, GridLinear):
+            raise NotImplementedError(f"constraint {name}: expression {key!r} is not a linear form of the SPINN output")
+        loss = cst.loss
+        sc = SpinnConstraint(name, self.model, val.c, key, lambda total, k=key: loss.term_scale(k, total), self.device,
+                             self.world_size, self.rank)
+        sc.batch_size = 0
+        sc.label_keys = [key]
+        return sc
+
     def _compile_constraint(self, name: str, cst) -> CompiledConstraint:
+        if self._is_spinn:
+            self._static[name] = False
+            return self._compile_spinn_constraint(name, cst)
         ds = getattr(cst.data_loader, "dataset", cst.data_loader)
         input_keys = list(ds.input_keys)
         label_keys = list(ds.label_keys)
@@ -187,9 +220,12 @@ class Solver:
                 for name, cc in self._compiled.items():
                     if not self._static[name]:
                         inp, lab, w = next(self.constraint[name].data_iter)
-                        cc.bind(inp, lab, w)
+                        if self._is_spinn:
+                            cc.bind(inp, lab)
+                        else:
+                            cc.bind(inp, lab, w)
                 reader_cost = time.perf_counter() - reader_tic
-                self.engine.forward_backward([c.fused for c in csts])
+                self.engine.forward_backward(csts if self._is_spinn else [c.fused for c in csts])
                 self.engine.allreduce()
                 self.optimizer.step(self.engine.grad,
                                     (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0)
@@ -229,7 +265,7 @@ class Solver:
         losses_all: Dict[str, float] = {}
         per_cst: Dict[str, float] = {}
         for name, cc in self._compiled.items():
-            vals = cc.fused.losses()
+            vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
             per_cst[name] = 0.0
             for k in cc.label_keys:
                 per_cst[name] += vals[k]
@@ -304,6 +340,11 @@ class Solver:
                 batch_size: Optional[int] = 64, no_grad: bool = True, return_numpy: bool = False):
         """solver.py:729-872.  With world_size > 1 the points are rank-strided (v[rank::world]) and the
         gathered result is restored to the input order, like the reference (:793-797, :847-855)."""
+        if self._is_spinn:  # tensor-product grid of the three coordinate vectors (helmholtz3d.py:205-213)
+            if expr_dict is not None:
+                raise NotImplementedError("expr_dict with a SPINN model")
+            out = self.model(input_dict)
+            return {k: v.detach().cpu().numpy() for k, v in out.items()} if return_numpy else out
         n = len(next(iter(input_dict.values())))
         batch_size = n if batch_size is None else batch_size
         keys = list(input_dict.keys())

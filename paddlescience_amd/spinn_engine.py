@@ -1,0 +1,110 @@
+"""Training engine for separable PINNs (ppsci.arch.SPINN): per constraint
+  3 x modmlp_fwd  ->  spinn_grid_fwd (residual + MSE + adjoint)  ->  spinn_grid_bwd  ->  3 x modmlp_bwd,
+then one fixed-order reduction per branch into the flat gradient, one all-reduce, one fused Adam.
+Counterpart of the generic engine.py for BASELINE config 5 (examples/spinn/helmholtz3d.py of the
+reference: one PDE constraint on the nc^3 grid + six boundary faces).  Data parallelism shards the
+x-axis points rank-strided (each rank owns an [nx/W, ny, nz] slab); y / z branch nets are replicated."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import hotpath as hp
+from .hotpath import _p, _stream_ptr
+
+
+class SpinnConstraint:
+    def __init__(self, name: str, model, coeffs: np.ndarray, label_key: str, scale_fn, device, world: int = 1,
+                 rank: int = 0):
+        self.name, self.model, self.label_key = name, model, label_key
+        self.coeffs = np.asarray(coeffs, dtype=np.float64)
+        self.scale_fn = scale_fn  # total_points -> loss scale
+        self.device, self.world, self.rank = device, world, rank
+        self.shape = None
+        self._last_ids = None
+
+    def _alloc(self, shape):
+        m, dev = self.model, self.device
+        self.shape = tuple(shape)
+        nx, ny, nz = shape
+        R, P = m.spec.R, m.branch_params
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x = [torch.zeros(n, **f32) for n in shape]
+        self.F = [torch.zeros((3, n, R), **f32) for n in shape]
+        self.Fbar = [torch.zeros((3, n, R), **f32) for n in shape]
+        self.stash = [torch.zeros(int(L.lib().ppsci_modmlp_stash_floats(C.byref(m.spec.desc), n)), **f32) for n in shape]
+        self.gpart = [torch.zeros((n, P), **f32) for n in shape]
+        total = nx * ny * nz
+        self.label = torch.zeros(total, **f32)
+        self.gadj = torch.zeros(total, **f32)
+        self.desc = L.SpinnGridDesc()
+        self.desc.n[0], self.desc.n[1], self.desc.n[2] = nx, ny, nz
+        self.desc.rank = R
+        self.desc.cu, self.desc.cxx, self.desc.cyy, self.desc.czz = (float(c) for c in self.coeffs)
+        self.lrows = int(L.lib().ppsci_spinn_grid_partial_rows(C.byref(self.desc)))
+        self.lpart = torch.zeros(self.lrows, **f32)
+        self.loss_term = torch.zeros(1, **f32)
+
+    def bind(self, input: Dict[str, np.ndarray], label: Dict[str, np.ndarray]):
+        keys = self.model.input_keys
+        arrs = [np.asarray(input[k], dtype=np.float32).reshape(-1) for k in keys]
+        lab = np.asarray(label[self.label_key], dtype=np.float32)
+        nx_global = arrs[0].shape[0]
+        if self.world > 1 and nx_global >= self.world:
+            arrs[0] = arrs[0][self.rank::self.world]
+            lab = lab.reshape(nx_global, -1)[self.rank::self.world]
+        shape = tuple(a.shape[0] for a in arrs)
+        if self.shape != shape:
+            self._alloc(shape)
+        ids = tuple(id(input[k]) for k in keys) + (id(label[self.label_key]),)
+        if ids != self._last_ids:  # the reference re-uploads every iteration; skip when the arrays are the same objects
+            for dst, a in zip(self.x, arrs):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+            self.label.copy_(torch.from_numpy(np.ascontiguousarray(lab.reshape(-1))))
+            self._last_ids = ids
+        total_global = nx_global * shape[1] * shape[2]
+        self.desc.scale = float(self.scale_fn(total_global))
+
+    def forward(self, train: bool):
+        m, lib = self.model, L.lib()
+        for b in range(3):
+            L.check(lib.ppsci_modmlp_fwd(C.byref(m.spec.desc), _p(m.branch(b)), self.x[b].numel(), _p(self.x[b]),
+                                         _p(self.F[b]), _p(self.stash[b]) if train else None, _stream_ptr(self.x[b])))
+        L.check(lib.ppsci_spinn_grid_fwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.label), None,
+                                         _p(self.gadj) if train else None, _p(self.lpart), _stream_ptr(self.label)))
+        hp.reduce_rows(self.lpart, self.lrows, 1, self.loss_term, False)
+
+    def backward(self):
+        m, lib = self.model, L.lib()
+        L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
+                                         _p(self.Fbar[0]), _p(self.Fbar[1]), _p(self.Fbar[2]), _stream_ptr(self.gadj)))
+        for b in range(3):
+            L.check(lib.ppsci_modmlp_bwd(C.byref(m.spec.desc), _p(m.branch(b)), self.x[b].numel(), _p(self.x[b]),
+                                         _p(self.Fbar[b]), _p(self.stash[b]), _p(self.gpart[b]), _stream_ptr(self.x[b])))
+
+    def loss(self) -> float:
+        return float(self.loss_term.cpu()[0])
+
+
+class SpinnEngine:
+    def __init__(self, model):
+        self.model = model
+        self.grad = torch.zeros_like(model.flat_params)
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.dp_reduce = "sum"
+
+    def forward_backward(self, constraints: Sequence[SpinnConstraint]):
+        P = self.model.branch_params
+        for i, c in enumerate(constraints):
+            c.forward(True)
+            c.backward()
+            for b in range(3):
+                hp.reduce_rows(c.gpart[b], c.gpart[b].shape[0], P, self.grad[b * P:(b + 1) * P], i > 0)
+
+    def allreduce(self):
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)

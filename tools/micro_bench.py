@@ -1,0 +1,78 @@
+"""Micro-benchmarks (run on the GPU box) for the secondary configs: SPINN Helmholtz3D step on a 128^3 grid
+(BASELINE config 5) and the FNO spectral convolution (config 4).  Prints one JSON line each."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ppsci  # noqa: E402
+from paddlescience_amd.arch import fno  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def spinn(nc=128):
+    np.random.seed(111)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), 32, 4, 64, "tanh")
+    eq = ppsci.equation.Helmholtz(3, 1.0)
+    eq.model = model
+    rng = np.random.default_rng(42)
+    xs = [rng.uniform(-1, 1, (nc, 1)).astype(np.float32) for _ in range(3)]
+    uc = rng.standard_normal((nc, nc, nc, 1)).astype(np.float32)
+    data = {"x": xs[0], "y": xs[1], "z": xs[2], "uc": uc}
+    lab = {"helmholtz": uc}
+    pde = ppsci.constraint.SupervisedConstraint(
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: data, "label": lambda d: lab}},
+        output_expr=eq.equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PDE": pde}, "/tmp/out_spinn", opt, epochs=1, iters_per_epoch=1)
+    cc = solver._compiled["PDE"]
+    cc.bind(data, lab)
+
+    def step():
+        solver.engine.forward_backward([cc])
+        opt.step(solver.engine.grad)
+
+    t = timeit(step)
+    pts = nc**3
+    print(json.dumps({"bench": "spinn_helmholtz3d_step", "nc": nc, "ms": t * 1e3, "grid_points_per_s": pts / t,
+                      "algorithmic_label_GBps": pts * 4 / t / 1e9}), flush=True)
+
+
+def spectral(B=16, C=32, H=64, W=64, modes=(12, 12)):
+    layer = fno.SpectralConv2d(C, C, modes, fft_norm="forward").cuda()
+    x = torch.randn(B, C, H, W, device="cuda")
+    x_ft = torch.fft.rfftn(x, norm="forward", dim=(-2, -1))
+    t_k = timeit(lambda: fno.spectral_contract(x_ft, layer.weight_real, layer.weight_imag))
+    t_l = timeit(lambda: layer(x))
+    eq = "abcd,becd->aecd"
+    xs = x_ft[:, :, 26:38, :7].contiguous()
+
+    def ref():
+        return (torch.einsum(eq, xs.real, layer.weight_real) - torch.einsum(eq, xs.imag, layer.weight_imag),
+                torch.einsum(eq, xs.imag, layer.weight_real) + torch.einsum(eq, xs.real, layer.weight_imag))
+
+    t_r = timeit(ref)
+    flops = 8.0 * B * C * C * modes[0] * (modes[1] // 2 + 1)
+    byts = 4.0 * (2 * C * C * 84 + 2 * 2 * B * C * 84)
+    print(json.dumps({"bench": "fno_spectral_contract", "ms_kernel_path": t_k * 1e3, "ms_layer_incl_fft": t_l * 1e3,
+                      "ms_torch_4_einsums": t_r * 1e3, "MFLOP": flops / 1e6, "operand_MB": byts / 1e6}), flush=True)
+
+
+if __name__ == "__main__":
+    spinn(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
+    spectral()
