@@ -208,8 +208,9 @@ int64_t ppsci_spinn_grid_partial_rows(const ppsci_spinn_grid_desc* d);
 int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
                          const float* label /* [nx*ny*nz] or NULL */, float* resid /* or NULL */,
                          float* gadj /* or NULL */, float* loss_partials, void* stream);
+int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_desc* d);
 int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
-                         const float* gadj, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream);
+                         const float* gadj, float* scratch, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream);
 
 #ifdef __cplusplus
 }

@@ -93,8 +93,9 @@ _SYMBOLS = {
     "ppsci_spinn_grid_partial_rows": (C.c_int64, [C.POINTER(SpinnGridDesc)]),
     "ppsci_spinn_grid_fwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_spinn_grid_bwd_scratch_floats": (C.c_int64, [C.POINTER(SpinnGridDesc)]),
     "ppsci_spinn_grid_bwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
 }

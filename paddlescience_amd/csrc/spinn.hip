@@ -282,40 +282,66 @@ struct GridArgs {
   float* gadj;           // [nx*ny*nz] adjoint of the residual (train) or null
   float* loss_partials;  // [gridDim.x]
   float* Fbar;           // bwd: [3][n_a][R] of `axis`
+  float* Fpart;          // bwd scratch: [n_a][groups][2][R]
   int axis;
   int iters;
 };
 
 #define GRID_BLOCK 256
+#define GRID_JT 8  // j rows per forward workgroup
 
+// Forward: one workgroup per (i, tile of GRID_JT j's); thread = k.  Per (j, r) the x/y factors are folded into
+//   p_r = (cu*fx + cxx*fx'')*fy + cyy*fx*fy''   and   q_r = czz*fx*fy     (LDS, broadcast reads)
+// so that  res(i,j,k) = sum_r p_r*fz[k,r] + q_r*fz''[k,r]:  two FMAs per rank and point, fz / fz'' read from an
+// LDS copy transposed to [r][k] (conflict-free, consecutive lanes = consecutive k).
 __global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_fwd_kernel(GridArgs a) {
-  PPSCI_DYN_SMEM(red);
+  PPSCI_DYN_SMEM(sm);
   const int R = a.d.rank, nx = a.d.n[0], ny = a.d.n[1], nz = a.d.n[2];
-  const long long total = (long long)nx * ny * nz;
+  const int njt = (ny + GRID_JT - 1) / GRID_JT;
+  const int i = blockIdx.x / njt, j0 = (blockIdx.x % njt) * GRID_JT;
+  const int KC = a.iters;  // k-chunk held in LDS
+  float* zT0 = sm;                   // [R][KC]
+  float* zT2 = zT0 + R * KC;         // [R][KC]
+  float* pq = zT2 + R * KC;          // [GRID_JT][2][R]
+  float* red = pq + GRID_JT * 2 * R; // [GRID_BLOCK]
+  const long long sx = (long long)nx * R, sy = (long long)ny * R, sz = (long long)nz * R;
+  (void)sx;
+  for (int t = threadIdx.x; t < GRID_JT * R; t += GRID_BLOCK) {
+    const int jj = t / R, r = t % R, j = j0 + jj;
+    float p = 0.f, q = 0.f;
+    if (j < ny) {
+      const float x0 = a.F[0][(long long)i * R + r], x2 = a.F[0][2 * (long long)nx * R + (long long)i * R + r];
+      const float y0 = a.F[1][(long long)j * R + r], y2 = a.F[1][2 * sy + (long long)j * R + r];
+      p = (a.d.cu * x0 + a.d.cxx * x2) * y0 + a.d.cyy * x0 * y2;
+      q = a.d.czz * x0 * y0;
+    }
+    pq[(jj * 2 + 0) * R + r] = p;
+    pq[(jj * 2 + 1) * R + r] = q;
+  }
   float lsum = 0.f;
-  for (int it = 0; it < a.iters; ++it) {
-    const long long p = ((long long)it * gridDim.x + blockIdx.x) * GRID_BLOCK + threadIdx.x;
-    if (p < total) {
-      const int k = (int)(p % nz), j = (int)((p / nz) % ny), i = (int)(p / ((long long)nz * ny));
-      const float* fx = a.F[0] + (long long)i * R;
-      const float* fy = a.F[1] + (long long)j * R;
-      const float* fz = a.F[2] + (long long)k * R;
-      const long long sx = (long long)nx * R, sy = (long long)ny * R, sz = (long long)nz * R;
-      float u = 0.f, uxx = 0.f, uyy = 0.f, uzz = 0.f;
-      for (int r = 0; r < R; ++r) {
-        const float x0 = fx[r], y0 = fy[r], z0 = fz[r];
-        u += x0 * y0 * z0;
-        uxx += fx[2 * sx + r] * y0 * z0;
-        uyy += x0 * fy[2 * sy + r] * z0;
-        uzz += x0 * y0 * fz[2 * sz + r];
+  for (int k0 = 0; k0 < nz; k0 += KC) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < KC * R; t += GRID_BLOCK) {  // coalesced global read, transposed LDS write
+      const int kk = t / R, r = t % R, k = k0 + kk;
+      zT0[r * KC + kk] = k < nz ? a.F[2][(long long)k * R + r] : 0.f;
+      zT2[r * KC + kk] = k < nz ? a.F[2][2 * sz + (long long)k * R + r] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < GRID_JT * KC; t += GRID_BLOCK) {
+      const int jj = t / KC, kk = t % KC, j = j0 + jj, k = k0 + kk;
+      if (j < ny && k < nz) {
+        float res = 0.f;
+        const float* pj = pq + jj * 2 * R;
+        for (int r = 0; r < R; ++r) res += pj[r] * zT0[r * KC + kk] + pj[R + r] * zT2[r * KC + kk];
+        const long long pidx = ((long long)i * ny + j) * nz + k;
+        if (a.resid) a.resid[pidx] = res;
+        const float diff = res - (a.label ? a.label[pidx] : 0.f);
+        lsum += a.d.scale * diff * diff;
+        if (a.gadj) a.gadj[pidx] = 2.f * a.d.scale * diff;
       }
-      const float res = a.d.cu * u + a.d.cxx * uxx + a.d.cyy * uyy + a.d.czz * uzz;
-      if (a.resid) a.resid[p] = res;
-      const float diff = res - (a.label ? a.label[p] : 0.f);
-      lsum += a.d.scale * diff * diff;
-      if (a.gadj) a.gadj[p] = 2.f * a.d.scale * diff;
     }
   }
+  __syncthreads();
   red[threadIdx.x] = lsum;
   __syncthreads();
   for (int s = GRID_BLOCK / 2; s > 0; s >>= 1) {
@@ -325,44 +351,89 @@ __global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_fwd_kernel(GridArgs a) 
   if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = red[0];
 }
 
-// One workgroup per index i of `axis`:  Fbar_value[i][r] = sum_{(j,k)} g * (cu yz + c_b y''z + c_c y z''),
-// Fbar_second[i][r] = c_axis * sum g * y z, where y / z denote the two other axes' branch outputs.
+// Reverse, axis `ax` with the two other axes (b, c), c the faster-varying one.  One workgroup per (index i,
+// group of GRID_JG rows jb); thread = (rank r, row slot).  fc / fc'' ([nc][R]) and the group's adjoint rows
+// g(i, jb, :) are staged in LDS; for each row the inner sum over kc
+//     t0[r] = sum_kc g(i,jb,kc) fc[kc,r],   t2[r] = sum_kc g(i,jb,kc) fc''[kc,r]
+// is two FMAs per element, then
+//     value  += fb[jb,r]*(cu*t0 + coef_c*t2) + fb''[jb,r]*coef_b*t0,     second += fb[jb,r]*t0
+// Row slots are summed through LDS in a fixed order; the per-group partials go to `Fpart` and are summed by
+// spinn_fbar_sum_kernel (fixed order as well).
+#define GRID_JG 16
 __global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_bwd_kernel(GridArgs a) {
-  PPSCI_DYN_SMEM(red);  // [GRID_BLOCK]
-  const int R = a.d.rank, ax = a.axis, b = (ax + 1) % 3, c = (ax + 2) % 3;
-  const int na = a.d.n[ax], nb = a.d.n[b], nc = a.d.n[c];
-  const int i = blockIdx.x;
+  PPSCI_DYN_SMEM(sm);
+  const int R = a.d.rank, ax = a.axis;
+  const int b = ax == 0 ? 1 : 0, c = ax == 2 ? 1 : 2;
+  const int nb = a.d.n[b], nc = a.d.n[c];
+  const int ngrp = (nb + GRID_JG - 1) / GRID_JG;
+  const int i = blockIdx.x / ngrp, grp = blockIdx.x % ngrp, jb0 = grp * GRID_JG;
   const float coef[3] = {a.d.cxx, a.d.cyy, a.d.czz};
   long long stride[3];
   stride[2] = 1; stride[1] = a.d.n[2]; stride[0] = (long long)a.d.n[1] * a.d.n[2];
   const long long sb = (long long)nb * R, sc = (long long)nc * R;
-  (void)na;
-  for (int r = 0; r < R; ++r) {
-    float v0 = 0.f, v2 = 0.f;
-    for (long long q = threadIdx.x; q < (long long)nb * nc; q += GRID_BLOCK) {
-      const int jb = (int)(q / nc), kc = (int)(q % nc);
-      const float g = a.gadj[i * stride[ax] + jb * stride[b] + kc * stride[c]];
-      const float y0 = a.F[b][(long long)jb * R + r], y2 = a.F[b][2 * sb + (long long)jb * R + r];
-      const float z0 = a.F[c][(long long)kc * R + r], z2 = a.F[c][2 * sc + (long long)kc * R + r];
-      v0 += g * (a.d.cu * y0 * z0 + coef[b] * y2 * z0 + coef[c] * y0 * z2);
-      v2 += g * y0 * z0;
-    }
-    for (int pass = 0; pass < 2; ++pass) {
-      __syncthreads();
-      red[threadIdx.x] = pass == 0 ? v0 : v2;
-      __syncthreads();
-      for (int s = GRID_BLOCK / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-      }
-      if (threadIdx.x == 0) {
-        const long long sa = (long long)a.d.n[ax] * R;
-        if (pass == 0) a.Fbar[(long long)i * R + r] = red[0];
-        else a.Fbar[2 * sa + (long long)i * R + r] = coef[ax] * red[0];
-      }
-    }
-    if (threadIdx.x == 0) a.Fbar[(long long)a.d.n[ax] * R + (long long)i * R + r] = 0.f;  // first-derivative stream unused
+  const int slots = GRID_BLOCK / R > 0 ? GRID_BLOCK / R : 1;
+  float* f0 = sm;                     // [nc][R]
+  float* f2 = f0 + (long long)nc * R; // [nc][R]
+  float* gs = f2 + (long long)nc * R; // [GRID_JG][nc]
+  float* red = gs + GRID_JG * nc;     // [2][slots][R]
+  for (int t = threadIdx.x; t < nc * R; t += GRID_BLOCK) {
+    f0[t] = a.F[c][t];
+    f2[t] = a.F[c][2 * sc + t];
   }
+  for (int t = threadIdx.x; t < GRID_JG * nc; t += GRID_BLOCK) {
+    const int jj = t / nc, kc = t % nc, jb = jb0 + jj;
+    gs[t] = jb < nb ? a.gadj[i * stride[ax] + jb * stride[b] + kc * stride[c]] : 0.f;
+  }
+  __syncthreads();
+  const int r = threadIdx.x % R, slot = threadIdx.x / R;
+  float v0 = 0.f, v2 = 0.f;
+  if (slot < slots) {
+    for (int jj = slot; jj < GRID_JG && jb0 + jj < nb; jj += slots) {
+      const int jb = jb0 + jj;
+      const float* g = gs + jj * nc;
+      float t0 = 0.f, t2 = 0.f;
+      for (int kc = 0; kc < nc; ++kc) {
+        const float gv = g[kc];
+        t0 += gv * f0[kc * R + r];
+        t2 += gv * f2[kc * R + r];
+      }
+      const float y0 = a.F[b][(long long)jb * R + r], y2 = a.F[b][2 * sb + (long long)jb * R + r];
+      v0 += y0 * (a.d.cu * t0 + coef[c] * t2) + y2 * coef[b] * t0;
+      v2 += y0 * t0;
+    }
+    red[slot * R + r] = v0;
+    red[(slots + slot) * R + r] = v2;
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)R) {
+    float s0 = 0.f, s2 = 0.f;
+    for (int q = 0; q < slots; ++q) {
+      s0 += red[q * R + r];
+      s2 += red[(slots + q) * R + r];
+    }
+    float* out = a.Fpart + ((long long)i * ngrp + grp) * 2 * R;
+    out[r] = s0;
+    out[R + r] = coef[ax] * s2;
+  }
+}
+
+__global__ void __launch_bounds__(GRID_BLOCK) spinn_fbar_sum_kernel(GridArgs a) {
+  const int R = a.d.rank, ax = a.axis, na = a.d.n[ax];
+  const int b = ax == 0 ? 1 : 0;
+  const int ngrp = (a.d.n[b] + GRID_JG - 1) / GRID_JG;
+  const long long t = (long long)blockIdx.x * GRID_BLOCK + threadIdx.x;
+  if (t >= (long long)na * R) return;
+  const int i = (int)(t / R), r = (int)(t % R);
+  float s0 = 0.f, s2 = 0.f;
+  for (int g = 0; g < ngrp; ++g) {
+    const float* p = a.Fpart + ((long long)i * ngrp + g) * 2 * R;
+    s0 += p[r];
+    s2 += p[R + r];
+  }
+  const long long sa = (long long)na * R;
+  a.Fbar[t] = s0;
+  a.Fbar[sa + t] = 0.f;  // first-derivative stream is not used by these residuals
+  a.Fbar[2 * sa + t] = s2;
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -424,23 +495,26 @@ extern "C" int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params,
   return PPSCI_OK;
 }
 
-static int grid_blocks(long long total, int* iters) {
-  long long blocks = (total + GRID_BLOCK - 1) / GRID_BLOCK;
-  long long g = blocks < 4096 ? blocks : 4096;
-  if (g < 1) g = 1;
-  *iters = (int)((blocks + g - 1) / g);
-  return (int)g;
+static int grid_fwd_blocks(const ppsci_spinn_grid_desc* d) {
+  return d->n[0] * ((d->n[1] + GRID_JT - 1) / GRID_JT);
+}
+
+static int grid_fwd_kc(const ppsci_spinn_grid_desc* d) {
+  int kc = 8192 / d->rank;  // 2*R*KC floats <= 64 KiB
+  if (kc > 256) kc = 256;
+  if (kc > d->n[2]) kc = d->n[2];
+  return kc < 1 ? 1 : kc;
 }
 
 extern "C" int64_t ppsci_spinn_grid_partial_rows(const ppsci_spinn_grid_desc* d) {
-  if (!d) return 0;
-  int it;
-  return grid_blocks((long long)d->n[0] * d->n[1] * d->n[2], &it);
+  if (!d || d->rank < 1) return 0;
+  return grid_fwd_blocks(d);
 }
 
 extern "C" int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
                                     const float* label, float* resid, float* gadj, float* loss_partials, void* stream) {
-  if (!d || !Fx || !Fy || !Fz || !loss_partials || d->rank < 1 || d->n[0] < 1 || d->n[1] < 1 || d->n[2] < 1) {
+  if (!d || !Fx || !Fy || !Fz || !loss_partials || d->rank < 1 || d->rank > GRID_BLOCK || d->n[0] < 1 || d->n[1] < 1 ||
+      d->n[2] < 1) {
     ppsci_set_error("spinn_grid_fwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -449,16 +523,34 @@ extern "C" int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float*
   a.d = *d;
   a.F[0] = Fx; a.F[1] = Fy; a.F[2] = Fz;
   a.label = label; a.resid = resid; a.gadj = gadj; a.loss_partials = loss_partials;
-  const int grid = grid_blocks((long long)d->n[0] * d->n[1] * d->n[2], &a.iters);
-  PPSCI_LAUNCH(spinn_grid_fwd_kernel, GridArgs, grid, GRID_BLOCK, GRID_BLOCK * sizeof(float), stream, a);
+  const int grid = grid_fwd_blocks(d);
+  a.iters = grid_fwd_kc(d);
+  const size_t lds = (size_t)(2 * d->rank * a.iters + GRID_JT * 2 * d->rank + GRID_BLOCK) * sizeof(float);
+  if (PPSCI_SET_MAX_LDS(spinn_grid_fwd_kernel, lds) != 0) {
+    ppsci_set_error("spinn_grid_fwd: cannot raise dynamic LDS to %zu B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  PPSCI_LAUNCH(spinn_grid_fwd_kernel, GridArgs, grid, GRID_BLOCK, lds, stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) { ppsci_set_error("spinn_grid_fwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   return PPSCI_OK;
 }
 
+extern "C" int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_desc* d) {
+  if (!d || d->rank < 1) return 0;
+  long long m = 0;
+  for (int ax = 0; ax < 3; ++ax) {
+    const int b = ax == 0 ? 1 : 0;
+    const long long v = (long long)d->n[ax] * ((d->n[b] + GRID_JG - 1) / GRID_JG) * 2 * d->rank;
+    if (v > m) m = v;
+  }
+  return m;
+}
+
 extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
-                                    const float* gadj, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream) {
-  if (!d || !Fx || !Fy || !Fz || !gadj || !Fbar_x || !Fbar_y || !Fbar_z) {
+                                    const float* gadj, float* scratch, float* Fbar_x, float* Fbar_y, float* Fbar_z,
+                                    void* stream) {
+  if (!d || !Fx || !Fy || !Fz || !gadj || !scratch || !Fbar_x || !Fbar_y || !Fbar_z || d->rank > GRID_BLOCK) {
     ppsci_set_error("spinn_grid_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -470,10 +562,25 @@ extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float*
     a.F[0] = Fx; a.F[1] = Fy; a.F[2] = Fz;
     a.gadj = (float*)gadj;
     a.Fbar = outs[ax];
+    a.Fpart = scratch;
     a.axis = ax;
-    PPSCI_LAUNCH(spinn_grid_bwd_kernel, GridArgs, d->n[ax], GRID_BLOCK, GRID_BLOCK * sizeof(float), stream, a);
+    const int b = ax == 0 ? 1 : 0, c = ax == 2 ? 1 : 2;
+    const int ngrp = (d->n[b] + GRID_JG - 1) / GRID_JG;
+    const size_t lds = ((size_t)2 * d->n[c] * d->rank + (size_t)GRID_JG * d->n[c] + 2 * GRID_BLOCK) * sizeof(float);
+    if (lds > (size_t)PPSCI_LDS_LIMIT_BYTES) {
+      ppsci_set_error("spinn_grid_bwd: axis of %d points x rank %d does not fit LDS", d->n[c], d->rank);
+      return PPSCI_E_UNSUPPORTED;
+    }
+    if (PPSCI_SET_MAX_LDS(spinn_grid_bwd_kernel, lds) != 0) {
+      ppsci_set_error("spinn_grid_bwd: cannot raise dynamic LDS to %zu B", lds);
+      return PPSCI_E_LAUNCH;
+    }
+    PPSCI_LAUNCH(spinn_grid_bwd_kernel, GridArgs, d->n[ax] * ngrp, GRID_BLOCK, lds, stream, a);
     int e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) { ppsci_set_error("spinn_grid_bwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
+    PPSCI_LAUNCH(spinn_fbar_sum_kernel, GridArgs, (d->n[ax] * d->rank + GRID_BLOCK - 1) / GRID_BLOCK, GRID_BLOCK, 0, stream, a);
+    e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) { ppsci_set_error("spinn_fbar_sum: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   }
   return PPSCI_OK;
 }

@@ -47,6 +47,7 @@ class SpinnConstraint:
         self.desc.cu, self.desc.cxx, self.desc.cyy, self.desc.czz = (float(c) for c in self.coeffs)
         self.lrows = int(L.lib().ppsci_spinn_grid_partial_rows(C.byref(self.desc)))
         self.lpart = torch.zeros(self.lrows, **f32)
+        self.bscratch = torch.zeros(max(4, int(L.lib().ppsci_spinn_grid_bwd_scratch_floats(C.byref(self.desc)))), **f32)
         self.loss_term = torch.zeros(1, **f32)
 
     def bind(self, input: Dict[str, np.ndarray], label: Dict[str, np.ndarray]):
@@ -81,7 +82,8 @@ class SpinnConstraint:
     def backward(self):
         m, lib = self.model, L.lib()
         L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
-                                         _p(self.Fbar[0]), _p(self.Fbar[1]), _p(self.Fbar[2]), _stream_ptr(self.gadj)))
+                                         _p(self.bscratch), _p(self.Fbar[0]), _p(self.Fbar[1]), _p(self.Fbar[2]),
+                                         _stream_ptr(self.gadj)))
         for b in range(3):
             L.check(lib.ppsci_modmlp_bwd(C.byref(m.spec.desc), _p(m.branch(b)), self.x[b].numel(), _p(self.x[b]),
                                          _p(self.Fbar[b]), _p(self.stash[b]), _p(self.gpart[b]), _stream_ptr(self.x[b])))
