@@ -32,7 +32,17 @@ __device__ __forceinline__ float ppsci_tanh(float x) {
 #endif
   const float x2 = x * x;
   const float p = x * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f))));
-  return ax < 0.35f ? p : copysignf(big, x);
+  const float bs = copysignf(big, x);
+#ifdef PPSCI_EMU
+  return ax < 0.35f ? p : bs;
+#else
+  // Both arms are always evaluated and blended with one v_cndmask.  Written as inline asm because the
+  // compiler turns the C++ select into a divergent branch around the exp/rcp arm, which ends the
+  // scheduling region four times per 16-feature block and keeps MFMAs from being interleaved with it.
+  float r;
+  asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(r) : "v"(ax), "v"(0.35f), "v"(bs), "v"(p) : "vcc");
+  return r;
+#endif
 }
 
 // value and first three derivatives of the activation (SURVEY.md Appendix A;
@@ -62,6 +72,23 @@ __device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, flo
     d1 = c;
     d2 = -s;
     d3 = -c;
+  }
+}
+
+// What taylor_fwd stashes for the value stream of a hidden layer and how taylor_bwd turns it back into the
+// activation value and its first three derivatives: for tanh the activation VALUE s = tanh(z) is stashed,
+// because every derivative is a polynomial in s (1 - s^2, -2 s s', s'(6 s^2 - 2)) and the reverse sweep never
+// needs z itself -- this removes the exp/rcp/polynomial evaluation (about 40 % of the reverse kernel's
+// pointwise VALU work, which on gfx950 issues on the same pipe as the fp32 MFMAs); silu and sin stash z.
+template <int ACT>
+__device__ __forceinline__ void ppsci_act_from_stash(float v, float& s, float& d1, float& d2, float& d3) {
+  if (ACT == PPSCI_ACT_TANH) {
+    s = v;
+    d1 = 1.f - s * s;
+    d2 = -2.f * s * d1;
+    d3 = d1 * (6.f * s * s - 2.f);
+  } else {
+    ppsci_act_eval<ACT>(v, s, d1, d2, d3);
   }
 }
 
@@ -190,12 +217,13 @@ int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
 // LDS carve sizes (floats)
+#define PPSCI_BWD_TINP_FLOATS (2 * (PPSCI_MAX_OUT * (1 + 2 * PPSCI_MAX_DIRS) + PPSCI_MAX_IN))  // 64-bit row pointers
 static inline int ppsci_fwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q) {
   // W0s[d0*HP] + Bs[L*HP] + WLs[m*HP] + BLs[4*ceil(m/4)]
   return (q.d0 + d.n_hidden + d.d_out) * q.HP + ((d.d_out + 3) / 4) * 4;
 }
 static inline int ppsci_bwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q, int S) {
-  // WLs[m*HP] gW0[d0*HP] gB[L*HP] gWL[m*HP] gBL[4*ceil(m/4)] scratch[WAVES*S*SCR]
+  // WLs[m*HP] gW0[d0*HP] gB[L*HP] gWL[m*HP] gBL[4*ceil(m/4)] scratch[WAVES*S*SCR] tile inputs x[WAVES*d_raw*16]
   return (2 * d.d_out + q.d0 + d.n_hidden) * q.HP + ((d.d_out + 3) / 4) * 4 +
-         PPSCI_BWD_WAVES * S * PPSCI_SCR_FLOATS;
+         PPSCI_BWD_WAVES * (S * PPSCI_SCR_FLOATS + d.d_raw * PPSCI_TILE) + PPSCI_BWD_TINP_FLOATS;
 }

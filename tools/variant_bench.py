@@ -35,6 +35,9 @@ def main():
         shapes += [("LAP 3x20 S5 10k", 2, 3, 20, 1, [[1.0, 0.0], [0.0, 1.0]], 2, 10_201),
                    ("NS 5x128 S5 125k", 2, 5, 128, 3, [[1.0, 0.0], [0.0, 1.0]], 2, 125_000)]
     libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "*.so")))
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+    if only:
+        libs = [p for p in libs if os.path.basename(p)[:-3] in only[0].split(",")]
     dev = "cuda"
     for path in libs:
         name = os.path.basename(path)[:-3]
@@ -55,9 +58,27 @@ def main():
             fn_med, fn_min = timeit(lambda: hp.taylor_fwd(desc, params, xs, U, None))
             ws = torch.zeros(max(4, hp.bwd_workspace_bytes(desc, N) // 4), device=dev)
             b_med, b_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
+            L._lib.ppsci_set_bwd_main_only(1)
+            m_med, m_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
+            L._lib.ppsci_set_bwd_main_only(0)
+            try:
+                import ctypes
+                raw = ctypes.CDLL(path)
+                buf = (ctypes.c_ulonglong * 8)()
+                raw.ppsci_bwd_read_phase_timers(buf, 1)
+                L._lib.ppsci_set_bwd_main_only(1)
+                hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp)
+                torch.cuda.synchronize()
+                L._lib.ppsci_set_bwd_main_only(0)
+                raw.ppsci_bwd_read_phase_timers(buf, 1)
+                tot = float(sum(buf)) or 1.0
+                print(json.dumps({"variant": name, "phase_cycles_per_tile": [round(v / ((N + 15) // 16)) for v in buf],
+                                  "phase_pct": [round(100.0 * v / tot, 1) for v in buf]}), flush=True)
+            except AttributeError:
+                pass
             print(json.dumps({"variant": name, "shape": label, "rows": rows, "fwd_ms": round(f_med, 4),
                               "fwd_nostash_ms": round(fn_med, 4), "bwd_ms": round(b_med, 4),
-                              "bwd_min_ms": round(b_min, 4)}), flush=True)
+                              "bwd_min_ms": round(b_min, 4), "bwd_main_ms": round(m_med, 4)}), flush=True)
           except Exception as e:  # noqa: BLE001
             print(json.dumps({"variant": name, "shape": label, "error": str(e)[:100]}), flush=True)
 
