@@ -169,8 +169,10 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
   const int tc = threadIdx.x % RED_COLS, rg = threadIdx.x / RED_COLS;
   const long long j = (long long)blockIdx.x * RED_COLS + tc;
   float s = 0.f;
-  if (j < a.cols)
+  if (j < a.cols) {
+#pragma unroll 8
     for (long long r = rg; r < a.rows; r += RED_GROUPS) s += a.partials[r * a.cols + j];
+  }
   red[rg * RED_COLS + tc] = s;
   __syncthreads();
   if (rg == 0 && j < a.cols) {

@@ -166,7 +166,14 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
 // Tile owned by (iteration, block, wave): consecutive tiles go to different workgroups first, so a
 // partially filled last round is spread over many CUs instead of filling a few of them.
 __device__ __forceinline__ int ppsci_tile_index(int it, int waves) {
-  return (it * waves + (int)(threadIdx.x >> 6)) * (int)gridDim.x + (int)blockIdx.x;
+  const int t = (it * waves + (int)(threadIdx.x >> 6)) * (int)gridDim.x + (int)blockIdx.x;
+#ifdef PPSCI_EMU
+  return t;
+#else
+  // wave-uniform by construction; telling the compiler moves the tile's address arithmetic to the scalar
+  // unit and turns every `tile < ntiles` guard into a scalar branch instead of an exec-mask region
+  return __builtin_amdgcn_readfirstlane(t);
+#endif
 }
 
 // ---- kernel argument blocks ------------------------------------------------------------------

@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(WRedArgs a) {
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
   const f32x4* src = (const f32x4*)a.wpart + j4;
   const long long stride4 = a.per_tile / 4;
-  for (int t = t0; t < t1; ++t) s += src[(long long)t * stride4];
+#pragma unroll 8
+  for (int t = t0; t < t1; ++t) s += __builtin_nontemporal_load(&src[(long long)t * stride4]);
   ((f32x4*)a.tmp)[(long long)chunk * stride4 + j4] = s;
 }
 
@@ -41,6 +42,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
       // block (ib, ob), lane 16g + c, component r  <->  (in = 16ib + 4g + r, out = 16ob + c)
       const long long j = (long long)(l - 1) * HP * HP +
                           ((long long)((in >> 4) * NB + (out >> 4)) * 64 + 16 * ((in & 15) >> 2) + (out & 15)) * 4 + (in & 3);
+      // independent loads, in-order adds: unrolled so that 8 loads are in flight per thread
+#pragma unroll 8
       for (int c = 0; c < a.nchunks; ++c) v += a.tmp[(long long)c * a.per_tile + j];
     }
   }
