@@ -488,3 +488,59 @@ def spinn_helmholtz(branches, xs, k: float = 1.0, coeffs=None):
     uxx, uyy, uzz = e(f2[0], f[1], f[2]), e(f[0], f2[1], f[2]), e(f[0], f[1], f2[2])
     c = coeffs if coeffs is not None else (k**2, 1.0, 1.0, 1.0)
     return u, c[0] * u + c[1] * uxx + c[2] * uyy + c[3] * uzz
+
+
+# ----------------------------------------------------------------------------- FNO (BASELINE config 4)
+def reference_spectral_conv2d(x, w_re, w_im, n_modes_x, fft_norm="backward", bias=None):
+    """Plain torch restatement of FactorizedSpectralConv.forward (fno_block.py:707-796) with the explicit
+    fftshift / slicing / four-einsum sequence; the oracle of csrc/spectral_conv.hip."""
+    B, ci, H, W = x.shape
+    co, mx, my = w_re.shape[1], w_re.shape[2], w_re.shape[3]
+    xf = torch.fft.rfftn(x, norm=fft_norm, dim=(-2, -1))
+    xf = torch.fft.fftshift(xf, dim=(-2,))
+    out = torch.zeros((B, co, H, W // 2 + 1), dtype=xf.dtype, device=x.device)
+    start = H - mx
+    rows = slice(start // 2, -start // 2) if start else slice(None)
+    cols = slice(None, my)
+    xs = xf[:, :, rows, cols]
+    eq = "abcd,becd->aecd"
+    o_r = torch.einsum(eq, xs.real, w_re) - torch.einsum(eq, xs.imag, w_im)
+    o_i = torch.einsum(eq, xs.imag, w_re) + torch.einsum(eq, xs.real, w_im)
+    out[:, :, rows, cols] = torch.complex(o_r, o_i)
+    out = torch.fft.fftshift(out, dim=(-2,))
+    y = torch.fft.irfftn(out, s=(H, W), dim=(-2, -1), norm=fft_norm)
+    return y if bias is None else y + bias
+
+
+def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5):
+    """FNONet.forward (tfnonet.py:179-193) with FNOBlocks.forward_with_postactivation (fno_block.py:1191-1220)
+    and fno_block.MLP (:313-320) written out on plain tensors.  P: dict of parameters named like the torch
+    modules of paddlescience_amd.arch.fno (lifting.fcs.i.weight [Co,Ci,1,1] ...)."""
+    import torch.nn.functional as F
+
+    def conv1x1(x, w, b=None):
+        y = torch.einsum("oi,bihw->bohw", w[:, :, 0, 0], x)
+        return y if b is None else y + b.view(1, -1, 1, 1)
+
+    def mlp(x, name, n):
+        for i in range(n):
+            x = conv1x1(x, P[f"{name}.fcs.{i}.weight"], P[f"{name}.fcs.{i}.bias"])
+            if i < n - 1:
+                x = F.gelu(x)
+        return x
+
+    n_lift = sum(1 for k in P if k.startswith("lifting.fcs.") and k.endswith(".weight"))
+    x = mlp(x, "lifting", n_lift)
+    for i in range(n_layers):
+        skip = conv1x1(x, P[f"fno_blocks.fno_skips.{i}.weight"]) if f"fno_blocks.fno_skips.{i}.weight" in P else x
+        y = reference_spectral_conv2d(x, P[f"fno_blocks.convs.{i}.weight_real"], P[f"fno_blocks.convs.{i}.weight_imag"],
+                                      n_modes[0], fft_norm, P[f"fno_blocks.convs.{i}.bias"])
+        if norm == "group_norm":  # nn.GroupNorm(num_groups=1): statistics over (C, H, W) per sample
+            mu = y.mean(dim=(1, 2, 3), keepdim=True)
+            var = y.var(dim=(1, 2, 3), keepdim=True, unbiased=False)
+            y = (y - mu) / torch.sqrt(var + eps)
+            y = y * P[f"fno_blocks.norm.{i}.weight"].view(1, -1, 1, 1) + P[f"fno_blocks.norm.{i}.bias"].view(1, -1, 1, 1)
+        x = y + skip
+        if i < n_layers - 1:
+            x = F.gelu(x)
+    return mlp(x, "projection", 2)

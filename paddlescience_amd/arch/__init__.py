@@ -1,9 +1,10 @@
 from .base import Arch  # noqa: F401
-from .fno import SpectralConv2d, spectral_contract  # noqa: F401
+from .fno import FNONet, SpectralConv2d, TFNO1dNet, TFNO2dNet, TFNO3dNet, spectral_contract  # noqa: F401
 from .mlp import MLP  # noqa: F401
 from .spinn import SPINN  # noqa: F401
 
-__all__ = ["Arch", "MLP", "SpectralConv2d", "spectral_contract", "SPINN", "build_model"]
+__all__ = ["Arch", "MLP", "SpectralConv2d", "spectral_contract", "SPINN", "FNONet", "TFNO1dNet", "TFNO2dNet", "TFNO3dNet",
+           "build_model"]
 
 
 def build_model(cfg):
@@ -12,4 +13,4 @@ def build_model(cfg):
     if isinstance(cfg, (list, tuple)):
         raise NotImplementedError("ModelList is not supported on the fused HIP path yet")
     (name, kwargs), = cfg.items()
-    return {"MLP": MLP, "SPINN": SPINN}[name](**kwargs)
+    return {"MLP": MLP, "SPINN": SPINN, "FNONet": FNONet, "TFNO2dNet": TFNO2dNet}[name](**kwargs)

@@ -5,8 +5,12 @@
 drawn N(0, sqrt(2/(Ci+Co))) (:621-622, :522-532), optional bias `[Co, 1, 1]`, `fft_norm` forwarded to the
 FFTs.  The FFTs run in hipFFT through torch.fft (glue, as SURVEY.md allows); the per-mode complex channel
 contraction -- the part the reference does with four real einsums -- is `ppsci_spectral_conv2d_fwd/bwd`,
-wired into torch autograd so the layer can sit inside a larger torch module (lifting / projection 1x1
-convolutions, GroupNorm, GELU of FNOBlocks are plain library ops)."""
+wired into torch autograd so the layer can sit inside a larger torch module.
+
+`FNOBlocks`, `FNONet`, `TFNO2dNet` follow fno_block.py:1047-1255 and tfnonet.py:13-406 for the configuration of
+BASELINE config 4 (post-activation blocks, linear skips, optional GroupNorm, dense weights); the lifting /
+projection / skip 1x1 convolutions, GroupNorm and GELU are plain library ops (MIOpen / rocBLAS through torch).
+Options of the reference signature that are not built raise NotImplementedError."""
 from __future__ import annotations
 
 import ctypes as C
@@ -18,6 +22,7 @@ import torch
 
 from .. import _lib as L
 from ..hotpath import _p, _require_device, _stream_ptr
+from . import base
 
 
 def _desc(B, ci, co, H, Wf, mx, my) -> L.SpectralDesc:
@@ -82,22 +87,205 @@ class SpectralConv2d(torch.nn.Module):
         return y
 
 
-def reference_spectral_conv2d(x, w_re, w_im, n_modes_x, fft_norm="backward", bias=None):
-    """Plain torch restatement of FactorizedSpectralConv.forward (fno_block.py:707-796) with the explicit
-    fftshift / slicing / four-einsum sequence; used by tests only."""
-    B, ci, H, W = x.shape
-    co, mx, my = w_re.shape[1], w_re.shape[2], w_re.shape[3]
-    xf = torch.fft.rfftn(x, norm=fft_norm, dim=(-2, -1))
-    xf = torch.fft.fftshift(xf, dim=(-2,))
-    out = torch.zeros((B, co, H, W // 2 + 1), dtype=xf.dtype, device=x.device)
-    start = H - mx
-    rows = slice(start // 2, -start // 2) if start else slice(None)
-    cols = slice(None, my)
-    xs = xf[:, :, rows, cols]
-    eq = "abcd,becd->aecd"
-    o_r = torch.einsum(eq, xs.real, w_re) - torch.einsum(eq, xs.imag, w_im)
-    o_i = torch.einsum(eq, xs.imag, w_re) + torch.einsum(eq, xs.real, w_im)
-    out[:, :, rows, cols] = torch.complex(o_r, o_i)
-    out = torch.fft.fftshift(out, dim=(-2,))
-    y = torch.fft.irfftn(out, s=(H, W), dim=(-2, -1), norm=fft_norm)
-    return y if bias is None else y + bias
+
+
+class ChannelMLP(torch.nn.Module):
+    """fno_block.MLP (fno_block.py:263-320): n_layers 1x1 convolutions with the non-linearity in between."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, hidden_channels: Optional[int] = None,
+                 n_layers: int = 2, non_linearity=torch.nn.functional.gelu):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        hidden_channels = in_channels if hidden_channels is None else hidden_channels
+        self.n_layers = n_layers
+        self.non_linearity = non_linearity
+        dims = [in_channels] + [hidden_channels] * (n_layers - 1) + [out_channels]
+        self.fcs = torch.nn.ModuleList([torch.nn.Conv2d(dims[i], dims[i + 1], 1) for i in range(n_layers)])
+
+    def forward(self, x):
+        for i, fc in enumerate(self.fcs):
+            x = fc(x)
+            if i < self.n_layers - 1:
+                x = self.non_linearity(x)
+        return x
+
+
+class FNOBlocks(torch.nn.Module):
+    """fno_block.FNOBlocks, post-activation form (fno_block.py:1191-1220): per layer
+    x <- act( norm(SpectralConv_i(x)) + skip_i(x) ), no activation after the last layer."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_modes: Tuple[int, int], n_layers: int = 1,
+                 non_linearity=torch.nn.functional.gelu, stabilizer: Optional[str] = None, norm: Optional[str] = None,
+                 fno_skip: str = "linear", fft_norm: str = "forward"):
+        super().__init__()
+        if in_channels != out_channels:
+            raise NotImplementedError("FNOBlocks with in_channels != out_channels")
+        if fno_skip not in ("linear", "identity"):
+            raise NotImplementedError(f"fno_skip={fno_skip!r} (built: 'linear', 'identity')")
+        if norm not in (None, "group_norm", "instance_norm"):
+            raise NotImplementedError(f"norm={norm!r} (built: None, 'group_norm', 'instance_norm')")
+        if stabilizer not in (None, "tanh"):
+            raise ValueError(f"stabilizer={stabilizer!r}")
+        self.n_layers, self.non_linearity, self.stabilizer = n_layers, non_linearity, stabilizer
+        # FactorizedSpectralConv holds the weights of all layers; bias per layer (fno_block.py:652-663)
+        self.convs = torch.nn.ModuleList([SpectralConv2d(in_channels, out_channels, n_modes, bias=True, fft_norm=fft_norm)
+                                          for _ in range(n_layers)])
+        self.fno_skips = torch.nn.ModuleList([
+            torch.nn.Conv2d(in_channels, out_channels, 1, bias=False) if fno_skip == "linear" else torch.nn.Identity()
+            for _ in range(n_layers)])
+        if norm == "group_norm":
+            self.norm = torch.nn.ModuleList([torch.nn.GroupNorm(1, out_channels) for _ in range(n_layers)])
+        elif norm == "instance_norm":
+            self.norm = torch.nn.ModuleList([torch.nn.InstanceNorm2d(out_channels) for _ in range(n_layers)])
+        else:
+            self.norm = None
+
+    def forward(self, x, index: int = 0):
+        x_skip = self.fno_skips[index](x)
+        if self.stabilizer == "tanh":
+            x = torch.tanh(x)
+        x_fno = self.convs[index](x)
+        if self.norm is not None:
+            x_fno = self.norm[index](x_fno)
+        x = x_fno + x_skip
+        if index < self.n_layers - 1:
+            x = self.non_linearity(x)
+        return x
+
+
+class FNONet(base.Arch, torch.nn.Module):
+    """ppsci.arch.FNONet for 2-D problems (tfnonet.py:13-193).  Input: dict with one `[B, C, H, W]` tensor per
+    input key (concatenated along the channel axis, like `concat_to_tensor` with the reference's layout);
+    output: `{output_keys[0]: [B, out_channels, H, W]}`.
+
+    The parameters live in ONE flat fp32 buffer (`flat_params`, module parameters are views into it) so that
+    the data-parallel all-reduce and the fused Adam kernel act on a single tensor, as for the PINN path."""
+
+    is_operator = True  # Solver: train through torch autograd around the HIP spectral kernel
+
+    def __init__(self, input_keys: Tuple[str, ...], output_keys: Tuple[str, ...], n_modes: Tuple[int, ...],
+                 hidden_channels: int, in_channels: int = 3, out_channels: int = 1, lifting_channels: int = 256,
+                 projection_channels: int = 256, n_layers: int = 4, use_mlp: bool = False, mlp=None,
+                 max_n_modes=None, non_linearity=torch.nn.functional.gelu, stabilizer: Optional[str] = None,
+                 norm: Optional[str] = None, ada_in_features=None, preactivation: bool = False,
+                 fno_skip: str = "linear", mlp_skip: str = "soft-gating", separable: bool = False,
+                 factorization: Optional[str] = None, rank: float = 1.0, joint_factorization: bool = False,
+                 implementation: str = "factorized", domain_padding=None, domain_padding_mode: str = "one-sided",
+                 fft_norm: str = "forward", patching_levels: int = 0, **kwargs):
+        torch.nn.Module.__init__(self)
+        base.Arch.__init__(self)
+        if len(n_modes) != 2:
+            raise NotImplementedError("only the 2-D spectral convolution has a HIP kernel (TFNO1dNet / TFNO3dNet)")
+        for name, val, ok in (("use_mlp", use_mlp, False), ("preactivation", preactivation, False),
+                              ("separable", separable, False), ("joint_factorization", joint_factorization, False),
+                              ("patching_levels", patching_levels, 0), ("ada_in_features", ada_in_features, None),
+                              ("max_n_modes", max_n_modes, None)):
+            if val != ok:
+                raise NotImplementedError(f"FNONet({name}={val!r}) is not built")
+        if domain_padding is not None and (sum(domain_padding) if isinstance(domain_padding, list) else domain_padding) > 0:
+            raise NotImplementedError("FNONet(domain_padding=...) is not built")
+        # `factorization`/`rank`: the reference's FactorizedTensor (fno_block.py:522-539) stores a DENSE complex
+        # weight whatever the name says, so "Tucker" with rank 1.0 and None are the same parametrisation.
+        self.input_keys, self.output_keys = tuple(input_keys), tuple(output_keys)
+        self.n_modes, self.n_layers = tuple(n_modes), n_layers
+        self.hidden_channels, self.in_channels, self.out_channels = hidden_channels, in_channels, out_channels
+        self.fno_blocks = FNOBlocks(hidden_channels, hidden_channels, self.n_modes, n_layers, non_linearity, stabilizer,
+                                    norm, fno_skip, fft_norm)
+        if lifting_channels:
+            self.lifting = ChannelMLP(in_channels, hidden_channels, lifting_channels, 2)
+        else:
+            self.lifting = ChannelMLP(in_channels, hidden_channels, hidden_channels, 1)
+        self.projection = ChannelMLP(hidden_channels, out_channels, projection_channels, 2, non_linearity)
+        self.flat_params: Optional[torch.Tensor] = None
+        self.flat_grad: Optional[torch.Tensor] = None
+        from ..device import get_device
+
+        self.to_device(get_device())
+
+    # ---- flat parameter buffer ---------------------------------------------------------------
+    def to_device(self, device):
+        """Moves the model and (re)packs every parameter as a view into `flat_params` / `flat_grad`."""
+        torch.nn.Module.to(self, device)
+        ps = [p for p in torch.nn.Module.parameters(self)]
+        n = sum(p.numel() for p in ps)
+        flat = torch.empty(n, dtype=torch.float32, device=device)
+        grad = torch.zeros(n, dtype=torch.float32, device=device)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + k].view_as(p.data)
+            p.grad = grad[off:off + k].view_as(p.data)
+            off += k
+        self.flat_params, self.flat_grad = flat, grad
+        return self
+
+    def parameters(self, recurse: bool = True):
+        return list(torch.nn.Module.parameters(self, recurse))
+
+    def state_dict(self, *args, **kwargs):
+        return {k: v.detach().clone() for k, v in torch.nn.Module.state_dict(self, *args, **kwargs).items()}
+
+    def set_state_dict(self, state):
+        own = torch.nn.Module.state_dict(self)
+        with torch.no_grad():
+            for k, v in state.items():
+                own[k].copy_(torch.as_tensor(v).to(own[k].device))
+
+    def train(self, mode: bool = True):
+        torch.nn.Module.train(self, mode)
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- forward (tfnonet.py:179-193) ---------------------------------------------------------
+    def forward_tensor(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.lifting(x)
+        for index in range(self.n_layers):
+            x = self.fno_blocks(x, index)
+        return self.projection(x)
+
+    def forward(self, x):
+        if self._input_transform is not None:
+            x = self._input_transform(x)
+        dev = self.flat_params.device
+        xs = [torch.as_tensor(x[k], dtype=torch.float32).to(dev) for k in self.input_keys]
+        xt = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+        out = {self.output_keys[0]: self.forward_tensor(xt)}
+        if self._output_transform is not None:
+            out = self._output_transform(x, out)
+        return out
+
+    __call__ = torch.nn.Module.__call__
+
+
+class TFNO2dNet(FNONet):
+    """ppsci.arch.TFNO2dNet (tfnonet.py:301-406)."""
+
+    def __init__(self, input_keys: Tuple[str, ...], output_keys: Tuple[str, ...], n_modes_height: int,
+                 n_modes_width: int, hidden_channels: int, in_channels: int = 3, out_channels: int = 1,
+                 lifting_channels: int = 256, projection_channels: int = 256, n_layers: int = 4,
+                 non_linearity=torch.nn.functional.gelu, use_mlp: bool = False, mlp=None, norm: Optional[str] = None,
+                 skip: str = "soft-gating", separable: bool = False, preactivation: bool = False,
+                 factorization: str = "Tucker", rank: float = 1.0, joint_factorization: bool = False,
+                 implementation: str = "factorized", domain_padding=None, domain_padding_mode: str = "one-sided",
+                 fft_norm: str = "forward", patching_levels: int = 0, **kwargs):
+        # the reference forwards `skip` into FNONet's **kwargs, where it is ignored (fno_skip stays "linear")
+        super().__init__(input_keys, output_keys, (n_modes_height, n_modes_width), hidden_channels, in_channels,
+                         out_channels, lifting_channels, projection_channels, n_layers, use_mlp, mlp, None,
+                         non_linearity, None, norm, None, preactivation, "linear", "soft-gating", separable,
+                         factorization, rank, joint_factorization, implementation, domain_padding,
+                         domain_padding_mode, fft_norm, patching_levels)
+        self.n_modes_height, self.n_modes_width = n_modes_height, n_modes_width
+
+
+class TFNO1dNet(FNONet):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("TFNO1dNet: only the 2-D spectral convolution has a HIP kernel")
+
+
+class TFNO3dNet(FNONet):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("TFNO3dNet: only the 2-D spectral convolution has a HIP kernel")

@@ -56,4 +56,16 @@ class L2Rel(Metric):
                 / torch.linalg.vector_norm(label_dict[k]).clamp(min=self.EPS) for k in label_dict}
 
 
-__all__ = ["Metric", "MSE", "RMSE", "MAE", "L2Rel"]
+__all__ = ["Metric", "MSE", "RMSE", "MAE", "L2Rel", "FunctionalMetric"]
+
+
+class FunctionalMetric(Metric):
+    """ppsci.metric.FunctionalMetric (/root/reference/ppsci/metric/func.py): user function of
+    (output_dict, label_dict) returning a dict of tensors."""
+
+    def __init__(self, metric_expr, keep_batch: bool = False):
+        super().__init__(keep_batch)
+        self.metric_expr = metric_expr
+
+    def forward(self, output_dict, label_dict):
+        return self.metric_expr(output_dict, label_dict)

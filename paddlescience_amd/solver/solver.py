@@ -127,13 +127,18 @@ class Solver:
         from ..arch.spinn import SPINN
 
         self._is_spinn = isinstance(self.model, SPINN)
+        self._is_operator = bool(getattr(self.model, "is_operator", False))
         if self._is_spinn:
             from ..spinn_engine import SpinnEngine
 
             self.engine = SpinnEngine(self.model)
+        elif self._is_operator:
+            from ..operator_engine import OperatorEngine
+
+            self.engine = OperatorEngine(self.model)
         else:
             self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
-        if self.optimizer is not None and not self._is_spinn:
+        if self.optimizer is not None and not self._is_spinn and not self._is_operator:
             self.engine.m, self.engine.v = self.optimizer.m, self.optimizer.v
             self.engine.beta1, self.engine.beta2, self.engine.eps = (self.optimizer.beta1, self.optimizer.beta2,
                                                                     self.optimizer.epsilon)
@@ -179,6 +184,13 @@ class Solver:
         if self._is_spinn:
             self._static[name] = False
             return self._compile_spinn_constraint(name, cst)
+        if self._is_operator:
+            from ..operator_engine import OperatorConstraint
+
+            ds = getattr(cst.data_loader, "dataset", cst.data_loader)
+            self._static[name] = False
+            bsz = getattr(getattr(cst.data_loader, "batch_sampler", None), "batch_size", 0) or 0
+            return OperatorConstraint(name, self.model, cst.output_expr, cst.loss, self.device, list(ds.label_keys), bsz)
         ds = getattr(cst.data_loader, "dataset", cst.data_loader)
         input_keys = list(ds.input_keys)
         label_keys = list(ds.label_keys)
@@ -225,7 +237,7 @@ class Solver:
                         else:
                             cc.bind(inp, lab, w)
                 reader_cost = time.perf_counter() - reader_tic
-                self.engine.forward_backward(csts if self._is_spinn else [c.fused for c in csts])
+                self.engine.forward_backward(csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts])
                 self.engine.allreduce()
                 self.optimizer.step(self.engine.grad,
                                     (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0)
@@ -265,9 +277,14 @@ class Solver:
         losses_all: Dict[str, float] = {}
         per_cst: Dict[str, float] = {}
         for name, cc in self._compiled.items():
-            vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
+            if self._is_operator:
+                vals = cc.losses()  # keys are whatever the loss returns (FunctionalLoss), not the label keys
+                keys = list(vals.keys())
+            else:
+                vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
+                keys = cc.label_keys
             per_cst[name] = 0.0
-            for k in cc.label_keys:
+            for k in keys:
                 per_cst[name] += vals[k]
                 losses_all[k] = losses_all.get(k, 0.0) + vals[k]
         total = float(self.loss_aggregator(losses_all, self.global_step))
@@ -299,6 +316,8 @@ class Solver:
             raise ValueError("Solver.eval needs at least one validator")
         target = float("inf")
         group: Dict[str, Dict[str, float]] = {}
+        if self._is_operator:
+            return self._eval_operator(epoch_id)
         for vname, val in self.validator.items():
             ds = getattr(val.data_loader, "dataset", val.data_loader)
             outs: Dict[str, list] = {}
@@ -335,11 +354,62 @@ class Solver:
                 target = float(next(iter(group[vname].values())))  # first metric of the first validator
         return target, group
 
+    def _eval_operator(self, epoch_id: int):
+        """eval.py _eval_by_dataset for models evaluated through torch (FNO): whole-dataset metrics."""
+        from ..operator_engine import _to_dev
+
+        target = float("inf")
+        group: Dict[str, Dict[str, float]] = {}
+        self.model.eval()
+        for vname, val in self.validator.items():
+            outs: Dict[str, list] = {}
+            labs: Dict[str, list] = {}
+            loss_sum, nb = 0.0, 0
+            with torch.no_grad():
+                for (inp, lab, w) in val.data_loader:
+                    inp_d, lab_d, w_d = _to_dev(inp, self.device), _to_dev(lab, self.device), _to_dev(w, self.device)
+                    out = self.model(inp_d)
+                    data = {**inp_d, **out}
+                    vals = {k: f(data) for k, f in val.output_expr.items()}
+                    loss_sum += float(sum(val.loss(vals, lab_d, w_d).values()))
+                    nb += 1
+                    for k in vals:
+                        outs.setdefault(k, []).append(vals[k])
+                    for k in lab_d:
+                        labs.setdefault(k, []).append(lab_d[k])
+            all_out = {k: misc.all_gather(torch.cat(v, 0)) for k, v in outs.items()}
+            all_lab = {k: misc.all_gather(torch.cat(v, 0)) for k, v in labs.items()}
+            group[vname] = {}
+            for mname, metric in (val.metric or {}).items():
+                for k, v in metric(all_out, all_lab).items():
+                    group[vname][f"{mname}.{k}"] = float(v)
+            msg = ", ".join(f"{k}: {v:.5f}" for k, v in group[vname].items())
+            logger.info(f"[Eval][Epoch {epoch_id}][{vname}] loss: {loss_sum / max(nb, 1):.5f}, {msg}")
+            if group[vname] and target == float("inf"):
+                target = float(next(iter(group[vname].values())))
+        self.model.train()
+        return target, group
+
     # ------------------------------------------------------------------ prediction
     def predict(self, input_dict: Dict[str, Union[np.ndarray, torch.Tensor]], expr_dict: Optional[Dict[str, Callable]] = None,
                 batch_size: Optional[int] = 64, no_grad: bool = True, return_numpy: bool = False):
         """solver.py:729-872.  With world_size > 1 the points are rank-strided (v[rank::world]) and the
         gathered result is restored to the input order, like the reference (:793-797, :847-855)."""
+        if self._is_operator:
+            from ..operator_engine import _to_dev
+
+            n = len(next(iter(input_dict.values())))
+            bs = n if batch_size is None else batch_size
+            exprs = expr_dict if expr_dict is not None else {k: (lambda out, k=k: out[k]) for k in self.model.output_keys}
+            res: Dict[str, list] = {k: [] for k in exprs}
+            with torch.no_grad():
+                for s0 in range(0, n, bs):
+                    chunk = _to_dev({k: v[s0:s0 + bs] for k, v in input_dict.items()}, self.device)
+                    data = {**chunk, **self.model(chunk)}
+                    for k, f in exprs.items():
+                        res[k].append(f(data))
+            pred = {k: torch.cat(v, 0) for k, v in res.items()}
+            return {k: v.cpu().numpy() for k, v in pred.items()} if return_numpy else pred
         if self._is_spinn:  # tensor-product grid of the three coordinate vectors (helmholtz3d.py:205-213)
             if expr_dict is not None:
                 raise NotImplementedError("expr_dict with a SPINN model")

@@ -31,8 +31,33 @@ def build_solver(outdir, world_batch, reduction, steps):
     return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
 
 
+def build_fno_solver(outdir, world_batch, steps):
+    """Operator-learning path: TFNO2dNet through torch autograd + the HIP spectral kernel, gradient averaged
+    over ranks (DataParallel semantics)."""
+    import ppsci
+
+    torch.manual_seed(5)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, hidden_channels=8, lifting_channels=16, projection_channels=16,
+                                 n_layers=2, norm="group_norm")
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((world_batch, 3, 8, 8)).astype(np.float32)
+    y = rng.standard_normal((world_batch, 1, 8, 8)).astype(np.float32)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def mse(output_dict, label_dict, weight_dict=None):
+        return {"l2": ((output_dict["y"] - label_dict["y"]) ** 2).mean()}
+
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": x}, "label": {"y": y}},
+           "batch_size": world_batch // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.FunctionalLoss(mse), name="Sup")
+    opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    return ppsci.solver.Solver(model, {"Sup": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model, x
+
+
 def main():
     outdir, reduction = sys.argv[1], sys.argv[2]
+    if reduction == "fno":
+        return main_fno(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -47,6 +72,26 @@ def main():
                            "x": np.linspace(-1, 1, 11, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)
     if not dist.is_initialized() or dist.get_rank() == 0:
         np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
+                 loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_fno(outdir):
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    solver, model, x = build_fno_solver(outdir, 4, 2)
+    solver.train()
+    pred = solver.predict({"x": x}, return_numpy=True)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["y"],
                  loss=np.asarray(solver.last_losses["loss"]))
     if dist.is_initialized():
         dist.barrier()

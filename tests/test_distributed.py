@@ -35,6 +35,16 @@ def test_two_ranks_reproduce_single_rank(tmp_path, reduction):
     assert np.isfinite(two["loss"])
 
 
+def test_two_ranks_reproduce_single_rank_fno(tmp_path):
+    """Operator path (TFNO2dNet): per-rank mean loss over its half of the batch, gradients averaged over ranks
+    == the single-rank run on the whole batch."""
+    d = str(tmp_path)
+    one = _run(d, 1, "fno")
+    two = _run(d, 2, "fno")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
+
+
 def test_iterable_dataset_refuses_world_size_gt_1():
     """data/__init__.py:62-66."""
     import ppsci.data as D

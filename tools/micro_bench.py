@@ -73,6 +73,34 @@ def spectral(B=16, C=32, H=64, W=64, modes=(12, 12)):
                       "ms_torch_4_einsums": t_r * 1e3, "MFLOP": flops / 1e6, "operand_MB": byts / 1e6}), flush=True)
 
 
+def tfno(B=16, H=64, W=64):
+    """BASELINE config 4 / SURVEY 8(d): TFNO2dNet in 3, hidden 32, lifting 256, projection 64, 4 layers,
+    n_modes (12, 12), group_norm, fft_norm forward; one training step = forward + MSE + backward + fused Adam."""
+    torch.manual_seed(0)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
+                                 lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm")
+    rng = np.random.default_rng(42)
+    x = torch.as_tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, H, W)).astype(np.float32)).cuda()
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+
+    def fwd():
+        with torch.no_grad():
+            return model.forward_tensor(x)
+
+    def step():
+        model.flat_grad.zero_()
+        loss = ((model.forward_tensor(x) - y) ** 2).mean()
+        loss.backward()
+        opt.step(model.flat_grad)
+
+    t_f = timeit(fwd)
+    t_s = timeit(step)
+    print(json.dumps({"bench": "tfno2d_darcy_64x64", "batch": B, "params": int(model.flat_params.numel()),
+                      "ms_forward": t_f * 1e3, "ms_train_step": t_s * 1e3, "samples_per_s": B / t_s}), flush=True)
+
+
 if __name__ == "__main__":
     spinn(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
     spectral()
+    tfno()
