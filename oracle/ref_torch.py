@@ -28,8 +28,11 @@ tests/test_oracle.py), and -- for the NN / autodiff numerics -- tests/golden/hot
 by executing the reference's OWN Python files (arch/mlp.py, autodiff/ad.py, utils/symbolic.py with
 fuse_derivative=True, equation/pde/*.py, loss/mse.py) with `paddle` replaced by a torch-backed shim
 (tests/golden/_paddle_shim.py, tests/golden/make_hotpath_golden.py); this restatement reproduces those
-fixtures to 1e-10 (tests/test_golden_hotpath.py).  What remains unpinned is PaddlePaddle's own kernel
-arithmetic (covered by the fp32-vs-fp64 tolerance) and the SPINN / FNO restatements at the end of this file.
+fixtures to 1e-10 (tests/test_golden_hotpath.py).  The SPINN / Helmholtz and FNO restatements at the end of
+this file are pinned the same way (tests/golden/make_spinn_golden.py -> spinn.npz, make_fno_golden.py ->
+fno.npz: the reference's arch/spinn.py, ModifiedMLP, equation/pde/helmholtz.py, arch/fno_block.py, tfnonet.py
+executed under the shim; tests/test_golden_spinn.py, tests/test_golden_fno.py).  What remains unpinned is
+PaddlePaddle's own kernel arithmetic (covered by the fp32-vs-fp64 tolerance).
 """
 from __future__ import annotations
 
