@@ -46,7 +46,7 @@ extern "C" int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_poi
   int grid = 0;
   if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
   // one row per workgroup (+ one row for the reduced per-tile hidden-layer weight gradients)
-  return grid + (a.q.NB <= PPSCI_BWD_DUMP_MAX_NB ? 1 : 0);
+  return grid + 1;
 }
 
 static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.n_hidden - 1) * a.q.HP * a.q.HP; }
@@ -54,7 +54,6 @@ static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.
 extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points) {
   BwdArgs a;
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
-  if (a.q.NB > PPSCI_BWD_DUMP_MAX_NB) return 16;
   const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
   const long long fl = ((long long)a.ntiles + chunks) * bwd_per_tile_floats(a);
   return fl * 4 + 16;
@@ -92,7 +91,7 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   a.wpart = (f32x4*)workspace;
   int grid = 0;
   int rc = run_bwd_act(a, stream, 1, &grid);
-  if (rc != PPSCI_OK || a.q.NB > PPSCI_BWD_DUMP_MAX_NB || ppsci_get_bwd_main_only()) return rc;
+  if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
   float* wpart = (float*)workspace;
   float* tmp = wpart + (long long)a.ntiles * bwd_per_tile_floats(a);
   return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, grad_partials + (long long)grid * a.q.P, stream);

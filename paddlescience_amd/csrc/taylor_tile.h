@@ -209,7 +209,6 @@ struct BwdArgs {
 // stage 1 sums chunks of tiles, stage 2 sums the chunks and scatters into the canonical layout of
 // one row of grad_partials (every other entry of that row is set to 0).
 #define PPSCI_WRED_CHUNKS 64
-#define PPSCI_BWD_DUMP_MAX_NB 4  // padded width <= 64: per-tile partials; wider: LDS atomics
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
                        float* row, void* stream);
 

@@ -194,6 +194,20 @@ def test_nonresident_wide_net_and_multi_iteration():
     assert _rel(got, ref) < 5e-6
 
 
+def test_ns_config_shape_5x128_three_outputs():
+    """BASELINE config 3 shape (2 -> 128 x 5 -> 3, S = 5): LDS budget of the lock-step mode and NB = 8 kernels."""
+    net = T.make_net(2, [128] * 5, 3, bias_scale=0.1)
+    rng = np.random.default_rng(8)
+    N = 40
+    X = rng.uniform(-0.05, 0.05, (N, 2)).astype(np.float32).astype(np.float64)
+    Ubar = rng.standard_normal((3, 5, N)).astype(np.float32).astype(np.float64)
+    got = _run_bwd(net, X, np.eye(2), 2, Ubar)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, cache = T.taylor_forward(net32, X, np.eye(2), 2, keep=True)
+    ref = T.flat_grads(*T.taylor_backward(net32, cache, Ubar))
+    assert _rel(got, ref) < 5e-6
+
+
 def test_resident_multi_block_multi_iteration():
     from paddlescience_amd import _lib
 

@@ -12,8 +12,6 @@ import __graft_entry__ as G  # noqa: E402
 VARIANTS = {
     "base": [],
     "timers": ["-DPPSCI_PHASE_TIMERS"],
-    "nt_dump": ["-DPPSCI_DUMP_NT"],
-    "nt_all": ["-DPPSCI_DUMP_NT", "-DPPSCI_STASH_NT"],
     "occ2": ["-DPPSCI_BWD_MIN_WAVES=2"],
     "bwd8occ2": ["-DPPSCI_BWD_MIN_WAVES=2", "-DPPSCI_BWD_WAVES=8"],
     "fwd8": ["-DPPSCI_FWD_WAVES=8"],
@@ -30,7 +28,7 @@ def build_variant(name, extra):
 
     def one(src):
         # only the tanh reverse kernel is rebuilt (bench shape only); everything else comes from the main build
-        if src not in ("taylor_bwd_tanh.hip", "taylor_fwd_tanh.hip"):
+        if src not in ("taylor_bwd_tanh.hip", "taylor_fwd_tanh.hip", "taylor_api.hip", "wgrad_reduce.hip"):
             return os.path.join(ROOT, "build", "gfx950", src.replace(".hip", ".o"))
         obj = os.path.join(out, src.replace(".hip", ".o"))
         subprocess.check_call([G.HIPCC] + G.FLAGS + extra + ["-DPPSCI_VARIANT_MIN", "-c", os.path.join(G.CSRC, src), "-o", obj],

@@ -100,7 +100,36 @@ def tfno(B=16, H=64, W=64):
                       "ms_forward": t_f * 1e3, "ms_train_step": t_s * 1e3, "samples_per_s": B / t_s}), flush=True)
 
 
+def ns(n=125_000):
+    """BASELINE config 3 per-GPU shard: LDC NavierStokes 2-D steady, MLP 2 -> 128 x 5 -> 3 tanh, 125 000
+    collocation points (1 M / 8 GPUs), continuity + momentum_x + momentum_y, MSE-sum with weight 1e-4, Adam."""
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = ppsci.arch.MLP(("x", "y"), ("u", "v", "p"), 5, 128, "tanh")
+    eq = ppsci.equation.NavierStokes(0.01, 1.0, 2, False)
+    X = np.random.default_rng(42).uniform(-0.05, 0.05, (n, 2)).astype(np.float32)
+    keys = ("continuity", "momentum_x", "momentum_y")
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": X[:, :1], "y": X[:, 1:]},
+                       "label": {k: np.zeros((n, 1), np.float32) for k in keys},
+                       "weight": {k: np.full((n, 1), 1e-4, np.float32) for k in keys}},
+           "batch_size": n, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    pde = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("sum"), eq.equations, name="EQ")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"EQ": pde}, "/tmp/out_ns", opt, epochs=1, iters_per_epoch=1)
+    cc = solver._compiled["EQ"]
+
+    def step():
+        solver.engine.forward_backward([cc.fused])
+        opt.step(solver.engine.grad)
+
+    t = timeit(step, reps=10, warm=3)
+    P, S = 2 * 128 + 4 * 128 * 128 + 128 * 3, 5
+    print(json.dumps({"bench": "ldc_navier_stokes_5x128_step", "points": n, "ms": t * 1e3, "points_per_s": n / t,
+                      "matrix_TFLOPs": 6.0 * P * S * n / t / 1e12}), flush=True)
+
+
 if __name__ == "__main__":
+    ns()
     spinn(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
     spectral()
     tfno()
