@@ -182,7 +182,7 @@ def main():
             "config": {"workload": "Allen-Cahn 1D+t, MLP 2->64x4->1 tanh, 100k collocation pts per GPU, "
                                    "residual+MSE-mean+grad+Adam (BASELINE.json configs[1])",
                        "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0, true>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0>", "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel_ms": t_bwd * 1e3,
                          "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12},
