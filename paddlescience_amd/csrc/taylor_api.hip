@@ -55,7 +55,7 @@ extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_
   BwdArgs a;
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
   const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
-  const long long fl = ((long long)a.ntiles + chunks) * bwd_per_tile_floats(a);
+  const long long fl = ((long long)a.ntiles + 1 + chunks) * bwd_per_tile_floats(a);  // + the spare slot
   return fl * 4 + 16;
 }
 
@@ -93,6 +93,6 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   int rc = run_bwd_act(a, stream, 1, &grid);
   if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
   float* wpart = (float*)workspace;
-  float* tmp = wpart + (long long)a.ntiles * bwd_per_tile_floats(a);
+  float* tmp = wpart + ((long long)a.ntiles + 1) * bwd_per_tile_floats(a);
   return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, grad_partials + (long long)grid * a.q.P, stream);
 }
