@@ -11,6 +11,7 @@ one RCCL all-reduce (torch.distributed, SUM) of that flat buffer when world_size
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -84,12 +85,42 @@ class Engine:
         self.beta1, self.beta2, self.eps = beta1, beta2, eps
         self.dp_reduce = dp_reduce
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        # The forward / epilogue / reverse / reduction kernels of all constraints (7 launches per constraint,
+        # every argument a fixed device buffer) are captured once into a HIP graph and replayed: small configs
+        # (Laplace2D: 10 k points, 2 constraints) are launch-bound from Python otherwise.  PPSCI_HIP_GRAPH=0
+        # turns it off; a failed capture falls back to eager launches for good.
+        self.use_graph = params.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0"
+        self._graphs: Dict[tuple, object] = {}
 
-    def forward_backward(self, constraints: Sequence[FusedConstraint]) -> None:
+    def _forward_backward_eager(self, constraints: Sequence[FusedConstraint]) -> None:
         for i, c in enumerate(constraints):
             c.forward(self.params, True)
             c.backward(self.params)
             hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+
+    def forward_backward(self, constraints: Sequence[FusedConstraint]) -> None:
+        if not self.use_graph:
+            return self._forward_backward_eager(constraints)
+        key = tuple(id(c) for c in constraints)
+        g = self._graphs.get(key)
+        if g is None:  # first step with this set of constraints: eager (also the warm-up a capture needs)
+            self._forward_backward_eager(constraints)
+            self._graphs[key] = False
+            return
+        if g is False:
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                    self._forward_backward_eager(constraints)
+                self._graphs[key] = graph
+                graph.replay()
+            except Exception:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+                self.use_graph = False
+                torch.cuda.synchronize()
+                self._forward_backward_eager(constraints)
+            return
+        g.replay()
 
     def allreduce(self) -> None:
         if self.world > 1:
