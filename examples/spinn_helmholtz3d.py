@@ -54,13 +54,15 @@ def main():
         return {"x": state["xc"], "y": state["yc"], "z": state["zc"], "uc": state["uc"]}
 
     constraint = {"PDE": ppsci.constraint.SupervisedConstraint(
-        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": interior, "label": lambda d: {"helmholtz": d["uc"]}}},
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": interior, "label": lambda d: {"helmholtz": d["uc"]}},
+         "shard_in_engine": True},  # multi-GPU: every rank draws the same grid, the engine keeps its x-slab
         output_expr=equation["Helmholtz"].equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")}
     for i in range(6):
         constraint[f"BC{i}"] = ppsci.constraint.SupervisedConstraint(
             {"dataset": {"name": "ContinuousNamedArrayDataset",
                          "input": (lambda i=i: dict(zip(("x", "y", "z"), state["faces"][i]))),
-                         "label": lambda d: {"u": np.zeros([len(d["x"]), len(d["y"]), len(d["z"]), 1], dtype)}}},
+                         "label": lambda d: {"u": np.zeros([len(d["x"]), len(d["y"]), len(d["z"]), 1], dtype)}},
+             "shard_in_engine": True},
             output_expr={"u": lambda out: out["u"]}, loss=ppsci.loss.MSELoss("mean"), name=f"BC{i}")
     sched = ppsci.optimizer.lr_scheduler.ExponentialDecay(cfg["epochs"], cfg["iters_per_epoch"], cfg["learning_rate"],
                                                           cfg["gamma"], cfg["decay_steps"])()

@@ -94,8 +94,12 @@ class InfiniteDataLoader:
 def build_dataloader(_dataset, cfg):
     world, rank = _world()
     if getattr(_dataset, "is_iterable", False):
-        if world > 1:
+        if world > 1 and not cfg.get("shard_in_engine", False):
+            # reference behaviour (data/__init__.py:62-66).  `shard_in_engine: True` is this framework's extension
+            # for separable nets (BASELINE config 5): every rank draws the same tensor-product batch and the
+            # SPINN engine keeps its own x-axis slab of it.
             raise ValueError(f"world_size({world}) should be 1 when using IterableDataset.")
+        _dataset.shard_in_engine = bool(cfg.get("shard_in_engine", False))
         return _dataset
     cfg = copy.deepcopy({k: v for k, v in cfg.items() if k != "dataset"})
     sampler_cfg = cfg.pop("sampler", None)

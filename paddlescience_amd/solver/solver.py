@@ -192,6 +192,8 @@ class Solver:
             bsz = getattr(getattr(cst.data_loader, "batch_sampler", None), "batch_size", 0) or 0
             return OperatorConstraint(name, self.model, cst.output_expr, cst.loss, self.device, list(ds.label_keys), bsz)
         ds = getattr(cst.data_loader, "dataset", cst.data_loader)
+        if getattr(ds, "shard_in_engine", False) and self.world_size > 1:
+            raise NotImplementedError(f"constraint {name}: 'shard_in_engine' datasets are only sharded by the SPINN engine")
         input_keys = list(ds.input_keys)
         label_keys = list(ds.label_keys)
         if hasattr(ds, "weight_fn"):  # ContinuousNamedArrayDataset

@@ -3,7 +3,7 @@
 then one fixed-order reduction per branch into the flat gradient, one all-reduce, one fused Adam.
 Counterpart of the generic engine.py for BASELINE config 5 (examples/spinn/helmholtz3d.py of the
 reference: one PDE constraint on the nc^3 grid + six boundary faces).  Data parallelism shards the
-x-axis points rank-strided (each rank owns an [nx/W, ny, nz] slab); y / z branch nets are replicated."""
+points of one axis rank-strided (each rank owns an [nx/W, ny, nz] slab of the interior grid); branch nets are replicated."""
 from __future__ import annotations
 
 import ctypes as C
@@ -54,10 +54,20 @@ class SpinnConstraint:
         keys = self.model.input_keys
         arrs = [np.asarray(input[k], dtype=np.float32).reshape(-1) for k in keys]
         lab = np.asarray(label[self.label_key], dtype=np.float32)
-        nx_global = arrs[0].shape[0]
-        if self.world > 1 and nx_global >= self.world:
-            arrs[0] = arrs[0][self.rank::self.world]
-            lab = lab.reshape(nx_global, -1)[self.rank::self.world]
+        gshape = tuple(a.shape[0] for a in arrs)
+        rep = 1.0
+        if self.world > 1:
+            # rank-strided slab along the first axis that has at least `world` points (x for the interior grid,
+            # y or z for the boundary faces whose x-axis is a single point); a grid smaller than that on every
+            # axis is evaluated by all ranks and weighted 1/world so that the SUM all-reduce stays exact
+            ax = next((i for i, n in enumerate(gshape) if n >= self.world), None)
+            if ax is None:
+                rep = 1.0 / self.world
+            else:
+                arrs[ax] = arrs[ax][self.rank::self.world]
+                idx = [slice(None)] * 3
+                idx[ax] = slice(self.rank, None, self.world)
+                lab = lab.reshape(gshape)[tuple(idx)]
         shape = tuple(a.shape[0] for a in arrs)
         if self.shape != shape:
             self._alloc(shape)
@@ -67,8 +77,8 @@ class SpinnConstraint:
                 dst.copy_(torch.from_numpy(np.ascontiguousarray(a)))
             self.label.copy_(torch.from_numpy(np.ascontiguousarray(lab.reshape(-1))))
             self._last_ids = ids
-        total_global = nx_global * shape[1] * shape[2]
-        self.desc.scale = float(self.scale_fn(total_global))
+        total_global = gshape[0] * gshape[1] * gshape[2]
+        self.desc.scale = float(self.scale_fn(total_global)) * rep
 
     def forward(self, train: bool):
         m, lib = self.model, L.lib()

@@ -58,6 +58,8 @@ def main():
     outdir, reduction = sys.argv[1], sys.argv[2]
     if reduction == "fno":
         return main_fno(outdir)
+    if reduction == "spinn":
+        return main_spinn(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -70,6 +72,49 @@ def main():
     solver.train()
     pred = solver.predict({"t": np.linspace(0, 1, 11, dtype=np.float32).reshape(-1, 1),
                            "x": np.linspace(-1, 1, 11, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
+                 loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_spinn(outdir):
+    """Separable path: the x-axis points are rank-strided (each rank owns an [nx/W, ny, nz] slab), the loss is
+    normalised by the global grid size, gradients are summed."""
+    import ppsci
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    np.random.seed(11)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), r=4, num_layers=2, hidden_size=16, activation="tanh")
+    eq = ppsci.equation.Helmholtz(3, 1.0)
+    eq.model = model
+    rng = np.random.default_rng(3)
+    shape = (6, 5, 4)
+    xs = [rng.uniform(-1, 1, (n, 1)).astype(np.float32) for n in shape]
+    uc = rng.standard_normal(shape + (1,)).astype(np.float32)
+    data = {"x": xs[0], "y": xs[1], "z": xs[2], "uc": uc}
+    pde = ppsci.constraint.SupervisedConstraint(
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: data, "label": lambda d: {"helmholtz": d["uc"]}},
+         "shard_in_engine": True},
+        output_expr=eq.equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+    face = {"x": np.asarray([[1.0]], np.float32), "y": xs[1], "z": xs[2]}  # x-axis of one point: sharded along y
+    bc = ppsci.constraint.SupervisedConstraint(
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: face,
+                     "label": lambda d: {"u": np.zeros([1, shape[1], shape[2], 1], np.float32)}}, "shard_in_engine": True},
+        output_expr={"u": lambda out: out["u"]}, loss=ppsci.loss.MSELoss("mean"), name="BC0")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PDE": pde, "BC0": bc}, outdir, opt, epochs=2, iters_per_epoch=1, log_freq=1,
+                                 equation={"Helmholtz": eq})
+    solver.train()
+    pred = solver.predict({"x": xs[0], "y": xs[1], "z": xs[2]}, batch_size=None, return_numpy=True)
     if not dist.is_initialized() or dist.get_rank() == 0:
         np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
                  loss=np.asarray(solver.last_losses["loss"]))
