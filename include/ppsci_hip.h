@@ -112,6 +112,10 @@ void ppsci_set_max_grid(int max_blocks);
  * two small tree-reduction kernels, so that HIP events around the call time that one kernel.  The
  * hidden-layer weight-gradient row is then left unwritten.  Default 0. */
 void ppsci_set_bwd_main_only(int on);
+/* Testing knob: nets whose padded width / 16 is at least this use the feature-split ("wide") kernels, in which
+ * the waves of a workgroup share one 16-point tile.  Default 8 (width > 64); 16 keeps width <= 128 on the
+ * single-wave kernels; width > 128 always uses the wide kernels. */
+void ppsci_set_wide_min_nb(int nb);
 /* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
 int ppsci_is_device_build(void);
 

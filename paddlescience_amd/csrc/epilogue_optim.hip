@@ -219,6 +219,9 @@ extern "C" int ppsci_get_max_grid(void) { return g_max_grid; }
 static int g_bwd_main_only = 0;
 extern "C" void ppsci_set_bwd_main_only(int on) { g_bwd_main_only = on ? 1 : 0; }
 extern "C" int ppsci_get_bwd_main_only(void) { return g_bwd_main_only; }
+static int g_wide_min_nb = 8;
+extern "C" void ppsci_set_wide_min_nb(int nb) { g_wide_min_nb = nb; }
+extern "C" int ppsci_get_wide_min_nb(void) { return g_wide_min_nb; }
 
 extern "C" int ppsci_is_device_build(void) {
 #ifdef PPSCI_EMU

@@ -41,6 +41,7 @@ __device__ __forceinline__ void ppsci_wave_sync() {
 
 extern "C" int ppsci_get_max_grid(void);
 extern "C" int ppsci_get_bwd_main_only(void);
+extern "C" int ppsci_get_wide_min_nb(void);
 
 #ifndef PPSCI_FWD_WAVES
 #define PPSCI_FWD_WAVES 8   // waves (16-point tiles in flight) per forward workgroup (8 measured 7% faster than 4)
@@ -72,9 +73,9 @@ static inline int ppsci_derive(const ppsci_mlp_desc* d, ppsci_derived* q) {
   int d0 = 0;
   for (int j = 0; j < d->d_raw; ++j) d0 += (d->embed[j] == PPSCI_EMBED_PERIOD) ? 2 : 1;
   q->d0 = d0;
-  // the kernels are instantiated for NB in {2, 4, 8}: round the padded width up
+  // the kernels are instantiated for NB in {2, 4, 8, 16}: round the padded width up
   int nb = (d->width + 15) / 16;
-  q->NB = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 8 ? 8 : nb));
+  q->NB = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 8 ? 8 : (nb <= 16 ? 16 : nb)));
   q->HP = q->NB * 16;
   int off = 0, fin = d0;
   for (int l = 0; l <= d->n_hidden; ++l) {

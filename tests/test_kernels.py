@@ -89,6 +89,28 @@ def test_fwd_streams_match_oracle(hidden, dout, dirs, n2, act, N):
         assert _rel(got[q], ref[q]) < 2e-6, (q, _rel(got[q], ref[q]))
 
 
+@pytest.mark.parametrize("hidden,dout,n2,N,knob", [([100, 100, 100], 3, 2, 37, 8), ([100, 100, 100], 3, 2, 37, 16),
+                                                   ([200, 200], 2, 1, 21, 8), ([256, 256, 256], 1, 2, 16, 8)])
+def test_fwd_wide_nets(hidden, dout, n2, N, knob):
+    """Feature-split forward kernel (one tile per workgroup, NB/4 waves): width 100 -> NB = 8 with the knob at 8
+    (wide) and at 16 (single-wave kernel), widths 200 / 256 -> NB = 16 (wide only)."""
+    from paddlescience_amd import _lib
+
+    dirs = np.eye(2)
+    net = T.make_net(2, hidden, dout, bias_scale=0.2)
+    X = np.random.default_rng(17).uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    _lib.lib().ppsci_set_wide_min_nb(knob)
+    try:
+        _, _, _, U, st = _run_fwd(net, X, dirs, n2, stash=True)
+    finally:
+        _lib.lib().ppsci_set_wide_min_nb(8)
+    ref = T.taylor_forward(net.astype(np.float32).astype(np.float64), X, dirs, n2).reshape(-1, N)
+    got = U.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all() and np.isfinite(st.cpu().numpy()).all()
+    for q in range(ref.shape[0]):
+        assert _rel(got[q], ref[q]) < 8e-6, (q, _rel(got[q], ref[q]))  # fp32 sums over up to 256 features
+
+
 def test_fwd_period_embedding_and_skip():
     w = 2 * np.pi / 2.0
     net = T.make_net(2, [20, 20, 20], 1, periods={1: float(np.float32(w))}, skip_connection=True, bias_scale=0.2)
@@ -206,6 +228,45 @@ def test_ns_config_shape_5x128_three_outputs():
     _, cache = T.taylor_forward(net32, X, np.eye(2), 2, keep=True)
     ref = T.flat_grads(*T.taylor_backward(net32, cache, Ubar))
     assert _rel(got, ref) < 5e-6
+
+
+@pytest.mark.parametrize("hidden,dout,dirs,n2,N,knob", [
+    ([100, 100, 100], 3, np.eye(2), 2, 37, 8),        # NB = 8, two waves per tile
+    ([128] * 5, 3, np.eye(2), 2, 40, 8),              # BASELINE config 3 shape
+    ([200, 200], 2, [[0, 1], [1, 0]], 1, 21, 8),      # NB = 16 (padded 256), four waves per tile
+    ([256, 256, 256, 256], 1, [[0, 1], [1, 0]], 1, 33, 8),  # reference allen_cahn.yaml width
+    ([72], 1, np.eye(2), 2, 19, 8),                   # single hidden layer: no hidden-to-hidden weights
+])
+def test_bwd_wide_nets(hidden, dout, dirs, n2, N, knob):
+    """Feature-split reverse kernel against the fp64 oracle; one block only so that several tiles share it."""
+    from paddlescience_amd import _lib
+
+    dirs = np.asarray(dirs, dtype=np.float64).reshape(-1, 2)
+    net = T.make_net(2, hidden, dout, bias_scale=0.1)
+    rng = np.random.default_rng(23)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    S = 1 + dirs.shape[0] + n2
+    Ubar = rng.standard_normal((dout, S, N)).astype(np.float32).astype(np.float64)
+    _lib.lib().ppsci_set_wide_min_nb(knob)
+    _lib.lib().ppsci_set_max_grid(2)
+    try:
+        got = _run_bwd(net, X, dirs, n2, Ubar)
+    finally:
+        _lib.lib().ppsci_set_wide_min_nb(8)
+        _lib.lib().ppsci_set_max_grid(0)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+    gW, gb = T.taylor_backward(net32, cache, Ubar)
+    ref = T.flat_grads(gW, gb)
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) < 1e-5, _rel(got, ref)
+    off = 0
+    for w, b in zip(gW, gb):
+        for t in (w, b):
+            n = t.size
+            if np.linalg.norm(t) > 0:
+                assert _rel(got[off:off + n], t.ravel()) < 3e-5
+            off += n
 
 
 def test_resident_multi_block_multi_iteration():
