@@ -17,6 +17,7 @@
 #define PPSCI_LAST_LAUNCH_ERROR() (0)
 #define PPSCI_OCCUPANCY(KERNEL, block, lds, out) (*(out) = 2, 0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define ppsci_block_sync_lds() __syncthreads()
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,13 @@ __device__ __forceinline__ void ppsci_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every in-flight stash
+// prefetch and partial-block store, at each of the ~10 exchange barriers per layer of the feature-split kernels.
+__device__ __forceinline__ void ppsci_block_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 #endif
 
