@@ -51,6 +51,28 @@ def test_allen_cahn_closure_with_period_embedding(tmp_path):
     assert rel(g, gref) < 3e-5
 
 
+def test_allen_cahn_reference_yaml_model_4x256(tmp_path):
+    """The model of /root/reference/examples/allen_cahn/conf/allen_cahn.yaml:38-42 (4 x 256 tanh, periods on x):
+    padded width 256 -> the feature-split kernels with four waves per tile."""
+    w = float(np.float32(2 * np.pi / 2.0))
+    model = ppsci.arch.MLP(("t", "x"), ("u",), 4, 256, "tanh", periods={"x": (2.0, False)})
+    net = T.make_net(2, [256] * 4, 1, periods={1: w}, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 24
+    X = np.random.default_rng(4).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    eq = ppsci.equation.AllenCahn(eps=0.01)
+    cst = _sup_constraint({"t": X[:, :1], "x": X[:, 1:]}, {"allen_cahn": np.zeros((N, 1), np.float32)}, eq.equations,
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("t", "x"), ("u",), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"t": X[:, :1].astype(np.float64), "x": X[:, 1:].astype(np.float64)},
+              exprs={"allen_cahn": R.allen_cahn_fn(0.01)}, label={"allen_cahn": np.zeros((N, 1))}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert solver._compiled["EQ"].fused.losses()["allen_cahn"] == pytest.approx(total, rel=5e-5)
+    assert rel(g, gref) < 1e-4
+
+
 @pytest.mark.parametrize("detach_keys", [None, ("u", "v__y")])
 def test_navier_stokes_2d_sum_loss_with_weights(tmp_path, detach_keys):
     model = ppsci.arch.MLP(("x", "y"), ("u", "v", "p"), 3, 20, "tanh")
