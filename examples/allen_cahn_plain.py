@@ -20,7 +20,7 @@ dtype = "float32"
 
 def main():
     cfg = parse(dict(seed=42, output_dir="./output_allen_cahn", epochs=5, iters_per_epoch=200, batch_size=4096,
-                     num_layers=4, hidden_size=64, learning_rate=1e-3, gamma=0.9, decay_steps=2000, log_freq=100,
+                     num_layers=4, hidden_size=256, learning_rate=1e-3, gamma=0.9, decay_steps=2000, log_freq=100,  # allen_cahn.yaml:38-42
                      period_x=True))
     ppsci.utils.misc.set_random_seed(cfg["seed"])
     logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
