@@ -164,6 +164,23 @@ int ppsci_adam_step(int64_t n, float* params, const float* grad, float* m, float
                     float beta1, float beta2, float eps, int64_t step_t, float grad_scale,
                     void* stream);
 
+/* The other first-order optimizers of ppsci/optimizer/optimizer.py (SGD :39-83, Momentum :86-176, RMSProp :326-383,
+ * AdamW :386-495) as one fused update of the flat parameter buffer.  hyper (HOST array of 7 floats):
+ *   [0] lr  [1] grad_scale  [2] L2Decay coefficient (added to the gradient)  [3..6] a, b, c, d
+ *   SGD       p -= lr g
+ *   MOMENTUM  v = a v + g;  p -= lr (flag ? g + a v : v)                  state1 = v; a = momentum, flag = nesterov
+ *   RMSPROP   r = a r + (1-a) g^2; (flag: mg = a mg + (1-a) g);  v = c v + lr g / sqrt(r - mg^2 + b);  p -= v
+ *             state1 = r, state2 = v, state3 = mg;  a = rho, b = epsilon, c = momentum, flag = centered
+ *   ADAMW     p *= c;  m = a m + (1-a) g;  v = d v + (1-d) g^2;  p -= lr m / (sqrt(v) + b)
+ *             state1 = m, state2 = v;  the caller passes lr = lr_base*sqrt(1-b2^t)/(1-b1^t), b = eps*sqrt(1-b2^t),
+ *             c = 1 - lr_base*weight_decay (decoupled decay), a = beta1, d = beta2 */
+#define PPSCI_OPT_SGD 0
+#define PPSCI_OPT_MOMENTUM 1
+#define PPSCI_OPT_RMSPROP 2
+#define PPSCI_OPT_ADAMW 3
+int ppsci_optim_step(int kind, int64_t n, float* params, const float* grad, float* state1, float* state2,
+                     float* state3, const float* hyper, int flag, void* stream);
+
 /* ---- FNO spectral convolution (BASELINE config 4) --------------------------------------------------
  * Replaces the per-mode complex channel contraction of FactorizedSpectralConv.forward
  * (ppsci/arch/fno_block.py:707-796) = _contract_dense_trick's four real einsums "abcd,becd->aecd"

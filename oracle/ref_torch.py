@@ -436,6 +436,45 @@ class Adam:
         return p - lr_t * (self.m / (np.sqrt(self.v) + self.eps * c2))
 
 
+class FirstOrder:
+    """paddle.optimizer.{SGD, Momentum, RMSProp, AdamW} update rules on a flat numpy vector, as documented by
+    PaddlePaddle for the classes that ppsci/optimizer/optimizer.py:39-176, :326-495 wrap (a float `weight_decay` of
+    SGD / Momentum / RMSProp is L2Decay: coeff * p is added to the gradient; AdamW's is decoupled)."""
+
+    def __init__(self, kind: str, n: int, lr=1e-3, dtype=np.float64, **kw):
+        self.kind, self.lr, self.kw, self.t = kind, lr, kw, 0
+        self.s = [np.zeros(n, dtype) for _ in range(3)]
+
+    def step(self, p: np.ndarray, g: np.ndarray) -> np.ndarray:
+        kw, lr = self.kw, self.lr
+        self.t += 1
+        if self.kind != "adamw":
+            g = g + kw.get("weight_decay", 0.0) * p
+        if self.kind == "sgd":
+            return p - lr * g
+        if self.kind == "momentum":
+            mu = kw["momentum"]
+            self.s[0] = mu * self.s[0] + g
+            return p - lr * ((g + mu * self.s[0]) if kw.get("use_nesterov", False) else self.s[0])
+        if self.kind == "rmsprop":
+            rho, eps, mom = kw.get("rho", 0.95), kw.get("epsilon", 1e-6), kw.get("momentum", 0.0)
+            self.s[0] = rho * self.s[0] + (1 - rho) * g * g
+            mg = 0.0
+            if kw.get("centered", False):
+                self.s[2] = rho * self.s[2] + (1 - rho) * g
+                mg = self.s[2]
+            self.s[1] = mom * self.s[1] + lr * g / np.sqrt(self.s[0] - mg * mg + eps)
+            return p - self.s[1]
+        if self.kind == "adamw":
+            b1, b2, eps, wd = kw.get("beta1", 0.9), kw.get("beta2", 0.999), kw.get("epsilon", 1e-8), kw.get("weight_decay", 0.001)
+            p = p * (1.0 - lr * wd)
+            self.s[0] = b1 * self.s[0] + (1 - b1) * g
+            self.s[1] = b2 * self.s[1] + (1 - b2) * g * g
+            c2 = math.sqrt(1 - b2**self.t)
+            return p - lr * c2 / (1 - b1**self.t) * (self.s[0] / (np.sqrt(self.s[1]) + eps * c2))
+        raise ValueError(self.kind)
+
+
 def exponential_decay_lr(lr0: float, gamma: float, decay_steps: int, step: int, by_epoch=False) -> float:
     """ppsci/optimizer/lr_scheduler.py:212-269: paddle ExponentialDecay with gamma**(1/decay_steps) per step."""
     return lr0 * (gamma ** (1.0 / decay_steps)) ** step

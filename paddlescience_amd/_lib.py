@@ -99,6 +99,8 @@ _SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_adam_step": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
+    "ppsci_optim_step": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_float), C.c_int, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SYMBOLS)

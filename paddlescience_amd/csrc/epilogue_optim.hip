@@ -202,6 +202,58 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   a.p[j] = a.p[j] - a.lr_t * (m / (sqrtf(v) + a.eps_t));
 }
 
+// SGD / Momentum / RMSProp / AdamW on the flat parameter buffer (paddle.optimizer semantics as wrapped by
+// /root/reference/ppsci/optimizer/optimizer.py:39-176, :326-383, :386-495).  hy: lr, grad_scale, l2 (L2Decay
+// coefficient added to the gradient), a, b, c, flag:
+//   SGD       p -= lr g
+//   MOMENTUM  v = a v + g;  p -= lr (flag ? g + a v : v)                          a = momentum, flag = nesterov
+//   RMSPROP   r = a r + (1-a) g^2;  [flag: mg = a mg + (1-a) g]  v = c v + lr g / sqrt(r - mg^2 + b);  p -= v
+//                                                                    a = rho, b = epsilon, c = momentum, flag = centered
+//   ADAMW     p *= (1 - lr_base * coeff) [in hy.c];  then Adam with lr_t (hy.lr) and eps_t (hy.b), a = beta1, flag: beta2 in hy.d
+struct OptimArgs {
+  float* p;
+  const float* g;
+  float* s1;
+  float* s2;
+  float* s3;
+  long long n;
+  int kind, flag;
+  float lr, grad_scale, l2, a, b, c, d;
+};
+
+__global__ void __launch_bounds__(256) optim_kernel(OptimArgs o) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= o.n) return;
+  float p = o.p[j];
+  float g = o.grad_scale * o.g[j] + o.l2 * p;
+  if (o.kind == PPSCI_OPT_SGD) {
+    p -= o.lr * g;
+  } else if (o.kind == PPSCI_OPT_MOMENTUM) {
+    const float v = o.a * o.s1[j] + g;
+    o.s1[j] = v;
+    p -= o.lr * (o.flag ? g + o.a * v : v);
+  } else if (o.kind == PPSCI_OPT_RMSPROP) {
+    const float r = o.a * o.s1[j] + (1.f - o.a) * g * g;
+    o.s1[j] = r;
+    float mg = 0.f;
+    if (o.flag) {
+      mg = o.a * o.s3[j] + (1.f - o.a) * g;
+      o.s3[j] = mg;
+    }
+    const float v = o.c * o.s2[j] + o.lr * g / sqrtf(r - mg * mg + o.b);
+    o.s2[j] = v;
+    p -= v;
+  } else {  // PPSCI_OPT_ADAMW
+    p *= o.c;
+    const float m = o.a * o.s1[j] + (1.f - o.a) * g;
+    const float v = o.d * o.s2[j] + (1.f - o.d) * g * g;
+    o.s1[j] = m;
+    o.s2[j] = v;
+    p -= o.lr * (m / (sqrtf(v) + o.b));
+  }
+  o.p[j] = p;
+}
+
 // ------------------------------------------------------------------------------------ host side
 static thread_local char g_err[512] = "";
 
@@ -345,6 +397,25 @@ extern "C" int ppsci_adam_step(int64_t n, float* params, const float* grad, floa
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("adam_step: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_optim_step(int kind, int64_t n, float* params, const float* grad, float* state1, float* state2,
+                                float* state3, const float* hyper, int flag, void* stream) {
+  if (!params || !grad || !hyper || n <= 0 || kind < PPSCI_OPT_SGD || kind > PPSCI_OPT_ADAMW ||
+      (kind != PPSCI_OPT_SGD && !state1) || ((kind == PPSCI_OPT_RMSPROP || kind == PPSCI_OPT_ADAMW) && !state2) ||
+      (kind == PPSCI_OPT_RMSPROP && flag && !state3)) {
+    ppsci_set_error("optim_step: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  OptimArgs o{params, grad, state1, state2, state3, n, kind, flag,
+              hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+  PPSCI_LAUNCH(optim_kernel, OptimArgs, (int)((n + 255) / 256), 256, 0, stream, o);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("optim_step: launch failed (hip error %d)", err);
     return PPSCI_E_LAUNCH;
   }
   return PPSCI_OK;

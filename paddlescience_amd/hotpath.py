@@ -152,6 +152,20 @@ def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
                                     step_t, grad_scale, _stream_ptr(params)))
 
 
+OPT_SGD, OPT_MOMENTUM, OPT_RMSPROP, OPT_ADAMW = 0, 1, 2, 3
+
+
+def optim_step(kind: int, params: torch.Tensor, grad: torch.Tensor, states: Sequence[Optional[torch.Tensor]],
+               hyper: Sequence[float], flag: bool = False) -> None:
+    """ppsci_optim_step: hyper = [lr, grad_scale, l2, a, b, c, d] (include/ppsci_hip.h)."""
+    _require_device(params)
+    _chk_f32(params, grad, *[t for t in states if t is not None])
+    st = list(states) + [None] * (3 - len(states))
+    hy = (C.c_float * 7)(*[float(v) for v in list(hyper) + [0.0] * (7 - len(hyper))])
+    L.check(L.lib().ppsci_optim_step(kind, params.numel(), _p(params), _p(grad), _p(st[0]), _p(st[1]), _p(st[2]), hy,
+                                     1 if flag else 0, _stream_ptr(params)))
+
+
 # ----------------------------------------------------------------------------- epilogue builder
 class Program:
     """Builds a ppsci_epilogue_desc in SSA form with common-subexpression reuse for loads/consts."""

@@ -1,7 +1,8 @@
 from . import lr_scheduler  # noqa: F401
-from .optimizer import Adam  # noqa: F401
+from .optimizer import LBFGS, SGD, Adam, AdamW, Momentum, OptimizerList, RMSProp  # noqa: F401
 
-__all__ = ["Adam", "lr_scheduler", "build_optimizer", "build_lr_scheduler"]
+__all__ = ["Adam", "AdamW", "SGD", "Momentum", "RMSProp", "LBFGS", "OptimizerList", "lr_scheduler", "build_optimizer",
+           "build_lr_scheduler"]
 
 
 def build_lr_scheduler(cfg, epochs, iters_per_epoch):
@@ -20,5 +21,6 @@ def build_optimizer(cfg, model_list, epochs, iters_per_epoch):
     else:
         sch = lr = build_lr_scheduler(lr_cfg, epochs, iters_per_epoch)
     cls = cfg.pop("name")
-    opt = {"Adam": Adam}[cls](learning_rate=lr, **cfg)(model_list)
+    opt = {"Adam": Adam, "AdamW": AdamW, "SGD": SGD, "Momentum": Momentum, "RMSProp": RMSProp, "LBFGS": LBFGS}[cls](
+        learning_rate=lr, **cfg)(model_list)
     return opt, sch

@@ -135,4 +135,136 @@ class Piecewise(LRBase):
         return self._build(fn)
 
 
-__all__ = ["Constant", "ConstLR", "ExponentialDecay", "Cosine", "Step", "Piecewise"]
+class Linear(LRBase):  # lr_scheduler.py:140-209 -> paddle PolynomialDecay
+    def __init__(self, epochs, iters_per_epoch, learning_rate, end_lr=0.0, power=1.0, cycle=False, warmup_epoch=0,
+                 warmup_start_lr=0.0, last_epoch=-1, by_epoch=False):
+        super().__init__(epochs, iters_per_epoch, learning_rate, warmup_epoch, warmup_start_lr, last_epoch, by_epoch)
+        self.decay_steps = (epochs - self.warmup_epoch) * iters_per_epoch
+        self.end_lr, self.power, self.cycle = end_lr, power, cycle
+        self.warmup_steps = round(self.warmup_epoch * iters_per_epoch)
+        if self.by_epoch:
+            self.decay_steps = self.epochs - self.warmup_epoch
+
+    def __call__(self):
+        if self.decay_steps <= 0:
+            return self._build(lambda t: self.learning_rate)
+
+        def fn(t):
+            n, steps = t, self.decay_steps
+            if self.cycle:
+                div = math.ceil(float(t) / float(self.decay_steps)) if t != 0 else 1
+                steps = self.decay_steps * div
+            else:
+                n = min(t, self.decay_steps)
+            return (self.learning_rate - self.end_lr) * ((1 - float(n) / float(steps)) ** self.power) + self.end_lr
+
+        return self._build(fn)
+
+
+class MultiStepDecay(LRBase):  # lr_scheduler.py:461-520
+    def __init__(self, epochs, iters_per_epoch, learning_rate, milestones: Tuple[int, ...], gamma: float = 0.1,
+                 warmup_epoch=0, warmup_start_lr=0.0, last_epoch=-1, by_epoch=False):
+        super().__init__(epochs, iters_per_epoch, learning_rate, warmup_epoch, warmup_start_lr, last_epoch, by_epoch)
+        self.milestones = list(milestones) if by_epoch else [x * iters_per_epoch for x in milestones]
+        self.gamma = gamma
+
+    def __call__(self):
+        def fn(t):
+            for i, ms in enumerate(self.milestones):
+                if t < ms:
+                    return self.learning_rate * (self.gamma ** i)
+            return self.learning_rate * (self.gamma ** len(self.milestones))
+
+        return self._build(fn)
+
+
+class CosineWarmRestarts(LRBase):  # lr_scheduler.py:523-658 (CosineAnnealingWarmRestarts, stepped sequentially)
+    def __init__(self, epochs, iters_per_epoch, learning_rate, T_0: int, T_mult: int, eta_min: float = 0.0,
+                 warmup_epoch=0, warmup_start_lr=0.0, last_epoch=-1, by_epoch=False):
+        super().__init__(epochs, iters_per_epoch, learning_rate, warmup_epoch, warmup_start_lr, last_epoch, by_epoch)
+        if T_0 <= 0 or not isinstance(T_0, int):
+            raise ValueError(f"Expected positive integer T_0, but got {T_0}")
+        if T_mult < 1 or not isinstance(T_mult, int):
+            raise ValueError(f"Expected integer T_mult >= 1, but got {T_mult}")
+        self.T_0 = T_0 if by_epoch else T_0 * iters_per_epoch
+        self.T_mult, self.eta_min = T_mult, eta_min
+
+    def __call__(self):
+        def fn(t):
+            t_cur, t_i = t, self.T_0  # position inside the current cycle
+            while t_cur >= t_i:
+                t_cur -= t_i
+                t_i *= self.T_mult
+            return self.eta_min + (self.learning_rate - self.eta_min) * (1 + math.cos(math.pi * t_cur / t_i)) / 2
+
+        return self._build(fn)
+
+
+class OneCycleLR(LRBase):  # lr_scheduler.py:661-741 -> paddle.optimizer.lr.OneCycleLR
+    def __init__(self, epochs, iters_per_epoch, max_learning_rate, divide_factor=25.0, end_learning_rate=0.0001,
+                 phase_pct=0.3, anneal_strategy="cos", three_phase=False, warmup_epoch=0, warmup_start_lr=0.0,
+                 last_epoch=-1, by_epoch=False):
+        super().__init__(epochs, iters_per_epoch, max_learning_rate, warmup_epoch, warmup_start_lr, last_epoch, by_epoch)
+        self.total_steps = epochs if by_epoch else epochs * iters_per_epoch
+        self.divide_factor, self.end_learning_rate, self.phase_pct = divide_factor, end_learning_rate, phase_pct
+        if anneal_strategy not in ("cos", "linear"):
+            raise ValueError(f"'anneal_strategy' must by one of 'cos' or 'linear', but received {anneal_strategy}")
+        self.anneal_strategy, self.three_phase = anneal_strategy, three_phase
+
+    def __call__(self):
+        max_lr, total = self.learning_rate, self.total_steps
+        initial, min_lr = max_lr / float(self.divide_factor), float(self.end_learning_rate)
+        if self.three_phase:
+            if self.phase_pct >= 0.5:
+                raise ValueError("When three_phase is True, 'phase_pct' must be less than 0.5")
+            cfg = [0, self.phase_pct * total - 1, 2 * self.phase_pct * total - 2, total - 1, total - 1]
+            lrs = [initial, max_lr, initial, min_lr]
+        else:
+            cfg = [0, self.phase_pct * total - 1, total - 1, total - 1]
+            lrs = [initial, max_lr, min_lr]
+        sizes = [cfg[i + 1] - cfg[i] for i in range(len(cfg) - 1)]
+
+        def anneal(a, b, pct):
+            if self.anneal_strategy == "cos":
+                return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1)
+            return (b - a) * pct + a
+
+        def fn(t):
+            for i, (end_step, size) in enumerate(zip(cfg[1:], sizes)):
+                if t <= end_step or i == len(lrs) - 2:
+                    return anneal(lrs[i], lrs[i + 1], (t - cfg[i]) / size)
+            return min_lr
+
+        return self._build(fn)
+
+
+class LambdaDecay(LRBase):  # lr_scheduler.py:744-804
+    def __init__(self, epochs, iters_per_epoch, learning_rate, lr_lambda: Callable, warmup_epoch=0, warmup_start_lr=0.0,
+                 last_epoch=-1, by_epoch=False, verbose=False):
+        super().__init__(epochs, iters_per_epoch, learning_rate, warmup_epoch, warmup_start_lr, last_epoch, by_epoch, verbose)
+        self.lr_lambda = lr_lambda
+
+    def __call__(self):
+        return self._build(lambda t: self.learning_rate * self.lr_lambda(t))
+
+
+class SchedulerList:  # lr_scheduler.py:807-843
+    def __init__(self, scheduler_list):
+        self._sch_list = tuple(scheduler_list)
+        self.by_epoch = False
+
+    def step(self):
+        for sch in self._sch_list:
+            sch.step()
+
+    def get_lr(self):
+        return self._sch_list[0].get_lr()
+
+    def _set_by_epoch(self, by_epoch: bool):
+        self.by_epoch = by_epoch
+        for sch in self._sch_list:
+            sch.by_epoch = by_epoch
+
+
+__all__ = ["Constant", "ConstLR", "ExponentialDecay", "Cosine", "Step", "Piecewise", "Linear", "MultiStepDecay",
+           "CosineWarmRestarts", "OneCycleLR", "LambdaDecay", "SchedulerList"]

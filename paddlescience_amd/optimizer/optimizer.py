@@ -1,4 +1,5 @@
-"""ppsci.optimizer.Adam (/root/reference/ppsci/optimizer/optimizer.py:179-248): a factory called with the
+"""ppsci.optimizer.{Adam, AdamW, SGD, Momentum, RMSProp, LBFGS}
+(/root/reference/ppsci/optimizer/optimizer.py:39-495).  Adam (:179-248): a factory called with the
 model(s); the returned object owns the Adam moments and performs the fused HIP update on the model's
 flat parameter buffer (paddle.optimizer.Adam semantics, beta1=0.9 beta2=0.999 epsilon=1e-8).
 weight_decay / grad_clip / amsgrad / lazy_mode of the reference signature are rejected when set."""
@@ -60,3 +61,217 @@ class Adam:
                 raise NotImplementedError("one model per optimizer on the fused HIP path")
             model_list = model_list[0]
         return _AdamState(model_list, self.learning_rate, self.beta1, self.beta2, self.epsilon)
+
+
+def _single(model_list):
+    if isinstance(model_list, (list, tuple)):
+        if len(model_list) != 1:
+            raise NotImplementedError("one model per optimizer on the fused HIP path")
+        return model_list[0]
+    return model_list
+
+
+def _l2(weight_decay) -> float:
+    if weight_decay is None:
+        return 0.0
+    if isinstance(weight_decay, (int, float)):
+        return float(weight_decay)  # paddle: a float means L2Decay(coeff)
+    raise NotImplementedError("regularizer objects (L1Decay / L2Decay instances) are not supported; pass a float")
+
+
+class _FusedState:
+    """Common part of the fused first-order optimizers: flat state tensors + one ppsci_optim_step per step."""
+
+    kind = hp.OPT_SGD
+    n_states = 0
+
+    def __init__(self, model, learning_rate):
+        self.model = model
+        self._lr = learning_rate
+        self.t = 0
+        self.states = [torch.zeros_like(model.flat_params) for _ in range(self.n_states)]
+        self._parameter_list = model.parameters()
+
+    def get_lr(self) -> float:
+        return float(self._lr.get_lr()) if hasattr(self._lr, "get_lr") else float(self._lr)
+
+    def set_lr(self, lr: float):
+        self._lr = lr
+
+    def clear_grad(self):
+        pass
+
+    def state_dict(self):
+        d = {f"s{i}": t for i, t in enumerate(self.states)}
+        d["t"] = self.t
+        # checkpoint files use the Adam field names (utils/save_load.py)
+        d["m"] = self.states[0] if self.states else torch.zeros(1)
+        d["v"] = self.states[1] if len(self.states) > 1 else torch.zeros(1)
+        return d
+
+    def set_state_dict(self, state):
+        for i, t in enumerate(self.states):
+            key = f"s{i}" if f"s{i}" in state else ("m", "v")[i] if i < 2 else None
+            if key is not None and key in state:
+                t.copy_(torch.as_tensor(state[key]).to(t.device))
+        self.t = int(state.get("t", 0))
+
+
+class _SGDState(_FusedState):
+    def __init__(self, model, lr, l2):
+        super().__init__(model, lr)
+        self.l2 = l2
+
+    def step(self, grad, grad_scale: float = 1.0):
+        self.t += 1
+        hp.optim_step(hp.OPT_SGD, self.model.flat_params, grad, [], [self.get_lr(), grad_scale, self.l2])
+
+
+class _MomentumState(_FusedState):
+    n_states = 1
+
+    def __init__(self, model, lr, momentum, l2, nesterov):
+        super().__init__(model, lr)
+        self.momentum, self.l2, self.nesterov = momentum, l2, nesterov
+
+    def step(self, grad, grad_scale: float = 1.0):
+        self.t += 1
+        hp.optim_step(hp.OPT_MOMENTUM, self.model.flat_params, grad, self.states,
+                      [self.get_lr(), grad_scale, self.l2, self.momentum], self.nesterov)
+
+
+class _RMSPropState(_FusedState):
+    n_states = 3
+
+    def __init__(self, model, lr, rho, epsilon, momentum, l2, centered):
+        super().__init__(model, lr)
+        self.rho, self.epsilon, self.momentum, self.l2, self.centered = rho, epsilon, momentum, l2, centered
+
+    def step(self, grad, grad_scale: float = 1.0):
+        self.t += 1
+        hp.optim_step(hp.OPT_RMSPROP, self.model.flat_params, grad, self.states,
+                      [self.get_lr(), grad_scale, self.l2, self.rho, self.epsilon, self.momentum], self.centered)
+
+
+class _AdamWState(_FusedState):
+    n_states = 2
+
+    def __init__(self, model, lr, beta1, beta2, epsilon, weight_decay):
+        super().__init__(model, lr)
+        self.beta1, self.beta2, self.epsilon, self.weight_decay = beta1, beta2, epsilon, weight_decay
+
+    @property
+    def m(self):
+        return self.states[0]
+
+    @property
+    def v(self):
+        return self.states[1]
+
+    def step(self, grad, grad_scale: float = 1.0):
+        self.t += 1
+        lr = self.get_lr()
+        c2 = (1.0 - self.beta2 ** self.t) ** 0.5
+        lr_t = lr * c2 / (1.0 - self.beta1 ** self.t)
+        hp.optim_step(hp.OPT_ADAMW, self.model.flat_params, grad, self.states,
+                      [lr_t, grad_scale, 0.0, self.beta1, self.epsilon * c2, 1.0 - lr * self.weight_decay, self.beta2])
+
+
+class SGD:
+    def __init__(self, learning_rate=0.001, weight_decay=None, grad_clip=None):
+        if grad_clip is not None:
+            raise NotImplementedError("grad_clip has no fused HIP kernel yet")
+        self.learning_rate, self.l2 = learning_rate, _l2(weight_decay)
+
+    def __call__(self, model_list):
+        return _SGDState(_single(model_list), self.learning_rate, self.l2)
+
+
+class Momentum:
+    def __init__(self, learning_rate, momentum: float, weight_decay=None, grad_clip=None, use_nesterov: bool = False,
+                 no_weight_decay_name: Optional[str] = None):
+        if grad_clip is not None or no_weight_decay_name:
+            raise NotImplementedError("grad_clip / no_weight_decay_name have no fused HIP kernel yet")
+        self.learning_rate, self.momentum, self.l2, self.nesterov = learning_rate, momentum, _l2(weight_decay), use_nesterov
+
+    def __call__(self, model_list):
+        return _MomentumState(_single(model_list), self.learning_rate, self.momentum, self.l2, self.nesterov)
+
+
+class RMSProp:
+    def __init__(self, learning_rate, rho: float = 0.95, epsilon: float = 1e-6, momentum: float = 0.0, weight_decay=None,
+                 grad_clip=None, centered: bool = False):
+        if grad_clip is not None:
+            raise NotImplementedError("grad_clip has no fused HIP kernel yet")
+        self.args = (learning_rate, rho, epsilon, momentum, _l2(weight_decay), centered)
+
+    def __call__(self, model_list):
+        return _RMSPropState(_single(model_list), *self.args)
+
+
+class AdamW:
+    def __init__(self, learning_rate=0.001, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8,
+                 weight_decay: float = 0.001, grad_clip=None, no_weight_decay_name: Optional[str] = None,
+                 one_dim_param_no_weight_decay: bool = False, amsgrad: bool = False):
+        if grad_clip is not None or no_weight_decay_name or one_dim_param_no_weight_decay or amsgrad:
+            raise NotImplementedError("grad_clip / per-parameter weight-decay masks / amsgrad have no fused HIP kernel yet")
+        self.args = (learning_rate, beta1, beta2, epsilon, weight_decay)
+
+    def __call__(self, model_list):
+        return _AdamWState(_single(model_list), *self.args)
+
+
+class _LBFGSState:
+    """paddle.optimizer.LBFGS as wrapped by optimizer.py:251-323: the two-loop recursion and the strong-Wolfe line
+    search run on the flat parameter vector (torch.optim.LBFGS, the same minFunc port); every closure evaluation is
+    one fused forward + reverse pass of the HIP engine (+ the all-reduce)."""
+
+    is_lbfgs = True
+
+    def __init__(self, model, lr, max_iter, max_eval, tolerance_grad, tolerance_change, history_size, line_search_fn):
+        self.model = model
+        self._lr = lr
+        self.t = 0
+        self._p = torch.nn.Parameter(model.flat_params, requires_grad=True)  # shares storage with flat_params
+        self._opt = torch.optim.LBFGS([self._p], lr=lr, max_iter=max_iter, max_eval=max_eval,
+                                      tolerance_grad=tolerance_grad, tolerance_change=tolerance_change,
+                                      history_size=history_size, line_search_fn=line_search_fn)
+        self._parameter_list = model.parameters()
+
+    def get_lr(self) -> float:
+        return float(self._lr)
+
+    def step(self, closure):
+        """closure() -> (loss: float, grad: flat tensor)."""
+        self.t += 1
+
+        def _c():
+            loss, grad = closure()
+            self._p.grad = grad.detach().clone()
+            return torch.as_tensor(float(loss), dtype=torch.float32, device=self._p.device)
+
+        return self._opt.step(_c)
+
+    def clear_grad(self):
+        self._p.grad = None
+
+    def state_dict(self):
+        return {"m": torch.zeros(1), "v": torch.zeros(1), "t": self.t}
+
+    def set_state_dict(self, state):
+        self.t = int(state.get("t", 0))
+
+
+class LBFGS:
+    def __init__(self, learning_rate: float = 1.0, max_iter: int = 1, max_eval: Optional[int] = None,
+                 tolerance_grad: float = 1e-07, tolerance_change: float = 1e-09, history_size: int = 100,
+                 line_search_fn: Optional[str] = "strong_wolfe"):
+        self.args = (learning_rate, max_iter, max_eval, tolerance_grad, tolerance_change, history_size, line_search_fn)
+
+    def __call__(self, model_list):
+        return _LBFGSState(_single(model_list), *self.args)
+
+
+class OptimizerList:
+    def __init__(self, optimizer_list):
+        raise NotImplementedError("OptimizerList (several optimizers over model groups) is not supported on the flat-buffer path")

@@ -138,7 +138,7 @@ class Solver:
             self.engine = OperatorEngine(self.model)
         else:
             self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
-        if self.optimizer is not None and not self._is_spinn and not self._is_operator:
+        if self.optimizer is not None and not self._is_spinn and not self._is_operator and hasattr(self.optimizer, "beta1"):
             self.engine.m, self.engine.v = self.optimizer.m, self.optimizer.v
             self.engine.beta1, self.engine.beta2, self.engine.eps = (self.optimizer.beta1, self.optimizer.beta2,
                                                                     self.optimizer.epsilon)
@@ -239,10 +239,26 @@ class Solver:
                         else:
                             cc.bind(inp, lab, w)
                 reader_cost = time.perf_counter() - reader_tic
-                self.engine.forward_backward(csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts])
-                self.engine.allreduce()
-                self.optimizer.step(self.engine.grad,
-                                    (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0)
+                eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts]
+                gscale = (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0
+                if getattr(self.optimizer, "is_lbfgs", False):
+                    # train_LBFGS_epoch_func (solver/train.py:216-315): the optimizer re-evaluates loss + gradient
+                    def closure():
+                        self.engine.forward_backward(eng_csts)
+                        self.engine.allreduce()
+                        self._update_train_loss()
+                        total = self.last_losses["loss"]
+                        if self.world_size > 1:  # the line search must see the same value on every rank
+                            tt = torch.tensor([total], dtype=torch.float64, device=self.device)
+                            dist.all_reduce(tt)
+                            total = float(tt[0]) * (gscale if gscale != 1.0 else 1.0)
+                        return total, self.engine.grad * gscale if gscale != 1.0 else self.engine.grad
+
+                    self.optimizer.step(closure)
+                else:
+                    self.engine.forward_backward(eng_csts)
+                    self.engine.allreduce()
+                    self.optimizer.step(self.engine.grad, gscale)
                 self.optimizer.clear_grad()
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
                     self.lr_scheduler.step()
