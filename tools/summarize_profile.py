@@ -10,9 +10,10 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out_stem = sys.argv[2] if len(sys.argv) > 2 else f"{tag}_bench"  # profiles/<out_stem>_{kernel_stats.csv,pmc_summary.json}
 src = os.path.join("gpurun_out", f"prof_{tag}")
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(os.path.join(src, "trace", "ac_kernel_stats.csv"), os.path.join("profiles", f"{tag}_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "trace", "ac_kernel_stats.csv"), os.path.join("profiles", f"{out_stem}_kernel_stats.csv"))
 summary = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_wait"):
     path = os.path.join(src, sub, "ac_counter_collection.csv")
@@ -31,5 +32,5 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_wait"):
 for k, e in summary.items():
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0
-json.dump(summary, open(os.path.join("profiles", f"{tag}_bench_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+json.dump(summary, open(os.path.join("profiles", f"{out_stem}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in summary.items()}, indent=1))
