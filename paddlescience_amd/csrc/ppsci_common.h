@@ -57,7 +57,9 @@ extern "C" int ppsci_get_wide_min_nb(void);
 #ifndef PPSCI_BWD_WAVES
 #define PPSCI_BWD_WAVES 4   // waves per reverse-sweep workgroup
 #endif
-#define PPSCI_NUM_CU 256
+#ifndef PPSCI_NUM_CU
+#define PPSCI_NUM_CU 256         // MI355X; the CPU emulator build uses 4 so that multi-round paths stay cheap to test
+#endif
 #define PPSCI_TILE 16            // collocation points per wave tile (= MFMA N)
 #define PPSCI_SCR_LD 20          // row stride (floats) of the per-wave 16x16 transpose scratch
 #define PPSCI_SCR_FLOATS (16 * PPSCI_SCR_LD)

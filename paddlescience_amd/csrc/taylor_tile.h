@@ -175,6 +175,7 @@ struct FwdArgs {
   int ntiles;
   int iters;     // tile iterations per wave (uniform over the grid)
   int resident;  // 1: all hidden-layer fragments stay in LDS; 0: re-staged per layer (lock-step)
+  int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
 };
 
 struct BwdArgs {
@@ -190,6 +191,7 @@ struct BwdArgs {
   int ntiles;
   int iters;
   int resident;
+  int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
 };
 
 // Two-stage, fixed-order reduction of the per-tile hidden-weight gradient partials (wgrad_reduce.hip):

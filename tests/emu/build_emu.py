@@ -25,7 +25,7 @@ def build() -> str:
     lib = os.path.join(OUT, "libppsci_emu.so")
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "ppsci_hip.h"),
                                                        os.path.join(ROOT, "tests", "emu", "hip_emu.h")]
-    flags = ["-x", "c++", "-DPPSCI_EMU", "-O1", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+    flags = ["-x", "c++", "-DPPSCI_EMU", "-DPPSCI_NUM_CU=4", "-O1", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
              "-I", os.path.join(ROOT, "tests", "emu")]
 
     def one(src):
