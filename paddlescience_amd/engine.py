@@ -128,6 +128,10 @@ class Engine:
             return
         g.replay()
 
+    def invalidate_graphs(self) -> None:
+        """Call after changing anything a captured launch holds by value (residual scales of an epilogue)."""
+        self._graphs.clear()
+
     def allreduce(self) -> None:
         if self.world > 1:
             torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)

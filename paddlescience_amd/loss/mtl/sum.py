@@ -1,6 +1,5 @@
 """ppsci.loss.mtl.Sum (/root/reference/ppsci/loss/mtl/sum.py:27-60): left fold `+=` over the loss dict in
-insertion order.  (The per-loss-gradient aggregators AGDA / GradNorm / NTK / PCGrad / Relobralo need one
-reverse sweep per loss term and are not implemented yet.)"""
+insertion order.  (GradNorm / NTK: grad_weight.py; AGDA / PCGrad / Relobralo are not implemented.)"""
 from .base import LossAggregator
 
 

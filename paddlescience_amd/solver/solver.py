@@ -76,8 +76,9 @@ class Solver:
             raise NotImplementedError("AMP / to_static are not available on the fused HIP path (fp32 only)")
         if update_freq != 1:
             raise NotImplementedError("gradient accumulation (update_freq > 1) is not implemented yet")
-        if loss_aggregator is not None and not isinstance(loss_aggregator, mtl.Sum):
-            raise NotImplementedError("only the Sum loss aggregator is fused; per-loss-gradient aggregators are not")
+        if loss_aggregator is not None and not (isinstance(loss_aggregator, mtl.Sum)
+                                                or getattr(loss_aggregator, "per_loss_grad", False)):
+            raise NotImplementedError("loss aggregators on the fused path: Sum, GradNorm, NTK")
         if visualizer:
             raise NotImplementedError("visualizers are out of scope of the hot path")
         self.cfg = cfg
@@ -226,6 +227,8 @@ class Solver:
         self.global_step = self.best_metric["epoch"] * self.iters_per_epoch
         start_epoch = self.best_metric["epoch"] + 1
         csts = list(self._compiled.values())
+        if getattr(self.loss_aggregator, "per_loss_grad", False):
+            self._apply_loss_weights()
         total_batch_size = sum(c.batch_size for c in csts)
         for epoch_id in range(start_epoch, self.epochs + 1):
             batch_tic = time.perf_counter()
@@ -258,6 +261,11 @@ class Solver:
                 else:
                     self.engine.forward_backward(eng_csts)
                     self.engine.allreduce()
+                    if getattr(self.loss_aggregator, "per_loss_grad", False):
+                        # GradNorm / NTK: the step above used the current weights; refresh them from the per-key
+                        # gradient norms at the same parameters (the total gradient is recomputed afterwards)
+                        if self.loss_aggregator.needs_update(self.global_step):
+                            self._update_loss_weights(eng_csts)
                     self.optimizer.step(self.engine.grad, gscale)
                 self.optimizer.clear_grad()
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
@@ -289,6 +297,48 @@ class Solver:
             save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
                                       self.output_dir, "latest", self.equation, print_log=(epoch_id == self.epochs))
 
+    # ------------------------------------------------------------------ per-loss gradient weighting (GradNorm / NTK)
+    def _loss_key_order(self):
+        keys = []
+        for cc in self._compiled.values():
+            for k in cc.label_keys:
+                if k not in keys:
+                    keys.append(k)
+        return keys
+
+    def _apply_loss_weights(self, mask_key=None):
+        """Residual scale = base scale x weight of its key (or, for a masked pass, base scale for one key and 0)."""
+        agg = self.loss_aggregator
+        keys = self._loss_key_order()
+        for cc in self._compiled.values():
+            if not hasattr(cc, "_base_scales"):
+                cc._base_scales = [cc.fused.edesc.res[i].scale for i in range(len(cc.label_keys))]
+            for i, k in enumerate(cc.label_keys):
+                if mask_key is None:
+                    cc.fused.edesc.res[i].scale = cc._base_scales[i] * float(agg.weight[keys.index(k)])
+                else:
+                    cc.fused.edesc.res[i].scale = cc._base_scales[i] if k == mask_key else 0.0
+        self.engine.invalidate_graphs()
+
+    def _update_loss_weights(self, eng_csts):
+        if self._is_spinn or self._is_operator:
+            raise NotImplementedError("GradNorm / NTK need the fused PINN engine")
+        saved = self.engine.grad.clone()
+        saved_terms = [cc.fused.loss_terms.clone() for cc in self._compiled.values()]
+        norms = []
+        for k in self._loss_key_order():
+            self._apply_loss_weights(mask_key=k)
+            self.engine.forward_backward(eng_csts)
+            self.engine.allreduce()
+            norms.append(float(torch.linalg.norm(self.engine.grad)))
+        self.loss_aggregator.update(norms)
+        self._apply_loss_weights()
+        # gradient of THIS step's weighted loss (old weights), which is what the optimizer consumes; the masked
+        # passes overwrote the loss terms too, but those are re-evaluated by the next step before being logged
+        self.engine.grad.copy_(saved)
+        for cc, t in zip(self._compiled.values(), saved_terms):
+            cc.fused.loss_terms.copy_(t)
+
     def _update_train_loss(self):
         """printer.update_train_loss: total `loss` = Sum aggregator over all terms (mtl/sum.py:45-60), plus one
         entry per constraint = sum of its keys (expression.py:120-126)."""
@@ -301,6 +351,10 @@ class Solver:
             else:
                 vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
                 keys = cc.label_keys
+                if getattr(self.loss_aggregator, "per_loss_grad", False) and hasattr(cc, "_base_scales"):
+                    # the kernels applied the aggregator's weights through the residual scales: report raw terms
+                    order = self._loss_key_order()
+                    vals = {k: vals[k] / max(float(self.loss_aggregator.weight[order.index(k)]), 1e-30) for k in keys}
             per_cst[name] = 0.0
             for k in keys:
                 per_cst[name] += vals[k]
