@@ -92,7 +92,17 @@ typedef struct ppsci_residual {
   int32_t weight;  /* aux index of the per-point weight array, or -1 for 1      */
   int32_t area;    /* aux index of the "area" array (mse.py:92-93), or -1       */
   float scale;
+  int32_t kind;    /* PPSCI_LOSS_*: how a point's difference d = v - label enters the sum */
 } ppsci_residual;
+/* per-point term, W = weight * area (1 when absent):
+ *   MSE      scale * W * d^2          MSELoss            loss/mse.py:82-105
+ *   ABS      scale * W * |d|          L1Loss / MAELoss   loss/l1.py:93-118, mae.py:85-108   ([N,1] variables)
+ *   SQRTABS  scale * sqrt(W) * |d|    L2Loss             loss/l2.py:88-113 (weights sit under the square root)
+ *   ABSREL   scale * weight * |d| / |label|   L2RelLoss  loss/l2.py:280-310 (no area factor) */
+#define PPSCI_LOSS_MSE 0
+#define PPSCI_LOSS_ABS 1
+#define PPSCI_LOSS_SQRTABS 2
+#define PPSCI_LOSS_ABSREL 3
 
 typedef struct ppsci_epilogue_desc {
   int32_t n_instr;

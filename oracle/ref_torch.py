@@ -363,6 +363,43 @@ def mse_loss(output_dict, label_dict, weight_dict=None, reduction="mean", weight
     return losses
 
 
+def point_loss(kind, output_dict, label_dict, weight_dict=None, reduction="mean", weight=None):
+    """L1Loss (l1.py:93-118), MAELoss (mae.py:85-108), L2Loss (l2.py:88-113), L2RelLoss (l2.py:280-310)."""
+    losses = {}
+    for key in label_dict:
+        x, y = output_dict[key], label_dict[key]
+        w = weight_dict[key] if (weight_dict and key in weight_dict) else None
+        if kind in ("l1", "mae"):
+            loss = (x - y).abs()
+            if w is not None:
+                loss = loss * w
+            if "area" in output_dict:
+                loss = loss * output_dict["area"]
+            if kind == "l1":
+                loss = loss.sum(dim=1)
+        elif kind == "l2":
+            loss = (x - y) ** 2
+            if w is not None:
+                loss = loss * w
+            if "area" in output_dict:
+                loss = loss * output_dict["area"]
+            loss = loss.sum(dim=1).sqrt()
+        elif kind == "l2rel":
+            n = x.shape[0]
+            loss = torch.linalg.norm((x - y).reshape(n, -1), dim=1) / torch.linalg.norm(y.reshape(n, -1), dim=1)
+            if w is not None:
+                loss = loss * w.reshape(n)
+        else:
+            raise ValueError(kind)
+        loss = loss.sum() if reduction == "sum" else loss.mean()
+        if isinstance(weight, (float, int)):
+            loss = loss * weight
+        elif isinstance(weight, dict) and key in weight:
+            loss = loss * weight[key]
+        losses[key] = loss
+    return losses
+
+
 def loss_sum(losses: Dict[str, torch.Tensor]):  # mtl/sum.py:45-60
     total = 0.0
     for i, k in enumerate(losses):
@@ -393,7 +430,10 @@ def train_forward(
         wd = None
         if c.get("weight"):
             wd = {k: torch.tensor(np.asarray(v), dtype=model.dtype) for k, v in c["weight"].items()}
-        losses = mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
+        if c.get("loss_kind", "mse") == "mse":
+            losses = mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
+        else:
+            losses = point_loss(c["loss_kind"], output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
         name = c.get("name", f"c{ci}")
         losses_constraint[name] = 0.0
         for k in losses:

@@ -68,7 +68,8 @@ class CompiledConstraint:
         for k in label_keys:
             losses.append(dict(key=k, label=LABEL_PREFIX + k, weight=(WEIGHT_PREFIX + k) if k in weight_keys else None,
                                area="area" if "area" in input_keys else None,
-                               scale=loss.term_scale(k, n_global) if loss is not None else 0.0))
+                               scale=loss.term_scale(k, n_global) if loss is not None else 0.0,
+                               kind=getattr(loss, "term_kind", 0) if loss is not None else 0))
         self.low = graph.lower(outputs, losses, extra_outputs)
         self.batch_size = batch_size
         self.label_keys = list(label_keys)

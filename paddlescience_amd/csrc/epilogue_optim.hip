@@ -85,13 +85,21 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
       const float rv = v[rs.value];
       if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
       const float lab = (rs.label >= 0) ? a.aux[rs.label][pp] : 0.f;
-      float w = rs.scale;
+      float w = 1.f;
       if (rs.weight >= 0) w *= a.aux[rs.weight][pp];
-      if (rs.area >= 0) w *= a.aux[rs.area][pp];
+      if (rs.area >= 0 && rs.kind != PPSCI_LOSS_ABSREL) w *= a.aux[rs.area][pp];
       const float diff = rv - lab;
       if (valid) {
-        lsum[k] += w * diff * diff;
-        adj[rs.value] += 2.f * w * diff;
+        if (rs.kind == PPSCI_LOSS_MSE) {
+          w *= rs.scale;
+          lsum[k] += w * diff * diff;
+          adj[rs.value] += 2.f * w * diff;
+        } else {
+          float f = rs.scale * (rs.kind == PPSCI_LOSS_SQRTABS ? sqrtf(w) : w);
+          if (rs.kind == PPSCI_LOSS_ABSREL) f /= fabsf(lab);
+          lsum[k] += f * fabsf(diff);
+          adj[rs.value] += diff > 0.f ? f : (diff < 0.f ? -f : 0.f);
+        }
       }
     }
     // ---- reverse
@@ -340,7 +348,8 @@ extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, co
   }
   for (int k = 0; k < e->n_res; ++k) {
     const ppsci_residual& r = e->res[k];
-    if (r.value < 0 || r.value >= e->n_instr || r.label >= e->n_aux || r.weight >= e->n_aux || r.area >= e->n_aux) {
+    if (r.value < 0 || r.value >= e->n_instr || r.label >= e->n_aux || r.weight >= e->n_aux || r.area >= e->n_aux ||
+        r.kind < PPSCI_LOSS_MSE || r.kind > PPSCI_LOSS_ABSREL) {
       ppsci_set_error("epilogue: bad residual %d", k);
       return PPSCI_E_INVALID;
     }

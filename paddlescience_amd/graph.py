@@ -377,7 +377,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         lab = aux_index(ls["label"]) if ls.get("label") else -1
         w = aux_index(ls["weight"]) if ls.get("weight") else -1
         ar = aux_index(ls["area"]) if ls.get("area") else -1
-        prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0))
+        prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0), ls.get("kind", 0))
         loss_keys.append(key)
     for name in extra_outputs:
         prog.residual(val[id(outputs[name])], -1, -1, -1, 0.0)
