@@ -38,7 +38,7 @@ extern "C" {
 #define PPSCI_MAX_AUX 16    /* auxiliary per-point arrays (labels, weights, sdf, ...) */
 
 enum { PPSCI_OK = 0, PPSCI_E_INVALID = -1, PPSCI_E_UNSUPPORTED = -2, PPSCI_E_LAUNCH = -3 };
-enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2 };
+enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGMOID = 3, PPSCI_ACT_COS = 4, PPSCI_ACT_GELU = 5 };
 enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1 };
 
 /* ppsci.arch.MLP (mlp.py:179-315) + the derivative set ppsci.autodiff would be asked for

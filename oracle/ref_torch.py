@@ -75,6 +75,12 @@ class MLP:
             return y * torch.sigmoid(y)  # activation.py:87-88
         if self.activation == "sin":
             return torch.sin(y)
+        if self.activation == "cos":
+            return torch.cos(y)
+        if self.activation == "sigmoid":
+            return torch.sigmoid(y)
+        if self.activation == "gelu":
+            return torch.nn.functional.gelu(y)  # nn.GELU() default: exact erf form
         raise ValueError(self.activation)
 
     def forward_tensor(self, x):  # mlp.py:281-296

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 
 MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16, 128, 8, 16
 
-ACT = {"tanh": 0, "silu": 1, "sin": 2}
+ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5}
 EMBED_NONE, EMBED_PERIOD = 0, 1
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,

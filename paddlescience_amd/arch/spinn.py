@@ -94,6 +94,8 @@ class SPINN(Arch):
             raise NotImplementedError("SPINN options beyond plain ModifiedMLP branches have no HIP kernel yet")
         self.input_keys, self.output_keys, self.r = tuple(input_keys), tuple(output_keys), r
         self.activation = act_mod.get_activation(activation)
+        if self.activation not in ("tanh", "silu", "sin"):
+            raise NotImplementedError(f"SPINN branch nets: activation {activation!r} has no HIP kernel (tanh, silu, sin)")
         self.spec = ModifiedMLPSpec(num_layers, hidden_size, r * len(output_keys), self.activation)
         self.branch_params = self.spec.n_params
         self.flat_params = torch.zeros(3 * self.branch_params, dtype=torch.float32, device=get_device())

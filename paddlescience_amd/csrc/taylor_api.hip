@@ -27,6 +27,9 @@ static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_TANH: return ppsci_fwd_run_tanh(a, stream, launch, grid);
     case PPSCI_ACT_SILU: return ppsci_fwd_run_silu(a, stream, launch, grid);
     case PPSCI_ACT_SIN: return ppsci_fwd_run_sin(a, stream, launch, grid);
+    case PPSCI_ACT_SIGMOID: return ppsci_fwd_run_sigmoid(a, stream, launch, grid);
+    case PPSCI_ACT_COS: return ppsci_fwd_run_cos(a, stream, launch, grid);
+    case PPSCI_ACT_GELU: return ppsci_fwd_run_gelu(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }
@@ -36,6 +39,9 @@ static int run_bwd_act(BwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_TANH: return ppsci_bwd_run_tanh(a, stream, launch, grid);
     case PPSCI_ACT_SILU: return ppsci_bwd_run_silu(a, stream, launch, grid);
     case PPSCI_ACT_SIN: return ppsci_bwd_run_sin(a, stream, launch, grid);
+    case PPSCI_ACT_SIGMOID: return ppsci_bwd_run_sigmoid(a, stream, launch, grid);
+    case PPSCI_ACT_COS: return ppsci_bwd_run_cos(a, stream, launch, grid);
+    case PPSCI_ACT_GELU: return ppsci_bwd_run_gelu(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }

@@ -53,6 +53,25 @@ __device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, flo
     d1 = g + z * g1;
     d2 = g1 * (2.f + z * t);
     d3 = 3.f * g1 * t + z * (g1 * t * t - 2.f * g1 * g1);
+  } else if (ACT == PPSCI_ACT_SIGMOID) {  // nn.Sigmoid
+    float g = 1.f / (1.f + expf(-z));
+    s = g;
+    d1 = g * (1.f - g);
+    d2 = d1 * (1.f - 2.f * g);
+    d3 = d1 * (1.f - 6.f * d1);
+  } else if (ACT == PPSCI_ACT_COS) {  // activation.py Cos
+    float sn = sinf(z);
+    s = cosf(z);
+    d1 = -sn;
+    d2 = -s;
+    d3 = sn;
+  } else if (ACT == PPSCI_ACT_GELU) {  // nn.GELU (exact, erf): x Phi(x)
+    const float phi = 0.3989422804014327f * expf(-0.5f * z * z);
+    const float Phi = 0.5f * (1.f + erff(z * 0.7071067811865476f));
+    s = z * Phi;
+    d1 = Phi + z * phi;
+    d2 = phi * (2.f - z * z);
+    d3 = phi * z * (z * z - 4.f);
   } else {
     s = sinf(z);
     float c = cosf(z);
@@ -206,9 +225,15 @@ int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntil
 int ppsci_fwd_run_tanh(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_silu(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sin(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_gelu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_cos(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_sigmoid(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_tanh(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_silu(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_gelu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_cos(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_sigmoid(BwdArgs& a, void* stream, int launch, int* grid_out);
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
 // LDS carve sizes (floats)

@@ -74,6 +74,9 @@ def _rel(a, b):
         ([20, 20], 3, np.eye(2), 2, "silu", 70),          # NS stream set, 3 outputs, >1 block
         ([24, 24, 24], 2, np.eye(2), 0, "sin", 5),
         ([16], 1, np.zeros((0, 2)), 0, "tanh", 33),       # plain forward, single hidden layer
+        ([20, 20], 1, np.eye(2), 2, "sigmoid", 21),
+        ([20, 20], 1, np.eye(2), 2, "cos", 21),
+        ([20, 20], 1, np.eye(2), 2, "gelu", 21),
     ],
 )
 def test_fwd_streams_match_oracle(hidden, dout, dirs, n2, act, N):
@@ -146,6 +149,9 @@ def _run_bwd(net, X, dirs, n2, Ubar):
         ([20, 20], 3, np.eye(2), 2, "silu", 70),
         ([24, 24, 24], 2, np.eye(2), 0, "sin", 5),
         ([16], 1, np.zeros((0, 2)), 0, "tanh", 33),
+        ([20, 20], 1, np.eye(2), 2, "sigmoid", 21),
+        ([20, 20], 1, np.eye(2), 2, "cos", 21),
+        ([20, 20, 20], 1, np.eye(2), 2, "gelu", 21),
         ([40, 40, 40], 1, np.eye(2), 2, "tanh", 19),     # NB = 4 (H=40 padded to 64)
         ([64, 64, 64, 64], 1, [[0, 1], [1, 0]], 1, "tanh", 40),  # bench shape: register-accumulator path
         ([20, 20, 20, 20, 20], 1, np.eye(2), 2, "tanh", 25),     # reference laplace2d.yaml depth (5x20)

@@ -41,7 +41,7 @@ def test_ns_expression_strings():
     )
 
 
-@pytest.mark.parametrize("act", ["tanh", "silu", "sin"])
+@pytest.mark.parametrize("act", ["tanh", "silu", "sin", "sigmoid", "cos", "gelu"])
 def test_laplace2d_streams_match_reverse_over_reverse(act):
     net = T.make_net(2, [20, 20, 20], 1, activation=act, bias_scale=0.1)
     X = _pts(37, 2)
