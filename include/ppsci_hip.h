@@ -57,6 +57,7 @@ typedef struct ppsci_mlp_desc {
   int32_t embed[PPSCI_MAX_IN];   /* PPSCI_EMBED_* per raw input (PeriodEmbedding mlp.py:95-114) */
   float omega[PPSCI_MAX_IN];     /* 2*pi/period for PERIOD inputs                            */
   float dirs[PPSCI_MAX_DIRS][PPSCI_MAX_IN];
+  float act_scale;               /* pre-activation multiplier w0 (activation.py:91-104 Siren: sin(30 z)); 0 means 1 */
 } ppsci_mlp_desc;
 
 /* Epilogue program: the pointwise part of a constraint -- the sympy operator tree that

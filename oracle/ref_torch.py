@@ -75,6 +75,8 @@ class MLP:
             return y * torch.sigmoid(y)  # activation.py:87-88
         if self.activation == "sin":
             return torch.sin(y)
+        if self.activation == "siren":
+            return torch.sin(30.0 * y)
         if self.activation == "cos":
             return torch.cos(y)
         if self.activation == "sigmoid":

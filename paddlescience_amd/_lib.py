@@ -14,6 +14,7 @@ from typing import List, Optional, Sequence
 MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16, 128, 8, 16
 
 ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5}
+SIREN_W0 = 30.0  # activation.py:98
 EMBED_NONE, EMBED_PERIOD = 0, 1
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
@@ -26,6 +27,7 @@ class MlpDesc(C.Structure):
         ("d_raw", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32), ("d_out", C.c_int32),
         ("activation", C.c_int32), ("skip_connection", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
         ("embed", C.c_int32 * MAX_IN), ("omega", C.c_float * MAX_IN), ("dirs", (C.c_float * MAX_IN) * MAX_DIRS),
+        ("act_scale", C.c_float),
     ]
 
 
@@ -160,6 +162,8 @@ def make_mlp_desc(d_raw: int, n_hidden: int, width: int, d_out: int, activation:
                   omega: Optional[Sequence[float]] = None) -> MlpDesc:
     d = MlpDesc()
     d.d_raw, d.n_hidden, d.width, d.d_out = d_raw, n_hidden, width, d_out
+    if activation == "siren":  # sin(30 z): the sin kernels with the pre-activation multiplier
+        activation, d.act_scale = "sin", SIREN_W0
     if activation not in ACT:
         raise NotImplementedError(f"activation {activation!r} has no HIP kernel (supported: {sorted(ACT)})")
     d.activation = ACT[activation]

@@ -113,9 +113,13 @@ class MLP(Arch):
     def _init_parameters(self):
         """paddle nn.Linear default: Xavier-uniform weight, zero bias (Paddle behaviour, SURVEY.md 8c);
         drawn from numpy's global RNG so that ppsci.utils.misc.set_random_seed controls it."""
-        for w, b in [(l.weight, l.bias) for l in self.linears] + [(self.last_fc.weight, self.last_fc.bias)]:
+        layers = [(l.weight, l.bias) for l in self.linears] + [(self.last_fc.weight, self.last_fc.bias)]
+        for i, (w, b) in enumerate(layers):
             fin, fout = w.shape
             lim = math.sqrt(6.0 / (fin + fout))
+            if self.activation == "siren" and i < len(self.linears):
+                # mlp.py:256-260 / activation.py:106-136: first layer U(-1/in, 1/in), hidden U(+-sqrt(6/in)/w0)
+                lim = 1.0 / fin if i == 0 else math.sqrt(6.0 / fin) / L.SIREN_W0
             w.copy_(torch.from_numpy(np.random.uniform(-lim, lim, size=(fin, fout)).astype(np.float32)))
             b.zero_()
 

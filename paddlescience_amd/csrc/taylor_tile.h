@@ -100,7 +100,8 @@ __device__ __forceinline__ void ppsci_act_from_stash(float v, float& s, float& d
 
 // mlp.py:286-291: `skip = y; y = y + skip` on even hidden layers after the first one.
 __device__ __forceinline__ float ppsci_zscale(const ppsci_mlp_desc& d, int layer) {
-  return (d.skip_connection && (layer & 1) == 0 && layer >= 2) ? 2.f : 1.f;
+  const float w0 = d.act_scale != 0.f ? d.act_scale : 1.f;  // Siren: act(w0 * z)
+  return ((d.skip_connection && (layer & 1) == 0 && layer >= 2) ? 2.f : 1.f) * w0;
 }
 
 // Sum over the 16 lanes of a DPP row (= over the 16 points of the tile, lanes sharing g).

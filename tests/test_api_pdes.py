@@ -144,6 +144,35 @@ def test_poisson_and_mixed_derivative_and_output_transform(tmp_path):
     assert rel(g, gref) < 5e-5
 
 
+def test_siren_mlp_laplace_residual_and_initialisation(tmp_path):
+    """activation "siren" (activation.py:91-136): sin(30 z) with the first-layer / hidden-layer uniform
+    initialisation of mlp.py:256-260; residual and parameter gradient against torch autograd."""
+    ppsci.utils.misc.set_random_seed(3)
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 3, 20, "siren")
+    w = [l.weight.cpu().numpy() for l in model.linears]
+    assert np.abs(w[0]).max() <= 1.0 / 2 and np.abs(w[0]).max() > 0.4
+    lim = np.sqrt(6.0 / 20) / 30.0
+    assert np.abs(w[1]).max() <= lim and np.abs(w[1]).max() > 0.9 * lim
+    assert float(model.linears[1].bias.abs().max()) == 0.0
+    net = T.make_net(2, [20, 20, 20], 1, activation="siren", bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 40
+    X = np.random.default_rng(2).uniform(-1, 1, (N, 2)).astype(np.float32)
+    eq = ppsci.equation.Laplace(dim=2)
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"laplace": np.zeros((N, 1), np.float32)}, eq.equations,
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("x", "y"), ("u",), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={"laplace": R.lambdify(R.laplace_exprs(2)["laplace"], omodel)}, label={"laplace": np.zeros((N, 1))},
+              reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    # the factor 30 amplifies the fp32 rounding of every pre-activation: looser than the tanh cases
+    assert solver._compiled["EQ"].fused.losses()["laplace"] == pytest.approx(total, rel=2e-4)
+    assert rel(g, gref) < 2e-4
+
+
 def test_autodiff_errors_follow_reference():
     from paddlescience_amd.graph import Sym
 

@@ -77,6 +77,7 @@ def _rel(a, b):
         ([20, 20], 1, np.eye(2), 2, "sigmoid", 21),
         ([20, 20], 1, np.eye(2), 2, "cos", 21),
         ([20, 20], 1, np.eye(2), 2, "gelu", 21),
+        ([20, 20, 20], 1, np.eye(2), 2, "siren", 21),
     ],
 )
 def test_fwd_streams_match_oracle(hidden, dout, dirs, n2, act, N):
@@ -88,8 +89,10 @@ def test_fwd_streams_match_oracle(hidden, dout, dirs, n2, act, N):
     ref = T.taylor_forward(net32, X, dirs, n2).reshape(-1, N)
     got = U.cpu().numpy().astype(np.float64)
     assert np.isfinite(got).all()
+    # siren: sin(30 z) turns the fp32 rounding of z (1e-7 relative) into 30x that much phase error per layer
+    tol = 4e-5 if act == "siren" else 2e-6
     for q in range(ref.shape[0]):
-        assert _rel(got[q], ref[q]) < 2e-6, (q, _rel(got[q], ref[q]))
+        assert _rel(got[q], ref[q]) < tol, (q, _rel(got[q], ref[q]))
 
 
 @pytest.mark.parametrize("hidden,dout,n2,N,knob", [([100, 100, 100], 3, 2, 37, 8), ([100, 100, 100], 3, 2, 37, 16),
@@ -152,6 +155,7 @@ def _run_bwd(net, X, dirs, n2, Ubar):
         ([20, 20], 1, np.eye(2), 2, "sigmoid", 21),
         ([20, 20], 1, np.eye(2), 2, "cos", 21),
         ([20, 20, 20], 1, np.eye(2), 2, "gelu", 21),
+        ([20, 20, 20], 1, np.eye(2), 2, "siren", 21),
         ([40, 40, 40], 1, np.eye(2), 2, "tanh", 19),     # NB = 4 (H=40 padded to 64)
         ([64, 64, 64, 64], 1, [[0, 1], [1, 0]], 1, "tanh", 40),  # bench shape: register-accumulator path
         ([20, 20, 20, 20, 20], 1, np.eye(2), 2, "tanh", 25),     # reference laplace2d.yaml depth (5x20)
@@ -170,14 +174,15 @@ def test_bwd_param_grads_match_oracle(hidden, dout, dirs, n2, act, N):
     gW, gb = T.taylor_backward(net32, cache, Ubar)
     ref = T.flat_grads(gW, gb)
     assert np.isfinite(got).all()
-    assert _rel(got, ref) < 5e-6, _rel(got, ref)
+    amp = 20.0 if act == "siren" else 1.0  # sin(30 z): 30x the phase error per layer (see the forward test)
+    assert _rel(got, ref) < 5e-6 * amp, _rel(got, ref)
     # per-tensor check so that a small tensor cannot hide behind a big one
     off = 0
     for w, b in zip(gW, gb):
         for t in (w, b):
             n = t.size
             if np.linalg.norm(t) > 0:
-                assert _rel(got[off:off + n], t.ravel()) < 2e-5
+                assert _rel(got[off:off + n], t.ravel()) < 2e-5 * amp
             else:
                 assert np.abs(got[off:off + n]).max() < 1e-6
             off += n
