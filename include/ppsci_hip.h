@@ -76,6 +76,10 @@ enum {
   PPSCI_OP_ABS, PPSCI_OP_SINH, PPSCI_OP_COSH, PPSCI_OP_TAN,
   PPSCI_OP_MAX, PPSCI_OP_MIN, PPSCI_OP_SIGN, PPSCI_OP_HEAVISIDE,
   PPSCI_OP_DETACH,    /* identity forward, blocks the adjoint (DetachNode) */
+  /* the rest of SYMPY_TO_PADDLE (symbolic.py:79-108) */
+  PPSCI_OP_ASIN, PPSCI_OP_ACOS, PPSCI_OP_ATAN, PPSCI_OP_ATAN2, /* atan2(v[a], v[b]) */
+  PPSCI_OP_ASINH, PPSCI_OP_ACOSH, PPSCI_OP_ATANH, PPSCI_OP_ERF, PPSCI_OP_LGAMMA,
+  PPSCI_OP_CEIL, PPSCI_OP_FLOOR,
   PPSCI_OP_COUNT
 };
 

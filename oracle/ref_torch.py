@@ -239,6 +239,10 @@ _UNARY = {
     sp.sin: torch.sin, sp.cos: torch.cos, sp.exp: torch.exp, sp.tanh: torch.tanh,
     sp.log: torch.log, sp.sqrt: torch.sqrt, sp.Abs: torch.abs, sp.sinh: torch.sinh,
     sp.cosh: torch.cosh, sp.tan: torch.tan,
+    # the rest of SYMPY_TO_PADDLE, symbolic.py:79-108
+    sp.asin: torch.asin, sp.acos: torch.acos, sp.atan: torch.atan, sp.asinh: torch.asinh, sp.acosh: torch.acosh,
+    sp.atanh: torch.atanh, sp.erf: torch.erf, sp.loggamma: torch.lgamma, sp.sign: torch.sign,
+    sp.ceiling: torch.ceil, sp.floor: torch.floor,
 }
 
 
@@ -281,6 +285,17 @@ def lambdify(expr: sp.Basic, model: MLP, dtype=None) -> Callable[[Dict[str, torc
                 data[key] = torch.pow(data[cvt_to_key(n.args[0])], data[cvt_to_key(n.args[1])])
             elif isinstance(n, sp.Function) and str(n.func) == DETACH_FUNC_NAME:
                 data[key] = data[cvt_to_key(n.args[0])].detach()
+            elif n.func in (sp.Max, sp.Min):  # symbolic.py:241-262: pairwise left fold
+                f = torch.maximum if n.func == sp.Max else torch.minimum
+                val = data[cvt_to_key(n.args[0])]
+                for a in n.args[1:]:
+                    val = f(val, data[cvt_to_key(a)])
+                data[key] = val
+            elif n.func == sp.Heaviside:  # symbolic.py:237-239: paddle.heaviside(x, 0)
+                x = data[cvt_to_key(n.args[0])]
+                data[key] = torch.heaviside(x, torch.zeros((), dtype=x.dtype))
+            elif n.func == sp.atan2:
+                data[key] = torch.atan2(data[cvt_to_key(n.args[0])], data[cvt_to_key(n.args[1])])
             elif isinstance(n, sp.Function) and n.func in _UNARY:
                 data[key] = _UNARY[n.func](data[cvt_to_key(n.args[0])])
             elif isinstance(n, sp.Function):  # LayerNode symbolic.py:406-430

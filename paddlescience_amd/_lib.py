@@ -19,7 +19,8 @@ EMBED_NONE, EMBED_PERIOD = 0, 1
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
  OP_TANH, OP_EXP, OP_LOG, OP_SQRT, OP_ABS, OP_SINH, OP_COSH, OP_TAN, OP_MAX, OP_MIN, OP_SIGN, OP_HEAVISIDE,
- OP_DETACH, OP_COUNT) = range(26)
+ OP_DETACH, OP_ASIN, OP_ACOS, OP_ATAN, OP_ATAN2, OP_ASINH, OP_ACOSH, OP_ATANH, OP_ERF, OP_LGAMMA, OP_CEIL, OP_FLOOR,
+ OP_COUNT) = range(37)
 
 
 class MlpDesc(C.Structure):

@@ -31,6 +31,23 @@ struct EpiArgs {
   int iters;
 };
 
+// d/dx lgamma(x) (the adjoint of paddle.lgamma): reflection for x < 0.5, recurrence up to x >= 6, then the
+// asymptotic series ln x - 1/(2x) - 1/(12x^2) + 1/(120x^4) - 1/(252x^6)  (truncation < 1e-8 at x = 6).
+__device__ __forceinline__ float epi_digamma(float x) {
+  float refl = 0.f;
+  if (x < 0.5f) {
+    refl = -3.14159265358979f / tanf(3.14159265358979f * x);
+    x = 1.f - x;
+  }
+  float acc = 0.f;
+  while (x < 6.f) {
+    acc -= 1.f / x;
+    x += 1.f;
+  }
+  const float i1 = 1.f / x, i2 = i1 * i1;
+  return refl + acc + logf(x) - 0.5f * i1 - i2 * (1.f / 12.f - i2 * (1.f / 120.f - i2 * (1.f / 252.f)));
+}
+
 __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
   PPSCI_DYN_SMEM(red);  // [EPI_BLOCK]
   const int tid = threadIdx.x;
@@ -74,6 +91,17 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
         case PPSCI_OP_SIGN: r = (v[ins.a] > 0.f) ? 1.f : ((v[ins.a] < 0.f) ? -1.f : 0.f); break;
         case PPSCI_OP_HEAVISIDE: r = (v[ins.a] > 0.f) ? 1.f : 0.f; break;  // heaviside(x, y=0)
         case PPSCI_OP_DETACH: r = v[ins.a]; break;
+        case PPSCI_OP_ASIN: r = asinf(v[ins.a]); break;
+        case PPSCI_OP_ACOS: r = acosf(v[ins.a]); break;
+        case PPSCI_OP_ATAN: r = atanf(v[ins.a]); break;
+        case PPSCI_OP_ATAN2: r = atan2f(v[ins.a], v[ins.b]); break;
+        case PPSCI_OP_ASINH: r = asinhf(v[ins.a]); break;
+        case PPSCI_OP_ACOSH: r = acoshf(v[ins.a]); break;
+        case PPSCI_OP_ATANH: r = atanhf(v[ins.a]); break;
+        case PPSCI_OP_ERF: r = erff(v[ins.a]); break;
+        case PPSCI_OP_LGAMMA: r = lgammaf(v[ins.a]); break;
+        case PPSCI_OP_CEIL: r = ceilf(v[ins.a]); break;
+        case PPSCI_OP_FLOOR: r = floorf(v[ins.a]); break;
         default: r = 0.f; break;
       }
       v[i] = r;
@@ -141,7 +169,20 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
           case PPSCI_OP_MIN:
             if (v[ins.a] <= v[ins.b]) adj[ins.a] += g; else adj[ins.b] += g;
             break;
-          default: break;  // LD_IN, LD_AUX, CONST, SIGN, HEAVISIDE, DETACH: no adjoint flows
+          case PPSCI_OP_ASIN: adj[ins.a] += g / sqrtf(1.f - v[ins.a] * v[ins.a]); break;
+          case PPSCI_OP_ACOS: adj[ins.a] -= g / sqrtf(1.f - v[ins.a] * v[ins.a]); break;
+          case PPSCI_OP_ATAN: adj[ins.a] += g / (1.f + v[ins.a] * v[ins.a]); break;
+          case PPSCI_OP_ATAN2: {
+            const float y = v[ins.a], x = v[ins.b], inv = 1.f / (x * x + y * y);
+            adj[ins.a] += g * x * inv;
+            adj[ins.b] -= g * y * inv;
+          } break;
+          case PPSCI_OP_ASINH: adj[ins.a] += g / sqrtf(v[ins.a] * v[ins.a] + 1.f); break;
+          case PPSCI_OP_ACOSH: adj[ins.a] += g / sqrtf(v[ins.a] * v[ins.a] - 1.f); break;
+          case PPSCI_OP_ATANH: adj[ins.a] += g / (1.f - v[ins.a] * v[ins.a]); break;
+          case PPSCI_OP_ERF: adj[ins.a] += g * 1.1283791670955126f * expf(-v[ins.a] * v[ins.a]); break;
+          case PPSCI_OP_LGAMMA: adj[ins.a] += g * epi_digamma(v[ins.a]); break;
+          default: break;  // LD_IN, LD_AUX, CONST, SIGN, HEAVISIDE, DETACH, CEIL, FLOOR: no adjoint flows
         }
       }
     }
@@ -337,7 +378,7 @@ extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, co
         ok = ins.a >= 0 && ins.a < i;
         const bool binary = ins.op == PPSCI_OP_ADD || ins.op == PPSCI_OP_SUB || ins.op == PPSCI_OP_MUL ||
                             ins.op == PPSCI_OP_DIV || ins.op == PPSCI_OP_POW || ins.op == PPSCI_OP_MAX ||
-                            ins.op == PPSCI_OP_MIN;
+                            ins.op == PPSCI_OP_MIN || ins.op == PPSCI_OP_ATAN2;
         if (binary) ok = ok && ins.b >= 0 && ins.b < i;
       }
     }

@@ -29,9 +29,11 @@ _UNARY_OPS = {
     "sin": L.OP_SIN, "cos": L.OP_COS, "tanh": L.OP_TANH, "exp": L.OP_EXP, "log": L.OP_LOG, "sqrt": L.OP_SQRT,
     "abs": L.OP_ABS, "sinh": L.OP_SINH, "cosh": L.OP_COSH, "tan": L.OP_TAN, "neg": L.OP_NEG, "sign": L.OP_SIGN,
     "heaviside": L.OP_HEAVISIDE, "detach": L.OP_DETACH,
+    "asin": L.OP_ASIN, "acos": L.OP_ACOS, "atan": L.OP_ATAN, "asinh": L.OP_ASINH, "acosh": L.OP_ACOSH,
+    "atanh": L.OP_ATANH, "erf": L.OP_ERF, "lgamma": L.OP_LGAMMA, "ceil": L.OP_CEIL, "floor": L.OP_FLOOR,
 }
 _BINARY_OPS = {"add": L.OP_ADD, "sub": L.OP_SUB, "mul": L.OP_MUL, "div": L.OP_DIV, "pow": L.OP_POW,
-               "max": L.OP_MAX, "min": L.OP_MIN}
+               "max": L.OP_MAX, "min": L.OP_MIN, "atan2": L.OP_ATAN2}
 
 
 class Sym:
@@ -208,9 +210,26 @@ def diff(e: Sym, var: str) -> Sym:
         if not is_const(db, 0.0):
             out = out + e * apply("log", a[0]) * db
         return out
+    if op == "atan2":  # atan2(y, x)
+        den = a[0] * a[0] + a[1] * a[1]
+        return (a[1] * diff(a[0], var) - a[0] * diff(a[1], var)) / den
     d = diff(a[0], var)
     if is_const(d, 0.0):
         return d
+    if op == "asin":
+        return d / apply("sqrt", 1.0 - a[0] * a[0])
+    if op == "acos":
+        return -(d / apply("sqrt", 1.0 - a[0] * a[0]))
+    if op == "atan":
+        return d / (1.0 + a[0] * a[0])
+    if op == "asinh":
+        return d / apply("sqrt", a[0] * a[0] + 1.0)
+    if op == "acosh":
+        return d / apply("sqrt", a[0] * a[0] - 1.0)
+    if op == "atanh":
+        return d / (1.0 - a[0] * a[0])
+    if op == "erf":
+        return apply("exp", -(a[0] * a[0])) * (2.0 / math.sqrt(math.pi)) * d
     if op == "sin":
         return apply("cos", a[0]) * d
     if op == "cos":
@@ -231,7 +250,7 @@ def diff(e: Sym, var: str) -> Sym:
         return apply("sinh", a[0]) * d
     if op == "tan":
         return (1.0 + e * e) * d
-    if op in ("sign", "heaviside"):
+    if op in ("sign", "heaviside", "ceil", "floor"):
         return Sym.const(0.0)
     raise NotImplementedError(f"derivative of {op!r}")
 

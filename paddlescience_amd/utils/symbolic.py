@@ -23,6 +23,8 @@ DATA_DICT = Dict[str, object]
 _SYMPY_UNARY = {
     sp.sin: "sin", sp.cos: "cos", sp.exp: "exp", sp.tanh: "tanh", sp.log: "log", sp.Abs: "abs",
     sp.sinh: "sinh", sp.cosh: "cosh", sp.tan: "tan", sp.sign: "sign",
+    sp.asin: "asin", sp.acos: "acos", sp.atan: "atan", sp.asinh: "asinh", sp.acosh: "acosh", sp.atanh: "atanh",
+    sp.erf: "erf", sp.loggamma: "lgamma", sp.ceiling: "ceil", sp.floor: "floor",
 }
 
 
@@ -96,6 +98,8 @@ class ComposedNode:
             for a in node.args[2:]:
                 val = apply(op, val, _as_sym(data[_cvt_to_key(a)]))
             return val
+        if node.func == sp.atan2:
+            return apply("atan2", _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
         if node.func == sp.Heaviside:
             return apply("heaviside", _as_sym(data[_cvt_to_key(node.args[0])]))
         if isinstance(node, sp.Function) and str(node.func) == DETACH_FUNC_NAME:  # DetachNode :165-181
@@ -112,7 +116,7 @@ class ComposedNode:
         for node, key in zip(self.sympy_nodes, self.keys):
             if key in data_dict:  # cache hit (also how precomputed 'sdf__x' inputs are used, :314-317)
                 continue
-            if isinstance(node, sp.Function) and node.func not in _SYMPY_UNARY and node.func != sp.Heaviside \
+            if isinstance(node, sp.Function) and node.func not in _SYMPY_UNARY and node.func not in (sp.Heaviside, sp.atan2) \
                     and str(node.func) != DETACH_FUNC_NAME and not isinstance(node, (sp.Max, sp.Min)):
                 # LayerNode symbolic.py:406-430
                 hit = [m for m in self.models if str(node.func) in m.output_keys]

@@ -173,6 +173,32 @@ def test_siren_mlp_laplace_residual_and_initialisation(tmp_path):
     assert rel(g, gref) < 2e-4
 
 
+def test_lambdify_with_the_remaining_sympy_functions(tmp_path):
+    """An expression over SYMPY_TO_PADDLE's less common entries (symbolic.py:79-108) around first and second
+    derivatives of the net: loss and parameter gradient against the oracle's lambdify."""
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 2, 20, "tanh")
+    net = T.make_net(2, [20, 20], 1, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 48
+    X = np.random.default_rng(8).uniform(0.1, 0.9, (N, 2)).astype(np.float32)
+    x, y = sp.symbols("x y")
+    u = sp.Function("u")(x, y)
+    expr = (sp.atan(u.diff(x)) + sp.erf(u) * sp.asinh(u.diff(y, 2)) + sp.atan2(u.diff(x, 2), 1 + x * x)
+            + sp.asin(u / 4) * sp.acos(x / 2) + sp.atanh(y / 2) * u + sp.acosh(2 + u * u)
+            + sp.loggamma(2 + y) * u.diff(y) + sp.floor(4 * x) * u + sp.ceiling(3 * y) * u.diff(x)
+            + sp.Max(u, u.diff(x), 0.1) + sp.Min(u.diff(y), x) + sp.Heaviside(x - 0.5) * u + sp.sign(y - 0.4) * u)
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"r": np.zeros((N, 1), np.float32)}, {"r": expr},
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("x", "y"), ("u",), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={"r": R.lambdify(expr, omodel)}, label={"r": np.zeros((N, 1))}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert solver._compiled["EQ"].fused.losses()["r"] == pytest.approx(total, rel=3e-5)
+    assert rel(g, gref) < 5e-5
+
+
 def test_autodiff_errors_follow_reference():
     from paddlescience_amd.graph import Sym
 

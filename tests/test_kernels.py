@@ -371,6 +371,46 @@ def test_epilogue_detach_blocks_adjoint_and_misc_ops():
     np.testing.assert_allclose(Ubar.cpu().numpy()[1], seed * (a64 - np.sin(x64) * a64**2 / b64**2), rtol=3e-5, atol=1e-6)
 
 
+def test_epilogue_remaining_sympy_map_ops():
+    """asin .. floor of SYMPY_TO_PADDLE (symbolic.py:79-108): values and adjoints against torch fp64 autograd."""
+    import torch
+
+    from paddlescience_amd import _lib as L
+    from paddlescience_amd import hotpath as hp
+
+    rng = np.random.default_rng(4)
+    N = 300
+    U = np.stack([rng.uniform(-0.8, 0.8, N), rng.uniform(1.2, 3.0, N)]).astype(np.float32)
+    pr = hp.Program(2, 0)
+    a, b = pr.ld_u(0), pr.ld_u(1)  # a in (-0.8, 0.8), b in (1.2, 3)
+    terms = [pr.op(L.OP_ASIN, a), pr.op(L.OP_ACOS, a), pr.op(L.OP_ATAN, b), pr.op(L.OP_ATAN2, a, b),
+             pr.op(L.OP_ASINH, b), pr.op(L.OP_ACOSH, b), pr.op(L.OP_ATANH, a), pr.op(L.OP_ERF, a),
+             pr.op(L.OP_LGAMMA, b), pr.op(L.OP_MUL, pr.op(L.OP_CEIL, b), a), pr.op(L.OP_MUL, pr.op(L.OP_FLOOR, b), a),
+             pr.op(L.OP_LGAMMA, pr.op(L.OP_SUB, a, pr.const(1.5)))]  # negative argument: reflection branch
+    coef = [1.0, 0.5, -0.7, 1.3, 0.9, -1.1, 0.6, 1.7, 0.8, 0.25, -0.35, 0.45]
+    r = None
+    for c, t in zip(coef, terms):
+        ct = pr.op(L.OP_MUL, pr.const(c), t)
+        r = ct if r is None else pr.op(L.OP_ADD, r, ct)
+    pr.residual(r, scale=1.0)
+    e = pr.build()
+    rows = hp.epilogue_partial_rows(N)
+    resid = _full((1, N), 0.0)
+    Ubar = _full((2, N), 0.0)
+    part = _full((rows, 1), 0.0)
+    hp.epilogue(e, N, [], _t(U), [], resid, Ubar, part)
+    ta = torch.tensor(U[0].astype(np.float64), requires_grad=True)
+    tb = torch.tensor(U[1].astype(np.float64), requires_grad=True)
+    fs = [torch.asin(ta), torch.acos(ta), torch.atan(tb), torch.atan2(ta, tb), torch.asinh(tb), torch.acosh(tb),
+          torch.atanh(ta), torch.erf(ta), torch.lgamma(tb), torch.ceil(tb) * ta, torch.floor(tb) * ta,
+          torch.lgamma(ta - 1.5)]
+    rr = sum(float(np.float32(c)) * f for c, f in zip(coef, fs))
+    (rr**2).sum().backward()
+    np.testing.assert_allclose(resid.cpu().numpy()[0], rr.detach().numpy(), rtol=5e-6, atol=5e-6)
+    np.testing.assert_allclose(Ubar.cpu().numpy()[0], ta.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(Ubar.cpu().numpy()[1], tb.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_adam_step_matches_oracle():
     from oracle import ref_torch as R
     from paddlescience_amd import hotpath as hp
