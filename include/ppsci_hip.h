@@ -40,6 +40,8 @@ extern "C" {
 enum { PPSCI_OK = 0, PPSCI_E_INVALID = -1, PPSCI_E_UNSUPPORTED = -2, PPSCI_E_LAUNCH = -3 };
 enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGMOID = 3, PPSCI_ACT_COS = 4, PPSCI_ACT_GELU = 5 };
 enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1 };
+/* layer parametrisations handled on the parameter buffers (csrc/reparam.hip) */
+enum { PPSCI_LINEAR_PLAIN = 0, PPSCI_LINEAR_WEIGHT_NORM = 1, PPSCI_LINEAR_RWF = 2, PPSCI_LINEAR_FOURIER = 3 };
 
 /* ppsci.arch.MLP (mlp.py:179-315) + the derivative set ppsci.autodiff would be asked for
  * (ad.py:95-160, 254-303).  Derivatives are *directional*: dirs[i][j] is the component of
@@ -58,6 +60,10 @@ typedef struct ppsci_mlp_desc {
   float omega[PPSCI_MAX_IN];     /* 2*pi/period for PERIOD inputs                            */
   float dirs[PPSCI_MAX_DIRS][PPSCI_MAX_IN];
   float act_scale;               /* pre-activation multiplier w0 (activation.py:91-104 Siren: sin(30 z)); 0 means 1 */
+  int32_t fourier_half;          /* > 0: FourierEmbedding (mlp.py:117-136) with fourier_half frequencies runs as
+                                    hidden layer 0: matrix [B, B] ([d0, 2*fourier_half], 2*fourier_half == width),
+                                    zero bias, cos on features < fourier_half and sin on the rest; n_hidden counts
+                                    it; the skip quirk / act_scale apply to the layers after it; tanh nets only */
 } ppsci_mlp_desc;
 
 /* Epilogue program: the pointwise part of a constraint -- the sympy operator tree that
@@ -195,6 +201,20 @@ int ppsci_adam_step(int64_t n, float* params, const float* grad, float* m, float
 #define PPSCI_OPT_ADAMW 3
 int ppsci_optim_step(int kind, int64_t n, float* params, const float* grad, float* state1, float* state2,
                      float* state3, const float* hyper, int flag, void* stream);
+
+/* ---- layer parametrisations (csrc/reparam.hip) ---------------------------------------------------------
+ * The Taylor kernels read ONE plain [in, out] matrix + bias per layer.  Factored or tied layers keep their
+ * trainable tensors elsewhere and are turned into that form before the forward sweep (materialize), and the
+ * gradient of the plain form is mapped back afterwards (pullback):
+ *   PPSCI_LINEAR_PLAIN        W = v                      nn.Linear (copy; used for last_fc of a factored net)
+ *   PPSCI_LINEAR_WEIGHT_NORM  W = g * v / ||v[:, j]||    WeightNormLinear.forward            mlp.py:50-54
+ *   PPSCI_LINEAR_RWF          W = g * v                  RandomWeightFactorization.forward   mlp.py:91-92
+ *   PPSCI_LINEAR_FOURIER      W = [v, v], b_out = 0      FourierEmbedding.kernel [in, out/2] mlp.py:123-136
+ * v: [fin, fout] ([fin, fout/2] for FOURIER), g: [fout], b / b_out / gb / gb_out: [fout] or NULL. */
+int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const float* g, const float* b, float* W,
+                             float* b_out, void* stream);
+int ppsci_linear_pullback(int kind, int fin, int fout, const float* v, const float* g, const float* gW,
+                          const float* gb, float* gv, float* gg, float* gb_out, void* stream);
 
 /* ---- FNO spectral convolution (BASELINE config 4) --------------------------------------------------
  * Replaces the per-mode complex channel contraction of FactorizedSpectralConv.forward

@@ -52,7 +52,11 @@ DETACH_FUNC_NAME = "detach"  # ppsci/equation/pde/base.py:27
 class MLP:
     """Restatement of ppsci.arch.MLP on explicit weights (never default-initialised)."""
 
-    def __init__(self, input_keys, output_keys, net: NetSpec, dtype=torch.float64):
+    def __init__(self, input_keys, output_keys, net: NetSpec, dtype=torch.float64, factor=None, weight_g=None,
+                 fourier_kernel=None):
+        """factor: None | "weight_norm" | "random_weight" -- the hidden `net.weights` are then weight_v and
+        `weight_g` lists one [out] vector per hidden layer (mlp.py:31-92); fourier_kernel: FourierEmbedding.kernel
+        [in, dim/2] (mlp.py:117-136), `net.weights[0]` then has dim rows."""
         self.input_keys = tuple(input_keys)
         self.output_keys = tuple(output_keys)
         self.dtype = dtype
@@ -61,12 +65,27 @@ class MLP:
         self.periods = {self.input_keys[j]: w for j, w in net.periods.items()}
         self.weights = [torch.tensor(w, dtype=dtype, requires_grad=True) for w in net.weights]
         self.biases = [torch.tensor(b, dtype=dtype, requires_grad=True) for b in net.biases]
+        self.factor = factor
+        self.weight_g = [torch.tensor(g, dtype=dtype, requires_grad=True) for g in (weight_g or [])]
+        self.fourier_kernel = (None if fourier_kernel is None
+                               else torch.tensor(fourier_kernel, dtype=dtype, requires_grad=True))
 
     def parameters(self) -> List[torch.Tensor]:
-        out = []
-        for w, b in zip(self.weights, self.biases):
-            out += [w, b]
+        """Registration order of mlp.py:196-277: fourier_emb, linears (weight_v, weight_g, bias), last_fc."""
+        out = [] if self.fourier_kernel is None else [self.fourier_kernel]
+        n_hidden = len(self.weights) - 1
+        for i, (w, b) in enumerate(zip(self.weights, self.biases)):
+            out += [w, self.weight_g[i], b] if (self.factor and i < n_hidden) else [w, b]
         return out
+
+    def _linear(self, i, y):
+        w = self.weights[i]
+        if self.factor == "weight_norm" and i < len(self.weights) - 1:  # mlp.py:50-54
+            norm = torch.linalg.vector_norm(w, ord=2, dim=0, keepdim=True)
+            w = self.weight_g[i] * w / norm
+        elif self.factor == "random_weight" and i < len(self.weights) - 1:  # mlp.py:91-92
+            w = self.weight_g[i] * w
+        return y @ w + self.biases[i]
 
     def _act(self, y):
         if self.activation == "tanh":
@@ -90,7 +109,7 @@ class MLP:
         skip = None
         n_hidden = len(self.weights) - 1
         for i in range(n_hidden):
-            y = y @ self.weights[i] + self.biases[i]
+            y = self._linear(i, y)
             if self.skip_connection and i % 2 == 0:
                 if skip is not None:
                     skip = y
@@ -107,6 +126,8 @@ class MLP:
                 y[k] = torch.cat([torch.cos(w * x[k]), torch.sin(w * x[k])], dim=-1)
             x = y
         t = torch.cat([x[k] for k in self.input_keys], dim=-1)  # base.py:109-112
+        if self.fourier_kernel is not None:  # mlp.py:308-309, :128-136
+            t = torch.cat([torch.cos(t @ self.fourier_kernel), torch.sin(t @ self.fourier_kernel)], dim=-1)
         t = self.forward_tensor(t)
         outs = torch.split(t, 1, dim=-1)  # base.py:145-148
         return {k: v for k, v in zip(self.output_keys, outs)}

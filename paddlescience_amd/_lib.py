@@ -15,6 +15,7 @@ MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16,
 
 ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5}
 SIREN_W0 = 30.0  # activation.py:98
+LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER = range(4)
 EMBED_NONE, EMBED_PERIOD = 0, 1
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
@@ -28,7 +29,7 @@ class MlpDesc(C.Structure):
         ("d_raw", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32), ("d_out", C.c_int32),
         ("activation", C.c_int32), ("skip_connection", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
         ("embed", C.c_int32 * MAX_IN), ("omega", C.c_float * MAX_IN), ("dirs", (C.c_float * MAX_IN) * MAX_DIRS),
-        ("act_scale", C.c_float),
+        ("act_scale", C.c_float), ("fourier_half", C.c_int32),
     ]
 
 
@@ -104,6 +105,10 @@ _SYMBOLS = {
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
     "ppsci_optim_step": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "ppsci_linear_materialize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "ppsci_linear_pullback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SYMBOLS)
@@ -160,8 +165,9 @@ def ptr_array(ptrs: Sequence[int]):
 
 def make_mlp_desc(d_raw: int, n_hidden: int, width: int, d_out: int, activation: str, skip_connection: bool,
                   dirs: Sequence[Sequence[float]], n2: int, embed: Optional[Sequence[int]] = None,
-                  omega: Optional[Sequence[float]] = None) -> MlpDesc:
+                  omega: Optional[Sequence[float]] = None, fourier_half: int = 0) -> MlpDesc:
     d = MlpDesc()
+    d.fourier_half = int(fourier_half)
     d.d_raw, d.n_hidden, d.width, d.d_out = d_raw, n_hidden, width, d_out
     if activation == "siren":  # sin(30 z): the sin kernels with the pre-activation multiplier
         activation, d.act_scale = "sin", SIREN_W0

@@ -8,8 +8,11 @@ Calling the model
   * with traced inputs (graph.Sym, during expression compilation) returns traced network outputs;
   * with tensors / numpy arrays runs the forward kernel (no derivative streams) and returns
     [N, 1] tensors per output key -- the reference's eager `model(input_dict)`.
-Options without a HIP kernel yet (weight_norm, fourier, random_weight, stan/siren/...,
-per-layer widths, input/output transforms on the fused path) raise NotImplementedError."""
+`weight_norm`, `random_weight` and `fourier` keep the reference's trainable tensors (weight_v / weight_g / bias,
+fourier_emb.kernel) in `flat_params`; the kernels read `kernel_params`, which `materialize()` rebuilds from
+them (csrc/reparam.hip), and `pull_back()` maps the kernel-layout gradient to the trainable tensors.
+Options without a HIP kernel yet (stan / swish, per-layer widths, input transforms on the fused path) raise
+NotImplementedError."""
 from __future__ import annotations
 
 import math
@@ -34,6 +37,26 @@ class _Linear:
 
     def parameters(self):
         return [self.weight, self.bias]
+
+
+class _FactoredLinear:
+    """WeightNormLinear / RandomWeightFactorization (mlp.py:31-92): views of weight_v [in, out], weight_g [out], bias."""
+
+    def __init__(self, weight_v: torch.Tensor, weight_g: torch.Tensor, bias: torch.Tensor):
+        self.weight_v, self.weight_g, self.bias = weight_v, weight_g, bias
+
+    def parameters(self):
+        return [self.weight_v, self.weight_g, self.bias]
+
+
+class _Kernel:
+    """FourierEmbedding.kernel [in, dim / 2] (mlp.py:123-126)."""
+
+    def __init__(self, kernel: torch.Tensor):
+        self.kernel = kernel
+
+    def parameters(self):
+        return [self.kernel]
 
 
 class PeriodEmbedding:
@@ -75,8 +98,8 @@ class MLP(Arch):
             hidden = [hidden_size] * num_layers
         else:
             raise ValueError(f"hidden_size should be list of int or int, but got {type(hidden_size)}")
-        if weight_norm or fourier or random_weight:
-            raise NotImplementedError("weight_norm / fourier / random_weight have no fused HIP kernel yet")
+        if weight_norm:
+            random_weight = None  # mlp.py:239-249: weight_norm is tested first
         if input_dim is not None or output_dim is not None:
             raise NotImplementedError("input_dim / output_dim overrides are not supported on the HIP path")
         if len(set(hidden)) != 1:
@@ -84,7 +107,7 @@ class MLP(Arch):
         self.activation = act_mod.get_activation(activation)
         self.skip_connection = bool(skip_connection)
         self.periods = periods
-        self.fourier = None
+        self.fourier = fourier
         embed = [L.EMBED_NONE] * len(self.input_keys)
         omega = [0.0] * len(self.input_keys)
         if periods:
@@ -92,36 +115,144 @@ class MLP(Arch):
             for k, w in self.period_emb.freqs_dict.items():
                 j = self.input_keys.index(k)
                 embed[j], omega[j] = L.EMBED_PERIOD, w
-        self.layout = hp.NetLayout(len(self.input_keys), len(hidden), hidden[0], len(self.output_keys),
-                                   self.activation, self.skip_connection, embed, omega)
-        self.flat_params = torch.zeros(self.layout.n_params, dtype=torch.float32, device=get_device())
+        fourier_half = 0
+        if fourier:
+            # mlp.py:233-237 + FourierEmbedding :117-136.  The kernels run the embedding as a hidden layer of
+            # width fourier["dim"] (matrix [B, B], cos | sin), so it has to equal the hidden width.
+            if int(fourier["dim"]) % 2 != 0:
+                raise ValueError(f"out_features must be even, but got {fourier['dim']}.")
+            if int(fourier["dim"]) != hidden[0] or self.activation != "tanh":
+                raise NotImplementedError("fourier embedding on the HIP path: dim must equal hidden_size, tanh only")
+            fourier_half = int(fourier["dim"]) // 2
+        self._linear_kind = (L.LINEAR_WEIGHT_NORM if weight_norm else L.LINEAR_RWF if random_weight
+                             else L.LINEAR_PLAIN)
+        self._rwf = dict(random_weight) if random_weight else None
+        self.reparam = bool(fourier_half) or self._linear_kind != L.LINEAR_PLAIN
+        self.layout = hp.NetLayout(len(self.input_keys), len(hidden) + (1 if fourier_half else 0), hidden[0],
+                                   len(self.output_keys), self.activation, self.skip_connection, embed, omega,
+                                   fourier_half)
+        dev = get_device()
+        # ---- trainable tensors in the reference's parameters() order (fourier_emb, linears, last_fc)
+        shapes: List[Tuple[str, Tuple[int, ...]]] = []
+        fin = self.layout.d0
+        if fourier_half:
+            shapes.append(("fourier_emb.kernel", (fin, fourier_half)))
+            fin = 2 * fourier_half
+        for l in range(len(hidden)):
+            if self._linear_kind == L.LINEAR_PLAIN:
+                shapes += [(f"linears.{l}.weight", (fin, hidden[0])), (f"linears.{l}.bias", (hidden[0],))]
+            else:  # WeightNormLinear / RandomWeightFactorization: weight_v, weight_g, bias (mlp.py:35-41, :69-75)
+                shapes += [(f"linears.{l}.weight_v", (fin, hidden[0])), (f"linears.{l}.weight_g", (hidden[0],)),
+                           (f"linears.{l}.bias", (hidden[0],))]
+            fin = hidden[0]
+        shapes += [("last_fc.weight", (fin, len(self.output_keys))), ("last_fc.bias", (len(self.output_keys),))]
+        n_train = sum(int(np.prod(shp)) for _, shp in shapes)
+        self.flat_params = torch.zeros(n_train, dtype=torch.float32, device=dev)
         self._names: List[str] = []
         self._views: List[torch.Tensor] = []
         off = 0
-        for name, shp in self.layout.param_shapes():
+        for name, shp in shapes:
             n = int(np.prod(shp))
             self._names.append(name)
             self._views.append(self.flat_params[off:off + n].view(*shp))
             off += n
-        self.linears = [_Linear(self._views[2 * i], self._views[2 * i + 1]) for i in range(len(hidden))]
-        self.last_fc = _Linear(self._views[-2], self._views[-1])
+        byname = dict(zip(self._names, self._views))
+        if self._linear_kind == L.LINEAR_PLAIN:
+            self.linears = [_Linear(byname[f"linears.{l}.weight"], byname[f"linears.{l}.bias"])
+                            for l in range(len(hidden))]
+        else:
+            self.linears = [_FactoredLinear(byname[f"linears.{l}.weight_v"], byname[f"linears.{l}.weight_g"],
+                                            byname[f"linears.{l}.bias"]) for l in range(len(hidden))]
+        self.last_fc = _Linear(byname["last_fc.weight"], byname["last_fc.bias"])
+        self.fourier_emb = _Kernel(byname["fourier_emb.kernel"]) if fourier_half else None
         self.acts = [self.activation] * len(hidden)
+        # ---- what the kernels read: for plain nets the very same buffer, otherwise a second buffer in the
+        # kernel layout (W0, b0, W1, b1, ...) that materialize() fills from the trainable tensors
+        if not self.reparam:
+            self.kernel_params = self.flat_params
+            self._records = []
+        else:
+            assert n_train != 0
+            self.kernel_params = torch.zeros(self.layout.n_params, dtype=torch.float32, device=dev)
+            self._grad_train = torch.zeros_like(self.flat_params)
+            gviews, off = {}, 0
+            for name, shp in shapes:
+                n = int(np.prod(shp))
+                gviews[name] = self._grad_train[off:off + n].view(*shp)
+                off += n
+            kviews, off = [], 0
+            for _, shp in self.layout.param_shapes():
+                n = int(np.prod(shp))
+                kviews.append((off, n, shp))
+                off += n
+            self._records = []  # (kind, fin, fout, v, g, b, kW(off, n), kb(off, n), gv, gg, gb)
+            kl = 0
+            if fourier_half:
+                w, b = kviews[0], kviews[1]
+                self._records.append((L.LINEAR_FOURIER, w[2][0], w[2][1], byname["fourier_emb.kernel"], None, None,
+                                      w, b, gviews["fourier_emb.kernel"], None, None))
+                kl = 1
+            for l in range(len(hidden)):
+                w, b = kviews[2 * (kl + l)], kviews[2 * (kl + l) + 1]
+                if self._linear_kind == L.LINEAR_PLAIN:
+                    nm = f"linears.{l}.weight"
+                    self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], byname[nm], None,
+                                          byname[f"linears.{l}.bias"], w, b, gviews[nm], None,
+                                          gviews[f"linears.{l}.bias"]))
+                else:
+                    self._records.append((self._linear_kind, w[2][0], w[2][1], byname[f"linears.{l}.weight_v"],
+                                          byname[f"linears.{l}.weight_g"], byname[f"linears.{l}.bias"], w, b,
+                                          gviews[f"linears.{l}.weight_v"], gviews[f"linears.{l}.weight_g"],
+                                          gviews[f"linears.{l}.bias"]))
+            w, b = kviews[-2], kviews[-1]
+            self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], byname["last_fc.weight"], None,
+                                  byname["last_fc.bias"], w, b, gviews["last_fc.weight"], None,
+                                  gviews["last_fc.bias"]))
         self._frozen = False
         self._init_parameters()
+
+    # ---- trainable tensors <-> kernel layout (csrc/reparam.hip); both are no-ops for a plain MLP
+    def materialize(self) -> torch.Tensor:
+        """Fill `kernel_params` from the trainable tensors; call before every forward sweep."""
+        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), _, _, _ in self._records:
+            hp.linear_materialize(kind, fin, fout, v, g, b, self.kernel_params[wo:wo + wn],
+                                  self.kernel_params[bo:bo + bn])
+        return self.kernel_params
+
+    def pull_back(self, grad_kernel: torch.Tensor) -> torch.Tensor:
+        """Gradient w.r.t. `kernel_params` -> gradient w.r.t. the trainable tensors (`flat_params` order)."""
+        if not self.reparam:
+            return grad_kernel
+        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), gv, gg, gb in self._records:
+            hp.linear_pullback(kind, fin, fout, v, g, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn], gv, gg, gb)
+        return self._grad_train
 
     # ---- parameters
     def _init_parameters(self):
         """paddle nn.Linear default: Xavier-uniform weight, zero bias (Paddle behaviour, SURVEY.md 8c);
         drawn from numpy's global RNG so that ppsci.utils.misc.set_random_seed controls it."""
-        layers = [(l.weight, l.bias) for l in self.linears] + [(self.last_fc.weight, self.last_fc.bias)]
-        for i, (w, b) in enumerate(layers):
+        if self.fourier_emb is not None:  # nn.initializer.Normal(std=scale), mlp.py:123-126
+            k = self.fourier_emb.kernel
+            k.copy_(torch.from_numpy(np.random.normal(0.0, float(self.fourier["scale"]), size=tuple(k.shape))
+                                     .astype(np.float32)))
+        for i, lin in enumerate(self.linears + [self.last_fc]):
+            w = lin.weight_v if isinstance(lin, _FactoredLinear) else lin.weight
             fin, fout = w.shape
             lim = math.sqrt(6.0 / (fin + fout))
             if self.activation == "siren" and i < len(self.linears):
                 # mlp.py:256-260 / activation.py:106-136: first layer U(-1/in, 1/in), hidden U(+-sqrt(6/in)/w0)
                 lim = 1.0 / fin if i == 0 else math.sqrt(6.0 / fin) / L.SIREN_W0
-            w.copy_(torch.from_numpy(np.random.uniform(-lim, lim, size=(fin, fout)).astype(np.float32)))
-            b.zero_()
+            if isinstance(lin, _FactoredLinear) and self._linear_kind == L.LINEAR_RWF:
+                # mlp.py:78-85: v ~ glorot normal, g ~ N(mean, std); g <- exp(g); v <- v / g
+                vv = np.random.normal(0.0, math.sqrt(2.0 / (fin + fout)), size=(fin, fout)).astype(np.float32)
+                gg = np.exp(np.random.normal(self._rwf["mean"], self._rwf["std"], size=(fout,)).astype(np.float32))
+                lin.weight_v.copy_(torch.from_numpy(vv / gg))
+                lin.weight_g.copy_(torch.from_numpy(gg))
+            else:
+                w.copy_(torch.from_numpy(np.random.uniform(-lim, lim, size=(fin, fout)).astype(np.float32)))
+                if isinstance(lin, _FactoredLinear):
+                    lin.weight_g.fill_(1.0)  # mlp.py:45-46
+            lin.bias.zero_()
 
     def parameters(self) -> List[torch.Tensor]:
         return list(self._views)
@@ -164,7 +295,7 @@ class MLP(Arch):
         n = ins[0].numel()
         desc = self.layout.desc(hp.StreamSpec([], 0))
         U = torch.empty((len(self.output_keys), n), dtype=torch.float32, device=dev)
-        hp.taylor_fwd(desc, self.flat_params, ins, U, None)
+        hp.taylor_fwd(desc, self.materialize(), ins, U, None)
         return {k: U[i].view(n, 1) for i, k in enumerate(self.output_keys)}
 
     def forward(self, x: Dict[str, object]) -> Dict[str, object]:  # mlp.py:298-315

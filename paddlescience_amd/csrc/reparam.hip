@@ -1,0 +1,137 @@
+// reparam.hip -- factored / tied layer parametrisations of ppsci.arch.MLP, applied to the parameter buffers
+// (never to activations): the Taylor kernels always see one plain [in, out] matrix + bias per layer.
+//
+//   WeightNormLinear            /root/reference/ppsci/arch/mlp.py:31-54    W = g * v / ||v||_col
+//   RandomWeightFactorization   /root/reference/ppsci/arch/mlp.py:57-92    W = g * v
+//   FourierEmbedding            /root/reference/ppsci/arch/mlp.py:117-136  [cos(x B), sin(x B)]: the kernels run it as
+//                               a first layer with the matrix [B, B] and zero bias (cos on the first half of its
+//                               features, sin on the second, taylor_tile.h), so B is duplicated here
+//
+// materialize: trainable tensors -> the layer's slice of the kernel parameter buffer (before the forward sweep);
+// pullback   : gradient of that slice -> gradients of the trainable tensors (after the reverse sweep).
+// One thread per output column; a column's rows are read with stride `fout`, so neighbouring threads coalesce.
+// Sizes are at most 256 x 256 per layer: launch-latency sized, not a hot spot.
+#include "ppsci_common.h"
+
+#ifndef PPSCI_EMU
+#include <hip/hip_runtime.h>
+#endif
+
+extern "C" void ppsci_set_error(const char* fmt, ...);
+
+struct ReparamArgs {
+  int kind, fin, fout;
+  const float* v;   // [fin, fout]  (FOURIER: [fin, fout / 2])
+  const float* g;   // [fout]       (WEIGHT_NORM / RWF)
+  const float* b;   // [fout] or null
+  float* W;         // [fin, fout]
+  float* b_out;     // [fout] or null
+  // pullback
+  const float* gW;  // [fin, fout]
+  const float* gb;  // [fout] or null
+  float* gv;
+  float* gg;
+  float* gb_out;
+};
+
+__global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.fout) return;
+  if (a.kind == PPSCI_LINEAR_FOURIER) {
+    const int half = a.fout / 2, jj = j < half ? j : j - half;
+    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = a.v[i * half + jj];
+    if (a.b_out) a.b_out[j] = 0.f;
+    return;
+  }
+  if (a.kind == PPSCI_LINEAR_PLAIN) {
+    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = a.v[i * a.fout + j];
+  } else if (a.kind == PPSCI_LINEAR_RWF) {
+    const float gj = a.g[j];
+    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j];
+  } else {  // weight norm: weight_g * weight_v / norm, in that order (mlp.py:53)
+    float ss = 0.f;
+    for (int i = 0; i < a.fin; ++i) {
+      const float x = a.v[i * a.fout + j];
+      ss += x * x;
+    }
+    const float nrm = sqrtf(ss), gj = a.g[j];
+    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j] / nrm;
+  }
+  if (a.b_out && a.b) a.b_out[j] = a.b[j];
+}
+
+__global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (a.kind == PPSCI_LINEAR_FOURIER) {
+    const int half = a.fout / 2;
+    if (j >= half) return;
+    for (int i = 0; i < a.fin; ++i) a.gv[i * half + j] = a.gW[i * a.fout + j] + a.gW[i * a.fout + j + half];
+    return;
+  }
+  if (j >= a.fout) return;
+  if (a.kind == PPSCI_LINEAR_PLAIN) {
+    for (int i = 0; i < a.fin; ++i) a.gv[i * a.fout + j] = a.gW[i * a.fout + j];
+  } else if (a.kind == PPSCI_LINEAR_RWF) {
+    const float gj = a.g[j];
+    float dot = 0.f;
+    for (int i = 0; i < a.fin; ++i) {
+      const float gw = a.gW[i * a.fout + j];
+      dot += gw * a.v[i * a.fout + j];
+      a.gv[i * a.fout + j] = gw * gj;
+    }
+    a.gg[j] = dot;
+  } else {
+    float ss = 0.f, dot = 0.f;
+    for (int i = 0; i < a.fin; ++i) {
+      const float x = a.v[i * a.fout + j];
+      ss += x * x;
+      dot += a.gW[i * a.fout + j] * x;
+    }
+    const float nrm = sqrtf(ss), gj = a.g[j];
+    const float s = gj / nrm, c = dot / ss;
+    for (int i = 0; i < a.fin; ++i) a.gv[i * a.fout + j] = s * (a.gW[i * a.fout + j] - c * a.v[i * a.fout + j]);
+    a.gg[j] = dot / nrm;
+  }
+  if (a.gb_out && a.gb) a.gb_out[j] = a.gb[j];
+}
+
+static bool reparam_kind_ok(int kind) { return kind >= PPSCI_LINEAR_PLAIN && kind <= PPSCI_LINEAR_FOURIER; }
+
+extern "C" int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const float* g, const float* b,
+                                        float* W, float* b_out, void* stream) {
+  const bool needs_g = kind == PPSCI_LINEAR_WEIGHT_NORM || kind == PPSCI_LINEAR_RWF;
+  if (!reparam_kind_ok(kind) || fin < 1 || fout < 1 || !v || !W || (needs_g && !g) ||
+      (kind == PPSCI_LINEAR_FOURIER && (fout & 1))) {
+    ppsci_set_error("linear_materialize: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  ReparamArgs a{};
+  a.kind = kind, a.fin = fin, a.fout = fout, a.v = v, a.g = g, a.b = b, a.W = W, a.b_out = b_out;
+  PPSCI_LAUNCH(linear_materialize_kernel, ReparamArgs, (fout + 255) / 256, 256, 0, stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("linear_materialize: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_linear_pullback(int kind, int fin, int fout, const float* v, const float* g, const float* gW,
+                                     const float* gb, float* gv, float* gg, float* gb_out, void* stream) {
+  const bool needs_g = kind == PPSCI_LINEAR_WEIGHT_NORM || kind == PPSCI_LINEAR_RWF;
+  if (!reparam_kind_ok(kind) || fin < 1 || fout < 1 || !gW || !gv || (needs_g && (!v || !g || !gg)) ||
+      (kind == PPSCI_LINEAR_FOURIER && (fout & 1))) {
+    ppsci_set_error("linear_pullback: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  ReparamArgs a{};
+  a.kind = kind, a.fin = fin, a.fout = fout, a.v = v, a.g = g, a.gW = gW, a.gb = gb, a.gv = gv, a.gg = gg,
+  a.gb_out = gb_out;
+  PPSCI_LAUNCH(linear_pullback_kernel, ReparamArgs, (fout + 255) / 256, 256, 0, stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("linear_pullback: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

@@ -23,6 +23,13 @@ static int fill_bwd(BwdArgs& a, const ppsci_mlp_desc* d, int64_t n_points) {
 }
 
 static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
+  if (a.d.fourier_half > 0) {
+    if (a.d.activation != PPSCI_ACT_TANH || 2 * a.d.fourier_half != a.d.width || a.d.n_hidden < 2) {
+      ppsci_set_error("fourier embedding: needs a tanh net whose width equals the embedding dimension");
+      return PPSCI_E_UNSUPPORTED;
+    }
+    return ppsci_fwd_run_tanh_fourier(a, stream, launch, grid);
+  }
   switch (a.d.activation) {
     case PPSCI_ACT_TANH: return ppsci_fwd_run_tanh(a, stream, launch, grid);
     case PPSCI_ACT_SILU: return ppsci_fwd_run_silu(a, stream, launch, grid);
@@ -35,6 +42,13 @@ static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
 }
 
 static int run_bwd_act(BwdArgs& a, void* stream, int launch, int* grid) {
+  if (a.d.fourier_half > 0) {
+    if (a.d.activation != PPSCI_ACT_TANH || 2 * a.d.fourier_half != a.d.width || a.d.n_hidden < 2) {
+      ppsci_set_error("fourier embedding: needs a tanh net whose width equals the embedding dimension");
+      return PPSCI_E_UNSUPPORTED;
+    }
+    return ppsci_bwd_run_tanh_fourier(a, stream, launch, grid);
+  }
   switch (a.d.activation) {
     case PPSCI_ACT_TANH: return ppsci_bwd_run_tanh(a, stream, launch, grid);
     case PPSCI_ACT_SILU: return ppsci_bwd_run_silu(a, stream, launch, grid);

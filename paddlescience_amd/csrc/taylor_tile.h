@@ -32,6 +32,19 @@ __device__ __forceinline__ float ppsci_tanh(float x) {
 #endif
 }
 
+// Internal template id: a tanh net whose hidden layer 0 is the Fourier embedding (ppsci_mlp_desc.fourier_half).
+#define PPSCI_ACT_TANH_FOURIER 16
+#define PPSCI_ACT_BASE(ACT) ((ACT) == PPSCI_ACT_TANH_FOURIER ? PPSCI_ACT_TANH : (ACT))
+
+// FourierEmbedding (mlp.py:128-136) as an activation: cos on the first half of the features, sin on the rest.
+__device__ __forceinline__ void ppsci_fourier_eval(float z, bool is_cos, float& s, float& d1, float& d2, float& d3) {
+  const float sn = sinf(z), cs = cosf(z);
+  s = is_cos ? cs : sn;
+  d1 = is_cos ? -sn : cs;
+  d2 = -s;
+  d3 = -d1;
+}
+
 // value and first three derivatives of the activation (SURVEY.md Appendix A;
 // /root/reference/ppsci/arch/activation.py:77-88 Silu = x*sigmoid(x), :139-154 tanh / sin)
 template <int ACT>
@@ -101,6 +114,10 @@ __device__ __forceinline__ void ppsci_act_from_stash(float v, float& s, float& d
 // mlp.py:286-291: `skip = y; y = y + skip` on even hidden layers after the first one.
 __device__ __forceinline__ float ppsci_zscale(const ppsci_mlp_desc& d, int layer) {
   const float w0 = d.act_scale != 0.f ? d.act_scale : 1.f;  // Siren: act(w0 * z)
+  if (d.fourier_half > 0) {  // kernel layer 0 is the embedding; self.linears[i] is kernel layer i + 1
+    if (layer == 0) return 1.f;
+    layer -= 1;
+  }
   return ((d.skip_connection && (layer & 1) == 0 && layer >= 2) ? 2.f : 1.f) * w0;
 }
 
@@ -224,12 +241,14 @@ int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntil
 // per-activation entry points (one translation unit each, so they compile in parallel).
 // launch == 0: only plan (fills a.resident / a.iters and *grid_out); launch == 1: plan + launch.
 int ppsci_fwd_run_tanh(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_tanh_fourier(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_silu(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sin(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_gelu(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_cos(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sigmoid(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_tanh(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_tanh_fourier(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_silu(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_gelu(BwdArgs& a, void* stream, int launch, int* grid_out);

@@ -63,10 +63,12 @@ class NetLayout:
     skip_connection: bool = False
     embed: Optional[List[int]] = None
     omega: Optional[List[float]] = None
+    fourier_half: int = 0  # > 0: hidden layer 0 is the FourierEmbedding as the kernels run it (counted in n_hidden)
 
     def desc(self, streams: StreamSpec) -> L.MlpDesc:
         return L.make_mlp_desc(self.d_raw, self.n_hidden, self.width, self.d_out, self.activation,
-                               self.skip_connection, streams.dirs, streams.n2, self.embed, self.omega)
+                               self.skip_connection, streams.dirs, streams.n2, self.embed, self.omega,
+                               self.fourier_half)
 
     @property
     def d0(self) -> int:
@@ -165,6 +167,24 @@ def optim_step(kind: int, params: torch.Tensor, grad: torch.Tensor, states: Sequ
     hy = (C.c_float * 7)(*[float(v) for v in list(hyper) + [0.0] * (7 - len(hyper))])
     L.check(L.lib().ppsci_optim_step(kind, params.numel(), _p(params), _p(grad), _p(st[0]), _p(st[1]), _p(st[2]), hy,
                                      1 if flag else 0, _stream_ptr(params)))
+
+
+def linear_materialize(kind: int, fin: int, fout: int, v: torch.Tensor, g: Optional[torch.Tensor],
+                       b: Optional[torch.Tensor], W: torch.Tensor, b_out: Optional[torch.Tensor]) -> None:
+    """ppsci_linear_materialize: trainable tensors of one layer -> its slice of the kernel parameter buffer."""
+    _require_device(W)
+    _chk_f32(*[t for t in (v, g, b, W, b_out) if t is not None])
+    L.check(L.lib().ppsci_linear_materialize(kind, fin, fout, _p(v), _p(g), _p(b), _p(W), _p(b_out), _stream_ptr(W)))
+
+
+def linear_pullback(kind: int, fin: int, fout: int, v: Optional[torch.Tensor], g: Optional[torch.Tensor],
+                    gW: torch.Tensor, gb: Optional[torch.Tensor], gv: torch.Tensor, gg: Optional[torch.Tensor],
+                    gb_out: Optional[torch.Tensor]) -> None:
+    """ppsci_linear_pullback: gradient of the kernel-layout slice -> gradients of the trainable tensors."""
+    _require_device(gW)
+    _chk_f32(*[t for t in (v, g, gW, gb, gv, gg, gb_out) if t is not None])
+    L.check(L.lib().ppsci_linear_pullback(kind, fin, fout, _p(v), _p(g), _p(gW), _p(gb), _p(gv), _p(gg), _p(gb_out),
+                                          _stream_ptr(gW)))
 
 
 # ----------------------------------------------------------------------------- epilogue builder

@@ -138,8 +138,12 @@ class Solver:
 
             self.engine = OperatorEngine(self.model)
         else:
-            self.engine = Engine(self.model.layout, self.model.flat_params, dp_reduce=dp_reduce)
-        if self.optimizer is not None and not self._is_spinn and not self._is_operator and hasattr(self.optimizer, "beta1"):
+            self.engine = Engine(self.model.layout, self.model.kernel_params, dp_reduce=dp_reduce)
+        # factored / tied layers (weight_norm, random_weight, fourier): the kernels read model.kernel_params,
+        # rebuilt from the trainable tensors before every sweep; their gradient is pulled back afterwards
+        self._reparam = bool(getattr(self.model, "reparam", False))
+        if (self.optimizer is not None and not self._is_spinn and not self._is_operator and not self._reparam
+                and hasattr(self.optimizer, "beta1")):
             self.engine.m, self.engine.v = self.optimizer.m, self.optimizer.v
             self.engine.beta1, self.engine.beta2, self.engine.eps = (self.optimizer.beta1, self.optimizer.beta2,
                                                                     self.optimizer.epsilon)
@@ -247,6 +251,7 @@ class Solver:
                 if getattr(self.optimizer, "is_lbfgs", False):
                     # train_LBFGS_epoch_func (solver/train.py:216-315): the optimizer re-evaluates loss + gradient
                     def closure():
+                        self._materialize()
                         self.engine.forward_backward(eng_csts)
                         self.engine.allreduce()
                         self._update_train_loss()
@@ -255,10 +260,12 @@ class Solver:
                             tt = torch.tensor([total], dtype=torch.float64, device=self.device)
                             dist.all_reduce(tt)
                             total = float(tt[0]) * (gscale if gscale != 1.0 else 1.0)
-                        return total, self.engine.grad * gscale if gscale != 1.0 else self.engine.grad
+                        g = self._train_grad()
+                        return total, g * gscale if gscale != 1.0 else g
 
                     self.optimizer.step(closure)
                 else:
+                    self._materialize()
                     self.engine.forward_backward(eng_csts)
                     self.engine.allreduce()
                     if getattr(self.loss_aggregator, "per_loss_grad", False):
@@ -266,7 +273,7 @@ class Solver:
                         # gradient norms at the same parameters (the total gradient is recomputed afterwards)
                         if self.loss_aggregator.needs_update(self.global_step):
                             self._update_loss_weights(eng_csts)
-                    self.optimizer.step(self.engine.grad, gscale)
+                    self.optimizer.step(self._train_grad(), gscale)
                 self.optimizer.clear_grad()
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
                     self.lr_scheduler.step()
@@ -320,6 +327,14 @@ class Solver:
                     cc.fused.edesc.res[i].scale = cc._base_scales[i] if k == mask_key else 0.0
         self.engine.invalidate_graphs()
 
+    def _materialize(self) -> None:
+        if self._reparam:
+            self.model.materialize()
+
+    def _train_grad(self) -> torch.Tensor:
+        """Gradient w.r.t. the optimizer's (trainable) parameters."""
+        return self.model.pull_back(self.engine.grad) if self._reparam else self.engine.grad
+
     def _update_loss_weights(self, eng_csts):
         if self._is_spinn or self._is_operator:
             raise NotImplementedError("GradNorm / NTK need the fused PINN engine")
@@ -330,7 +345,7 @@ class Solver:
             self._apply_loss_weights(mask_key=k)
             self.engine.forward_backward(eng_csts)
             self.engine.allreduce()
-            norms.append(float(torch.linalg.norm(self.engine.grad)))
+            norms.append(float(torch.linalg.norm(self._train_grad())))
         self.loss_aggregator.update(norms)
         self._apply_loss_weights()
         # gradient of THIS step's weighted loss (old weights), which is what the optimizer consumes; the masked
@@ -405,7 +420,7 @@ class Solver:
                         list((ds.weight or {}).keys()), val.loss, bsz, bsz, self.device, train=False, want_values=True)
                 cc = self._compiled_val[key]
                 cc.bind(inp, lab, w)
-                cc.fused.forward(self.model.flat_params, False)
+                cc.fused.forward(self.model.materialize(), False)
                 vals = cc.values()
                 lv = cc.fused.losses()
                 for k in cc.label_keys:
@@ -511,7 +526,7 @@ class Solver:
                                                             extra_outputs=out_keys)
             cc = self._predict_cache[ck]
             cc.bind(chunk, {}, {})
-            cc.fused.forward(self.model.flat_params, False)
+            cc.fused.forward(self.model.materialize(), False)
             vals = cc.values()
             for k in out_keys:
                 results[k].append(vals[k].clone())

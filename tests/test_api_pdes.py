@@ -199,6 +199,73 @@ def test_lambdify_with_the_remaining_sympy_functions(tmp_path):
     assert rel(g, gref) < 5e-5
 
 
+@pytest.mark.parametrize("variant", ["weight_norm", "random_weight", "fourier", "fourier_rwf_periods"])
+def test_factored_and_fourier_mlp_variants(tmp_path, variant):
+    """MLP(weight_norm=True) / MLP(random_weight=...) / MLP(fourier=...) (mlp.py:31-136, :233-249; the model of
+    examples/allen_cahn/conf/allen_cahn_causal_fourier_rwf.yaml:35-48 at a smaller width): Allen-Cahn loss and the
+    gradient w.r.t. the reference's trainable tensors (fourier_emb.kernel, weight_v, weight_g, bias) against torch
+    autograd, then one Adam step on them."""
+    H, nl = 32, 3
+    rng = np.random.default_rng(12)
+    kw, okw = {}, {}
+    periods = None
+    if variant in ("weight_norm", "random_weight"):
+        kw = {"weight_norm": True} if variant == "weight_norm" else {"random_weight": {"mean": 0.5, "std": 0.1}}
+        okw = {"factor": variant}
+    elif variant == "fourier":
+        kw = {"fourier": {"dim": H, "scale": 1.0}}
+    else:
+        kw = {"fourier": {"dim": H, "scale": 1.0}, "random_weight": {"mean": 0.5, "std": 0.1},
+              "periods": {"x": (2.0, False)}}
+        okw = {"factor": "random_weight"}
+        periods = {1: float(np.float32(2 * np.pi / 2.0))}
+    ppsci.utils.misc.set_random_seed(5)
+    model = ppsci.arch.MLP(("t", "x"), ("u",), nl, H, "tanh", **kw)
+    fourier = "fourier" in variant
+    d0 = 2 + (1 if periods else 0)
+    net = T.make_net(2, [H] * nl, 1, periods=periods, bias_scale=0.05)
+    if fourier:
+        B = rng.normal(0.0, 1.0, (d0, H // 2))
+        net.weights[0] = rng.uniform(-0.3, 0.3, (H, H))  # the first Linear sees the embedding, not the raw inputs
+        okw["fourier_kernel"] = B.astype(np.float32).astype(np.float64)
+    if "factor" in okw:
+        okw["weight_g"] = [rng.uniform(0.6, 1.6, H).astype(np.float32).astype(np.float64) for _ in range(nl)]
+    net32 = net.astype(np.float32).astype(np.float64)
+    omodel = R.MLP(("t", "x"), ("u",), net32, **okw)
+    # the model's trainable tensors are in the oracle's parameters() order
+    assert [tuple(p.shape) for p in model.parameters()] == [tuple(p.shape) for p in omodel.parameters()]
+    flat = np.concatenate([p.detach().numpy().ravel() for p in omodel.parameters()])
+    model.flat_params.copy_(torch.tensor(flat, dtype=torch.float32).to(model.flat_params.device))
+    names = [n for n, _ in model.named_parameters()]
+    if fourier:
+        assert names[0] == "fourier_emb.kernel"
+    if "factor" in okw:
+        assert "linears.0.weight_v" in names and "linears.0.weight_g" in names
+    N = 45
+    X = rng.uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    eq = ppsci.equation.AllenCahn(eps=0.01)
+    cst = _sup_constraint({"t": X[:, :1], "x": X[:, 1:]}, {"allen_cahn": np.zeros((N, 1), np.float32)}, eq.equations,
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    solver._materialize()
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver._train_grad().cpu().numpy().astype(np.float64)
+    oc = dict(name="EQ", input={"t": X[:, :1].astype(np.float64), "x": X[:, 1:].astype(np.float64)},
+              exprs={"allen_cahn": R.allen_cahn_fn(0.01)}, label={"allen_cahn": np.zeros((N, 1))}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert solver._compiled["EQ"].fused.losses()["allen_cahn"] == pytest.approx(total, rel=5e-5)
+    assert rel(g, gref) < 1e-4
+    # numeric forward of the model (eager `model(dict)`)
+    out = model({"t": X[:, :1], "x": X[:, 1:]})["u"].cpu().numpy()
+    oref = omodel({"t": torch.tensor(X[:, :1].astype(np.float64)), "x": torch.tensor(X[:, 1:].astype(np.float64))})["u"]
+    assert rel(out, oref.detach().numpy()) < 1e-5
+    # one training step through Solver.train moves the trainable tensors like the oracle's Adam
+    solver.train()
+    adam = R.Adam(flat.size, lr=1e-3)
+    pref = adam.step(flat, gref)
+    assert rel(model.flat_params.cpu().numpy(), pref) < 1e-5
+
+
 def test_autodiff_errors_follow_reference():
     from paddlescience_amd.graph import Sym
 

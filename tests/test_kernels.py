@@ -48,7 +48,7 @@ def _run_fwd(net, X, dirs, n2, stash=False):
     emb = [1 if j in net.periods else 0 for j in range(net.d_raw)]
     om = [net.periods.get(j, 0.0) for j in range(net.d_raw)]
     lay = hp.NetLayout(net.d_raw, net.n_hidden, net.weights[1].shape[0], net.d_out, net.activation,
-                       net.skip_connection, emb, om)
+                       net.skip_connection, emb, om, net.fourier_half)
     spec = hp.StreamSpec([list(map(float, r)) for r in dirs], n2)
     desc = lay.desc(spec)
     params = _t(T.flat_params(net))
@@ -409,6 +409,84 @@ def test_epilogue_remaining_sympy_map_ops():
     np.testing.assert_allclose(resid.cpu().numpy()[0], rr.detach().numpy(), rtol=5e-6, atol=5e-6)
     np.testing.assert_allclose(Ubar.cpu().numpy()[0], ta.grad.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(Ubar.cpu().numpy()[1], tb.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _fourier_net(width, n_linears, dout, periods=None, skip=False, seed=5):
+    """Kernel-layout net behind a FourierEmbedding of dimension `width` (mlp.py:117-136, :233-237): layer 0 is
+    [B, B] with zero bias, B ~ N(0, 1)."""
+    net = T.make_net(2, [width] * (n_linears + 1), dout, periods=periods, skip_connection=skip, bias_scale=0.2)
+    d0 = net.weights[0].shape[0]
+    B = np.random.default_rng(seed).normal(0.0, 1.0, (d0, width // 2))
+    net.weights[0] = np.concatenate([B, B], axis=1)
+    net.biases[0] = np.zeros(width)
+    net.fourier_half = width // 2
+    return net
+
+
+@pytest.mark.parametrize("width,nl,dout,n2,N,periods,skip", [(32, 2, 1, 2, 37, None, False), (64, 3, 2, 1, 21, {1: 3.0}, True),
+                                                             (128, 2, 1, 2, 19, None, False), (256, 2, 1, 1, 16, {1: 3.0}, False)])
+def test_fourier_embedding_layer_fwd_and_bwd(width, nl, dout, n2, N, periods, skip):
+    """FourierEmbedding run as hidden layer 0 (cos | sin by feature index) in the single-wave (NB = 2, 4) and
+    the feature-split (NB = 8, 16) kernels; the skip quirk counts self.linears, not the embedding layer."""
+    net = _fourier_net(width, nl, dout, periods, skip)
+    rng = np.random.default_rng(23)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    dirs = np.eye(2)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, _, _, U, _ = _run_fwd(net, X, dirs, n2)
+    ref, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+    got = U.cpu().numpy().astype(np.float64)
+    for q in range(got.shape[0]):
+        assert _rel(got[q], ref.reshape(-1, N)[q]) < 8e-6, (q, _rel(got[q], ref.reshape(-1, N)[q]))
+    S = 1 + 2 + n2
+    Ubar = rng.standard_normal((dout, S, N)).astype(np.float32).astype(np.float64)
+    g = _run_bwd(net, X, dirs, n2, Ubar)
+    gW, gb = T.taylor_backward(net32, cache, Ubar)
+    assert _rel(g, T.flat_grads(gW, gb)) < 1e-5
+
+
+def test_linear_materialize_and_pullback_kinds():
+    """csrc/reparam.hip against torch autograd of the reference formulas (mlp.py:50-54, :91-92, :128-136)."""
+    import torch
+
+    from paddlescience_amd import _lib as L
+    from paddlescience_amd import hotpath as hp
+
+    rng = np.random.default_rng(2)
+    fin, fout = 37, 48
+    v = rng.standard_normal((fin, fout)).astype(np.float32)
+    g = rng.uniform(0.5, 2.0, fout).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    gW = rng.standard_normal((fin, fout)).astype(np.float32)
+    gb = rng.standard_normal(fout).astype(np.float32)
+    for kind in (L.LINEAR_PLAIN, L.LINEAR_WEIGHT_NORM, L.LINEAR_RWF, L.LINEAR_FOURIER):
+        vv = v[:, : fout // 2].copy() if kind == L.LINEAR_FOURIER else v
+        tv = torch.tensor(vv.astype(np.float64), requires_grad=True)
+        tg = torch.tensor(g.astype(np.float64), requires_grad=True)
+        if kind == L.LINEAR_PLAIN:
+            Wref = tv
+        elif kind == L.LINEAR_WEIGHT_NORM:
+            Wref = tg * tv / torch.linalg.vector_norm(tv, ord=2, dim=0, keepdim=True)
+        elif kind == L.LINEAR_RWF:
+            Wref = tg * tv
+        else:
+            Wref = torch.cat([tv, tv], dim=1)
+        (Wref * torch.tensor(gW.astype(np.float64))).sum().backward()
+        has_g = kind in (L.LINEAR_WEIGHT_NORM, L.LINEAR_RWF)
+        W, bo = _full((fin, fout), float("nan")), _full((fout,), float("nan"))
+        dv, dg = _t(vv), _t(g) if has_g else None
+        hp.linear_materialize(kind, fin, fout, dv, dg, None if kind == L.LINEAR_FOURIER else _t(b), W, bo)
+        np.testing.assert_allclose(W.cpu().numpy(), Wref.detach().numpy(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(bo.cpu().numpy(), np.zeros(fout) if kind == L.LINEAR_FOURIER else b)
+        gv = _full(vv.shape, float("nan"))
+        gg = _full((fout,), float("nan")) if has_g else None
+        gbo = _full((fout,), float("nan")) if kind != L.LINEAR_FOURIER else None
+        hp.linear_pullback(kind, fin, fout, dv, dg, _t(gW), _t(gb), gv, gg, gbo)
+        np.testing.assert_allclose(gv.cpu().numpy(), tv.grad.numpy(), rtol=2e-5, atol=2e-6)
+        if has_g:
+            np.testing.assert_allclose(gg.cpu().numpy(), tg.grad.numpy(), rtol=2e-5, atol=2e-6)
+        if gbo is not None:
+            np.testing.assert_allclose(gbo.cpu().numpy(), gb)
 
 
 def test_adam_step_matches_oracle():
