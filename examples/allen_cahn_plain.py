@@ -4,6 +4,10 @@ solution from dataset/allen_cahn.mat (not shipped, no network); here the initial
 form u(0,x) = x^2 cos(pi x) and evaluation reports the PDE residual.
 
     python examples/allen_cahn_plain.py epochs=5 iters_per_epoch=200 batch_size=4096
+
+`causal=True fourier=True rwf=True` gives the configuration of allen_cahn_causal.py with
+conf/allen_cahn_causal_fourier_rwf.yaml:35-69 (time-sorted batches + CausalMSELoss with 32 windows,
+FourierEmbedding dim 256 scale 1.0, RandomWeightFactorization mean 0.5 std 0.1).
 """
 import os
 import sys
@@ -21,25 +25,30 @@ dtype = "float32"
 def main():
     cfg = parse(dict(seed=42, output_dir="./output_allen_cahn", epochs=5, iters_per_epoch=200, batch_size=4096,
                      num_layers=4, hidden_size=256, learning_rate=1e-3, gamma=0.9, decay_steps=2000, log_freq=100,  # allen_cahn.yaml:38-42
-                     period_x=True))
+                     period_x=True, causal=False, n_chunks=32, tol=1.0, fourier=False, rwf=False))
     ppsci.utils.misc.set_random_seed(cfg["seed"])
     logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
     periods = {"x": [2.0, False]} if cfg["period_x"] else None
-    model = ppsci.arch.MLP(("t", "x"), ("u",), cfg["num_layers"], cfg["hidden_size"], "tanh", periods=periods)
+    model = ppsci.arch.MLP(("t", "x"), ("u",), cfg["num_layers"], cfg["hidden_size"], "tanh", periods=periods,
+                           fourier={"dim": cfg["hidden_size"], "scale": 1.0} if cfg["fourier"] else None,
+                           random_weight={"mean": 0.5, "std": 0.1} if cfg["rwf"] else None)
     equation = {"AllenCahn": ppsci.equation.AllenCahn(eps=0.01)}
     t0, t1, x0, x1 = 0.0, 1.0, -1.0, 1.0
     x_star = np.linspace(x0, x1, 512, endpoint=False, dtype=dtype)
 
     def gen_input_batch():
         tx = np.random.uniform([t0, x0], [t1, x1], (cfg["batch_size"], 2)).astype(dtype)
-        return {"t": tx[:, 0:1], "x": tx[:, 1:2]}
+        # allen_cahn_causal.py:88-91: the causal loss needs the batch ordered in time
+        return {"t": np.sort(tx[:, 0:1], axis=0) if cfg["causal"] else tx[:, 0:1], "x": tx[:, 1:2]}
 
     def gen_label_batch(input_batch):
         return {"allen_cahn": np.zeros([cfg["batch_size"], 1], dtype)}
 
     pde = ppsci.constraint.SupervisedConstraint(
         {"dataset": {"name": "ContinuousNamedArrayDataset", "input": gen_input_batch, "label": gen_label_batch}},
-        output_expr=equation["AllenCahn"].equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+        output_expr=equation["AllenCahn"].equations,
+        loss=(ppsci.loss.CausalMSELoss(cfg["n_chunks"], "mean", tol=cfg["tol"]) if cfg["causal"]
+              else ppsci.loss.MSELoss("mean")), name="PDE")
     ic_input = {"t": np.full([len(x_star), 1], t0, dtype), "x": x_star.reshape([-1, 1])}
     ic_label = {"u": (x_star**2 * np.cos(np.pi * x_star)).reshape([-1, 1]).astype(dtype)}
     ic = ppsci.constraint.SupervisedConstraint(

@@ -165,6 +165,15 @@ int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* 
                    const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                    float* loss_partials, void* stream);
 
+/* Causal weighting of CausalMSELoss.forward (mse.py:158-177) for one loss key: the batch is n_chunks
+ * consecutive time windows of N / n_chunks points; with l_p = weight_p * area_p * (value_p - label_p)^2 and
+ * m_k = mean of l over window k, every point of window k gets  cw_p = exp(-tol * sum_{j<k} m_j) * area_p
+ * (a constant for the reverse sweep: `.detach()` in the reference).  The caller then runs ppsci_epilogue with
+ * `cw` in the residual's `area` slot.  value: [N] from a first ppsci_epilogue pass (residual_out row); label /
+ * weight / area: [N] or NULL; chunk_scratch: n_chunks floats.  N must be a multiple of n_chunks. */
+int ppsci_causal_weights(int64_t n_points, int n_chunks, float tol, const float* value, const float* label,
+                         const float* weight, const float* area, float* chunk_scratch, float* cw, void* stream);
+
 /* Reverse sweep through the Taylor-mode forward: dL/dparams from dL/dU (replaces
  * total_loss.backward() train.py:158 through the double-backward graph).  workspace:
  * ppsci_bwd_workspace_bytes() bytes of scratch.  grad_partials: [ppsci_bwd_partial_rows(N), P],

@@ -444,6 +444,28 @@ def point_loss(kind, output_dict, label_dict, weight_dict=None, reduction="mean"
     return losses
 
 
+def causal_mse_loss(output_dict, label_dict, weight_dict=None, reduction="mean", weight=None, n_chunks=1, tol=1.0):
+    """CausalMSELoss.forward, mse.py:158-187."""
+    losses = {}
+    for key in label_dict:
+        loss = (output_dict[key] - label_dict[key]) ** 2  # F.mse_loss(..., "none")
+        if weight_dict and key in weight_dict:
+            loss = loss * weight_dict[key]
+        if "area" in output_dict:
+            loss = loss * output_dict["area"]
+        acc_mat = torch.tril(torch.ones(n_chunks, n_chunks, dtype=loss.dtype), -1)
+        loss_t = loss.reshape(n_chunks, -1)
+        weight_t = torch.exp(-tol * (acc_mat @ loss_t.mean(-1, keepdim=True)))
+        loss = loss_t * weight_t.detach()
+        loss = loss.sum() if reduction == "sum" else loss.mean()
+        if isinstance(weight, (float, int)):
+            loss = loss * weight
+        elif isinstance(weight, dict) and key in weight:
+            loss = loss * weight[key]
+        losses[key] = loss
+    return losses
+
+
 def loss_sum(losses: Dict[str, torch.Tensor]):  # mtl/sum.py:45-60
     total = 0.0
     for i, k in enumerate(losses):
@@ -474,7 +496,10 @@ def train_forward(
         wd = None
         if c.get("weight"):
             wd = {k: torch.tensor(np.asarray(v), dtype=model.dtype) for k, v in c["weight"].items()}
-        if c.get("loss_kind", "mse") == "mse":
+        if c.get("loss_kind", "mse") == "causal_mse":
+            losses = causal_mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"),
+                                     c["n_chunks"], c.get("tol", 1.0))
+        elif c.get("loss_kind", "mse") == "mse":
             losses = mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
         else:
             losses = point_loss(c["loss_kind"], output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))

@@ -105,6 +105,8 @@ _SYMBOLS = {
                                   C.c_float, C.c_float, C.c_int64, C.c_float, C.c_void_p]),
     "ppsci_optim_step": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "ppsci_causal_weights": (C.c_int, [C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_linear_materialize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     "ppsci_linear_pullback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -16,7 +16,7 @@ from . import autodiff, graph
 from .engine import FusedConstraint
 from .graph import Sym
 
-LABEL_PREFIX, WEIGHT_PREFIX = "label:", "weight:"
+LABEL_PREFIX, WEIGHT_PREFIX, CAUSAL_PREFIX = "label:", "weight:", "causal:"
 
 
 def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable]) -> Dict[str, Sym]:
@@ -69,8 +69,13 @@ class CompiledConstraint:
             losses.append(dict(key=k, label=LABEL_PREFIX + k, weight=(WEIGHT_PREFIX + k) if k in weight_keys else None,
                                area="area" if "area" in input_keys else None,
                                scale=loss.term_scale(k, n_global) if loss is not None else 0.0,
-                               kind=getattr(loss, "term_kind", 0) if loss is not None else 0))
+                               kind=getattr(loss, "term_kind", 0) if loss is not None else 0,
+                               causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None))
         self.low = graph.lower(outputs, losses, extra_outputs)
+        causal = getattr(loss, "causal", None)
+        if causal and batch_size % int(causal["n_chunks"]) != 0:
+            raise ValueError(f"CausalMSELoss: batch size {batch_size} is not a multiple of n_chunks "
+                             f"{causal['n_chunks']} (loss.reshape([n_chunks, -1]), mse.py:168)")
         self.batch_size = batch_size
         self.label_keys = list(label_keys)
         dev = device
@@ -78,7 +83,9 @@ class CompiledConstraint:
         inputs = [zeros() for _ in self.low.input_names]
         aux = [zeros() for _ in self.low.aux_names]
         self.fused = FusedConstraint(name, model.layout, self.low.streams, self.low.program.build(), inputs, aux,
-                                     self.low.loss_keys, want_residual=want_values)
+                                     self.low.loss_keys, want_residual=want_values or bool(self.low.causal))
+        if self.low.causal:
+            self.fused.set_causal(self.low.causal, int(causal["n_chunks"]), float(causal["tol"]))
         self.train = train
 
     def bind(self, input: Dict[str, object], label: Optional[Dict[str, object]], weight: Optional[Dict[str, object]]):
@@ -92,6 +99,8 @@ class CompiledConstraint:
                 src = label[name[len(LABEL_PREFIX):]]
             elif name.startswith(WEIGHT_PREFIX):
                 src = weight[name[len(WEIGHT_PREFIX):]]
+            elif name.startswith(CAUSAL_PREFIX):
+                continue  # written on the device every step (engine.FusedConstraint.forward)
             else:
                 src = input[name]
             dst.copy_(_to_dev(src, dev))

@@ -415,6 +415,65 @@ extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, co
   return PPSCI_OK;
 }
 
+// ---- CausalMSELoss (mse.py:158-177): window means, then the exclusive running sum as a per-point factor
+struct CausalArgs {
+  const float *value, *label, *weight, *area;
+  float *chunk, *cw;
+  long long N;
+  int n_chunks, per;  // per = N / n_chunks
+  float tol;
+};
+
+__global__ void __launch_bounds__(256) causal_chunk_mean_kernel(CausalArgs a) {
+  PPSCI_DYN_SMEM(red);  // [256]
+  const int k = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < a.per; i += 256) {
+    const long long p = (long long)k * a.per + i;
+    const float d = a.value[p] - (a.label ? a.label[p] : 0.f);
+    float l = d * d;
+    if (a.weight) l *= a.weight[p];
+    if (a.area) l *= a.area[p];
+    s += l;
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) a.chunk[k] = red[0] / (float)a.per;
+}
+
+__global__ void __launch_bounds__(256) causal_weight_kernel(CausalArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.N) return;
+  const int k = (int)(p / a.per);
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) acc += a.chunk[j];  // acc_mat @ means: strictly lower-triangular ones (mse.py:153-155)
+  const float w = expf(-a.tol * acc);
+  a.cw[p] = a.area ? w * a.area[p] : w;
+}
+
+extern "C" int ppsci_causal_weights(int64_t n_points, int n_chunks, float tol, const float* value,
+                                    const float* label, const float* weight, const float* area,
+                                    float* chunk_scratch, float* cw, void* stream) {
+  if (n_points <= 0 || n_chunks <= 0 || n_points % n_chunks != 0 || !value || !chunk_scratch || !cw) {
+    ppsci_set_error("causal_weights: invalid argument (N must be a multiple of n_chunks)");
+    return PPSCI_E_INVALID;
+  }
+  CausalArgs a{value, label, weight, area, chunk_scratch, cw, (long long)n_points, n_chunks,
+               (int)(n_points / n_chunks), tol};
+  PPSCI_LAUNCH(causal_chunk_mean_kernel, CausalArgs, n_chunks, 256, 256 * sizeof(float), stream, a);
+  PPSCI_LAUNCH(causal_weight_kernel, CausalArgs, (int)((n_points + 255) / 256), 256, 0, stream, a);
+  int err = PPSCI_LAST_LAUNCH_ERROR();
+  if (err != 0) {
+    ppsci_set_error("causal_weights: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
 extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t cols, float* out, int accumulate,
                                  void* stream) {
   if (!partials || !out || rows < 0 || cols <= 0) {

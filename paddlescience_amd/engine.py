@@ -58,8 +58,21 @@ class FusedConstraint:
             for dst, src in zip(self.aux, aux):
                 dst.copy_(src.view(-1))
 
+    def set_causal(self, rows: Sequence[tuple], n_chunks: int, tol: float) -> None:
+        """CausalMSELoss (mse.py:109-189): rows = (residual row, label aux, weight aux, area aux, factor aux)."""
+        self.causal, self.n_chunks, self.tol = list(rows), n_chunks, tol
+        self.chunk_scratch = torch.zeros((len(self.causal), n_chunks), dtype=torch.float32, device=self.U.device)
+
     def forward(self, params: torch.Tensor, train: bool) -> None:
         hp.taylor_fwd(self.desc, params, self.inputs, self.U, self.stash if train else None)
+        if getattr(self, "causal", None):
+            # first pass: the per-point values only; then the causal factor of every key from its window means
+            # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
+            hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, None, self.loss_partials)
+            ax = lambda i: self.aux[i] if i >= 0 else None  # noqa: E731
+            for j, (row, lab, w, ar, cw) in enumerate(self.causal):
+                hp.causal_weights(self.n_chunks, self.tol, self.resid[row], ax(lab), ax(w), ax(ar),
+                                  self.chunk_scratch[j], self.aux[cw])
         hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
                     self.loss_partials)
         hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)

@@ -284,6 +284,7 @@ class Lowered:
         self.model, self.streams, self.program = model, streams, program
         self.input_names, self.aux_names, self.loss_keys = input_names, aux_names, loss_keys
         self.value_index = value_index  # output name -> program value index
+        self.causal: List[tuple] = []
 
 
 def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = ()) -> Lowered:
@@ -391,15 +392,24 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 val[id(n)] = prog.op(_UNARY_OPS[n.op], val[id(n.args[0])])
 
     loss_keys = []
+    causal = []  # (residual row, label aux, weight aux, area aux, causal-factor aux) -- CausalMSELoss
     for ls in losses:
         key = ls["key"]
         lab = aux_index(ls["label"]) if ls.get("label") else -1
         w = aux_index(ls["weight"]) if ls.get("weight") else -1
         ar = aux_index(ls["area"]) if ls.get("area") else -1
+        if ls.get("causal"):
+            # the residual's area slot carries exp(-tol * running loss) * area, written by ppsci_causal_weights
+            cw = aux_index(ls["causal"])
+            causal.append((len(loss_keys), lab, w, ar, cw))
+            prog.n_aux = max(prog.n_aux, ar + 1)
+            ar = cw
         prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0), ls.get("kind", 0))
         loss_keys.append(key)
     for name in extra_outputs:
         prog.residual(val[id(outputs[name])], -1, -1, -1, 0.0)
         loss_keys.append(name)
     value_index = {k: val[id(v)] for k, v in outputs.items()}
-    return Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
+    low = Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
+    low.causal = causal
+    return low

@@ -169,6 +169,16 @@ def optim_step(kind: int, params: torch.Tensor, grad: torch.Tensor, states: Sequ
                                      1 if flag else 0, _stream_ptr(params)))
 
 
+def causal_weights(n_chunks: int, tol: float, value: torch.Tensor, label: Optional[torch.Tensor],
+                   weight: Optional[torch.Tensor], area: Optional[torch.Tensor], chunk_scratch: torch.Tensor,
+                   cw: torch.Tensor) -> None:
+    """ppsci_causal_weights: per-point causal factor of CausalMSELoss for one loss key (mse.py:158-177)."""
+    _require_device(cw)
+    _chk_f32(*[t for t in (value, label, weight, area, chunk_scratch, cw) if t is not None])
+    L.check(L.lib().ppsci_causal_weights(value.numel(), n_chunks, float(tol), _p(value), _p(label), _p(weight),
+                                         _p(area), _p(chunk_scratch), _p(cw), _stream_ptr(cw)))
+
+
 def linear_materialize(kind: int, fin: int, fout: int, v: torch.Tensor, g: Optional[torch.Tensor],
                        b: Optional[torch.Tensor], W: torch.Tensor, b_out: Optional[torch.Tensor]) -> None:
     """ppsci_linear_materialize: trainable tensors of one layer -> its slice of the kernel parameter buffer."""

@@ -2,13 +2,13 @@ from . import mtl  # noqa: F401
 from .base import Loss  # noqa: F401
 from .func import FunctionalLoss  # noqa: F401
 from .l1l2 import L1Loss, L2Loss, L2RelLoss, MAELoss  # noqa: F401
-from .mse import MSELoss  # noqa: F401
+from .mse import CausalMSELoss, MSELoss  # noqa: F401
 
-__all__ = ["Loss", "MSELoss", "FunctionalLoss", "L1Loss", "L2Loss", "L2RelLoss", "MAELoss", "mtl", "build_loss"]
+__all__ = ["Loss", "MSELoss", "CausalMSELoss", "FunctionalLoss", "L1Loss", "L2Loss", "L2RelLoss", "MAELoss", "mtl", "build_loss"]
 
 
 def build_loss(cfg):
     cfg = dict(cfg)
     cls = cfg.pop("name")
-    return {"MSELoss": MSELoss, "FunctionalLoss": FunctionalLoss, "L1Loss": L1Loss, "L2Loss": L2Loss,
+    return {"MSELoss": MSELoss, "CausalMSELoss": CausalMSELoss, "FunctionalLoss": FunctionalLoss, "L1Loss": L1Loss, "L2Loss": L2Loss,
             "L2RelLoss": L2RelLoss, "MAELoss": MAELoss}[cls](**cfg)

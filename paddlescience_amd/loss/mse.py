@@ -41,3 +41,37 @@ class MSELoss(Loss):
                 loss = loss * self.weight[key]
             losses[key] = loss
         return losses
+
+
+class CausalMSELoss(MSELoss):
+    """mse.py:109-189: the batch is `n_chunks` consecutive time windows; window i is weighted with
+    exp(-tol * sum of the mean losses of the windows before it) (a constant w.r.t. the parameters).
+    On the fused path: one extra value-only epilogue pass + ppsci_causal_weights per key (engine.py)."""
+
+    def __init__(self, n_chunks: int, reduction: str = "mean", weight: Optional[Union[float, Dict[str, float]]] = None,
+                 tol: float = 1.0):
+        if n_chunks <= 0:
+            raise ValueError(f"n_chunks should be positive, but got {n_chunks}")
+        super().__init__(reduction, weight)
+        self.n_chunks, self.tol = n_chunks, tol
+        self.causal = {"n_chunks": n_chunks, "tol": tol}
+        self.acc_mat = torch.tril(torch.ones(n_chunks, n_chunks), -1)
+
+    def forward(self, output_dict, label_dict, weight_dict=None) -> Dict[str, torch.Tensor]:
+        losses = {}
+        for key in label_dict:
+            loss = (output_dict[key] - label_dict[key]) ** 2
+            if weight_dict and key in weight_dict:
+                loss = loss * weight_dict[key]
+            if "area" in output_dict:
+                loss = loss * output_dict["area"]
+            loss_t = loss.reshape(self.n_chunks, -1)
+            weight_t = torch.exp(-self.tol * (self.acc_mat.to(loss_t) @ loss_t.mean(-1, keepdim=True)))
+            loss = loss_t * weight_t.detach()
+            loss = loss.sum() if self.reduction == "sum" else loss.mean()
+            if isinstance(self.weight, (float, int)):
+                loss = loss * self.weight
+            elif isinstance(self.weight, dict) and key in self.weight:
+                loss = loss * self.weight[key]
+            losses[key] = loss
+        return losses
