@@ -79,9 +79,16 @@ class CompiledConstraint:
         self.batch_size = batch_size
         self.label_keys = list(label_keys)
         dev = device
-        zeros = lambda: torch.zeros(batch_size, dtype=torch.float32, device=dev)  # noqa: E731
-        inputs = [zeros() for _ in self.low.input_names]
-        aux = [zeros() for _ in self.low.aux_names]
+        # all per-point arrays of the batch are rows of ONE device block, so that a fresh batch
+        # (ContinuousNamedArrayDataset: new points every iteration, array_dataset.py:208-228) is one
+        # asynchronous H2D copy from a pinned staging block instead of one blocking copy per array
+        n_in, n_aux = len(self.low.input_names), len(self.low.aux_names)
+        self._block = torch.zeros((max(1, n_in + n_aux), batch_size), dtype=torch.float32, device=dev)
+        inputs = [self._block[i] for i in range(n_in)]
+        aux = [self._block[n_in + i] for i in range(n_aux)]
+        self._stage: List[torch.Tensor] = []
+        self._stage_done: List[Optional[torch.cuda.Event]] = []
+        self._flip = 0
         self.fused = FusedConstraint(name, model.layout, self.low.streams, self.low.program.build(), inputs, aux,
                                      self.low.loss_keys, want_residual=want_values or bool(self.low.causal))
         if self.low.causal:
@@ -90,20 +97,40 @@ class CompiledConstraint:
 
     def bind(self, input: Dict[str, object], label: Optional[Dict[str, object]], weight: Optional[Dict[str, object]]):
         """Upload one batch (named [n,1] arrays) into the constraint's device buffers."""
-        f = self.fused
-        dev = f.inputs[0].device if f.inputs else f.U.device
-        for dst, name in zip(f.inputs, self.low.input_names):
-            dst.copy_(_to_dev(input[name], dev))
-        for dst, name in zip(f.aux, self.low.aux_names):
-            if name.startswith(LABEL_PREFIX):
-                src = label[name[len(LABEL_PREFIX):]]
+        names = list(self.low.input_names) + list(self.low.aux_names)
+        srcs: List[object] = []
+        for i, name in enumerate(names):
+            if i < len(self.low.input_names):
+                srcs.append(input[name])
+            elif name.startswith(LABEL_PREFIX):
+                srcs.append(label[name[len(LABEL_PREFIX):]])
             elif name.startswith(WEIGHT_PREFIX):
-                src = weight[name[len(WEIGHT_PREFIX):]]
+                srcs.append(weight[name[len(WEIGHT_PREFIX):]])
             elif name.startswith(CAUSAL_PREFIX):
-                continue  # written on the device every step (engine.FusedConstraint.forward)
+                srcs.append(None)  # written on the device every step (engine.FusedConstraint.forward)
             else:
-                src = input[name]
-            dst.copy_(_to_dev(src, dev))
+                srcs.append(input[name])
+        if not self._block.is_cuda or any(isinstance(v, torch.Tensor) and v.is_cuda for v in srcs):
+            for row, src in zip(self._block, srcs):
+                if src is not None:
+                    row.copy_(_to_dev(src, self._block.device))
+            return
+        if not self._stage:  # two pinned blocks: batch k+1 is staged while the copy of batch k may be in flight
+            self._stage = [torch.zeros(self._block.shape, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._stage_done = [None, None]
+        k = self._flip
+        self._flip ^= 1
+        if self._stage_done[k] is not None:
+            self._stage_done[k].synchronize()
+        st = self._stage[k].numpy()
+        for i, src in enumerate(srcs):
+            if src is not None:
+                a = src.detach().numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
+                np.copyto(st[i], a.reshape(-1), casting="same_kind" if a.dtype.kind == "f" else "unsafe")
+        self._block.copy_(self._stage[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stage_done[k] = ev
 
     def values(self) -> Dict[str, torch.Tensor]:
         """Per-point values of every loss key / extra output ([n,1] tensors), after a forward."""
