@@ -105,8 +105,31 @@ class Engine:
         self.use_graph = params.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0"
         self._graphs: Dict[tuple, object] = {}
         self.graph_max_work = 1.0e9  # points x parameters x streams per step below which the step is launch-bound
+        self.multi_stream = os.environ.get("PPSCI_MULTI_STREAM", "1") != "0"
+        self.multi_stream_max_points = 16384  # a constraint this small cannot fill the chip on its own
+        self._streams: List[torch.cuda.Stream] = []
 
     def _forward_backward_eager(self, constraints: Sequence[FusedConstraint]) -> None:
+        # Constraints are independent until their gradients are summed.  A small one (a boundary or initial
+        # condition with a few hundred points, or the reference's 4 096-point PDE batches) occupies a fraction of
+        # the 256 CUs for the latency of one tile's layer chain, so such sets run concurrently, one HIP stream per
+        # constraint, and join before the fixed-order gradient sum (also inside a captured graph: parallel
+        # branches).  PPSCI_MULTI_STREAM=0 turns it off.
+        if (self.multi_stream and len(constraints) > 1 and self.params.is_cuda
+                and min(c.n for c in constraints) <= self.multi_stream_max_points):
+            cur = torch.cuda.current_stream()
+            while len(self._streams) < len(constraints):
+                self._streams.append(torch.cuda.Stream())
+            for c, st in zip(constraints, self._streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    c.forward(self.params, True)
+                    c.backward(self.params)
+            for st in self._streams[:len(constraints)]:
+                cur.wait_stream(st)
+            for i, c in enumerate(constraints):
+                hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+            return
         for i, c in enumerate(constraints):
             c.forward(self.params, True)
             c.backward(self.params)

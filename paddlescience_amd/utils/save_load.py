@@ -1,12 +1,17 @@
 """Checkpointing with the file set and key names of /root/reference/ppsci/utils/save_load.py:213-290:
-`<output_dir>/checkpoints/<prefix>.{pdparams,pdopt,pdstates}` written by rank 0 only.  The payload is a
-numpy .npz archive (paddle's pickle format needs PaddlePaddle); parameter keys are the reference's
-(`linears.0.weight`, ..., `last_fc.bias`, mlp.py:264-277) so a converter to/from .pdparams is a pure
-renaming-free re-serialisation."""
+`<output_dir>/checkpoints/<prefix>.{pdparams,pdopt,pdstates}` written by rank 0 only.
+
+`.pdparams` is written the way `paddle.save(model.state_dict(), path)` writes it -- a protocol-4 pickle of
+{structured name: numpy array} plus the "StructuredToParameterName@@" name table (Paddle behaviour, recalled
+from paddle/framework/io.py, not visible in the reference tree) -- with the reference's parameter keys
+(`linears.0.weight`, ..., `last_fc.bias`, mlp.py:264-277), so the reference can `paddle.load` it and files
+saved by the reference (its published `*_pretrained.pdparams`) load here.  Reading uses a restricted unpickler
+(numpy array reconstruction only).  `.pdopt` holds this framework's flat optimizer state (npz)."""
 from __future__ import annotations
 
 import json
 import os
+import pickle
 from typing import Dict, Optional
 
 import numpy as np
@@ -35,6 +40,42 @@ def _load_npz(path: str) -> Dict[str, np.ndarray]:
         return {k: z[k] for k in z.files}
 
 
+NAME_TABLE_KEY = "StructuredToParameterName@@"
+
+
+def _save_pdparams(path: str, arrays: Dict[str, np.ndarray]):
+    obj = {k: np.ascontiguousarray(v) for k, v in arrays.items()}
+    obj[NAME_TABLE_KEY] = {k: k for k in arrays}
+    with open(path, "wb") as f:
+        pickle.dump(obj, f, protocol=4)
+
+
+class _ArrayUnpickler(pickle.Unpickler):
+    """Only what a pickled dict of numpy arrays needs; anything else in the stream is refused."""
+
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"),
+                ("numpy._core.multiarray", "scalar"), ("collections", "OrderedDict")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a checkpoint")
+
+
+def _load_pdparams(path: str) -> Dict[str, np.ndarray]:
+    with open(path, "rb") as f:
+        head = f.read(2)
+    if head == b"PK":  # archives written by earlier versions of this package
+        return _load_npz(path)
+    with open(path, "rb") as f:
+        obj = _ArrayUnpickler(f).load()
+    if not isinstance(obj, dict):
+        raise ValueError(f"{path}: expected a state dict, got {type(obj).__name__}")
+    obj.pop(NAME_TABLE_KEY, None)
+    return {k: np.asarray(v) for k, v in obj.items()}
+
+
 def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None, grad_scaler=None,
                     output_dir: Optional[str] = None, prefix: str = "model", equation=None, print_log: bool = True,
                     ema_model=None, aggregator=None):
@@ -46,7 +87,7 @@ def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None,
     ckpt_dir = os.path.join(output_dir, "checkpoints")
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, prefix)
-    _save_npz(path + ".pdparams", {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    _save_pdparams(path + ".pdparams", {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
     if optimizer is not None:
         st = optimizer.state_dict()
         _save_npz(path + ".pdopt", {"m": st["m"].detach().cpu().numpy(), "v": st["v"].detach().cpu().numpy(),
@@ -62,7 +103,7 @@ def load_checkpoint(path: str, model, optimizer=None, equation=None, grad_scaler
                     ) -> Dict[str, float]:
     if not os.path.exists(f"{path}.pdparams"):
         raise FileNotFoundError(f"{path}.pdparams not exist.")
-    model.set_state_dict(_load_npz(f"{path}.pdparams"))
+    model.set_state_dict(_load_pdparams(f"{path}.pdparams"))
     if optimizer is not None and os.path.exists(f"{path}.pdopt"):
         st = _load_npz(f"{path}.pdopt")
         optimizer.set_state_dict({"m": st["m"], "v": st["v"], "t": int(st["t"])})
@@ -78,5 +119,5 @@ def load_pretrain(model, path: str, equation=None):
     path = path[:-len(".pdparams")] if path.endswith(".pdparams") else path
     if not os.path.exists(f"{path}.pdparams"):
         raise FileNotFoundError(f"{path}.pdparams not exist.")
-    model.set_state_dict(_load_npz(f"{path}.pdparams"))
+    model.set_state_dict(_load_pdparams(f"{path}.pdparams"))
     logger.message(f"Finish loading pretrained model from: {path}.pdparams")
