@@ -76,6 +76,19 @@ def _load_pdparams(path: str) -> Dict[str, np.ndarray]:
     return {k: np.asarray(v) for k, v in obj.items()}
 
 
+def _state_arrays(model) -> Dict[str, np.ndarray]:
+    """state_dict as numpy arrays; models whose tensors are views of one flat buffer take ONE device->host copy."""
+    sd = model.state_dict()
+    flat = getattr(model, "flat_params", None)
+    if isinstance(flat, torch.Tensor) and sd and all(
+            v.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for v in sd.values()):
+        host = flat.detach().cpu().numpy()
+        base = flat.storage_offset()
+        return {k: host[v.storage_offset() - base: v.storage_offset() - base + v.numel()].reshape(tuple(v.shape))
+                for k, v in sd.items()}
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
 def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None, grad_scaler=None,
                     output_dir: Optional[str] = None, prefix: str = "model", equation=None, print_log: bool = True,
                     ema_model=None, aggregator=None):
@@ -87,7 +100,7 @@ def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None,
     ckpt_dir = os.path.join(output_dir, "checkpoints")
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, prefix)
-    _save_pdparams(path + ".pdparams", {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    _save_pdparams(path + ".pdparams", _state_arrays(model))
     if optimizer is not None:
         st = optimizer.state_dict()
         _save_npz(path + ".pdopt", {"m": st["m"].detach().cpu().numpy(), "v": st["v"].detach().cpu().numpy(),
