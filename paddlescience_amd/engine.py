@@ -85,6 +85,56 @@ class FusedConstraint:
         return {k: vals[i] for i, k in enumerate(self.loss_keys)}
 
 
+class StepGraph:
+    """Capture-once / replay of a fixed launch sequence (every argument a persistent device buffer) as a HIP graph,
+    through torch.cuda.CUDAGraph on the launch stream.  First call with a key: eager (also the warm-up a capture
+    needs); second: capture + replay; later: replay.  A failed capture falls back to eager launches for good."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self._graphs: Dict[tuple, object] = {}
+
+    def run(self, key: tuple, eager) -> None:
+        if not self.enabled:
+            return eager()
+        g = self._graphs.get(key)
+        if g is None:
+            eager()
+            self._graphs[key] = False
+            return
+        if g is False:
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+                    eager()
+                self._graphs[key] = graph
+                graph.replay()
+            except Exception:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+                self.enabled = False
+                torch.cuda.synchronize()
+                eager()
+            return
+        g.replay()
+
+    def clear(self) -> None:
+        self._step_graph.clear()
+
+
+def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
+    """Run independent launch sequences concurrently, one HIP stream each, forked from and joined back into the
+    current stream (inside a capture: parallel branches of the graph)."""
+    cur = torch.cuda.current_stream()
+    while len(streams) < len(jobs):
+        streams.append(torch.cuda.Stream())
+    for job, st in zip(jobs, streams):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            job()
+    for st in streams[:len(jobs)]:
+        cur.wait_stream(st)
+
+
 class Engine:
     def __init__(self, layout: hp.NetLayout, params: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8,
                  dp_reduce: str = "sum"):
@@ -103,7 +153,7 @@ class Engine:
         # (Laplace2D: 10 k points, 2 constraints) are launch-bound from Python otherwise.  PPSCI_HIP_GRAPH=0
         # turns it off; a failed capture falls back to eager launches for good.
         self.use_graph = params.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0"
-        self._graphs: Dict[tuple, object] = {}
+        self._step_graph = StepGraph(self.use_graph)
         self.graph_max_work = 1.0e9  # points x parameters x streams per step below which the step is launch-bound
         self.multi_stream = os.environ.get("PPSCI_MULTI_STREAM", "1") != "0"
         self.multi_stream_max_points = 16384  # a constraint this small cannot fill the chip on its own
@@ -117,16 +167,10 @@ class Engine:
         # branches).  PPSCI_MULTI_STREAM=0 turns it off.
         if (self.multi_stream and len(constraints) > 1 and self.params.is_cuda
                 and min(c.n for c in constraints) <= self.multi_stream_max_points):
-            cur = torch.cuda.current_stream()
-            while len(self._streams) < len(constraints):
-                self._streams.append(torch.cuda.Stream())
-            for c, st in zip(constraints, self._streams):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    c.forward(self.params, True)
-                    c.backward(self.params)
-            for st in self._streams[:len(constraints)]:
-                cur.wait_stream(st)
+            def job(c):
+                return lambda: (c.forward(self.params, True), c.backward(self.params))
+
+            run_on_streams(self._streams, [job(c) for c in constraints])
             for i, c in enumerate(constraints):
                 hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
             return
@@ -143,30 +187,13 @@ class Engine:
         work = sum(c.n * self.layout.n_params * c.streams.S for c in constraints)
         if work > self.graph_max_work:
             return self._forward_backward_eager(constraints)
-        key = tuple(id(c) for c in constraints)
-        g = self._graphs.get(key)
-        if g is None:  # first step with this set of constraints: eager (also the warm-up a capture needs)
-            self._forward_backward_eager(constraints)
-            self._graphs[key] = False
-            return
-        if g is False:
-            try:
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, capture_error_mode="relaxed"):
-                    self._forward_backward_eager(constraints)
-                self._graphs[key] = graph
-                graph.replay()
-            except Exception:  # noqa: BLE001 -- capture is an optimisation, never a requirement
-                self.use_graph = False
-                torch.cuda.synchronize()
-                self._forward_backward_eager(constraints)
-            return
-        g.replay()
+        self._step_graph.enabled = self.use_graph
+        self._step_graph.run(tuple(id(c) for c in constraints), lambda: self._forward_backward_eager(constraints))
+        self.use_graph = self._step_graph.enabled
 
     def invalidate_graphs(self) -> None:
         """Call after changing anything a captured launch holds by value (residual scales of an epilogue)."""
-        self._graphs.clear()
+        self._step_graph.clear()
 
     def allreduce(self) -> None:
         if self.world > 1:
