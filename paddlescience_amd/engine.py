@@ -118,7 +118,7 @@ class StepGraph:
         g.replay()
 
     def clear(self) -> None:
-        self._step_graph.clear()
+        self._graphs.clear()
 
 
 def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
