@@ -144,9 +144,11 @@ int ppsci_is_device_build(void);
 int64_t ppsci_param_count(const ppsci_mlp_desc* d);
 /* Bytes of stash ppsci_taylor_fwd writes for N points (0 is never returned for N > 0). */
 int64_t ppsci_stash_bytes(const ppsci_mlp_desc* d, int64_t n_points);
-/* Rows ([rows, P] fp32) of gradient partials ppsci_taylor_bwd writes for N points. */
+/* Rows ([rows, P] fp32) of gradient partials ppsci_taylor_bwd writes for N points.  Currently 1: the
+ * per-workgroup partial sums live in the workspace and are reduced (fixed order) before the call returns. */
 int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_points);
-/* Bytes of scratch ppsci_taylor_bwd needs for N points (per-tile hidden-weight gradient blocks). */
+/* Bytes of scratch ppsci_taylor_bwd needs for N points (per-tile hidden-weight gradient blocks, chunk sums,
+ * per-workgroup rows of the first-layer / bias / last-layer gradients). */
 int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points);
 /* Rows ([rows, n_res] fp32) of loss partials ppsci_epilogue writes for N points. */
 int64_t ppsci_epilogue_partial_rows(int64_t n_points);

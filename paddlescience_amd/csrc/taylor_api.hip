@@ -65,8 +65,9 @@ extern "C" int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_poi
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
   int grid = 0;
   if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
-  // one row per workgroup (+ one row for the reduced per-tile hidden-layer weight gradients)
-  return grid + 1;
+  // the per-workgroup partial sums are reduced inside ppsci_taylor_bwd (workspace): one finished row
+  (void)grid;
+  return 1;
 }
 
 static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.n_hidden - 1) * a.q.HP * a.q.HP; }
@@ -74,8 +75,12 @@ static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.
 extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points) {
   BwdArgs a;
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
+  int grid = 0;
+  if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
   const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
-  const long long fl = ((long long)a.ntiles + 1 + chunks) * bwd_per_tile_floats(a);  // + the spare slot
+  // per-tile hidden-weight blocks (+ the spare slot) | chunk sums | per-workgroup small-parameter rows | their sum
+  const long long fl = ((long long)a.ntiles + 1 + chunks) * bwd_per_tile_floats(a) +
+                       ((long long)grid + 1) * ppsci_small_params(a.d, a.q);
   return fl * 4 + 16;
 }
 
@@ -107,12 +112,20 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   for (int j = 0; j < d->d_raw; ++j) a.x[j] = inputs_host[j];
   a.Ubar = Ubar;
   a.stash = (const f32x4*)stash;
-  a.partials = grad_partials;
-  a.wpart = (f32x4*)workspace;
   int grid = 0;
-  int rc = run_bwd_act(a, stream, 1, &grid);
-  if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
+  if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return PPSCI_E_UNSUPPORTED;
+  const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
+  const int psmall = ppsci_small_params(a.d, a.q);
   float* wpart = (float*)workspace;
   float* tmp = wpart + ((long long)a.ntiles + 1) * bwd_per_tile_floats(a);
-  return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, grad_partials + (long long)grid * a.q.P, stream);
+  float* small_rows = tmp + chunks * bwd_per_tile_floats(a);
+  float* small_sum = small_rows + (long long)grid * psmall;
+  a.partials = small_rows;
+  a.wpart = (f32x4*)workspace;
+  int rc = run_bwd_act(a, stream, 1, &grid);
+  if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
+  // W0 / biases / W_last: fixed-order sum over the workgroups' compact rows (a few hundred KB, not rows x P)
+  rc = ppsci_reduce_rows(small_rows, grid, psmall, small_sum, 0, stream);
+  if (rc != PPSCI_OK) return rc;
+  return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
 }

@@ -222,7 +222,7 @@ struct BwdArgs {
   const float* x[PPSCI_MAX_IN];
   const float* Ubar;
   const f32x4* stash;
-  float* partials;  // [gridDim.x + 1, P]
+  float* partials;  // [gridDim.x][ppsci_small_params]: per-workgroup sums of W0 | b_0..b_{L-1} | W_last | b_last
   f32x4* wpart;     // [ntiles][L-1][NB*NB][64] float4: per-tile hidden-weight gradient blocks
   long long N;
   int ntiles;
@@ -231,12 +231,18 @@ struct BwdArgs {
   int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
 };
 
+// Parameters that are NOT hidden-to-hidden matrices, in the compact order the reverse kernels flush their LDS
+// accumulators in: W0 [d0, H] | b_0 .. b_{L-1} [H each] | W_last [H, m] | b_last [m].
+__host__ __device__ inline int ppsci_small_params(const ppsci_mlp_desc& d, const ppsci_derived& q) {
+  return q.d0 * d.width + d.n_hidden * d.width + d.width * d.d_out + d.d_out;
+}
+
 // Two-stage, fixed-order reduction of the per-tile hidden-weight gradient partials (wgrad_reduce.hip):
-// stage 1 sums chunks of tiles, stage 2 sums the chunks and scatters into the canonical layout of
-// one row of grad_partials (every other entry of that row is set to 0).
+// stage 1 sums chunks of tiles, stage 2 sums the chunks and writes the gradient in the canonical parameter
+// layout; the entries that are not hidden-to-hidden weights are taken from `small_sum` (compact order above).
 #define PPSCI_WRED_CHUNKS 64
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
-                       float* row, void* stream);
+                       const float* small_sum, float* row, void* stream);
 
 // per-activation entry points (one translation unit each, so they compile in parallel).
 // launch == 0: only plan (fills a.resident / a.iters and *grid_out); launch == 1: plan + launch.

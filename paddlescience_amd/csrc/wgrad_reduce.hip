@@ -7,6 +7,8 @@ struct WRedArgs {
   const float* wpart;  // [ntiles][per_tile]
   float* tmp;          // [nchunks][per_tile]
   float* row;          // [P]
+  const float* small;  // [ppsci_small_params]: summed W0 | biases | W_last | b_last gradients
+  int m, d0;
   ppsci_derived q;
   int L, H, ntiles, nchunks, nb4;  // nb4 = workgroups per chunk (each covers 256 float4)
   long long per_tile;              // (L-1)*HP*HP floats
@@ -32,10 +34,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= a.q.P) return;
   float v = 0.f;
+  bool hidden = false;
   // is idx inside a hidden-to-hidden weight matrix?
   for (int l = 1; l < a.L; ++l) {
     const int off = a.q.offW[l];
     if (idx >= off && idx < off + a.H * a.H) {
+      hidden = true;
       const int e = idx - off;
       const int in = e / a.H, out = e - in * a.H;
       const int NB = a.q.NB, HP = a.q.HP;
@@ -47,12 +51,28 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
       for (int c = 0; c < a.nchunks; ++c) v += a.tmp[(long long)c * a.per_tile + j];
     }
   }
+  if (!hidden) {  // W0, a bias, W_last or b_last: compact index into the summed small block
+    const int H = a.H, L = a.L;
+    int ci;
+    if (idx >= a.q.offB[L]) ci = (a.d0 + L + a.m) * H + (idx - a.q.offB[L]);
+    else if (idx >= a.q.offW[L]) ci = (a.d0 + L) * H + (idx - a.q.offW[L]);
+    else if (idx < a.q.offW[0] + a.d0 * H) ci = idx - a.q.offW[0];
+    else {
+      int l = 0;
+      while (l + 1 < L && idx >= a.q.offW[l + 1]) ++l;  // the bias that follows W_l
+      ci = a.d0 * H + l * H + (idx - a.q.offB[l]);
+    }
+    v = a.small[ci];
+  }
   a.row[idx] = v;
 }
 
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
-                       float* row, void* stream) {
+                       const float* small_sum, float* row, void* stream) {
   WRedArgs a;
+  a.small = small_sum;
+  a.m = d.d_out;
+  a.d0 = q.d0;
   a.wpart = wpart;
   a.tmp = tmp;
   a.row = row;
