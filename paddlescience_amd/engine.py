@@ -184,8 +184,10 @@ class Engine:
             return self._forward_backward_eager(constraints)
         # launch-bound only: a replayed HIP graph adds ~1.5 us of dependency handling per kernel node, which costs
         # the GPU-bound 100 k-point Allen-Cahn step 2 % (0.458 -> 0.468 ms) while it makes Laplace2D 4x faster
+        # ... and so does a step whose constraints are all small (the reference's 4 096-point batches on a 4 x 256
+        # net: ~16 launches of 10-250 us, issued from Python in about the time the GPU needs for them)
         work = sum(c.n * self.layout.n_params * c.streams.S for c in constraints)
-        if work > self.graph_max_work:
+        if work > self.graph_max_work and max(c.n for c in constraints) > self.multi_stream_max_points:
             return self._forward_backward_eager(constraints)
         self._step_graph.enabled = self.use_graph
         self._step_graph.run(tuple(id(c) for c in constraints), lambda: self._forward_backward_eager(constraints))
