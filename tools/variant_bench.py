@@ -34,6 +34,8 @@ def main():
     if "--more" in sys.argv:
         shapes += [("LAP 3x20 S5 10k", 2, 3, 20, 1, [[1.0, 0.0], [0.0, 1.0]], 2, 10_201),
                    ("NS 5x128 S5 125k", 2, 5, 128, 3, [[1.0, 0.0], [0.0, 1.0]], 2, 125_000)]
+    if "--wide" in sys.argv:  # width 256 (feature-split kernels): one tile per CU, half a wave of tiles, full load
+        shapes = [(f"AC 4x256 S4 {n}", 2, 4, 256, 1, [[0.0, 1.0], [1.0, 0.0]], 1, n) for n in (4096, 100_000)]
     libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "*.so")))
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     if only:
