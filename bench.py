@@ -144,6 +144,8 @@ def main():
     _lib.lib().ppsci_set_bwd_main_only(1)  # time the dominant kernel alone (not its two small reduce kernels)
     t_bwd = time_kernel(lambda: cst.backward(params))
     _lib.lib().ppsci_set_bwd_main_only(0)
+    # SURVEY.md 8(d) "R": residual evaluation only (forward streams + epilogue, no stash, no adjoints)
+    t_res = time_kernel(lambda: cst.forward(params, False))
     p_mat = 2 * WIDTH + (HIDDEN - 1) * WIDTH * WIDTH + WIDTH  # matrix weights (P = 12 480)
     S = streams.S
     flops_bwd = 4.0 * p_mat * S * N_PER_GPU   # reverse sweep: 2 GEMMs per layer  (F_T - F_R)
@@ -181,7 +183,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Allen-Cahn 1D+t, MLP 2->64x4->1 tanh, 100k collocation pts per GPU, "
                                    "residual+MSE-mean+grad+Adam (BASELINE.json configs[1])",
-                       "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss},
+                       "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss,
+                       "residual_only_points_per_s_per_gpu": N_PER_GPU / t_res},
             "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0>", "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "kernel_ms": t_bwd * 1e3,
