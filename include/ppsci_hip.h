@@ -35,6 +35,7 @@ extern "C" {
 #define PPSCI_MAX_HIDDEN 16 /* hidden layers */
 #define PPSCI_MAX_PROG 128  /* epilogue program length */
 #define PPSCI_MAX_RES 8     /* residual/loss terms per epilogue */
+#define PPSCI_MAX_EPARAM 8  /* learnable equation parameters (PDE.learnable_parameters, equation/pde/base.py:38) */
 #define PPSCI_MAX_AUX 16    /* auxiliary per-point arrays (labels, weights, sdf, ...) */
 
 enum { PPSCI_OK = 0, PPSCI_E_INVALID = -1, PPSCI_E_UNSUPPORTED = -2, PPSCI_E_LAUNCH = -3 };
@@ -86,6 +87,7 @@ enum {
   PPSCI_OP_ASIN, PPSCI_OP_ACOS, PPSCI_OP_ATAN, PPSCI_OP_ATAN2, /* atan2(v[a], v[b]) */
   PPSCI_OP_ASINH, PPSCI_OP_ACOSH, PPSCI_OP_ATANH, PPSCI_OP_ERF, PPSCI_OP_LGAMMA,
   PPSCI_OP_CEIL, PPSCI_OP_FLOOR,
+  PPSCI_OP_LD_PARAM,  /* a = slot of a learnable equation parameter (ParameterNode, symbolic.py:471-485) */
   PPSCI_OP_COUNT
 };
 
@@ -166,6 +168,14 @@ int ppsci_taylor_fwd(const ppsci_mlp_desc* d, const float* params, int64_t n_poi
 int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
                    const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                    float* loss_partials, void* stream);
+
+/* ppsci_epilogue for programs that read learnable equation parameters (PPSCI_OP_LD_PARAM; e.g. the damping and
+ * stiffness exponents of equation/pde/viv.py:41-62): eq_params: [PPSCI_MAX_EPARAM] current values (broadcast over
+ * the points, as ParameterNode.forward does); eq_param_partials: [ppsci_epilogue_partial_rows(N), PPSCI_MAX_EPARAM]
+ * receiving per-block sums of d(sum_k loss_k)/d(param) (NULL when Ubar is NULL); summed with ppsci_reduce_rows. */
+int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                          const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                          float* loss_partials, const float* eq_params, float* eq_param_partials, void* stream);
 
 /* Causal weighting of CausalMSELoss.forward (mse.py:158-177) for one loss key: the batch is n_chunks
  * consecutive time windows of N / n_chunks points; with l_p = weight_p * area_p * (value_p - label_p)^2 and

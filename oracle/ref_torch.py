@@ -267,13 +267,15 @@ _UNARY = {
 }
 
 
-def lambdify(expr: sp.Basic, model: MLP, dtype=None) -> Callable[[Dict[str, torch.Tensor]], torch.Tensor]:
+def lambdify(expr: sp.Basic, model: MLP, dtype=None,
+             extra_parameters: Optional[Dict[str, torch.Tensor]] = None) -> Callable[[Dict[str, torch.Tensor]], torch.Tensor]:
     """symbolic.py:681-981 without derivative fusion (fusion does not change values,
     test/utils/test_symbolic.py:93-149)."""
     dtype = dtype or model.dtype
     expr = expr.subs(1.0, 1)  # symbolic.py:791
     nodes = post_traverse(expr, [])
-    nodes = [n for n in nodes if not n.is_Symbol]  # symbolic.py:799-803 (no extra parameters)
+    extra_parameters = extra_parameters or {}  # name -> 0-D tensor (ParameterNode, symbolic.py:471-485)
+    nodes = [n for n in nodes if (not n.is_Symbol) or n.name in extra_parameters]  # symbolic.py:797-803
     nodes = list(dict.fromkeys(nodes))  # symbolic.py:806
 
     def run(data: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -281,7 +283,9 @@ def lambdify(expr: sp.Basic, model: MLP, dtype=None) -> Callable[[Dict[str, torc
             key = cvt_to_key(n)
             if key in data:
                 continue
-            if isinstance(n, sp.Derivative):  # symbolic.py:310-333
+            if n.is_Symbol:
+                data[key] = extra_parameters[n.name]
+            elif isinstance(n, sp.Derivative):  # symbolic.py:310-333
                 val = data[cvt_to_key(n.args[0])]
                 for sym, order in n.args[1:]:
                     order = int(order)

@@ -21,7 +21,8 @@ EMBED_NONE, EMBED_PERIOD = 0, 1
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
  OP_TANH, OP_EXP, OP_LOG, OP_SQRT, OP_ABS, OP_SINH, OP_COSH, OP_TAN, OP_MAX, OP_MIN, OP_SIGN, OP_HEAVISIDE,
  OP_DETACH, OP_ASIN, OP_ACOS, OP_ATAN, OP_ATAN2, OP_ASINH, OP_ACOSH, OP_ATANH, OP_ERF, OP_LGAMMA, OP_CEIL, OP_FLOOR,
- OP_COUNT) = range(37)
+ OP_LD_PARAM, OP_COUNT) = range(38)
+MAX_EPARAM = 8
 
 
 class MlpDesc(C.Structure):
@@ -82,6 +83,9 @@ _SYMBOLS = {
                                    C.c_void_p, C.c_void_p]),
     "ppsci_epilogue": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_epilogue_params": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     "ppsci_taylor_bwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),

@@ -19,7 +19,8 @@ from .graph import Sym
 LABEL_PREFIX, WEIGHT_PREFIX, CAUSAL_PREFIX = "label:", "weight:", "causal:"
 
 
-def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable]) -> Dict[str, Sym]:
+def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable],
+                extra_parameters: Sequence = ()) -> Dict[str, Sym]:
     """expression.py:96-102 on proxies: model forward, then every named expression on the data dict."""
     data: Dict[str, object] = {}
     for k in input_keys:
@@ -34,7 +35,7 @@ def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable]) ->
         if isinstance(ex, sp.Basic):
             from .utils.symbolic import lambdify
 
-            ex = lambdify(ex, model)
+            ex = lambdify(ex, model, extra_parameters)
         val = ex(data)
         if not isinstance(val, Sym):
             val = graph._lift(val)
@@ -54,9 +55,10 @@ class CompiledConstraint:
 
     def __init__(self, name: str, model, exprs: Dict[str, Callable], input_keys: Sequence[str],
                  label_keys: Sequence[str], weight_keys: Sequence[str], loss, batch_size: int, n_global: int,
-                 device, train: bool = True, want_values: bool = False, extra_outputs: Sequence[str] = ()):
+                 device, train: bool = True, want_values: bool = False, extra_outputs: Sequence[str] = (),
+                 extra_parameters: Sequence = ()):
         self.name, self.model, self.loss = name, model, loss
-        outputs = trace_exprs(model, input_keys, exprs)
+        outputs = trace_exprs(model, input_keys, exprs, extra_parameters)
         for k in label_keys:
             if k not in outputs:
                 # a label on a raw network output (expression.py: output_dict holds the model outputs too)
@@ -91,6 +93,10 @@ class CompiledConstraint:
         self._flip = 0
         self.fused = FusedConstraint(name, model.layout, self.low.streams, self.low.program.build(), inputs, aux,
                                      self.low.loss_keys, want_residual=want_values or bool(self.low.causal))
+        if self.low.param_slots:
+            from .equation.pde.base import EqParamStore
+
+            self.fused.set_eq_params(EqParamStore.get())
         if self.low.causal:
             self.fused.set_causal(self.low.causal, int(causal["n_chunks"]), float(causal["tol"]))
         self.train = train

@@ -27,6 +27,8 @@ struct EpiArgs {
   float* resid;     // may be null: [n_res, N]
   float* Ubar;      // may be null: [n_streams, N]
   float* partials;  // [gridDim.x, n_res]
+  const float* ep;  // [PPSCI_MAX_EPARAM] learnable equation parameters (may be null)
+  float* ep_part;   // [gridDim.x, PPSCI_MAX_EPARAM] (may be null)
   long long N;
   int iters;
 };
@@ -54,6 +56,9 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
   const int n = a.e.n_instr;
   float lsum[PPSCI_MAX_RES];
   for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
+  float padj[PPSCI_MAX_EPARAM];  // adjoints of the equation parameters, summed over this lane's points
+#pragma unroll
+  for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
 
   for (int it = 0; it < a.iters; ++it) {
     const long long p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
@@ -70,6 +75,7 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
         case PPSCI_OP_LD_U: r = a.U[(long long)ins.a * a.N + pp]; break;
         case PPSCI_OP_LD_AUX: r = a.aux[ins.a][pp]; break;
         case PPSCI_OP_CONST: r = ins.c; break;
+        case PPSCI_OP_LD_PARAM: r = a.ep[ins.a]; break;
         case PPSCI_OP_ADD: r = v[ins.a] + v[ins.b]; break;
         case PPSCI_OP_SUB: r = v[ins.a] - v[ins.b]; break;
         case PPSCI_OP_MUL: r = v[ins.a] * v[ins.b]; break;
@@ -139,6 +145,11 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
           case PPSCI_OP_LD_U:
             if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
             break;
+          case PPSCI_OP_LD_PARAM:
+#pragma unroll
+            for (int k = 0; k < PPSCI_MAX_EPARAM; ++k)
+              if (ins.a == k) padj[k] += g;  // invalid lanes carry g = 0 (their seeds are never set)
+            break;
           case PPSCI_OP_ADD: adj[ins.a] += g; adj[ins.b] += g; break;
           case PPSCI_OP_SUB: adj[ins.a] += g; adj[ins.b] -= g; break;
           case PPSCI_OP_MUL: adj[ins.a] += g * v[ins.b]; adj[ins.b] += g * v[ins.a]; break;
@@ -198,6 +209,19 @@ __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
       __syncthreads();
     }
     if (tid == 0) a.partials[(long long)blockIdx.x * a.e.n_res + k] = red[0];
+  }
+  if (a.ep_part != nullptr) {
+#pragma unroll
+    for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) {
+      __syncthreads();
+      red[tid] = padj[k];
+      __syncthreads();
+      for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+      }
+      if (tid == 0) a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = red[0];
+    }
   }
 }
 
@@ -362,11 +386,20 @@ extern "C" int64_t ppsci_epilogue_partial_rows(int64_t n_points) {
 extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
                               const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                               float* loss_partials, void* stream) {
+  return ppsci_epilogue_params(e, n_points, inputs_host, U, aux_host, residual_out, Ubar, loss_partials, nullptr,
+                               nullptr, stream);
+}
+
+extern "C" int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                                     const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                                     float* loss_partials, const float* eq_params, float* eq_param_partials,
+                                     void* stream) {
   if (!e || n_points <= 0 || !loss_partials || e->n_instr < 1 || e->n_instr > PPSCI_MAX_PROG || e->n_res < 0 ||
       e->n_res > PPSCI_MAX_RES || e->n_in < 0 || e->n_in > PPSCI_MAX_IN || e->n_aux < 0 || e->n_aux > PPSCI_MAX_AUX) {
     ppsci_set_error("epilogue: invalid argument");
     return PPSCI_E_INVALID;
   }
+  bool uses_params = false;
   for (int i = 0; i < e->n_instr; ++i) {
     const ppsci_instr& ins = e->prog[i];
     bool ok = ins.op >= 0 && ins.op < PPSCI_OP_COUNT;
@@ -374,6 +407,10 @@ extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, co
       if (ins.op == PPSCI_OP_LD_IN) ok = ins.a >= 0 && ins.a < e->n_in && inputs_host;
       else if (ins.op == PPSCI_OP_LD_U) ok = ins.a >= 0 && ins.a < e->n_streams && U;
       else if (ins.op == PPSCI_OP_LD_AUX) ok = ins.a >= 0 && ins.a < e->n_aux && aux_host;
+      else if (ins.op == PPSCI_OP_LD_PARAM) {
+        ok = ins.a >= 0 && ins.a < PPSCI_MAX_EPARAM && eq_params && (Ubar == nullptr || eq_param_partials);
+        uses_params = true;
+      }
       else if (ins.op != PPSCI_OP_CONST) {
         ok = ins.a >= 0 && ins.a < i;
         const bool binary = ins.op == PPSCI_OP_ADD || ins.op == PPSCI_OP_SUB || ins.op == PPSCI_OP_MUL ||
@@ -404,6 +441,8 @@ extern "C" int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, co
   a.resid = residual_out;
   a.Ubar = Ubar;
   a.partials = loss_partials;
+  a.ep = eq_params;
+  a.ep_part = (uses_params && Ubar != nullptr) ? eq_param_partials : nullptr;
   a.N = n_points;
   const int grid = epi_grid(n_points, &a.iters);
   PPSCI_LAUNCH(epilogue_kernel, EpiArgs, grid, EPI_BLOCK, EPI_BLOCK * sizeof(float), stream, a);

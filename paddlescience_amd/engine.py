@@ -58,6 +58,12 @@ class FusedConstraint:
             for dst, src in zip(self.aux, aux):
                 dst.copy_(src.view(-1))
 
+    def set_eq_params(self, store) -> None:
+        """The epilogue reads learnable equation parameters (OP_LD_PARAM): their adjoints are summed per block into
+        `eq_partials` and, in backward(), added into the store's gradient vector."""
+        self.eq_store = store
+        self.eq_partials = torch.zeros((self.loss_rows, L.MAX_EPARAM), dtype=torch.float32, device=self.U.device)
+
     def set_causal(self, rows: Sequence[tuple], n_chunks: int, tol: float) -> None:
         """CausalMSELoss (mse.py:109-189): rows = (residual row, label aux, weight aux, area aux, factor aux)."""
         self.causal, self.n_chunks, self.tol = list(rows), n_chunks, tol
@@ -68,14 +74,20 @@ class FusedConstraint:
         if getattr(self, "causal", None):
             # first pass: the per-point values only; then the causal factor of every key from its window means
             # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
-            hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, None, self.loss_partials)
+            hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, None, self.loss_partials,
+                        *self._eq_args(False))
             ax = lambda i: self.aux[i] if i >= 0 else None  # noqa: E731
             for j, (row, lab, w, ar, cw) in enumerate(self.causal):
                 hp.causal_weights(self.n_chunks, self.tol, self.resid[row], ax(lab), ax(w), ax(ar),
                                   self.chunk_scratch[j], self.aux[cw])
         hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
-                    self.loss_partials)
+                    self.loss_partials, *self._eq_args(train))
+
         hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)
+
+    def _eq_args(self, train: bool):
+        st = getattr(self, "eq_store", None)
+        return (None, None) if st is None else (st.values, self.eq_partials if train else None)
 
     def backward(self, params: torch.Tensor) -> None:
         hp.taylor_bwd(self.desc, params, self.inputs, self.Ubar, self.stash, self.workspace, self.grad_partials)
@@ -173,11 +185,17 @@ class Engine:
             run_on_streams(self._streams, [job(c) for c in constraints])
             for i, c in enumerate(constraints):
                 hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
-            return
-        for i, c in enumerate(constraints):
-            c.forward(self.params, True)
-            c.backward(self.params)
-            hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+        else:
+            for i, c in enumerate(constraints):
+                c.forward(self.params, True)
+                c.backward(self.params)
+                hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+        # d loss / d (learnable equation parameter): per-block sums of every constraint that reads one, in order
+        first = True
+        for c in constraints:
+            if getattr(c, "eq_store", None) is not None:
+                hp.reduce_rows(c.eq_partials, c.loss_rows, L.MAX_EPARAM, c.eq_store.grad, not first)
+                first = False
 
     def forward_backward(self, constraints: Sequence[FusedConstraint]) -> None:
         if not self.use_graph:

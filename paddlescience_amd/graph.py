@@ -66,6 +66,11 @@ class Sym:
         return Sym("aux", name=name)
 
     @staticmethod
+    def param(name: str, slot: int) -> "Sym":
+        """A learnable equation parameter (ParameterNode, symbolic.py:471-485): one scalar for all points."""
+        return Sym("param", name=name, comp=int(slot))
+
+    @staticmethod
     def const(v: Number) -> "Sym":
         return Sym("const", value=float(v))
 
@@ -86,6 +91,8 @@ class Sym:
             return self.name
         if self.kind == "aux":
             return f"aux:{self.name}"
+        if self.kind == "param":
+            return f"param:{self.name}"
         if self.kind == "const":
             return repr(self.value)
         if self.kind == "net":
@@ -179,7 +186,7 @@ def diff(e: Sym, var: str) -> Sym:
     k = e.kind
     if k == "in":
         return Sym.const(1.0 if e.name == var else 0.0)
-    if k in ("aux", "const"):
+    if k in ("aux", "const", "param"):
         return Sym.const(0.0)
     if k == "net":
         if var not in e.model.input_keys:
@@ -285,6 +292,7 @@ class Lowered:
         self.input_names, self.aux_names, self.loss_keys = input_names, aux_names, loss_keys
         self.value_index = value_index  # output name -> program value index
         self.causal: List[tuple] = []
+        self.param_slots: List[int] = []  # slots of the learnable equation parameters the program reads
 
 
 def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = ()) -> Lowered:
@@ -359,6 +367,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         return aux_names.index(name)
 
     val: Dict[int, int] = {}
+    param_slots = set()
     for n in nodes:
         if n.kind == "in":
             if n.name in input_names:
@@ -367,6 +376,9 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 val[id(n)] = prog.ld_aux(aux_index(n.name))
         elif n.kind == "aux":
             val[id(n)] = prog.ld_aux(aux_index(n.name))
+        elif n.kind == "param":
+            val[id(n)] = prog.ld_param(n.comp)
+            param_slots.add(n.comp)
         elif n.kind == "const":
             val[id(n)] = prog.const(n.value)
         elif n.kind == "net":
@@ -412,4 +424,5 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     value_index = {k: val[id(v)] for k, v in outputs.items()}
     low = Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
     low.causal = causal
+    low.param_slots = sorted(param_slots)
     return low

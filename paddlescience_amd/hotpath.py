@@ -123,13 +123,21 @@ def taylor_fwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Ten
 
 def epilogue(edesc: L.EpilogueDesc, n: int, inputs: Sequence[torch.Tensor], U: Optional[torch.Tensor],
              aux: Sequence[torch.Tensor], resid: Optional[torch.Tensor], Ubar: Optional[torch.Tensor],
-             loss_partials: torch.Tensor) -> None:
+             loss_partials: torch.Tensor, eq_params: Optional[torch.Tensor] = None,
+             eq_param_partials: Optional[torch.Tensor] = None) -> None:
+    """eq_params / eq_param_partials: learnable equation parameters ([MAX_EPARAM]) and the per-block sums of their
+    adjoints ([rows, MAX_EPARAM]) for programs with OP_LD_PARAM (ppsci_epilogue_params)."""
     _require_device(loss_partials)
-    _chk_f32(U, resid, Ubar, loss_partials, *inputs, *aux)
+    _chk_f32(U, resid, Ubar, loss_partials, eq_params, eq_param_partials, *inputs, *aux)
     ip = L.ptr_array([t.data_ptr() for t in inputs])
     ap = L.ptr_array([t.data_ptr() for t in aux])
-    L.check(L.lib().ppsci_epilogue(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar), _p(loss_partials),
-                                   _stream_ptr(loss_partials)))
+    if eq_params is None:
+        L.check(L.lib().ppsci_epilogue(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar), _p(loss_partials),
+                                       _stream_ptr(loss_partials)))
+    else:
+        L.check(L.lib().ppsci_epilogue_params(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar),
+                                              _p(loss_partials), _p(eq_params), _p(eq_param_partials),
+                                              _stream_ptr(loss_partials)))
 
 
 def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], Ubar: torch.Tensor,
@@ -231,6 +239,9 @@ class Program:
     def ld_aux(self, k: int) -> int:
         self.n_aux = max(self.n_aux, k + 1)
         return self._emit(L.OP_LD_AUX, k)
+
+    def ld_param(self, slot: int) -> int:
+        return self._emit(L.OP_LD_PARAM, slot)
 
     def const(self, c: float) -> int:
         import numpy as np

@@ -35,6 +35,19 @@ class _AdamState:
         hp.adam_step(self.model.flat_params, grad, self.m, self.v, self.get_lr(), self.t, self.beta1, self.beta2,
                      self.epsilon, grad_scale)
 
+        if self.eq_store is not None:  # the learnable equation parameters: same rule, their own moments
+            hp.adam_step(self.eq_store.values, self.eq_store.grad, self.eq_m, self.eq_v, self.get_lr(), self.t,
+                         self.beta1, self.beta2, self.epsilon, grad_scale)
+
+    eq_store = None
+
+    def attach_equation_parameters(self):
+        from ..equation.pde.base import EqParamStore
+
+        self.eq_store = EqParamStore.get()
+        self.eq_m = torch.zeros_like(self.eq_store.values)
+        self.eq_v = torch.zeros_like(self.eq_store.values)
+
     def clear_grad(self):
         pass  # the flat gradient is overwritten by every reduce_rows
 
@@ -56,11 +69,19 @@ class Adam:
         self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
 
     def __call__(self, model_list) -> _AdamState:
+        """`Adam(lr)(model)` or, for inverse problems, `Adam(lr)((model,) + tuple(equation.values()))`
+        (examples/fsi/viv.py:121): equations contribute their learnable parameters."""
+        eqs = []
         if isinstance(model_list, (list, tuple)):
-            if len(model_list) != 1:
-                raise NotImplementedError("one model per optimizer on the fused HIP path")
-            model_list = model_list[0]
-        return _AdamState(model_list, self.learning_rate, self.beta1, self.beta2, self.epsilon)
+            eqs = [m for m in model_list if hasattr(m, "learnable_parameters") and hasattr(m, "equations")]
+            nets = [m for m in model_list if m not in eqs]
+            if len(nets) != 1:
+                raise NotImplementedError("one network per optimizer on the fused HIP path")
+            model_list = nets[0]
+        st = _AdamState(model_list, self.learning_rate, self.beta1, self.beta2, self.epsilon)
+        if any(e.learnable_parameters for e in eqs):
+            st.attach_equation_parameters()
+        return st
 
 
 def _single(model_list):

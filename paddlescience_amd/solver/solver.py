@@ -218,7 +218,8 @@ class Solver:
             if len(cst.data_loader) == 1:
                 bsz = cst.data_loader.batch_sampler.num_samples
         cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
-                                bsz * self.world_size, self.device, train=True)
+                                bsz * self.world_size, self.device, train=True,
+                                extra_parameters=self._extra_parameters())
         self._static[name] = _is_full_static_batch(cst)
         if self._static[name]:
             inp, lab, w = next(cst.data_iter)
@@ -270,6 +271,7 @@ class Solver:
                     self._materialize()
                     self.engine.forward_backward(eng_csts)
                     self.engine.allreduce()
+                    self._allreduce_eq_params()
                     if getattr(self.loss_aggregator, "per_loss_grad", False):
                         # GradNorm / NTK: the step above used the current weights; refresh them from the per-key
                         # gradient norms at the same parameters (the total gradient is recomputed afterwards)
@@ -335,6 +337,17 @@ class Solver:
                 else:
                     cc.fused.edesc.res[i].scale = cc._base_scales[i] if k == mask_key else 0.0
         self.engine.invalidate_graphs()
+
+    def _extra_parameters(self):
+        """solver.py:490-494 of the reference: the learnable parameters of every equation go to lambdify."""
+        out = []
+        for eq in (self.equation or {}).values():
+            out += list(getattr(eq, "learnable_parameters", []))
+        return out
+
+    def _allreduce_eq_params(self) -> None:
+        if self.world_size > 1 and getattr(self.optimizer, "eq_store", None) is not None:
+            dist.all_reduce(self.optimizer.eq_store.grad)
 
     def _materialize(self) -> None:
         if self._reparam:
@@ -426,7 +439,8 @@ class Solver:
                 if key not in self._compiled_val:
                     self._compiled_val[key] = CompiledConstraint(
                         vname, self.model, val.output_expr, list(ds.input_keys), list(ds.label_keys),
-                        list((ds.weight or {}).keys()), val.loss, bsz, bsz, self.device, train=False, want_values=True)
+                        list((ds.weight or {}).keys()), val.loss, bsz, bsz, self.device, train=False, want_values=True,
+                        extra_parameters=self._extra_parameters())
                 cc = self._compiled_val[key]
                 cc.bind(inp, lab, w)
                 cc.fused.forward(self.model.materialize(), False)
@@ -532,7 +546,8 @@ class Solver:
             if ck not in self._predict_cache:
                 self._predict_cache[ck] = CompiledConstraint("predict", self.model, exprs, keys, [], [], None, bsz, bsz,
                                                             self.device, train=False, want_values=True,
-                                                            extra_outputs=out_keys)
+                                                            extra_outputs=out_keys,
+                                                            extra_parameters=self._extra_parameters())
             cc = self._predict_cache[ck]
             cc.bind(chunk, {}, {})
             cc.fused.forward(self.model.materialize(), False)

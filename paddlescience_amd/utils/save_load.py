@@ -89,6 +89,22 @@ def _state_arrays(model) -> Dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
+def _load_equation(path: str, equation) -> None:
+    """save_load.py:65-81 / :168-197: `<path>.pdeqn` = {equation name: state dict}."""
+    if equation is None:
+        return
+    if not os.path.exists(f"{path}.pdeqn"):
+        n = sum(len(eq.learnable_parameters) for eq in equation.values())
+        if n > 0:
+            logger.warning(f"There are a total of {n} learnable parameters in the equation, but {path}.pdeqn not found.")
+        return
+    with open(f"{path}.pdeqn", "rb") as f:
+        eq_dict = _ArrayUnpickler(f).load()
+    for name, eq in equation.items():
+        eq.set_state_dict(eq_dict[name])
+    logger.message(f"Finish loading equation parameters from: {path}.pdeqn")
+
+
 def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None, grad_scaler=None,
                     output_dir: Optional[str] = None, prefix: str = "model", equation=None, print_log: bool = True,
                     ema_model=None, aggregator=None):
@@ -105,6 +121,11 @@ def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None,
         st = optimizer.state_dict()
         _save_npz(path + ".pdopt", {"m": st["m"].detach().cpu().numpy(), "v": st["v"].detach().cpu().numpy(),
                                     "t": np.asarray(st["t"])})
+    if equation is not None and sum(len(eq.learnable_parameters) for eq in equation.values()) > 0:
+        # save_load.py:267-276: {equation name: ParameterList state dict}
+        with open(path + ".pdeqn", "wb") as f:
+            pickle.dump({key: {k: np.asarray(v) for k, v in eq.state_dict().items()} for key, eq in equation.items()},
+                        f, protocol=4)
     with open(path + ".pdstates", "w") as f:
         json.dump({"metric": float(metric["metric"]) if metric else float("inf"),
                    "epoch": int(metric["epoch"]) if metric else 0}, f)
@@ -120,6 +141,7 @@ def load_checkpoint(path: str, model, optimizer=None, equation=None, grad_scaler
     if optimizer is not None and os.path.exists(f"{path}.pdopt"):
         st = _load_npz(f"{path}.pdopt")
         optimizer.set_state_dict({"m": st["m"], "v": st["v"], "t": int(st["t"])})
+    _load_equation(path, equation)
     with open(f"{path}.pdstates") as f:
         metric = json.load(f)
     logger.message(f"Finish loading checkpoint from {path}")
@@ -134,3 +156,4 @@ def load_pretrain(model, path: str, equation=None):
         raise FileNotFoundError(f"{path}.pdparams not exist.")
     model.set_state_dict(_load_pdparams(f"{path}.pdparams"))
     logger.message(f"Finish loading pretrained model from: {path}.pdparams")
+    _load_equation(path, equation)

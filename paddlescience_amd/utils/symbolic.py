@@ -61,11 +61,11 @@ def _post_traverse(cur: sp.Basic, nodes: List[sp.Basic]) -> List[sp.Basic]:
 class ComposedNode:
     """symbolic.py:488-504: runs the node list in order and returns the value of the root."""
 
-    def __init__(self, sympy_nodes: List[sp.Basic], models: Tuple, parameter_names: Tuple[str, ...]):
+    def __init__(self, sympy_nodes: List[sp.Basic], models: Tuple, parameters: Tuple = ()):
         assert len(sympy_nodes)
         self.sympy_nodes = sympy_nodes
         self.models = models
-        self.parameter_names = parameter_names
+        self.parameters = tuple(parameters)
         self.keys = [_cvt_to_key(n) for n in sympy_nodes]
 
     def _eval(self, node: sp.Basic, data: DATA_DICT):
@@ -127,8 +127,10 @@ class ComposedNode:
                 elif str(node.func) != "sdf":
                     raise ValueError(f"Node {node} can not match any model in given model(s).")
                 continue
-            if isinstance(node, sp.Symbol):  # ParameterNode: learnable equation parameters
-                raise NotImplementedError("learnable equation parameters are not supported on the fused HIP path yet")
+            if isinstance(node, sp.Symbol):  # ParameterNode symbolic.py:471-485: one scalar, broadcast over the points
+                hit = [p for p in self.parameters if p.name == node.name]
+                data_dict[key] = Sym.param(hit[0].name, hit[0].slot)
+                continue
             data_dict[key] = self._eval(node, data_dict)
         return data_dict[self.keys[-1]]
 
@@ -150,8 +152,11 @@ def lambdify(
     retain_graph: Optional[bool] = None,
     fuse_derivative: bool = False,
 ) -> Union[ComposedNode, List[ComposedNode]]:
-    if extra_parameters:
-        raise NotImplementedError("learnable equation parameters are not supported on the fused HIP path yet")
+    extra_parameters = tuple(extra_parameters or ())
+    for prm in extra_parameters:
+        if not hasattr(prm, "slot"):
+            raise TypeError("extra_parameters must be equation parameters (ppsci.equation.pde.base.EqParam)")
+    parameter_names = tuple(prm.name for prm in extra_parameters)
     if models is not None and hasattr(models, "model_list"):
         models = tuple(models.model_list)
     if not isinstance(models, (tuple, list)):
@@ -160,9 +165,9 @@ def lambdify(
     def convert(single: sp.Basic) -> ComposedNode:
         single = single.subs(1.0, 1)
         nodes = _post_traverse(single, [])
-        nodes = [n for n in nodes if not n.is_Symbol]
+        nodes = [n for n in nodes if (not n.is_Symbol) or (_cvt_to_key(n) in parameter_names)]  # symbolic.py:797-803
         nodes = list(dict.fromkeys(nodes))
-        return ComposedNode(nodes, tuple(models), ())
+        return ComposedNode(nodes, tuple(models), extra_parameters)
 
     if isinstance(expr, sp.Basic):
         return convert(expr)

@@ -282,3 +282,55 @@ def test_autodiff_errors_follow_reference():
         jacobian(out["u"], torch.zeros(3, 1))
     ppsci.autodiff.clear()
     assert ppsci.autodiff.hessian.Hs == {} and ppsci.autodiff.jacobian.Js == {}
+
+
+def test_learnable_equation_parameters_vibration(tmp_path):
+    """ParameterNode (symbolic.py:471-485) through equation/pde/viv.py:41-62: rho*eta_tt + exp(k1)*eta_t + exp(k2)*eta
+    with learnable k1, k2 trained together with the network by Adam((model,) + equations) (examples/fsi/viv.py:121):
+    loss, network gradient, d loss / d k1, d loss / d k2 and one optimizer step against torch autograd."""
+    from paddlescience_amd.equation.pde.base import EqParamStore
+
+    EqParamStore.reset()
+    model = ppsci.arch.MLP(("t_f",), ("eta",), 2, 20, "tanh")
+    net = T.make_net(1, [20, 20], 1, bias_scale=0.1)
+    set_model_weights(model, net)
+    eq = ppsci.equation.Vibration(2.0, 0.7, -0.4)
+    assert [p.name for p in eq.parameters()] == [eq.k1.name, eq.k2.name] and set(eq.state_dict()) == {"0", "1"}
+    N = 41
+    rng = np.random.default_rng(6)
+    t = rng.uniform(0, 1, (N, 1)).astype(np.float32)
+    f_lab = rng.standard_normal((N, 1)).astype(np.float32)
+    eta_lab = rng.standard_normal((N, 1)).astype(np.float32) * 0.1
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": {"t_f": t}, "label": {"eta": eta_lab, "f": f_lab}}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), {"eta": lambda out: out["eta"], **eq.equations},
+                                                name="Sup")
+    opt = ppsci.optimizer.Adam(1e-2)((model,) + (eq,))
+    solver = ppsci.solver.Solver(model, {"Sup": cst}, str(tmp_path), opt, epochs=1, iters_per_epoch=1,
+                                 equation={"VIV": eq})
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver.engine.grad.cpu().numpy().astype(np.float64)
+    store = EqParamStore.get()
+    gk = store.grad.cpu().numpy().astype(np.float64)[:2]
+    # oracle
+    omodel = R.MLP(("t_f",), ("eta",), net.astype(np.float32).astype(np.float64))
+    k = {eq.k1.name: torch.tensor(float(np.float32(0.7)), dtype=torch.float64, requires_grad=True),
+         eq.k2.name: torch.tensor(float(np.float32(-0.4)), dtype=torch.float64, requires_grad=True)}
+    oc = dict(name="Sup", input={"t_f": t.astype(np.float64)},
+              exprs={"eta": lambda d: d["eta"], "f": R.lambdify(eq.equations["f"], omodel, extra_parameters=k)},
+              label={"eta": eta_lab.astype(np.float64), "f": f_lab.astype(np.float64)}, reduction="mean")
+    losses_all, _, _ = R.train_forward(omodel, [oc])
+    total = R.loss_sum(losses_all)
+    grads = torch.autograd.grad(total, omodel.parameters() + list(k.values()), allow_unused=True)
+    gref = np.concatenate([(torch.zeros_like(p) if gg is None else gg).numpy().ravel()
+                           for gg, p in zip(grads[:-2], omodel.parameters())])
+    got = solver._compiled["Sup"].fused.losses()
+    for key in ("eta", "f"):
+        assert got[key] == pytest.approx(float(losses_all[key]), rel=3e-5)
+    assert rel(g, gref) < 5e-5
+    assert gk[0] == pytest.approx(float(grads[-2]), rel=5e-5) and gk[1] == pytest.approx(float(grads[-1]), rel=5e-5)
+    # one training step: network and the two exponents move by Adam's first step (lr * sign-like update)
+    solver.train()
+    adam = R.Adam(2, lr=1e-2)
+    kref = adam.step(np.array([float(np.float32(0.7)), float(np.float32(-0.4))]), np.array([float(grads[-2]), float(grads[-1])]))
+    assert eq.k1.item() == pytest.approx(kref[0], rel=1e-5) and eq.k2.item() == pytest.approx(kref[1], rel=1e-5)
+    EqParamStore.reset()

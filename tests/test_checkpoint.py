@@ -74,3 +74,21 @@ def test_unpickler_refuses_anything_but_arrays(tmp_path, dev):
         pickle.dump({"linears.0.weight": Evil()}, f, protocol=4)
     with pytest.raises(pickle.UnpicklingError):
         save_load.load_pretrain(_model(), str(tmp_path / "evil.pdparams"))
+
+
+def test_equation_parameters_round_trip(tmp_path, dev):
+    """`.pdeqn` = {equation name: ParameterList state dict} (save_load.py:267-276, :168-197)."""
+    from paddlescience_amd.equation.pde.base import EqParamStore
+
+    EqParamStore.reset()
+    eq = {"VIV": ppsci.equation.Vibration(1.0, 4.0, -1.0)}
+    model = ppsci.arch.MLP(("t_f",), ("eta",), 2, 16, "tanh")
+    save_load.save_checkpoint(model, None, {"metric": 1.0, "epoch": 1}, None, str(tmp_path), "e1", eq)
+    path = os.path.join(str(tmp_path), "checkpoints", "e1")
+    with open(path + ".pdeqn", "rb") as f:
+        raw = pickle.load(f)
+    assert set(raw) == {"VIV"} and float(raw["VIV"]["0"]) == 4.0 and float(raw["VIV"]["1"]) == -1.0
+    eq["VIV"].k1.set_value(0.5)
+    save_load.load_checkpoint(path, model, None, eq)
+    assert eq["VIV"].k1.item() == 4.0 and eq["VIV"].k2.item() == -1.0
+    EqParamStore.reset()
