@@ -6,7 +6,7 @@ What differs by design: every constraint is compiled ONCE into (Taylor-mode stre
 program) and a training iteration is a fixed sequence of kernel launches (engine.Engine); loss values
 are only read back (one device->host sync) every `log_freq` iterations, whereas the reference syncs on
 `.item()` for every loss term of every iteration (expression.py:122, train.py:145).
-Not supported (raise): AMP, update_freq > 1, L-BFGS, loss aggregators other than Sum, to_static,
+Not supported (raise): AMP, loss aggregators other than Sum, to_static,
 visualizers."""
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .. import autodiff
+from .. import hotpath as hp
 from ..compile import CompiledConstraint
 from ..device import get_device
 from ..engine import Engine
@@ -74,8 +75,8 @@ class Solver:
     ):
         if use_amp or to_static:
             raise NotImplementedError("AMP / to_static are not available on the fused HIP path (fp32 only)")
-        if update_freq != 1:
-            raise NotImplementedError("gradient accumulation (update_freq > 1) is not implemented yet")
+        if int(update_freq) < 1:
+            raise ValueError(f"update_freq should be a positive integer, but got {update_freq}")
         if loss_aggregator is not None and not (isinstance(loss_aggregator, mtl.Sum)
                                                 or getattr(loss_aggregator, "per_loss_grad", False)):
             raise NotImplementedError("loss aggregators on the fused path: Sum, GradNorm, NTK")
@@ -142,6 +143,7 @@ class Solver:
         # factored / tied layers (weight_norm, random_weight, fourier): the kernels read model.kernel_params,
         # rebuilt from the trainable tensors before every sweep; their gradient is pulled back afterwards
         self._reparam = bool(getattr(self.model, "reparam", False))
+        self._acc_grad, self._acc_count = None, 0  # gradient accumulation (update_freq > 1)
         self.latest_save_interval = float(os.environ.get("PPSCI_LATEST_SAVE_INTERVAL", "1.0"))  # seconds; 0 = every epoch
         self._latest_saved_at = float("-inf")
         if (self.optimizer is not None and not self._is_spinn and not self._is_operator and not self._reparam
@@ -277,7 +279,21 @@ class Solver:
                         # gradient norms at the same parameters (the total gradient is recomputed afterwards)
                         if self.loss_aggregator.needs_update(self.global_step):
                             self._update_loss_weights(eng_csts)
-                    self.optimizer.step(self._train_grad(), gscale)
+                    if self.update_freq > 1:
+                        # train.py:141-142, :163-180: every loss is divided by update_freq, gradients accumulate and
+                        # the optimizer steps every update_freq-th iteration and at the end of the epoch
+                        if getattr(self.optimizer, "eq_store", None) is not None:
+                            raise NotImplementedError("update_freq > 1 together with learnable equation parameters")
+                        g = self._train_grad()
+                        if self._acc_grad is None:
+                            self._acc_grad = torch.zeros_like(g)
+                        hp.reduce_rows(g.view(1, -1), 1, g.numel(), self._acc_grad, self._acc_count > 0)
+                        self._acc_count += 1
+                        if iter_id % self.update_freq == 0 or iter_id == self.iters_per_epoch:
+                            self.optimizer.step(self._acc_grad, gscale / self.update_freq)
+                            self._acc_count = 0
+                    else:
+                        self.optimizer.step(self._train_grad(), gscale)
                 self.optimizer.clear_grad()
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
                     self.lr_scheduler.step()
@@ -397,6 +413,8 @@ class Solver:
                 per_cst[name] += vals[k]
                 losses_all[k] = losses_all.get(k, 0.0) + vals[k]
         total = float(self.loss_aggregator(losses_all, self.global_step))
+        if self.update_freq > 1:
+            total /= self.update_freq  # train.py:141-142: the logged total is the scaled one
         self.last_losses = {"loss": total, **per_cst}
         for k, v in self.last_losses.items():
             if k not in self.train_output_info:

@@ -113,3 +113,41 @@ def test_predict_and_eval(tmp_path):
     mse = np.mean((uv - val.data_loader.label["u"][:, 0].astype(np.float64)) ** 2)
     assert group["MSE_Metric"]["MSE.u"] == pytest.approx(mse, rel=1e-4)
     assert metric == pytest.approx(mse, rel=1e-4)
+
+
+def test_update_freq_accumulates_gradients(tmp_path):
+    """train.py:141-142, :163-180: losses divided by update_freq, gradients accumulated, optimizer steps every
+    update_freq-th iteration and at the last iteration of the epoch (5 iterations, update_freq 2: steps after
+    iterations 2, 4 and 5 with accumulated gradients g, g and g/2 of the then-current parameters)."""
+    np.random.seed(2024)
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 3, 20, "tanh")
+    net = T.make_net(2, [20, 20, 20], 1, seed=1234, bias_scale=0.05)
+    set_model_weights(model, net)
+    equation = {"laplace": ppsci.equation.Laplace(dim=2)}
+    geom = {"rect": ppsci.geometry.Rectangle((0.0, 0.0), (1.0, 1.0))}
+    cfg = {"dataset": "IterableNamedArrayDataset", "iters_per_epoch": 5}
+    pde = ppsci.constraint.InteriorConstraint(equation["laplace"].equations, {"laplace": 0}, geom["rect"],
+                                              {**cfg, "batch_size": 49}, ppsci.loss.MSELoss("sum"), evenly=True, name="EQ")
+    bc = ppsci.constraint.BoundaryConstraint({"u": lambda out: out["u"]}, {"u": u_solution_func}, geom["rect"],
+                                             {**cfg, "batch_size": 16}, ppsci.loss.MSELoss("sum"), name="BC")
+    optimizer = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    solver = ppsci.solver.Solver(model, {pde.name: pde, bc.name: bc}, str(tmp_path), optimizer, epochs=1,
+                                 iters_per_epoch=5, update_freq=2, equation=equation, geom=geom, log_freq=1)
+    solver.train()
+    net32 = net.astype(np.float32).astype(np.float64)
+    omodel = R.MLP(("x", "y"), ("u",), net32)
+    csts = oracle_constraints(omodel, pde, bc)
+    p = T.flat_params(net32)
+    adam = R.Adam(p.size, 1e-3)
+    for n_acc in (2, 2, 1):
+        off = 0
+        with torch.no_grad():
+            for t in omodel.parameters():
+                n = t.numel()
+                t.copy_(torch.tensor(p[off:off + n].reshape(t.shape)))
+                off += n
+        _, _, g, _ = R.loss_and_grads(omodel, csts)
+        p = adam.step(p, g * n_acc / 2.0)  # same batch every iteration: n_acc identical gradients, each / 2
+    got = model.flat_params.cpu().numpy().astype(np.float64)
+    assert np.abs(got - p).max() < 5e-6
+    assert optimizer.t == 3
