@@ -7,6 +7,7 @@ Mirrors ExpressionSolver.train_forward + train_epoch_func for a supervised const
 (/root/reference/ppsci/utils/expression.py:60-131, ppsci/solver/train.py:58-213)."""
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import numpy as np
@@ -35,10 +36,24 @@ class OperatorConstraint:
         self.label_keys = list(label_keys)
         self.batch_size = batch_size
         self.inp = self.lab = self.w = None
+        self.version = 0  # bumped when the device tensors are re-allocated
         self._last: Dict[str, torch.Tensor] = {}
 
     def bind(self, inp, lab, w=None):
-        self.inp, self.lab, self.w = _to_dev(inp, self.device), _to_dev(lab, self.device), _to_dev(w, self.device)
+        """Upload a batch.  Same-shaped batches are copied into the SAME device tensors, so that a captured step
+        (OperatorEngine: HIP graph) keeps reading valid addresses."""
+        new = (_to_dev(inp, self.device), _to_dev(lab, self.device), _to_dev(w, self.device))
+        old = (self.inp, self.lab, self.w)
+        same = all(o is not None and o.keys() == n.keys() and all(
+            isinstance(n[k], torch.Tensor) == isinstance(o[k], torch.Tensor)
+            and (not isinstance(n[k], torch.Tensor) or n[k].shape == o[k].shape) for k in n) for o, n in zip(old, new))
+        if same and all(isinstance(v, torch.Tensor) for d in new for v in d.values()):
+            for o, n in zip(old, new):
+                for k in n:
+                    o[k].copy_(n[k])
+        else:
+            self.inp, self.lab, self.w = new
+            self.version += 1
 
     def outputs(self) -> Dict[str, torch.Tensor]:
         out = self.model(self.inp)
@@ -65,11 +80,21 @@ class OperatorEngine:
         self.model = model
         self.grad = model.flat_grad
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        from .engine import StepGraph
 
-    def forward_backward(self, constraints: List[OperatorConstraint]):
+        self._step_graph = StepGraph(self.grad.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0")
+
+    def _forward_backward_eager(self, constraints: List[OperatorConstraint]):
         self.grad.zero_()
         for c in constraints:
             c.forward_loss().backward()
+
+    def forward_backward(self, constraints: List[OperatorConstraint]):
+        # An FNO step is ~200 kernels of ~10 us (FFTs, the spectral contraction, 1x1 convolutions, norms, their
+        # backward): launch-bound from Python/autograd, so forward + loss + backward is captured once per batch shape
+        # into a HIP graph and replayed (engine.StepGraph; PPSCI_HIP_GRAPH=0 or a failed capture -> eager).
+        key = tuple((id(c), c.version) for c in constraints)
+        self._step_graph.run(key, lambda: self._forward_backward_eager(constraints))
 
     def allreduce(self):
         if self.world > 1:
