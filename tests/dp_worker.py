@@ -31,6 +31,52 @@ def build_solver(outdir, world_batch, reduction, steps):
     return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
 
 
+def build_viv_solver(outdir, world_batch, steps):
+    """Factored layers (random_weight) + learnable equation parameters (Vibration): the kernel-layout gradient is
+    all-reduced and pulled back, the equation-parameter gradient has its own all-reduce."""
+    import ppsci
+    from paddlescience_amd.equation.pde.base import EqParamStore
+
+    EqParamStore.reset()
+    ppsci.utils.misc.set_random_seed(11)
+    model = ppsci.arch.MLP(("t_f",), ("eta",), 2, 16, "tanh", random_weight={"mean": 0.5, "std": 0.1})
+    eq = ppsci.equation.Vibration(1.5, 0.3, -0.2)
+    N = world_batch
+    rng = np.random.default_rng(3)
+    t = rng.uniform(0, 1, (N, 1)).astype(np.float32)
+    lab = {"eta": rng.standard_normal((N, 1)).astype(np.float32) * 0.1, "f": rng.standard_normal((N, 1)).astype(np.float32)}
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"t_f": t}, "label": lab},
+           "batch_size": N // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"),
+                                                {"eta": lambda out: out["eta"], **eq.equations}, name="Sup")
+    opt = ppsci.optimizer.Adam(learning_rate=1e-2)((model, eq))
+    solver = ppsci.solver.Solver(model, {"Sup": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1,
+                                 equation={"VIV": eq})
+    return solver, model, eq
+
+
+def main_viv(outdir):
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    solver, model, eq = build_viv_solver(outdir, 48, 3)
+    solver.train()
+    pred = solver.predict({"t_f": np.linspace(0, 1, 9, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        np.savez(os.path.join(outdir, f"result_w{world}.npz"),
+                 params=np.concatenate([model.flat_params.numpy(), [eq.k1.item(), eq.k2.item()]]), pred=pred["eta"],
+                 loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def build_fno_solver(outdir, world_batch, steps):
     """Operator-learning path: TFNO2dNet through torch autograd + the HIP spectral kernel, gradient averaged
     over ranks (DataParallel semantics)."""
@@ -60,6 +106,8 @@ def main():
         return main_fno(outdir)
     if reduction == "spinn":
         return main_spinn(outdir)
+    if reduction == "viv":
+        return main_viv(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 

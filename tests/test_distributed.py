@@ -54,6 +54,16 @@ def test_two_ranks_reproduce_single_rank_spinn(tmp_path):
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
 
 
+def test_two_ranks_reproduce_single_rank_factored_layers_and_equation_parameters(tmp_path):
+    """MLP(random_weight=...) + Vibration's learnable k1, k2: network parameters (trainable layout), the two exponents
+    and the prediction after three Adam steps are the same on one and on two ranks."""
+    d = str(tmp_path)
+    one = _run(d, 1, "viv")
+    two = _run(d, 2, "viv")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
+
+
 def test_iterable_dataset_refuses_world_size_gt_1():
     """data/__init__.py:62-66."""
     import ppsci.data as D
