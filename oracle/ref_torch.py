@@ -133,6 +133,24 @@ class MLP:
         return {k: v for k, v in zip(self.output_keys, outs)}
 
 
+class ModelList:
+    """ppsci.arch.ModelList (model_list.py:24-72): members share the input dict, outputs are merged."""
+
+    def __init__(self, models: Sequence[MLP]):
+        self.model_list = list(models)
+        self.output_keys = tuple(k for m in self.model_list for k in m.output_keys)
+        self.dtype = self.model_list[0].dtype
+
+    def parameters(self) -> List[torch.Tensor]:
+        return [p for m in self.model_list for p in m.parameters()]
+
+    def __call__(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        y_all: Dict[str, torch.Tensor] = {}
+        for m in self.model_list:
+            y_all.update(m(x))
+        return y_all
+
+
 # ----------------------------------------------------------------------------- autodiff
 def _grad(y, xs, create_graph=True):
     single = not isinstance(xs, (list, tuple))

@@ -147,24 +147,10 @@ class MLP(Arch):
             fin = hidden[0]
         shapes += [("last_fc.weight", (fin, len(self.output_keys))), ("last_fc.bias", (len(self.output_keys),))]
         n_train = sum(int(np.prod(shp)) for _, shp in shapes)
-        self.flat_params = torch.zeros(n_train, dtype=torch.float32, device=dev)
-        self._names: List[str] = []
-        self._views: List[torch.Tensor] = []
-        off = 0
-        for name, shp in shapes:
-            n = int(np.prod(shp))
-            self._names.append(name)
-            self._views.append(self.flat_params[off:off + n].view(*shp))
-            off += n
+        self._shapes = shapes
+        self._n_hidden_linears, self._fourier_half = len(hidden), fourier_half
+        self._bind_views(torch.zeros(n_train, dtype=torch.float32, device=dev))
         byname = dict(zip(self._names, self._views))
-        if self._linear_kind == L.LINEAR_PLAIN:
-            self.linears = [_Linear(byname[f"linears.{l}.weight"], byname[f"linears.{l}.bias"])
-                            for l in range(len(hidden))]
-        else:
-            self.linears = [_FactoredLinear(byname[f"linears.{l}.weight_v"], byname[f"linears.{l}.weight_g"],
-                                            byname[f"linears.{l}.bias"]) for l in range(len(hidden))]
-        self.last_fc = _Linear(byname["last_fc.weight"], byname["last_fc.bias"])
-        self.fourier_emb = _Kernel(byname["fourier_emb.kernel"]) if fourier_half else None
         self.acts = [self.activation] * len(hidden)
         # ---- what the kernels read: for plain nets the very same buffer, otherwise a second buffer in the
         # kernel layout (W0, b0, W1, b1, ...) that materialize() fills from the trainable tensors
@@ -210,6 +196,37 @@ class MLP(Arch):
                                   gviews["last_fc.bias"]))
         self._frozen = False
         self._init_parameters()
+
+    def _bind_views(self, flat: torch.Tensor) -> None:
+        """(Re)build the per-tensor views of the trainable parameters over `flat` (ModelList re-homes its members'
+        parameters into one buffer so that the optimizer and the all-reduce see a single tensor)."""
+        self.flat_params = flat
+        self._names, self._views = [], []
+        off = 0
+        for name, shp in self._shapes:
+            n = int(np.prod(shp))
+            self._names.append(name)
+            self._views.append(flat[off:off + n].view(*shp))
+            off += n
+        byname = dict(zip(self._names, self._views))
+        nl = self._n_hidden_linears
+        if self._linear_kind == L.LINEAR_PLAIN:
+            self.linears = [_Linear(byname[f"linears.{l}.weight"], byname[f"linears.{l}.bias"]) for l in range(nl)]
+        else:
+            self.linears = [_FactoredLinear(byname[f"linears.{l}.weight_v"], byname[f"linears.{l}.weight_g"],
+                                            byname[f"linears.{l}.bias"]) for l in range(nl)]
+        self.last_fc = _Linear(byname["last_fc.weight"], byname["last_fc.bias"])
+        self.fourier_emb = _Kernel(byname["fourier_emb.kernel"]) if self._fourier_half else None
+        if not self.reparam:
+            self.kernel_params = flat
+
+    def rehome(self, flat: torch.Tensor) -> None:
+        """Move the parameters into `flat` (a slice of a larger buffer), keeping their values."""
+        if self.reparam:
+            raise NotImplementedError("ModelList members with weight_norm / random_weight / fourier")
+        assert flat.numel() == self.flat_params.numel()
+        flat.copy_(self.flat_params)
+        self._bind_views(flat)
 
     # ---- trainable tensors <-> kernel layout (csrc/reparam.hip); both are no-ops for a plain MLP
     def materialize(self) -> torch.Tensor:

@@ -1,0 +1,76 @@
+"""ppsci.arch.ModelList (/root/reference/ppsci/arch/model_list.py:24-72): several networks that share the input
+dict; the outputs are merged.  On the fused path every member keeps its own Taylor-mode kernels, and their
+parameters are re-homed into ONE flat buffer (members' `flat_params` become slices of it), so that the optimizer,
+the gradient all-reduce and the checkpoint see a single tensor as they do for one MLP."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from .base import Arch
+from .mlp import MLP
+
+
+class ModelList(Arch):
+    def __init__(self, model_list: Tuple[Arch, ...]):
+        super().__init__()
+        model_list = tuple(model_list)
+        for m in model_list:
+            if not isinstance(m, MLP):
+                raise NotImplementedError("ModelList members must be ppsci.arch.MLP on the fused HIP path")
+        keys: List[str] = []
+        for m in model_list:  # the reference keeps a set; a stable order is needed for the kernels' input arrays
+            keys += [k for k in m.input_keys if k not in keys]
+        self.input_keys = tuple(keys)
+        seen = set()
+        for m in model_list:
+            dup = seen & set(m.output_keys)
+            if dup:
+                raise ValueError(f"output_keys of model from model_list should be unique,but got duplicate keys: {dup}")
+            seen |= set(m.output_keys)
+        self.output_keys = tuple(k for m in model_list for k in m.output_keys)
+        self.model_list = list(model_list)
+        pad = lambda n: (n + 63) // 64 * 64  # noqa: E731 -- every member starts on a 256-byte boundary (the
+        # kernels use 16-byte vector loads of weights); the padding floats stay zero: their gradient is never written
+        total = sum(pad(m.flat_params.numel()) for m in model_list)
+        self.flat_params = torch.zeros(total, dtype=torch.float32, device=model_list[0].flat_params.device)
+        off = 0
+        for m in model_list:
+            n = m.flat_params.numel()
+            m.rehome(self.flat_params[off:off + n])
+            m._param_offset = off
+            off += pad(n)
+        self.kernel_params = self.flat_params
+        self.reparam = False
+        self.layout = None  # one layout per member: see compile.CompiledConstraint
+
+    def materialize(self) -> torch.Tensor:
+        return self.flat_params
+
+    def forward(self, x: Dict[str, object]) -> Dict[str, object]:
+        y_all: Dict[str, object] = {}
+        for m in self.model_list:
+            y_all.update(m({k: x[k] for k in x}))
+        if self._output_transform is not None:
+            y_all = self._output_transform(x, y_all)
+        return y_all
+
+    def parameters(self) -> List[torch.Tensor]:
+        return [p for m in self.model_list for p in m.parameters()]
+
+    def named_parameters(self):
+        return [(f"model_list.{i}.{n}", p) for i, m in enumerate(self.model_list) for n, p in m.named_parameters()]
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return dict(self.named_parameters())  # nn.LayerList naming: model_list.<i>.<param>
+
+    def set_state_dict(self, state):
+        missing, unexpected = [], []
+        for i, m in enumerate(self.model_list):
+            pre = f"model_list.{i}."
+            mi, un = m.set_state_dict({k[len(pre):]: v for k, v in state.items() if k.startswith(pre)})
+            missing += [pre + k for k in mi]
+            unexpected += [pre + k for k in un]
+        unexpected += [k for k in state if not k.startswith("model_list.")]
+        return missing, unexpected

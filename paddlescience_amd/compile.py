@@ -91,7 +91,10 @@ class CompiledConstraint:
         self._stage: List[torch.Tensor] = []
         self._stage_done: List[Optional[torch.cuda.Event]] = []
         self._flip = 0
-        self.fused = FusedConstraint(name, model.layout, self.low.streams, self.low.program.build(), inputs, aux,
+        nets = [(m.layout, getattr(m, "_param_offset", 0), spec, idx) for m, spec, _, idx in self.low.nets]
+        if not nets:
+            raise NotImplementedError("a constraint that evaluates no network has nothing to train")
+        self.fused = FusedConstraint(name, nets, self.low.streams, self.low.program.build(), inputs, aux,
                                      self.low.loss_keys, want_residual=want_values or bool(self.low.causal))
         if self.low.param_slots:
             from .equation.pde.base import EqParamStore

@@ -21,33 +21,51 @@ from . import hotpath as hp
 
 
 class FusedConstraint:
-    """Device-resident state of one constraint batch: inputs, aux arrays, streams, stash, partials."""
+    """Device-resident state of one constraint batch: inputs, aux arrays, streams, stash, partials.
 
-    def __init__(self, name: str, layout: hp.NetLayout, streams: hp.StreamSpec, edesc: L.EpilogueDesc,
+    `nets`: one entry per network the constraint evaluates -- (layout, offset of its parameters in the flat
+    parameter buffer, StreamSpec in its own input order, indices of its inputs among `inputs`); a plain layout stands
+    for a single network at offset 0 that takes all inputs.  The members' streams are consecutive row blocks of U."""
+
+    def __init__(self, name: str, nets, streams: hp.StreamSpec, edesc: L.EpilogueDesc,
                  inputs: Sequence[torch.Tensor], aux: Sequence[torch.Tensor], loss_keys: Sequence[str],
                  want_residual: bool = False):
         self.name = name
-        self.layout, self.streams, self.edesc = layout, streams, edesc
-        self.desc = layout.desc(streams)
+        self.streams, self.edesc = streams, edesc
         self.inputs = [t.contiguous().view(-1) for t in inputs]
         self.aux = [t.contiguous().view(-1) for t in aux]
         self.n = self.inputs[0].numel()
         self.loss_keys = list(loss_keys)
         dev = self.inputs[0].device
-        q = layout.d_out * streams.S
         f32 = dict(dtype=torch.float32, device=dev)
+        if isinstance(nets, hp.NetLayout):
+            nets = [(nets, 0, streams, list(range(len(self.inputs))))]
+        q = sum(lay.d_out for lay, _, _, _ in nets) * streams.S
         self.U = torch.zeros((q, self.n), **f32)
         self.Ubar = torch.zeros((q, self.n), **f32)  # rows never loaded by the program stay 0
-        self.stash = torch.empty(hp.stash_bytes(self.desc, self.n) // 4, **f32)
+        self.nets = []
+        row = 0
+        for lay, off, spec, idx in nets:
+            desc = lay.desc(spec)
+            rows = hp.bwd_partial_rows(desc, self.n)
+            if rows <= 0:
+                raise NotImplementedError(
+                    f"network {lay.n_hidden}x{lay.width} with {spec.S} streams has no HIP reverse kernel")
+            nr = lay.d_out * streams.S
+            self.nets.append(dict(
+                layout=lay, off=off, desc=desc, inputs=[self.inputs[j] for j in idx],
+                U=self.U[row:row + nr], Ubar=self.Ubar[row:row + nr],
+                stash=torch.empty(hp.stash_bytes(desc, self.n) // 4, **f32), grad_rows=rows,
+                grad_partials=torch.empty((rows, lay.n_params), **f32),
+                workspace=torch.empty(max(4, hp.bwd_workspace_bytes(desc, self.n) // 4), **f32)))
+            row += nr
+        first = self.nets[0]  # single-network accessors (bench.py, tests, tools)
+        self.layout, self.desc, self.stash = first["layout"], first["desc"], first["stash"]
+        self.grad_rows, self.grad_partials, self.workspace = first["grad_rows"], first["grad_partials"], first["workspace"]
+        self.work = sum(self.n * nt["layout"].n_params * streams.S for nt in self.nets)
         self.loss_rows = hp.epilogue_partial_rows(self.n)
         self.loss_partials = torch.zeros((self.loss_rows, max(1, edesc.n_res)), **f32)
         self.loss_terms = torch.zeros(max(1, edesc.n_res), **f32)
-        self.grad_rows = hp.bwd_partial_rows(self.desc, self.n)
-        if self.grad_rows <= 0:
-            raise NotImplementedError(
-                f"network {layout.n_hidden}x{layout.width} with {streams.S} streams has no HIP reverse kernel")
-        self.grad_partials = torch.empty((self.grad_rows, layout.n_params), **f32)
-        self.workspace = torch.empty(max(4, hp.bwd_workspace_bytes(self.desc, self.n) // 4), **f32)
         self.resid = torch.zeros((max(1, edesc.n_res), self.n), **f32) if want_residual else None
 
     def set_inputs(self, inputs: Sequence[torch.Tensor], aux: Optional[Sequence[torch.Tensor]] = None) -> None:
@@ -70,7 +88,9 @@ class FusedConstraint:
         self.chunk_scratch = torch.zeros((len(self.causal), n_chunks), dtype=torch.float32, device=self.U.device)
 
     def forward(self, params: torch.Tensor, train: bool) -> None:
-        hp.taylor_fwd(self.desc, params, self.inputs, self.U, self.stash if train else None)
+        for nt in self.nets:
+            hp.taylor_fwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["U"],
+                          nt["stash"] if train else None)
         if getattr(self, "causal", None):
             # first pass: the per-point values only; then the causal factor of every key from its window means
             # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
@@ -90,7 +110,15 @@ class FusedConstraint:
         return (None, None) if st is None else (st.values, self.eq_partials if train else None)
 
     def backward(self, params: torch.Tensor) -> None:
-        hp.taylor_bwd(self.desc, params, self.inputs, self.Ubar, self.stash, self.workspace, self.grad_partials)
+        for nt in self.nets:
+            hp.taylor_bwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["Ubar"],
+                          nt["stash"], nt["workspace"], nt["grad_partials"])
+
+    def reduce_grads(self, grad: torch.Tensor, accumulate: bool) -> None:
+        """grad[member's slice] (+)= this constraint's gradient of that member (fixed order)."""
+        for nt in self.nets:
+            n = nt["layout"].n_params
+            hp.reduce_rows(nt["grad_partials"], nt["grad_rows"], n, grad[nt["off"]:nt["off"] + n], accumulate)
 
     def losses(self) -> Dict[str, float]:
         vals = self.loss_terms.detach().cpu().tolist()  # one device->host sync, only when logging
@@ -150,7 +178,7 @@ def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
 class Engine:
     def __init__(self, layout: hp.NetLayout, params: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8,
                  dp_reduce: str = "sum"):
-        assert params.numel() == layout.n_params
+        assert layout is None or params.numel() == layout.n_params  # None: several networks (ModelList)
         self.layout = layout
         self.params = params
         self.grad = torch.zeros_like(params)
@@ -184,12 +212,12 @@ class Engine:
 
             run_on_streams(self._streams, [job(c) for c in constraints])
             for i, c in enumerate(constraints):
-                hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+                c.reduce_grads(self.grad, i > 0)
         else:
             for i, c in enumerate(constraints):
                 c.forward(self.params, True)
                 c.backward(self.params)
-                hp.reduce_rows(c.grad_partials, c.grad_rows, self.layout.n_params, self.grad, i > 0)
+                c.reduce_grads(self.grad, i > 0)
         # d loss / d (learnable equation parameter): per-block sums of every constraint that reads one, in order
         first = True
         for c in constraints:
@@ -204,7 +232,7 @@ class Engine:
         # the GPU-bound 100 k-point Allen-Cahn step 2 % (0.458 -> 0.468 ms) while it makes Laplace2D 4x faster
         # ... and so does a step whose constraints are all small (the reference's 4 096-point batches on a 4 x 256
         # net: ~16 launches of 10-250 us, issued from Python in about the time the GPU needs for them)
-        work = sum(c.n * self.layout.n_params * c.streams.S for c in constraints)
+        work = sum(c.work for c in constraints)
         if work > self.graph_max_work and max(c.n for c in constraints) > self.multi_stream_max_points:
             return self._forward_backward_eager(constraints)
         self._step_graph.enabled = self.use_graph

@@ -293,6 +293,7 @@ class Lowered:
         self.value_index = value_index  # output name -> program value index
         self.causal: List[tuple] = []
         self.param_slots: List[int] = []  # slots of the learnable equation parameters the program reads
+        self.nets: List[tuple] = []  # (model, StreamSpec, first U row, input indices) per network of the constraint
 
 
 def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = ()) -> Lowered:
@@ -302,10 +303,9 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
        scale-0 residual rows so that eval / predict can read their values."""
     roots = list(outputs.values())
     nodes = _walk(roots)
-    models = {id(n.model): n.model for n in nodes if n.kind == "net"}
-    if len(models) > 1:
-        raise NotImplementedError("one constraint may reference a single network on the fused HIP path")
-    model = next(iter(models.values())) if models else None
+    models = {id(n.model): n.model for n in nodes if n.kind == "net"}  # ModelList members: in order of appearance
+    model_list = list(models.values())
+    model = model_list[0] if model_list else None
 
     # ---- derivative set -> stream specification
     firsts, seconds, mixed = set(), set(), set()
@@ -321,7 +321,9 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             else:
                 mixed.add((a, b))
                 seconds.update((a, b))
-    in_keys = list(model.input_keys) if model is not None else []
+    in_keys: List[str] = []  # union of the members' inputs: the constraint's input arrays
+    for mm in model_list:
+        in_keys += [k for k in mm.input_keys if k not in in_keys]
     order_second = [v for v in in_keys if v in seconds]
     order_first = [v for v in in_keys if v in firsts and v not in seconds]
     dir_names: List[object] = list(order_second) + sorted(mixed) + order_first
@@ -355,8 +357,18 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     S = streams.S
     dir_index = {d: i for i, d in enumerate(dir_names)}
 
-    n_out = len(model.output_keys) if model is not None else 0
-    prog = hp.Program(n_out * S, len(in_keys))
+    # every member carries the same stream set; its direction vectors are expressed in ITS input order (a
+    # variable a member does not take contributes nothing: its derivative along it is zero), and its streams
+    # are a block of rows of the constraint's U / Ubar arrays
+    nets = []  # (model, StreamSpec, first U row, indices of its inputs in in_keys)
+    row0: Dict[int, int] = {}
+    rows = 0
+    for mm in model_list:
+        idx = [in_keys.index(k) for k in mm.input_keys]
+        nets.append((mm, hp.StreamSpec([[v[j] for j in idx] for v in dirs_vec], n2p), rows, idx))
+        row0[id(mm)] = rows
+        rows += len(mm.output_keys) * S
+    prog = hp.Program(rows, len(in_keys))
     # inputs that are not network inputs (e.g. parameters of a boundary function) are shipped as aux arrays
     input_names = list(in_keys)
     aux_names: List[str] = []
@@ -382,7 +394,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         elif n.kind == "const":
             val[id(n)] = prog.const(n.value)
         elif n.kind == "net":
-            c = n.comp
+            c = n.comp + row0[id(n.model)] // S  # rows of a member start at a multiple of S
             if len(n.dirs) == 0:
                 val[id(n)] = prog.ld_u(c * S)
             elif len(n.dirs) == 1:
@@ -425,4 +437,5 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     low = Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
     low.causal = causal
     low.param_slots = sorted(param_slots)
+    low.nets = nets
     return low

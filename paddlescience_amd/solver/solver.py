@@ -139,7 +139,7 @@ class Solver:
 
             self.engine = OperatorEngine(self.model)
         else:
-            self.engine = Engine(self.model.layout, self.model.kernel_params, dp_reduce=dp_reduce)
+            self.engine = Engine(getattr(self.model, "layout", None), self.model.kernel_params, dp_reduce=dp_reduce)
         # factored / tied layers (weight_norm, random_weight, fourier): the kernels read model.kernel_params,
         # rebuilt from the trainable tensors before every sweep; their gradient is pulled back afterwards
         self._reparam = bool(getattr(self.model, "reparam", False))

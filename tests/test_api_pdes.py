@@ -334,3 +334,58 @@ def test_learnable_equation_parameters_vibration(tmp_path):
     kref = adam.step(np.array([float(np.float32(0.7)), float(np.float32(-0.4))]), np.array([float(grads[-2]), float(grads[-1])]))
     assert eq.k1.item() == pytest.approx(kref[0], rel=1e-5) and eq.k2.item() == pytest.approx(kref[1], rel=1e-5)
     EqParamStore.reset()
+
+
+def test_model_list_two_networks_in_one_residual(tmp_path):
+    """ppsci.arch.ModelList (model_list.py:24-72): a velocity net (x, y) -> (u, v) and a pressure net (x, y) -> p with a
+    different depth, width and activation, coupled in NS-like residuals; losses and the gradient of BOTH members against
+    torch autograd, then Adam steps on the shared flat buffer."""
+    net_a = T.make_net(2, [20, 20], 2, seed=3, bias_scale=0.05)
+    net_b = T.make_net(2, [16, 16, 16], 1, seed=4, activation="silu", bias_scale=0.05)
+    ma = ppsci.arch.MLP(("x", "y"), ("u", "v"), 2, 20, "tanh")
+    mb = ppsci.arch.MLP(("x", "y"), ("p",), 3, 16, "silu")
+    set_model_weights(ma, net_a)
+    set_model_weights(mb, net_b)
+    model = ppsci.arch.ModelList((ma, mb))
+    assert model.output_keys == ("u", "v", "p") and set(model.input_keys) == {"x", "y"}
+    assert "model_list.1.last_fc.bias" in model.state_dict()
+    np.testing.assert_array_equal(mb.flat_params.cpu().numpy(), T.flat_params(net_b).astype(np.float32))
+    N = 39
+    X = np.random.default_rng(10).uniform(-1, 1, (N, 2)).astype(np.float32)
+    x, y = sp.symbols("x y")
+    u, v, p = (sp.Function(k)(x, y) for k in ("u", "v", "p"))
+    nu = 0.05
+    exprs = {"continuity": u.diff(x) + v.diff(y),
+             "momentum_x": u * u.diff(x) + v * u.diff(y) - nu * (u.diff(x, 2) + u.diff(y, 2)) + p.diff(x),
+             "momentum_y": u * v.diff(x) + v * v.diff(y) - nu * (v.diff(x, 2) + v.diff(y, 2)) + p.diff(y)}
+    lab = {k: np.zeros((N, 1), np.float32) for k in exprs}
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, lab, exprs, ppsci.loss.MSELoss("sum"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver.engine.grad.cpu().numpy().astype(np.float64)
+    oa = R.MLP(("x", "y"), ("u", "v"), net_a.astype(np.float32).astype(np.float64))
+    ob = R.MLP(("x", "y"), ("p",), net_b.astype(np.float32).astype(np.float64))
+    om = R.ModelList((oa, ob))
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={k: R.lambdify(e, om) for k, e in exprs.items()}, label={k: np.zeros((N, 1)) for k in exprs},
+              reduction="sum")
+    losses_all, _, _ = R.train_forward(om, [oc])
+    total = R.loss_sum(losses_all)
+    got = solver._compiled["EQ"].fused.losses()
+    for k in exprs:
+        assert got[k] == pytest.approx(float(losses_all[k]), rel=3e-5)
+    for mem, omem in ((ma, oa), (mb, ob)):
+        gr = torch.autograd.grad(total, omem.parameters(), allow_unused=True, retain_graph=True)
+        gref = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gr, omem.parameters())])
+        off, n = mem._param_offset, mem.flat_params.numel()
+        assert rel(g[off:off + n], gref) < 5e-5
+    # eager forward of the list and a training run
+    out = model({"x": X[:, :1], "y": X[:, 1:]})
+    ref = om({"x": torch.tensor(X[:, :1].astype(np.float64)), "y": torch.tensor(X[:, 1:].astype(np.float64))})
+    for k in ("u", "v", "p"):
+        assert rel(out[k].cpu().numpy(), ref[k].detach().numpy()) < 1e-5
+    before = model.flat_params.clone()
+    solver.train()
+    assert float((model.flat_params - before).abs().max()) > 1e-4
+    pred = solver.predict({"x": X[:5, :1], "y": X[:5, 1:]}, return_numpy=True)
+    assert set(pred) >= {"u", "v", "p"}
