@@ -205,6 +205,9 @@ class Engine:
         # the 256 CUs for the latency of one tile's layer chain, so such sets run concurrently, one HIP stream per
         # constraint, and join before the fixed-order gradient sum (also inside a captured graph: parallel
         # branches).  PPSCI_MULTI_STREAM=0 turns it off.
+        several = self.layout is None  # ModelList: a constraint may touch only some members' slices of the gradient,
+        if several:                    # so start from zero and always accumulate
+            self.grad.zero_()
         if (self.multi_stream and len(constraints) > 1 and self.params.is_cuda
                 and min(c.n for c in constraints) <= self.multi_stream_max_points):
             def job(c):
@@ -212,12 +215,12 @@ class Engine:
 
             run_on_streams(self._streams, [job(c) for c in constraints])
             for i, c in enumerate(constraints):
-                c.reduce_grads(self.grad, i > 0)
+                c.reduce_grads(self.grad, several or i > 0)
         else:
             for i, c in enumerate(constraints):
                 c.forward(self.params, True)
                 c.backward(self.params)
-                c.reduce_grads(self.grad, i > 0)
+                c.reduce_grads(self.grad, several or i > 0)
         # d loss / d (learnable equation parameter): per-block sums of every constraint that reads one, in order
         first = True
         for c in constraints:

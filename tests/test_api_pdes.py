@@ -389,3 +389,43 @@ def test_model_list_two_networks_in_one_residual(tmp_path):
     assert float((model.flat_params - before).abs().max()) > 1e-4
     pred = solver.predict({"x": X[:5, :1], "y": X[:5, 1:]}, return_numpy=True)
     assert set(pred) >= {"u", "v", "p"}
+
+
+def test_model_list_constraints_touching_different_members(tmp_path):
+    """Two constraints, each on ONE member of a ModelList (the second member also takes fewer inputs): the gradient
+    slice of a member comes only from the constraints that evaluate it, every step."""
+    net_a = T.make_net(2, [20, 20], 1, seed=3, bias_scale=0.05)
+    net_b = T.make_net(1, [16, 16], 1, seed=4, bias_scale=0.05)
+    ma = ppsci.arch.MLP(("x", "y"), ("u",), 2, 20, "tanh")
+    mb = ppsci.arch.MLP(("x",), ("q",), 2, 16, "tanh")
+    set_model_weights(ma, net_a)
+    set_model_weights(mb, net_b)
+    model = ppsci.arch.ModelList((ma, mb))
+    N = 30
+    rng = np.random.default_rng(12)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    eq = ppsci.equation.Laplace(dim=2)
+    c1 = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"laplace": np.zeros((N, 1), np.float32)}, eq.equations,
+                         ppsci.loss.MSELoss("mean"), name="A")
+    labq = rng.standard_normal((N, 1)).astype(np.float32)
+    c2 = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"q": labq}, {"q": lambda out: out["q"] + jacobian(out["q"], out["x"])},
+                         ppsci.loss.MSELoss("mean"), name="B")
+    solver = _solver(tmp_path, model, {"A": c1, "B": c2})
+    for _ in range(2):  # the second pass must not accumulate onto the first
+        solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver.engine.grad.cpu().numpy().astype(np.float64)
+    oa = R.MLP(("x", "y"), ("u",), net_a.astype(np.float32).astype(np.float64))
+    ob = R.MLP(("x",), ("q",), net_b.astype(np.float32).astype(np.float64))
+    # member A: Laplace residual
+    ca = dict(name="A", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={"laplace": R.lambdify(R.laplace_exprs(2)["laplace"], oa)}, label={"laplace": np.zeros((N, 1))},
+              reduction="mean")
+    _, _, ga, _ = R.loss_and_grads(oa, [ca])
+    xb = torch.tensor(X[:, :1].astype(np.float64), requires_grad=True)
+    qb = ob({"x": xb})["q"]
+    rb = qb + torch.autograd.grad(qb.sum(), xb, create_graph=True)[0]
+    lb = ((rb - torch.tensor(labq.astype(np.float64))) ** 2).mean()
+    gb = torch.autograd.grad(lb, ob.parameters(), allow_unused=True)
+    gb = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gb, ob.parameters())])
+    assert rel(g[ma._param_offset:ma._param_offset + ga.size], ga) < 5e-5
+    assert rel(g[mb._param_offset:mb._param_offset + gb.size], gb) < 5e-5
