@@ -39,10 +39,15 @@ extern "C" {
 #define PPSCI_MAX_AUX 16    /* auxiliary per-point arrays (labels, weights, sdf, ...) */
 
 enum { PPSCI_OK = 0, PPSCI_E_INVALID = -1, PPSCI_E_UNSUPPORTED = -2, PPSCI_E_LAUNCH = -3 };
-enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGMOID = 3, PPSCI_ACT_COS = 4, PPSCI_ACT_GELU = 5 };
+enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGMOID = 3, PPSCI_ACT_COS = 4, PPSCI_ACT_GELU = 5,
+       /* activations with a trainable per-feature parameter p (one [width] vector per hidden layer, stored behind the
+        * last bias in the parameter buffer): Swish x*sigmoid(p x) (activation.py:49-58, its scalar beta broadcast by
+        * the caller) and Stan tanh(x)*(1 + p x) (activation.py:28-46) */
+       PPSCI_ACT_SWISH = 6, PPSCI_ACT_STAN = 7 };
 enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1 };
 /* layer parametrisations handled on the parameter buffers (csrc/reparam.hip) */
-enum { PPSCI_LINEAR_PLAIN = 0, PPSCI_LINEAR_WEIGHT_NORM = 1, PPSCI_LINEAR_RWF = 2, PPSCI_LINEAR_FOURIER = 3 };
+enum { PPSCI_LINEAR_PLAIN = 0, PPSCI_LINEAR_WEIGHT_NORM = 1, PPSCI_LINEAR_RWF = 2, PPSCI_LINEAR_FOURIER = 3,
+       PPSCI_LINEAR_BROADCAST = 4 /* W[0, j] = v[0]: Swish's scalar beta as a per-feature vector (fin == 1) */ };
 
 /* ppsci.arch.MLP (mlp.py:179-315) + the derivative set ppsci.autodiff would be asked for
  * (ad.py:95-160, 254-303).  Derivatives are *directional*: dirs[i][j] is the component of
@@ -231,6 +236,7 @@ int ppsci_optim_step(int kind, int64_t n, float* params, const float* grad, floa
  *   PPSCI_LINEAR_WEIGHT_NORM  W = g * v / ||v[:, j]||    WeightNormLinear.forward            mlp.py:50-54
  *   PPSCI_LINEAR_RWF          W = g * v                  RandomWeightFactorization.forward   mlp.py:91-92
  *   PPSCI_LINEAR_FOURIER      W = [v, v], b_out = 0      FourierEmbedding.kernel [in, out/2] mlp.py:123-136
+ *   PPSCI_LINEAR_BROADCAST    W[0, j] = v[0]             Swish.beta (shape []) activation.py:49-58; gv = sum_j gW
  * v: [fin, fout] ([fin, fout/2] for FOURIER), g: [fout], b / b_out / gb / gb_out: [fout] or NULL. */
 int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const float* g, const float* b, float* W,
                              float* b_out, void* stream);

@@ -53,7 +53,7 @@ class MLP:
     """Restatement of ppsci.arch.MLP on explicit weights (never default-initialised)."""
 
     def __init__(self, input_keys, output_keys, net: NetSpec, dtype=torch.float64, factor=None, weight_g=None,
-                 fourier_kernel=None):
+                 fourier_kernel=None, act_beta=None):
         """factor: None | "weight_norm" | "random_weight" -- the hidden `net.weights` are then weight_v and
         `weight_g` lists one [out] vector per hidden layer (mlp.py:31-92); fourier_kernel: FourierEmbedding.kernel
         [in, dim/2] (mlp.py:117-136), `net.weights[0]` then has dim rows."""
@@ -67,6 +67,8 @@ class MLP:
         self.biases = [torch.tensor(b, dtype=dtype, requires_grad=True) for b in net.biases]
         self.factor = factor
         self.weight_g = [torch.tensor(g, dtype=dtype, requires_grad=True) for g in (weight_g or [])]
+        # swish: one 0-D beta per hidden layer (activation.py:49-58); stan: one [H] beta per layer (:28-46)
+        self.act_beta = [torch.tensor(b, dtype=dtype, requires_grad=True) for b in (act_beta or [])]
         self.fourier_kernel = (None if fourier_kernel is None
                                else torch.tensor(fourier_kernel, dtype=dtype, requires_grad=True))
 
@@ -75,6 +77,8 @@ class MLP:
         out = [] if self.fourier_kernel is None else [self.fourier_kernel]
         n_hidden = len(self.weights) - 1
         for i, (w, b) in enumerate(zip(self.weights, self.biases)):
+            if i == n_hidden:
+                out += self.act_beta  # self.acts is registered before self.last_fc (mlp.py:262-263, :274)
             out += [w, self.weight_g[i], b] if (self.factor and i < n_hidden) else [w, b]
         return out
 
@@ -87,7 +91,11 @@ class MLP:
             w = self.weight_g[i] * w
         return y @ w + self.biases[i]
 
-    def _act(self, y):
+    def _act(self, y, i=0):
+        if self.activation == "swish":
+            return y * torch.sigmoid(self.act_beta[i] * y)
+        if self.activation == "stan":
+            return torch.tanh(y) * (1 + self.act_beta[i] * y)
         if self.activation == "tanh":
             return torch.tanh(y)
         if self.activation == "silu":
@@ -116,7 +124,7 @@ class MLP:
                     y = y + skip
                 else:
                     skip = y
-            y = self._act(y)
+            y = self._act(y, i)
         return y @ self.weights[-1] + self.biases[-1]
 
     def __call__(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:  # mlp.py:298-315

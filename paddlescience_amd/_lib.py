@@ -13,9 +13,10 @@ from typing import List, Optional, Sequence
 
 MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16, 128, 8, 16
 
-ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5}
+ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5, "swish": 6, "stan": 7}
+PARAM_ACTS = ("swish", "stan")  # a trainable per-feature parameter vector per hidden layer (behind the last bias)
 SIREN_W0 = 30.0  # activation.py:98
-LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER = range(4)
+LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER, LINEAR_BROADCAST = range(5)
 EMBED_NONE, EMBED_PERIOD = 0, 1
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,

@@ -1,7 +1,8 @@
 """Activation registry (/root/reference/ppsci/arch/activation.py:139-154).  Only the activations
 with a fused HIP implementation are accepted on the hot path: tanh, silu (= x*sigmoid(x), :77-88),
-sin, cos, sigmoid, gelu (exact, erf) and siren (= sin(30 x), :91-136, with its own weight initialisation).  Asking for another one raises at model-construction time."""
-HIP_ACTIVATIONS = ("tanh", "silu", "sin", "sigmoid", "cos", "gelu", "siren")
+sin, cos, sigmoid, gelu (exact, erf), siren (= sin(30 x), :91-136, with its own weight initialisation), swish
+(x*sigmoid(beta x), trainable scalar beta per layer, :49-58) and stan (tanh(x)(1 + beta x), trainable beta[H], :28-46).  Asking for another one raises at model-construction time."""
+HIP_ACTIVATIONS = ("tanh", "silu", "sin", "sigmoid", "cos", "gelu", "siren", "swish", "stan")
 REFERENCE_ACTIVATIONS = ("elu", "relu", "selu", "gelu", "leaky_relu", "sigmoid", "silu", "sin", "cos", "swish",
                          "tanh", "identity", "siren", "stan")
 

@@ -127,7 +127,10 @@ class MLP(Arch):
         self._linear_kind = (L.LINEAR_WEIGHT_NORM if weight_norm else L.LINEAR_RWF if random_weight
                              else L.LINEAR_PLAIN)
         self._rwf = dict(random_weight) if random_weight else None
-        self.reparam = bool(fourier_half) or self._linear_kind != L.LINEAR_PLAIN
+        self._param_act = self.activation in L.PARAM_ACTS  # swish (scalar beta per layer) / stan (beta[H] per layer)
+        if self._param_act and fourier_half:
+            raise NotImplementedError("fourier embedding together with a learnable activation")
+        self.reparam = bool(fourier_half) or self._linear_kind != L.LINEAR_PLAIN or self._param_act
         self.layout = hp.NetLayout(len(self.input_keys), len(hidden) + (1 if fourier_half else 0), hidden[0],
                                    len(self.output_keys), self.activation, self.skip_connection, embed, omega,
                                    fourier_half)
@@ -145,6 +148,8 @@ class MLP(Arch):
                 shapes += [(f"linears.{l}.weight_v", (fin, hidden[0])), (f"linears.{l}.weight_g", (hidden[0],)),
                            (f"linears.{l}.bias", (hidden[0],))]
             fin = hidden[0]
+        if self._param_act:  # self.acts is registered between self.linears and self.last_fc (mlp.py:262-263, :274)
+            shapes += [(f"acts.{l}.beta", () if self.activation == "swish" else (hidden[0],)) for l in range(len(hidden))]
         shapes += [("last_fc.weight", (fin, len(self.output_keys))), ("last_fc.bias", (len(self.output_keys),))]
         n_train = sum(int(np.prod(shp)) for _, shp in shapes)
         self._shapes = shapes
@@ -164,7 +169,7 @@ class MLP(Arch):
             gviews, off = {}, 0
             for name, shp in shapes:
                 n = int(np.prod(shp))
-                gviews[name] = self._grad_train[off:off + n].view(*shp)
+                gviews[name] = self._grad_train[off:off + n].view(tuple(shp))
                 off += n
             kviews, off = [], 0
             for _, shp in self.layout.param_shapes():
@@ -190,10 +195,22 @@ class MLP(Arch):
                                           byname[f"linears.{l}.weight_g"], byname[f"linears.{l}.bias"], w, b,
                                           gviews[f"linears.{l}.weight_v"], gviews[f"linears.{l}.weight_g"],
                                           gviews[f"linears.{l}.bias"]))
-            w, b = kviews[-2], kviews[-1]
+            nlin = 2 * (kl + len(hidden))  # kernel layout: the last linear follows the hidden ones ...
+            w, b = kviews[nlin], kviews[nlin + 1]
             self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], byname["last_fc.weight"], None,
                                   byname["last_fc.bias"], w, b, gviews["last_fc.weight"], None,
                                   gviews["last_fc.bias"]))
+            if self._param_act:  # ... and then one [H] parameter vector per hidden layer
+                none = (0, 0, ())
+                for l in range(len(hidden)):
+                    a = kviews[nlin + 2 + l]
+                    nm = f"acts.{l}.beta"
+                    if self.activation == "swish":  # Swish.beta has shape [] (activation.py:52-55): broadcast
+                        self._records.append((L.LINEAR_BROADCAST, 1, hidden[0], byname[nm].view(1), None, None, a, none,
+                                              gviews[nm].view(1), None, None))
+                    else:  # Stan.beta [out_features] (activation.py:37-40)
+                        self._records.append((L.LINEAR_PLAIN, 1, hidden[0], byname[nm], None, None, a, none,
+                                              gviews[nm], None, None))
         self._frozen = False
         self._init_parameters()
 
@@ -206,7 +223,7 @@ class MLP(Arch):
         for name, shp in self._shapes:
             n = int(np.prod(shp))
             self._names.append(name)
-            self._views.append(flat[off:off + n].view(*shp))
+            self._views.append(flat[off:off + n].view(tuple(shp)))
             off += n
         byname = dict(zip(self._names, self._views))
         nl = self._n_hidden_linears
@@ -233,7 +250,7 @@ class MLP(Arch):
         """Fill `kernel_params` from the trainable tensors; call before every forward sweep."""
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), _, _, _ in self._records:
             hp.linear_materialize(kind, fin, fout, v, g, b, self.kernel_params[wo:wo + wn],
-                                  self.kernel_params[bo:bo + bn])
+                                  self.kernel_params[bo:bo + bn] if bn else None)
         return self.kernel_params
 
     def pull_back(self, grad_kernel: torch.Tensor) -> torch.Tensor:
@@ -241,7 +258,8 @@ class MLP(Arch):
         if not self.reparam:
             return grad_kernel
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), gv, gg, gb in self._records:
-            hp.linear_pullback(kind, fin, fout, v, g, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn], gv, gg, gb)
+            hp.linear_pullback(kind, fin, fout, v, g, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn] if bn else None,
+                               gv, gg, gb)
         return self._grad_train
 
     # ---- parameters
@@ -252,6 +270,10 @@ class MLP(Arch):
             k = self.fourier_emb.kernel
             k.copy_(torch.from_numpy(np.random.normal(0.0, float(self.fourier["scale"]), size=tuple(k.shape))
                                      .astype(np.float32)))
+        if self._param_act:  # Swish(beta=1.0) / Stan: Constant(1) (activation.py:37-40, :50-55)
+            for n_, v_ in zip(self._names, self._views):
+                if n_.startswith("acts."):
+                    v_.fill_(1.0)
         for i, lin in enumerate(self.linears + [self.last_fc]):
             w = lin.weight_v if isinstance(lin, _FactoredLinear) else lin.weight
             fin, fout = w.shape

@@ -73,7 +73,10 @@ struct ppsci_derived {
   int32_t P;    // parameter count
   int32_t offW[PPSCI_MAX_HIDDEN + 1];
   int32_t offB[PPSCI_MAX_HIDDEN + 1];
+  int32_t offA;  // activation parameters p_l[H], l = 0 .. L-1 (behind the last bias); == P when there are none
 };
+
+__host__ __device__ static inline bool ppsci_act_has_param(int act) { return act == PPSCI_ACT_SWISH || act == PPSCI_ACT_STAN; }
 
 static inline int ppsci_derive(const ppsci_mlp_desc* d, ppsci_derived* q) {
   if (d->d_raw < 1 || d->d_raw > PPSCI_MAX_IN) return PPSCI_E_INVALID;
@@ -96,6 +99,8 @@ static inline int ppsci_derive(const ppsci_mlp_desc* d, ppsci_derived* q) {
     off += fout;
     fin = fout;
   }
+  q->offA = off;
+  if (ppsci_act_has_param(d->activation)) off += d->n_hidden * d->width;
   q->P = off;
   return PPSCI_OK;
 }

@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) 
     if (a.b_out) a.b_out[j] = 0.f;
     return;
   }
+  if (a.kind == PPSCI_LINEAR_BROADCAST) {
+    a.W[j] = a.v[0];
+    return;
+  }
   if (a.kind == PPSCI_LINEAR_PLAIN) {
     for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = a.v[i * a.fout + j];
   } else if (a.kind == PPSCI_LINEAR_RWF) {
@@ -66,6 +70,13 @@ __global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
     const int half = a.fout / 2;
     if (j >= half) return;
     for (int i = 0; i < a.fin; ++i) a.gv[i * half + j] = a.gW[i * a.fout + j] + a.gW[i * a.fout + j + half];
+    return;
+  }
+  if (a.kind == PPSCI_LINEAR_BROADCAST) {  // one thread: a fixed-order sum of at most 256 values
+    if (j != 0) return;
+    float sum = 0.f;
+    for (int k = 0; k < a.fout; ++k) sum += a.gW[k];
+    a.gv[0] = sum;
     return;
   }
   if (j >= a.fout) return;
@@ -95,7 +106,7 @@ __global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
   if (a.gb_out && a.gb) a.gb_out[j] = a.gb[j];
 }
 
-static bool reparam_kind_ok(int kind) { return kind >= PPSCI_LINEAR_PLAIN && kind <= PPSCI_LINEAR_FOURIER; }
+static bool reparam_kind_ok(int kind) { return kind >= PPSCI_LINEAR_PLAIN && kind <= PPSCI_LINEAR_BROADCAST; }
 
 extern "C" int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const float* g, const float* b,
                                         float* W, float* b_out, void* stream) {

@@ -37,6 +37,8 @@ static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_SIGMOID: return ppsci_fwd_run_sigmoid(a, stream, launch, grid);
     case PPSCI_ACT_COS: return ppsci_fwd_run_cos(a, stream, launch, grid);
     case PPSCI_ACT_GELU: return ppsci_fwd_run_gelu(a, stream, launch, grid);
+    case PPSCI_ACT_SWISH: return ppsci_fwd_run_swish(a, stream, launch, grid);
+    case PPSCI_ACT_STAN: return ppsci_fwd_run_stan(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }
@@ -56,6 +58,8 @@ static int run_bwd_act(BwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_SIGMOID: return ppsci_bwd_run_sigmoid(a, stream, launch, grid);
     case PPSCI_ACT_COS: return ppsci_bwd_run_cos(a, stream, launch, grid);
     case PPSCI_ACT_GELU: return ppsci_bwd_run_gelu(a, stream, launch, grid);
+    case PPSCI_ACT_SWISH: return ppsci_bwd_run_swish(a, stream, launch, grid);
+    case PPSCI_ACT_STAN: return ppsci_bwd_run_stan(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }

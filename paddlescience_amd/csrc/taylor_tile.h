@@ -94,6 +94,48 @@ __device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, flo
   }
 }
 
+// Activations with a trainable per-feature parameter p: value, three derivatives w.r.t. z, and -- for the reverse
+// sweep -- the derivatives of (s, d1, d2) w.r.t. p.
+//   Swish  s = z g(pz), g = sigmoid                (activation.py:49-58)
+//   Stan   s = tanh(z) (1 + p z)                    (activation.py:28-46)
+template <int ACT>
+__device__ __forceinline__ void ppsci_act_eval_p(float z, float p, float& s, float& d1, float& d2, float& d3,
+                                                 float& sp, float& d1p, float& d2p) {
+  if (ACT == PPSCI_ACT_SWISH) {
+    const float g = 1.f / (1.f + expf(-p * z));
+    const float g1 = g * (1.f - g), g2 = g1 * (1.f - 2.f * g), g3 = g1 * (1.f - 6.f * g1);
+    s = z * g;
+    d1 = g + p * z * g1;
+    d2 = 2.f * p * g1 + p * p * z * g2;
+    d3 = 3.f * p * p * g2 + p * p * p * z * g3;
+    sp = z * z * g1;
+    d1p = 2.f * z * g1 + p * z * z * g2;
+    d2p = 2.f * g1 + 4.f * p * z * g2 + p * p * z * z * g3;
+  } else {  // Stan
+    const float t = tanhf(z);
+    const float t1 = 1.f - t * t, t2 = -2.f * t * t1, t3 = t1 * (6.f * t * t - 2.f);
+    const float q = 1.f + p * z;
+    s = t * q;
+    d1 = t1 * q + p * t;
+    d2 = t2 * q + 2.f * p * t1;
+    d3 = t3 * q + 3.f * p * t2;
+    sp = z * t;
+    d1p = z * t1 + t;
+    d2p = z * t2 + 2.f * t1;
+  }
+}
+
+// the four parameters of features 16*blk + 4g .. +3 of hidden layer l (zero outside the unpadded width)
+__device__ __forceinline__ f32x4 ppsci_act_params4(const float* params, const ppsci_derived& q, int H, int l, int blk, int g) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int f = 16 * blk + 4 * g + r;
+    v[r] = f < H ? params[q.offA + l * H + f] : 0.f;
+  }
+  return v;
+}
+
 // What taylor_fwd stashes for the value stream of a hidden layer and how taylor_bwd turns it back into the
 // activation value and its first three derivatives: for tanh the activation VALUE s = tanh(z) is stashed,
 // because every derivative is a polynomial in s (1 - s^2, -2 s s', s'(6 s^2 - 2)) and the reverse sweep never
@@ -234,7 +276,8 @@ struct BwdArgs {
 // Parameters that are NOT hidden-to-hidden matrices, in the compact order the reverse kernels flush their LDS
 // accumulators in: W0 [d0, H] | b_0 .. b_{L-1} [H each] | W_last [H, m] | b_last [m].
 __host__ __device__ inline int ppsci_small_params(const ppsci_mlp_desc& d, const ppsci_derived& q) {
-  return q.d0 * d.width + d.n_hidden * d.width + d.width * d.d_out + d.d_out;
+  return q.d0 * d.width + d.n_hidden * d.width + d.width * d.d_out + d.d_out +
+         (ppsci_act_has_param(d.activation) ? d.n_hidden * d.width : 0);  // ... | p_0 .. p_{L-1} [H each]
 }
 
 // Two-stage, fixed-order reduction of the per-tile hidden-weight gradient partials (wgrad_reduce.hip):
@@ -251,6 +294,8 @@ int ppsci_fwd_run_tanh_fourier(FwdArgs& a, void* stream, int launch, int* grid_o
 int ppsci_fwd_run_silu(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sin(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_gelu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_swish(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_stan(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_cos(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sigmoid(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_tanh(BwdArgs& a, void* stream, int launch, int* grid_out);
@@ -258,6 +303,8 @@ int ppsci_bwd_run_tanh_fourier(BwdArgs& a, void* stream, int launch, int* grid_o
 int ppsci_bwd_run_silu(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_gelu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_swish(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_stan(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_cos(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_sigmoid(BwdArgs& a, void* stream, int launch, int* grid_out);
 extern "C" void ppsci_set_error(const char* fmt, ...);
@@ -271,5 +318,6 @@ static inline int ppsci_fwd_small_floats(const ppsci_mlp_desc& d, const ppsci_de
 static inline int ppsci_bwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q, int S) {
   // WLs[m*HP] gW0[d0*HP] gB[L*HP] gWL[m*HP] gBL[4*ceil(m/4)] scratch[WAVES*S*SCR] tile inputs x[WAVES*d_raw*16]
   return (2 * d.d_out + q.d0 + d.n_hidden) * q.HP + ((d.d_out + 3) / 4) * 4 +
+         (ppsci_act_has_param(d.activation) ? d.n_hidden * q.HP : 0) +  // gP: activation-parameter gradients
          PPSCI_BWD_WAVES * (S * PPSCI_SCR_FLOATS + d.d_raw * PPSCI_TILE) + PPSCI_BWD_TINP_FLOATS;
 }

@@ -82,6 +82,8 @@ class NetLayout:
             out += [(f"linears.{l}.weight", (fin, self.width)), (f"linears.{l}.bias", (self.width,))]
             fin = self.width
         out += [("last_fc.weight", (fin, self.d_out)), ("last_fc.bias", (self.d_out,))]
+        if self.activation in L.PARAM_ACTS:  # kernel layout: the activation parameters follow the last bias
+            out += [(f"acts.{l}.param", (self.width,)) for l in range(self.n_hidden)]
         return out
 
     @property

@@ -429,3 +429,45 @@ def test_model_list_constraints_touching_different_members(tmp_path):
     gb = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gb, ob.parameters())])
     assert rel(g[ma._param_offset:ma._param_offset + ga.size], ga) < 5e-5
     assert rel(g[mb._param_offset:mb._param_offset + gb.size], gb) < 5e-5
+
+
+@pytest.mark.parametrize("act", ["swish", "stan"])
+def test_learnable_activation_mlp(tmp_path, act):
+    """MLP(activation="swish" / "stan") (activation.py:28-58): the trainable tensors are in the reference's parameters()
+    order (linears, acts.<l>.beta -- a scalar for Swish, [hidden] for Stan --, last_fc); Poisson-type loss and the
+    gradient of every one of them against torch autograd; betas start at 1."""
+    H, nl = 20, 3
+    ppsci.utils.misc.set_random_seed(8)
+    model = ppsci.arch.MLP(("x", "y"), ("u",), nl, H, act)
+    names = [n for n, _ in model.named_parameters()]
+    assert names[2 * nl:2 * nl + nl] == [f"acts.{l}.beta" for l in range(nl)] and names[-2:] == ["last_fc.weight", "last_fc.bias"]
+    assert all(float(p.min()) == 1.0 for n, p in model.named_parameters() if n.startswith("acts."))
+    rng = np.random.default_rng(14)
+    net = T.make_net(2, [H] * nl, 1, activation=act, bias_scale=0.05)
+    beta = [np.float32(rng.uniform(0.7, 1.3)) if act == "swish" else rng.uniform(0.7, 1.3, H).astype(np.float32) for _ in range(nl)]
+    omodel = R.MLP(("x", "y"), ("u",), net.astype(np.float32).astype(np.float64),
+                   act_beta=[np.asarray(b, dtype=np.float64) for b in beta])
+    assert [tuple(p.shape) for p in model.parameters()] == [tuple(p.shape) for p in omodel.parameters()]
+    flat = np.concatenate([p.detach().numpy().ravel() for p in omodel.parameters()])
+    model.flat_params.copy_(torch.tensor(flat, dtype=torch.float32).to(model.flat_params.device))
+    N = 33
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    eq = ppsci.equation.Laplace(dim=2)
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"laplace": np.full((N, 1), 0.2, np.float32)}, eq.equations,
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    solver._materialize()
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver._train_grad().cpu().numpy().astype(np.float64)
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={"laplace": R.lambdify(R.laplace_exprs(2)["laplace"], omodel)},
+              label={"laplace": np.full((N, 1), float(np.float32(0.2)))}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert solver._compiled["EQ"].fused.losses()["laplace"] == pytest.approx(total, rel=5e-5)
+    assert rel(g, gref) < 1e-4
+    off = sum(int(np.prod(p.shape)) for p in model.parameters()[:2 * nl])
+    nb = nl if act == "swish" else nl * H
+    assert rel(g[off:off + nb], gref[off:off + nb]) < 1e-4  # the betas on their own
+    solver.train()
+    adam = R.Adam(flat.size, lr=1e-3)
+    assert rel(model.flat_params.cpu().numpy(), adam.step(flat, gref)) < 1e-5

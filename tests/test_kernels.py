@@ -489,6 +489,34 @@ def test_linear_materialize_and_pullback_kinds():
             np.testing.assert_allclose(gbo.cpu().numpy(), gb)
 
 
+@pytest.mark.parametrize("act,hidden,dout,n2,N", [("swish", [20, 20, 20], 1, 2, 37), ("stan", [24, 24], 2, 1, 21),
+                                                  ("swish", [40, 40], 1, 2, 19), ("stan", [100, 100], 1, 1, 16)])
+def test_learnable_activations_fwd_and_bwd(act, hidden, dout, n2, N):
+    """Swish x*sigmoid(p x) / Stan tanh(x)(1 + p x) with a trainable per-feature vector p per hidden layer (kernel
+    layout: behind the last bias): streams, weight / bias gradients and dL/dp against the numpy oracle.  Width 100 runs
+    on the single-wave NB = 8 kernels (the feature-split ones do not carry the parameter)."""
+    net = T.make_net(2, hidden, dout, activation=act, bias_scale=0.2)
+    rng = np.random.default_rng(29)
+    net.act_params = [rng.uniform(0.6, 1.4, hidden[0]) for _ in hidden]
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    dirs = np.eye(2)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, _, _, U, _ = _run_fwd(net, X, dirs, n2)
+    ref, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+    got = U.cpu().numpy().astype(np.float64)
+    for q in range(got.shape[0]):
+        assert _rel(got[q], ref.reshape(-1, N)[q]) < 8e-6, (q, _rel(got[q], ref.reshape(-1, N)[q]))
+    S = 1 + 2 + n2
+    Ubar = rng.standard_normal((dout, S, N)).astype(np.float32).astype(np.float64)
+    g = _run_bwd(net, X, dirs, n2, Ubar)
+    gW, gb = T.taylor_backward(net32, cache, Ubar)
+    gref = T.flat_grads(gW, gb, cache["gP"])
+    assert g.size == gref.size
+    nP = sum(p.size for p in net.act_params)
+    assert _rel(g[:-nP], gref[:-nP]) < 1e-5
+    assert _rel(g[-nP:], gref[-nP:]) < 1e-5, _rel(g[-nP:], gref[-nP:])
+
+
 def test_adam_step_matches_oracle():
     from oracle import ref_torch as R
     from paddlescience_amd import hotpath as hp
