@@ -1,4 +1,5 @@
 // taylor_bwd_swish.hip -- reverse kernels for activation "swish" (trainable per-feature parameter).
+#define PPSCI_ACT_HAS_PARAM 1
 #define PPSCI_ACT_ID PPSCI_ACT_SWISH
 #define PPSCI_BWD_RUN_NAME ppsci_bwd_run_swish
 #include "taylor_bwd.inc"
