@@ -111,10 +111,25 @@ class Geometry:
             out[:, i: i + 1] = (self.sdf_func(x + h) - self.sdf_func(x - h)) / epsilon
         return out
 
-    def _no_csg(self, *_):
-        raise NotImplementedError("CSG geometry (union / difference / intersection) is not implemented yet")
+    # ---- CSG (geometry.py:520-660)
+    def union(self, other: "Geometry") -> "Geometry":
+        from .boolean import CSGUnion
 
-    union = __or__ = __add__ = difference = __sub__ = intersection = __and__ = _no_csg
+        return CSGUnion(self, other)
+
+    def difference(self, other: "Geometry") -> "Geometry":
+        from .boolean import CSGDifference
+
+        return CSGDifference(self, other)
+
+    def intersection(self, other: "Geometry") -> "Geometry":
+        from .boolean import CSGIntersection
+
+        return CSGIntersection(self, other)
+
+    __or__ = __add__ = union
+    __sub__ = difference
+    __and__ = intersection
 
     def __str__(self) -> str:
         return ", ".join([self.__class__.__name__, f"ndim = {self.ndim}", f"bbox = {self.bbox}", f"diam = {self.diam}",

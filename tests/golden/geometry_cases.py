@@ -63,4 +63,24 @@ def run(ns) -> dict:
     out["rect.sdf"] = np.asarray(rect.sdf_func(pts))
     out["rect.sdf_deriv"] = np.asarray(rect.sdf_derivatives(pts))
     out["cuboid.sdf"] = np.asarray(cub.sdf_func(np.array([[0.5, 0.0, 1.0], [0.0, -1.0, 0.5]], dtype="float32")))
+    if hasattr(ns, "Disk"):  # Disk and the boolean (CSG) geometries
+        disk = ns.Disk((0.5, 0.5), 0.25)
+        big = ns.Rectangle((0.0, 0.0), (2.0, 1.0))
+        shapes = {"disk": disk, "diff": big - disk, "union": rect | ns.Disk((1.0, 0.5), 0.4),
+                  "inter": big & ns.Disk((0.0, 0.5), 0.7)}
+        for i, (nm, geo) in enumerate(shapes.items()):
+            case(f"{nm}.interior_rand", 40 + i, lambda geo=geo: geo.sample_interior(53))
+            case(f"{nm}.interior_sdfd", 50 + i, lambda geo=geo: geo.sample_interior(7, "pseudo", None, False, True))
+            case(f"{nm}.boundary_rand", 60 + i, lambda geo=geo: geo.sample_boundary(47))
+        case("disk.boundary_even", 70, lambda: disk.sample_boundary(32, evenly=True))
+        case("diff.interior_crit", 71, lambda: shapes["diff"].sample_interior(40, criteria=lambda x, y: x > 0.3))
+        cyl = ns.TimeXGeometry(ns.TimeDomain(0.0, 1.0, time_step=0.2), shapes["diff"])
+        case("cyl.interior", 72, lambda: cyl.sample_interior(61))
+        case("cyl.boundary", 73, lambda: cyl.sample_boundary(29))
+        q = np.array([[0.5, 0.75], [0.5, 0.5], [0.0, 0.2], [2.0, 1.0], [0.75, 0.5], [1.3, 0.4]], dtype="float32")
+        for nm, geo in shapes.items():
+            out[f"{nm}.is_inside"] = np.asarray(geo.is_inside(q))
+            out[f"{nm}.on_boundary"] = np.asarray(geo.on_boundary(q))
+            out[f"{nm}.sdf"] = np.asarray(geo.sdf_func(q))
+        out["diff.normal"] = np.asarray(shapes["diff"].boundary_normal(q[[0, 2, 4]]))
     return out
