@@ -44,7 +44,12 @@ enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGM
         * last bias in the parameter buffer): Swish x*sigmoid(p x) (activation.py:49-58, its scalar beta broadcast by
         * the caller) and Stan tanh(x)*(1 + p x) (activation.py:28-46) */
        PPSCI_ACT_SWISH = 6, PPSCI_ACT_STAN = 7 };
-enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1 };
+enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1,
+       /* inputs[j] is an [S, N] block holding this network input AND its derivative streams (value, first
+        * derivatives along the n1 directions, second along the first n2): a registered input transform
+        * (Arch.register_input_transform, arch/base.py:150-183; MLP.forward mlp.py:299-300) computed by the caller,
+        * e.g. with an epilogue program; `dirs` is not used for such an input */
+       PPSCI_EMBED_STREAMS = 2 };
 /* layer parametrisations handled on the parameter buffers (csrc/reparam.hip) */
 enum { PPSCI_LINEAR_PLAIN = 0, PPSCI_LINEAR_WEIGHT_NORM = 1, PPSCI_LINEAR_RWF = 2, PPSCI_LINEAR_FOURIER = 3,
        PPSCI_LINEAR_BROADCAST = 4 /* W[0, j] = v[0]: Swish's scalar beta as a per-feature vector (fin == 1) */ };

@@ -17,7 +17,7 @@ ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5, "swish
 PARAM_ACTS = ("swish", "stan")  # a trainable per-feature parameter vector per hidden layer (behind the last bias)
 SIREN_W0 = 30.0  # activation.py:98
 LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER, LINEAR_BROADCAST = range(5)
-EMBED_NONE, EMBED_PERIOD = 0, 1
+EMBED_NONE, EMBED_PERIOD, EMBED_STREAMS = 0, 1, 2
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
  OP_TANH, OP_EXP, OP_LOG, OP_SQRT, OP_ABS, OP_SINH, OP_COSH, OP_TAN, OP_MAX, OP_MIN, OP_SIGN, OP_HEAVISIDE,

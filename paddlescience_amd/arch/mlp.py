@@ -340,7 +340,18 @@ class MLP(Arch):
     def forward(self, x: Dict[str, object]) -> Dict[str, object]:  # mlp.py:298-315
         traced = any(isinstance(v, Sym) for v in x.values())
         if self._input_transform is not None:
-            raise NotImplementedError("input transforms are not lowered to the fused HIP path yet")
+            # mlp.py:299-300: the network sees transform(x); x itself stays in the data dict for the expressions
+            xt = self._input_transform(dict(x))
+            if traced:
+                from ..graph import _lift
+
+                self._traced_features = {k: _lift(xt[k]) for k in self.input_keys}
+                y = {k: Sym.net(self, i) for i, k in enumerate(self.output_keys)}
+            else:
+                y = self._forward_numeric(xt)
+            if self._output_transform is not None:
+                y = self._output_transform(x, y)
+            return y
         if traced:
             for k in self.input_keys:
                 v = x[k]

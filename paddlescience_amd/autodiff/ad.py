@@ -13,7 +13,7 @@ from ..graph import Sym, diff
 
 
 def _check_x(x):
-    if not isinstance(x, Sym) or x.kind != "in":
+    if not isinstance(x, Sym) or x.kind not in ("in", "aux"):
         raise TypeError(
             "jacobian/hessian: `xs` must be input variables of the data dict (e.g. out['x']); got "
             f"{x!r}.  Numeric tensors carry no autograd graph on the fused HIP path.")

@@ -25,7 +25,9 @@ def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable],
     data: Dict[str, object] = {}
     for k in input_keys:
         data[k] = Sym.input(k) if k in model.input_keys else Sym.aux(k)
-    missing = [k for k in model.input_keys if k not in data]
+    members = getattr(model, "model_list", [model])
+    transformed = any(getattr(m, "_input_transform", None) is not None for m in members)
+    missing = [] if transformed else [k for k in model.input_keys if k not in data]  # (features come from the transform)
     if missing:
         raise KeyError(f"model input(s) {missing} are not provided by the dataset (has {list(input_keys)})")
     output_dict = model(data)
@@ -91,7 +93,18 @@ class CompiledConstraint:
         self._stage: List[torch.Tensor] = []
         self._stage_done: List[Optional[torch.cuda.Event]] = []
         self._flip = 0
-        nets = [(m.layout, getattr(m, "_param_offset", 0), spec, idx) for m, spec, _, idx in self.low.nets]
+        nets = []
+        for m, spec, _, idx, pre in self.low.nets:
+            lay = m.layout
+            if pre is not None:  # input transform: every network input is an [S, N] stream block
+                import dataclasses
+
+                from . import _lib as L_
+
+                if any(e_ != L_.EMBED_NONE for e_ in (lay.embed or [])):
+                    raise NotImplementedError("periods together with a registered input transform")
+                lay = dataclasses.replace(lay, embed=[L_.EMBED_STREAMS] * lay.d_raw, omega=[0.0] * lay.d_raw)
+            nets.append((lay, getattr(m, "_param_offset", 0), spec, idx, [(pg.build(), r0, nr) for pg, r0, nr in pre] if pre else None))
         if not nets:
             raise NotImplementedError("a constraint that evaluates no network has nothing to train")
         self.fused = FusedConstraint(name, nets, self.low.streams, self.low.program.build(), inputs, aux,

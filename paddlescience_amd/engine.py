@@ -39,21 +39,30 @@ class FusedConstraint:
         dev = self.inputs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         if isinstance(nets, hp.NetLayout):
-            nets = [(nets, 0, streams, list(range(len(self.inputs))))]
-        q = sum(lay.d_out for lay, _, _, _ in nets) * streams.S
+            nets = [(nets, 0, streams, list(range(len(self.inputs))), None)]
+        nets = [tuple(nt) + (None,) * (5 - len(nt)) for nt in nets]
+        q = sum(nt[0].d_out for nt in nets) * streams.S
         self.U = torch.zeros((q, self.n), **f32)
         self.Ubar = torch.zeros((q, self.n), **f32)  # rows never loaded by the program stay 0
         self.nets = []
         row = 0
-        for lay, off, spec, idx in nets:
+        for lay, off, spec, idx, pre in nets:
             desc = lay.desc(spec)
             rows = hp.bwd_partial_rows(desc, self.n)
             if rows <= 0:
                 raise NotImplementedError(
                     f"network {lay.n_hidden}x{lay.width} with {spec.S} streams has no HIP reverse kernel")
             nr = lay.d_out * streams.S
+            if pre is not None:
+                # input transform: the epilogue VM computes every input feature and its derivative streams from the
+                # raw variables ([d_in * S, N], <= MAX_RES rows per program); the kernels read [S, N] blocks
+                feat = torch.zeros((lay.d_raw * streams.S, self.n), **f32)
+                net_inputs = [feat[k * streams.S:(k + 1) * streams.S].reshape(-1) for k in range(lay.d_raw)]
+                pre = [(ed, feat[r0:r0 + nr]) for ed, r0, nr in pre]
+            else:
+                net_inputs = [self.inputs[j] for j in idx]
             self.nets.append(dict(
-                layout=lay, off=off, desc=desc, inputs=[self.inputs[j] for j in idx],
+                layout=lay, off=off, desc=desc, inputs=net_inputs, pre=pre,
                 U=self.U[row:row + nr], Ubar=self.Ubar[row:row + nr],
                 stash=torch.empty(hp.stash_bytes(desc, self.n) // 4, **f32), grad_rows=rows,
                 grad_partials=torch.empty((rows, lay.n_params), **f32),
@@ -64,6 +73,7 @@ class FusedConstraint:
         self.grad_rows, self.grad_partials, self.workspace = first["grad_rows"], first["grad_partials"], first["workspace"]
         self.work = sum(self.n * nt["layout"].n_params * streams.S for nt in self.nets)
         self.loss_rows = hp.epilogue_partial_rows(self.n)
+        self._pre_partials = torch.zeros((self.loss_rows, L.MAX_RES), **f32)  # unused sums of the stream programs
         self.loss_partials = torch.zeros((self.loss_rows, max(1, edesc.n_res)), **f32)
         self.loss_terms = torch.zeros(max(1, edesc.n_res), **f32)
         self.resid = torch.zeros((max(1, edesc.n_res), self.n), **f32) if want_residual else None
@@ -89,8 +99,11 @@ class FusedConstraint:
 
     def forward(self, params: torch.Tensor, train: bool) -> None:
         for nt in self.nets:
+            if nt["pre"] is not None:
+                for ed, rows in nt["pre"]:
+                    hp.epilogue(ed, self.n, self.inputs, None, self.aux, rows, None, self._pre_partials)
             hp.taylor_fwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["U"],
-                          nt["stash"] if train else None)
+                          nt["stash"] if train else None, self.n)
         if getattr(self, "causal", None):
             # first pass: the per-point values only; then the causal factor of every key from its window means
             # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
@@ -112,7 +125,7 @@ class FusedConstraint:
     def backward(self, params: torch.Tensor) -> None:
         for nt in self.nets:
             hp.taylor_bwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["Ubar"],
-                          nt["stash"], nt["workspace"], nt["grad_partials"])
+                          nt["stash"], nt["workspace"], nt["grad_partials"], self.n)
 
     def reduce_grads(self, grad: torch.Tensor, accumulate: bool) -> None:
         """grad[member's slice] (+)= this constraint's gradient of that member (fixed order)."""

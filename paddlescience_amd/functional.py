@@ -1,0 +1,60 @@
+"""Elementwise math for user closures (output / input transforms, `output_expr` lambdas).  The reference's scripts
+call `paddle.sin(x)` etc. on tensors; here the same closure is traced once on proxy values (graph.Sym) and also run
+on torch tensors (eager `model(dict)`), so these functions dispatch on the argument: a traced value becomes an op of
+the epilogue program, a tensor / array / number is computed directly.
+
+    import ppsci.functional as F
+    model.register_input_transform(lambda d: {"sin(x)": F.sin(b * d["x"] + c), "y": d["y"]})
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import Sym, _lift, apply
+
+_TORCH = {"sin": torch.sin, "cos": torch.cos, "tanh": torch.tanh, "exp": torch.exp, "log": torch.log,
+          "sqrt": torch.sqrt, "abs": torch.abs, "sinh": torch.sinh, "cosh": torch.cosh, "tan": torch.tan,
+          "asin": torch.asin, "acos": torch.acos, "atan": torch.atan, "asinh": torch.asinh, "acosh": torch.acosh,
+          "atanh": torch.atanh, "erf": torch.erf, "sign": torch.sign, "floor": torch.floor, "ceil": torch.ceil}
+
+
+_NUMPY = {"abs": "abs", "asin": "arcsin", "acos": "arccos", "atan": "arctan", "asinh": "arcsinh", "acosh": "arccosh",
+          "atanh": "arctanh"}
+
+
+def _unary(name):
+    def f(x):
+        if isinstance(x, Sym):
+            return apply(name, x)
+        if isinstance(x, torch.Tensor):
+            return _TORCH[name](x)
+        if name == "erf":
+            return torch.erf(torch.as_tensor(x)).numpy()
+        return getattr(np, _NUMPY.get(name, name))(x)
+
+    f.__name__ = name
+    return f
+
+
+for _n in _TORCH:
+    globals()[_n] = _unary(_n)
+
+
+def _binary(name, tfn, nfn):
+    def f(a, b):
+        if isinstance(a, Sym) or isinstance(b, Sym):
+            return apply(name, _lift(a), _lift(b))
+        if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+            return tfn(torch.as_tensor(a), torch.as_tensor(b))
+        return nfn(a, b)
+
+    f.__name__ = name
+    return f
+
+
+maximum = _binary("max", torch.maximum, np.maximum)
+minimum = _binary("min", torch.minimum, np.minimum)
+pow = _binary("pow", torch.pow, np.power)  # noqa: A001
+atan2 = _binary("atan2", torch.atan2, np.arctan2)
+__all__ = sorted(list(_TORCH) + ["maximum", "minimum", "pow", "atan2"])

@@ -181,15 +181,44 @@ def apply(op: str, *args: Sym) -> Sym:
 
 
 # ----------------------------------------------------------------------------- differentiation
+def net_raw_vars(model) -> Tuple[str, ...]:
+    """The data-dict variables a network's outputs depend on: its input keys, or -- with a registered input
+    transform -- the raw variables its input features are built from."""
+    feats = getattr(model, "_traced_features", None)
+    if not feats:
+        return tuple(model.input_keys)
+    names: List[str] = []
+    for n in _walk(list(feats.values())):
+        if n.kind in ("in", "aux") and n.name not in names:
+            names.append(n.name)
+    return tuple(names)
+
+
+def directional(e: Sym, d, order: int) -> Sym:
+    """order-th derivative of e along direction d: a variable name, or a pair (a, b) for the direction a + b."""
+    if isinstance(d, tuple):
+        a, b = d
+        if order == 1:
+            return diff(e, a) + diff(e, b)
+        ea = diff(e, a)
+        return diff(ea, a) + 2.0 * diff(ea, b) + diff(diff(e, b), b)
+    out = e
+    for _ in range(order):
+        out = diff(out, d)
+    return out
+
+
 def diff(e: Sym, var: str) -> Sym:
     """d e / d var, symbolically (what jacobian() obtains numerically in the reference)."""
     k = e.kind
     if k == "in":
         return Sym.const(1.0 if e.name == var else 0.0)
-    if k in ("aux", "const", "param"):
+    if k == "aux":  # a dataset column that is not a network input (raw variable of an input transform, nu, sdf, ...)
+        return Sym.const(1.0 if e.name == var else 0.0)
+    if k in ("const", "param"):
         return Sym.const(0.0)
     if k == "net":
-        if var not in e.model.input_keys:
+        if var not in net_raw_vars(e.model):
             return Sym.const(0.0)
         if len(e.dirs) >= 2:
             raise NotImplementedError(
@@ -323,7 +352,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 seconds.update((a, b))
     in_keys: List[str] = []  # union of the members' inputs: the constraint's input arrays
     for mm in model_list:
-        in_keys += [k for k in mm.input_keys if k not in in_keys]
+        in_keys += [k for k in net_raw_vars(mm) if k not in in_keys]
     order_second = [v for v in in_keys if v in seconds]
     order_first = [v for v in in_keys if v in firsts and v not in seconds]
     dir_names: List[object] = list(order_second) + sorted(mixed) + order_first
@@ -363,9 +392,26 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     nets = []  # (model, StreamSpec, first U row, indices of its inputs in in_keys)
     row0: Dict[int, int] = {}
     rows = 0
+    pre_nets: Dict[int, list] = {}  # id(model) -> per-feature stream expressions (input transform)
     for mm in model_list:
-        idx = [in_keys.index(k) for k in mm.input_keys]
-        nets.append((mm, hp.StreamSpec([[v[j] for j in idx] for v in dirs_vec], n2p), rows, idx))
+        feats = getattr(mm, "_traced_features", None)
+        if feats:
+            # a registered input transform: the network's inputs are functions phi_k of the raw variables; the
+            # kernels take phi_k and its derivative streams along the directions as [S, N] blocks (EMBED_STREAMS)
+            idx = None
+            padded = list(dir_names) + [None] * (n1p - len(dir_names))
+            blocks = []
+            for k in mm.input_keys:
+                phi = feats[k]
+                rows_k = [phi] + [Sym.const(0.0) if d is None else directional(phi, d, 1) for d in padded]
+                rows_k += [Sym.const(0.0) if d is None else directional(phi, d, 2) for d in padded[:n2p]]
+                blocks.append(rows_k)
+            pre_nets[id(mm)] = blocks
+            spec = hp.StreamSpec([[0.0] * len(mm.input_keys) for _ in range(n1p)], n2p)
+        else:
+            idx = [in_keys.index(k) for k in mm.input_keys]
+            spec = hp.StreamSpec([[v[j] for j in idx] for v in dirs_vec], n2p)
+        nets.append((mm, spec, rows, idx))
         row0[id(mm)] = rows
         rows += len(mm.output_keys) * S
     prog = hp.Program(rows, len(in_keys))
@@ -380,6 +426,23 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
 
     val: Dict[int, int] = {}
     param_slots = set()
+
+    def emit_pointwise(pg: hp.Program, pnodes, pval: Dict[int, int]) -> None:
+        """Inputs, aux arrays, constants and operators only (the stream programs of an input transform)."""
+        for n in pnodes:
+            if n.kind == "in":
+                pval[id(n)] = pg.ld_in(input_names.index(n.name)) if n.name in input_names else pg.ld_aux(aux_index(n.name))
+            elif n.kind == "aux":
+                pval[id(n)] = pg.ld_in(input_names.index(n.name)) if n.name in input_names else pg.ld_aux(aux_index(n.name))
+            elif n.kind == "const":
+                pval[id(n)] = pg.const(n.value)
+            elif n.kind in ("net", "param"):
+                raise NotImplementedError("an input transform may only use the data-dict variables")
+            elif n.op in _BINARY_OPS:
+                pval[id(n)] = pg.op(_BINARY_OPS[n.op], pval[id(n.args[0])], pval[id(n.args[1])])
+            else:
+                pval[id(n)] = pg.op(_UNARY_OPS[n.op], pval[id(n.args[0])])
+
     for n in nodes:
         if n.kind == "in":
             if n.name in input_names:
@@ -387,7 +450,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             else:
                 val[id(n)] = prog.ld_aux(aux_index(n.name))
         elif n.kind == "aux":
-            val[id(n)] = prog.ld_aux(aux_index(n.name))
+            val[id(n)] = prog.ld_in(input_names.index(n.name)) if n.name in input_names else prog.ld_aux(aux_index(n.name))
         elif n.kind == "param":
             val[id(n)] = prog.ld_param(n.comp)
             param_slots.add(n.comp)
@@ -437,5 +500,19 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     low = Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
     low.causal = causal
     low.param_slots = sorted(param_slots)
-    low.nets = nets
+    # ---- stream programs of the input transforms: <= MAX_RES output rows per program, rows in (feature, stream) order
+    pre = {}
+    for mid, blocks in pre_nets.items():
+        flat_rows = [e for rows_k in blocks for e in rows_k]
+        progs = []
+        for r0 in range(0, len(flat_rows), L.MAX_RES):
+            chunk = flat_rows[r0:r0 + L.MAX_RES]
+            pg = hp.Program(0, len(in_keys))
+            pval: Dict[int, int] = {}
+            emit_pointwise(pg, _walk(chunk), pval)
+            for e in chunk:
+                pg.residual(pval[id(e)], -1, -1, -1, 0.0)
+            progs.append((pg, r0, len(chunk)))
+        pre[mid] = progs
+    low.nets = [(mm, spec, r, idx, pre.get(id(mm))) for mm, spec, r, idx in nets]
     return low

@@ -114,8 +114,10 @@ def epilogue_partial_rows(n: int) -> int:
 
 
 def taylor_fwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], U: torch.Tensor,
-               stash: Optional[torch.Tensor]) -> None:
-    n = inputs[0].numel()
+               stash: Optional[torch.Tensor], n: Optional[int] = None) -> None:
+    """inputs[j]: [N] array of raw input j -- or, for desc.embed[j] == EMBED_STREAMS, its [S, N] stream block
+    (then pass the number of points `n`)."""
+    n = inputs[0].numel() if n is None else n
     _require_device(params)
     _chk_f32(params, U, *inputs)
     assert U.numel() == desc.d_out * (1 + desc.n1 + desc.n2) * n
@@ -143,8 +145,9 @@ def epilogue(edesc: L.EpilogueDesc, n: int, inputs: Sequence[torch.Tensor], U: O
 
 
 def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Tensor], Ubar: torch.Tensor,
-               stash: torch.Tensor, workspace: torch.Tensor, grad_partials: torch.Tensor) -> None:
-    n = inputs[0].numel()
+               stash: torch.Tensor, workspace: torch.Tensor, grad_partials: torch.Tensor,
+               n: Optional[int] = None) -> None:
+    n = inputs[0].numel() if n is None else n
     _require_device(params)
     _chk_f32(params, Ubar, grad_partials, *inputs)
     ptrs = L.ptr_array([t.data_ptr() for t in inputs])

@@ -4,10 +4,10 @@ import sys
 
 import paddlescience_amd as _impl
 from paddlescience_amd import *  # noqa: F401,F403
-from paddlescience_amd import (arch, autodiff, constraint, data, equation, geometry, loss, metric, optimizer,  # noqa: F401
+from paddlescience_amd import (arch, autodiff, constraint, data, equation, functional, geometry, loss, metric, optimizer,  # noqa: F401
                                solver, utils, validate)
 
-for _name in ("arch", "autodiff", "constraint", "data", "equation", "geometry", "loss", "metric", "optimizer", "solver",
+for _name in ("arch", "autodiff", "constraint", "data", "equation", "functional", "geometry", "loss", "metric", "optimizer", "solver",
               "utils", "validate"):
     sys.modules[f"ppsci.{_name}"] = getattr(_impl, _name)
 sys.modules["ppsci.loss.mtl"] = _impl.loss.mtl

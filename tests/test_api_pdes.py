@@ -471,3 +471,60 @@ def test_learnable_activation_mlp(tmp_path, act):
     solver.train()
     adam = R.Adam(flat.size, lr=1e-3)
     assert rel(model.flat_params.cpu().numpy(), adam.step(flat, gref)) < 1e-5
+
+
+@pytest.mark.parametrize("width,mixed", [(20, 0.5), (128, 0.0)])
+def test_registered_input_transform_nonlinear_features(tmp_path, width, mixed):
+    """Arch.register_input_transform (base.py:150-183, MLP.forward mlp.py:299-300) in the style of
+    examples/pipe/poiseuille_flow.py:76-83: the network takes (sin(bx+c), cos(bx+c), y, nu) computed from the raw
+    (x, y, nu); the residual differentiates w.r.t. the RAW x and y (first, second and mixed), so the chain rule
+    through the features is carried by the input streams (EMBED_STREAMS).  Width 128 uses the feature-split kernels."""
+    import ppsci.functional as F
+
+    b, c = 1.7, 0.3
+    feats = ("sin(x)", "cos(x)", "y", "nu")
+
+    def trans(d):
+        return {"sin(x)": 0.8 * F.sin(b * d["x"] + c), "cos(x)": 0.8 * F.cos(b * d["x"] + c), "y": d["y"], "nu": d["nu"]}
+
+    model = ppsci.arch.MLP(feats, ("u",), 2, width, "tanh")
+    net = T.make_net(4, [width, width], 1, bias_scale=0.05)
+    set_model_weights(model, net)
+    model.register_input_transform(trans)
+    model.register_output_transform(lambda d, out: {"u": out["u"] * (1.0 - d["y"] * d["y"])})
+    N = 35
+    rng = np.random.default_rng(21)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+    nu = rng.uniform(0.01, 0.1, (N, 1)).astype(np.float32)
+
+    def resid(out):
+        u, x, y = out["u"], out["x"], out["y"]
+        r = jacobian(u, x) * u - out["nu"] * (hessian(u, x) + hessian(u, y))
+        return r + mixed * jacobian(jacobian(u, x), y) if mixed else r  # (the mixed term needs the (3, 3) stream set)
+
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:], "nu": nu}, {"r": np.zeros((N, 1), np.float32)}, {"r": resid},
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    # torch autograd on the same construction
+    omodel = R.MLP(feats, ("u",), net.astype(np.float32).astype(np.float64))
+    x = torch.tensor(X[:, :1].astype(np.float64), requires_grad=True)
+    y = torch.tensor(X[:, 1:].astype(np.float64), requires_grad=True)
+    tnu = torch.tensor(nu.astype(np.float64))
+    k08, kb, kc = float(np.float32(0.8)), float(np.float32(b)), float(np.float32(c))
+    fx = {"sin(x)": k08 * torch.sin(kb * x + kc), "cos(x)": k08 * torch.cos(kb * x + kc), "y": y, "nu": tnu}
+    u = omodel(fx)["u"] * (1.0 - y * y)
+    ux = torch.autograd.grad(u.sum(), x, create_graph=True)[0]
+    uy = torch.autograd.grad(u.sum(), y, create_graph=True)[0]
+    uxx = torch.autograd.grad(ux.sum(), x, create_graph=True)[0]
+    uyy = torch.autograd.grad(uy.sum(), y, create_graph=True)[0]
+    uxy = torch.autograd.grad(ux.sum(), y, create_graph=True)[0]
+    r = ux * u - tnu * (uxx + uyy) + mixed * uxy
+    loss = (r**2).mean()
+    gref = torch.autograd.grad(loss, omodel.parameters(), allow_unused=True)
+    gref = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gref, omodel.parameters())])
+    assert solver._compiled["EQ"].fused.losses()["r"] == pytest.approx(float(loss.detach()), rel=5e-5)
+    assert rel(g, gref) < 1e-4
+    # eager forward runs the transform on tensors
+    out = model({"x": X[:, :1], "y": X[:, 1:], "nu": nu})["u"].cpu().numpy()
+    assert rel(out, u.detach().numpy()) < 1e-5
