@@ -526,5 +526,7 @@ def test_registered_input_transform_nonlinear_features(tmp_path, width, mixed):
     assert solver._compiled["EQ"].fused.losses()["r"] == pytest.approx(float(loss.detach()), rel=5e-5)
     assert rel(g, gref) < 1e-4
     # eager forward runs the transform on tensors
-    out = model({"x": X[:, :1], "y": X[:, 1:], "nu": nu})["u"].cpu().numpy()
+    dev_ = model.flat_params.device
+    out = model({"x": torch.tensor(X[:, :1], device=dev_), "y": torch.tensor(X[:, 1:], device=dev_),
+                 "nu": torch.tensor(nu, device=dev_)})["u"].cpu().numpy()
     assert rel(out, u.detach().numpy()) < 1e-5
