@@ -83,4 +83,16 @@ def run(ns) -> dict:
             out[f"{nm}.on_boundary"] = np.asarray(geo.on_boundary(q))
             out[f"{nm}.sdf"] = np.asarray(geo.sdf_func(q))
         out["diff.normal"] = np.asarray(shapes["diff"].boundary_normal(q[[0, 2, 4]]))
+    if hasattr(ns, "PointCloud"):
+        rng = np.random.default_rng(5)
+        pts = {"x": rng.uniform(0, 1, (40, 1)).astype("float32"), "y": rng.uniform(-1, 1, (40, 1)).astype("float32"),
+               "nu": rng.uniform(0.01, 0.1, (40, 1)).astype("float32")}
+        bnd = {k: v[:9].copy() for k, v in pts.items()}
+        pc = ns.PointCloud(pts, ("x", "y", "nu"), bnd)
+        case("pointcloud.interior_rand", 80, lambda: pc.sample_interior(17))
+        case("pointcloud.interior_even", 81, lambda: pc.sample_interior(12, evenly=True))
+        case("pointcloud.random_boundary", 82, lambda: pc.random_boundary_points(5))
+        probe = np.concatenate([pc.interior[:3], pc.interior[3:5] + 0.01])
+        out["pointcloud.is_inside"] = np.asarray(pc.is_inside(probe))
+        out["pointcloud.bbox"] = np.stack([np.asarray(b) for b in pc.bbox])
     return out

@@ -25,7 +25,8 @@ def main():
     g3 = _ref_import.ref_module("ppsci.geometry.geometry_3d")
     td = _ref_import.ref_module("ppsci.geometry.timedomain")
     ns = types.SimpleNamespace(Interval=g1.Interval, Rectangle=g2.Rectangle, Cuboid=g3.Cuboid, Hypercube=gnd.Hypercube,
-                               TimeDomain=td.TimeDomain, TimeXGeometry=td.TimeXGeometry, Disk=g2.Disk)
+                               TimeDomain=td.TimeDomain, TimeXGeometry=td.TimeXGeometry, Disk=g2.Disk,
+                               PointCloud=_ref_import.ref_module("ppsci.geometry.pointcloud").PointCloud)
     cases = geometry_cases.run(ns)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **cases)
     print(f"wrote {len(cases)} arrays")
