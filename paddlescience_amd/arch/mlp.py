@@ -165,52 +165,37 @@ class MLP(Arch):
         else:
             assert n_train != 0
             self.kernel_params = torch.zeros(self.layout.n_params, dtype=torch.float32, device=dev)
-            self._grad_train = torch.zeros_like(self.flat_params)
-            gviews, off = {}, 0
-            for name, shp in shapes:
-                n = int(np.prod(shp))
-                gviews[name] = self._grad_train[off:off + n].view(tuple(shp))
-                off += n
+            self._bind_grad(torch.zeros_like(self.flat_params))
             kviews, off = [], 0
             for _, shp in self.layout.param_shapes():
                 n = int(np.prod(shp))
                 kviews.append((off, n, shp))
                 off += n
-            self._records = []  # (kind, fin, fout, v, g, b, kW(off, n), kb(off, n), gv, gg, gb)
+            # (kind, fin, fout, name of v, of g, of b, kernel slice of W (off, n, shape), of b): the tensors are
+            # looked up by name at every call, so re-homing the buffers (ModelList) needs no bookkeeping here
+            self._records = []
             kl = 0
             if fourier_half:
                 w, b = kviews[0], kviews[1]
-                self._records.append((L.LINEAR_FOURIER, w[2][0], w[2][1], byname["fourier_emb.kernel"], None, None,
-                                      w, b, gviews["fourier_emb.kernel"], None, None))
+                self._records.append((L.LINEAR_FOURIER, w[2][0], w[2][1], "fourier_emb.kernel", None, None, w, b))
                 kl = 1
             for l in range(len(hidden)):
                 w, b = kviews[2 * (kl + l)], kviews[2 * (kl + l) + 1]
                 if self._linear_kind == L.LINEAR_PLAIN:
-                    nm = f"linears.{l}.weight"
-                    self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], byname[nm], None,
-                                          byname[f"linears.{l}.bias"], w, b, gviews[nm], None,
-                                          gviews[f"linears.{l}.bias"]))
+                    self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], f"linears.{l}.weight", None,
+                                          f"linears.{l}.bias", w, b))
                 else:
-                    self._records.append((self._linear_kind, w[2][0], w[2][1], byname[f"linears.{l}.weight_v"],
-                                          byname[f"linears.{l}.weight_g"], byname[f"linears.{l}.bias"], w, b,
-                                          gviews[f"linears.{l}.weight_v"], gviews[f"linears.{l}.weight_g"],
-                                          gviews[f"linears.{l}.bias"]))
+                    self._records.append((self._linear_kind, w[2][0], w[2][1], f"linears.{l}.weight_v",
+                                          f"linears.{l}.weight_g", f"linears.{l}.bias", w, b))
             nlin = 2 * (kl + len(hidden))  # kernel layout: the last linear follows the hidden ones ...
             w, b = kviews[nlin], kviews[nlin + 1]
-            self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], byname["last_fc.weight"], None,
-                                  byname["last_fc.bias"], w, b, gviews["last_fc.weight"], None,
-                                  gviews["last_fc.bias"]))
+            self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], "last_fc.weight", None, "last_fc.bias", w, b))
             if self._param_act:  # ... and then one [H] parameter vector per hidden layer
                 none = (0, 0, ())
                 for l in range(len(hidden)):
-                    a = kviews[nlin + 2 + l]
-                    nm = f"acts.{l}.beta"
-                    if self.activation == "swish":  # Swish.beta has shape [] (activation.py:52-55): broadcast
-                        self._records.append((L.LINEAR_BROADCAST, 1, hidden[0], byname[nm].view(1), None, None, a, none,
-                                              gviews[nm].view(1), None, None))
-                    else:  # Stan.beta [out_features] (activation.py:37-40)
-                        self._records.append((L.LINEAR_PLAIN, 1, hidden[0], byname[nm], None, None, a, none,
-                                              gviews[nm], None, None))
+                    # Swish.beta has shape [] (activation.py:52-55): broadcast; Stan.beta [out_features] (:37-40)
+                    kind = L.LINEAR_BROADCAST if self.activation == "swish" else L.LINEAR_PLAIN
+                    self._records.append((kind, 1, hidden[0], f"acts.{l}.beta", None, None, kviews[nlin + 2 + l], none))
         self._frozen = False
         self._init_parameters()
 
@@ -225,7 +210,7 @@ class MLP(Arch):
             self._names.append(name)
             self._views.append(flat[off:off + n].view(tuple(shp)))
             off += n
-        byname = dict(zip(self._names, self._views))
+        byname = self._byname = dict(zip(self._names, self._views))
         nl = self._n_hidden_linears
         if self._linear_kind == L.LINEAR_PLAIN:
             self.linears = [_Linear(byname[f"linears.{l}.weight"], byname[f"linears.{l}.bias"]) for l in range(nl)]
@@ -237,29 +222,45 @@ class MLP(Arch):
         if not self.reparam:
             self.kernel_params = flat
 
-    def rehome(self, flat: torch.Tensor) -> None:
-        """Move the parameters into `flat` (a slice of a larger buffer), keeping their values."""
-        if self.reparam:
-            raise NotImplementedError("ModelList members with weight_norm / random_weight / fourier")
+    def _bind_grad(self, flat_grad: torch.Tensor) -> None:
+        """Views of the trainable-layout gradient (reparametrised nets only)."""
+        self._grad_train = flat_grad
+        self._gviews, off = {}, 0
+        for name, shp in self._shapes:
+            n = int(np.prod(shp))
+            self._gviews[name] = flat_grad[off:off + n].view(tuple(shp))
+            off += n
+
+    def rehome(self, flat: torch.Tensor, flat_grad: Optional[torch.Tensor] = None,
+               kernel: Optional[torch.Tensor] = None) -> None:
+        """Move the trainable parameters into `flat` (a slice of a larger buffer), keeping their values; for a
+        reparametrised net also its trainable-layout gradient and its kernel-layout buffer."""
         assert flat.numel() == self.flat_params.numel()
         flat.copy_(self.flat_params)
         self._bind_views(flat)
+        if self.reparam:
+            assert flat_grad is not None and kernel is not None and kernel.numel() == self.layout.n_params
+            self._bind_grad(flat_grad)
+            self.kernel_params = kernel
 
     # ---- trainable tensors <-> kernel layout (csrc/reparam.hip); both are no-ops for a plain MLP
     def materialize(self) -> torch.Tensor:
         """Fill `kernel_params` from the trainable tensors; call before every forward sweep."""
-        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), _, _, _ in self._records:
-            hp.linear_materialize(kind, fin, fout, v, g, b, self.kernel_params[wo:wo + wn],
-                                  self.kernel_params[bo:bo + bn] if bn else None)
+        t = self._byname
+        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
+            hp.linear_materialize(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, t[b] if b else None,
+                                  self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn] if bn else None)
         return self.kernel_params
 
     def pull_back(self, grad_kernel: torch.Tensor) -> torch.Tensor:
         """Gradient w.r.t. `kernel_params` -> gradient w.r.t. the trainable tensors (`flat_params` order)."""
         if not self.reparam:
             return grad_kernel
-        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _), gv, gg, gb in self._records:
-            hp.linear_pullback(kind, fin, fout, v, g, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn] if bn else None,
-                               gv, gg, gb)
+        t, gt = self._byname, self._gviews
+        for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
+            hp.linear_pullback(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, grad_kernel[wo:wo + wn],
+                               grad_kernel[bo:bo + bn] if bn else None, gt[v].reshape(-1), gt[g] if g else None,
+                               gt[b] if b else None)
         return self._grad_train
 
     # ---- parameters

@@ -33,20 +33,50 @@ class ModelList(Arch):
         self.model_list = list(model_list)
         pad = lambda n: (n + 63) // 64 * 64  # noqa: E731 -- every member starts on a 256-byte boundary (the
         # kernels use 16-byte vector loads of weights); the padding floats stay zero: their gradient is never written
-        total = sum(pad(m.flat_params.numel()) for m in model_list)
-        self.flat_params = torch.zeros(total, dtype=torch.float32, device=model_list[0].flat_params.device)
-        off = 0
+        dev = model_list[0].flat_params.device
+        self.reparam = any(m.reparam for m in model_list)
+        self.flat_params = torch.zeros(sum(pad(m.flat_params.numel()) for m in model_list), dtype=torch.float32, device=dev)
+        if self.reparam:
+            # some member keeps factored / tied / activation parameters: the kernels read a second buffer in the
+            # kernel layout (one slice per member, filled by materialize()); its gradient is pulled back per member
+            self.kernel_params = torch.zeros(sum(pad(m.layout.n_params) for m in model_list), dtype=torch.float32, device=dev)
+            self._grad_train = torch.zeros_like(self.flat_params)
+        else:
+            self.kernel_params = self.flat_params
+        off = koff = 0
         for m in model_list:
-            n = m.flat_params.numel()
-            m.rehome(self.flat_params[off:off + n])
-            m._param_offset = off
+            n, nk = m.flat_params.numel(), m.layout.n_params
+            if m.reparam:
+                m.rehome(self.flat_params[off:off + n], self._grad_train[off:off + n], self.kernel_params[koff:koff + nk])
+            else:
+                m.rehome(self.flat_params[off:off + n])
+            m._train_offset = off
+            m._param_offset = koff if self.reparam else off  # where the KERNELS find this member's parameters
             off += pad(n)
-        self.kernel_params = self.flat_params
-        self.reparam = False
+            koff += pad(nk)
         self.layout = None  # one layout per member: see compile.CompiledConstraint
 
     def materialize(self) -> torch.Tensor:
-        return self.flat_params
+        if self.reparam:
+            for m in self.model_list:
+                if m.reparam:
+                    m.materialize()
+                else:  # same layout: a copy into its slice of the kernel buffer
+                    n = m.flat_params.numel()
+                    self.kernel_params[m._param_offset:m._param_offset + n].copy_(m.flat_params)
+        return self.kernel_params
+
+    def pull_back(self, grad_kernel: torch.Tensor) -> torch.Tensor:
+        if not self.reparam:
+            return grad_kernel
+        for m in self.model_list:
+            nk = m.layout.n_params
+            gk = grad_kernel[m._param_offset:m._param_offset + nk]
+            if m.reparam:
+                m.pull_back(gk)  # writes its slice of self._grad_train
+            else:
+                self._grad_train[m._train_offset:m._train_offset + nk].copy_(gk)
+        return self._grad_train
 
     def forward(self, x: Dict[str, object]) -> Dict[str, object]:
         y_all: Dict[str, object] = {}

@@ -530,3 +530,49 @@ def test_registered_input_transform_nonlinear_features(tmp_path, width, mixed):
     out = model({"x": torch.tensor(X[:, :1], device=dev_), "y": torch.tensor(X[:, 1:], device=dev_),
                  "nu": torch.tensor(nu, device=dev_)})["u"].cpu().numpy()
     assert rel(out, u.detach().numpy()) < 1e-5
+
+
+def test_model_list_with_a_learnable_activation_member(tmp_path):
+    """A ModelList whose members have different parameter layouts: a swish net (trainable betas: kernel layout !=
+    trainable layout) next to a plain tanh net.  Gradient w.r.t. the trainable tensors of both, and an Adam step."""
+    rng = np.random.default_rng(15)
+    net_a = T.make_net(2, [20, 20], 1, seed=3, activation="swish", bias_scale=0.05)
+    net_b = T.make_net(2, [16, 16], 1, seed=4, bias_scale=0.05)
+    ma = ppsci.arch.MLP(("x", "y"), ("u",), 2, 20, "swish")
+    mb = ppsci.arch.MLP(("x", "y"), ("p",), 2, 16, "tanh")
+    beta = [np.float32(rng.uniform(0.7, 1.3)) for _ in range(2)]
+    oa = R.MLP(("x", "y"), ("u",), net_a.astype(np.float32).astype(np.float64), act_beta=[np.asarray(b, np.float64) for b in beta])
+    ob = R.MLP(("x", "y"), ("p",), net_b.astype(np.float32).astype(np.float64))
+    ma.flat_params.copy_(torch.tensor(np.concatenate([p.detach().numpy().ravel() for p in oa.parameters()]), dtype=torch.float32))
+    set_model_weights(mb, net_b)
+    model = ppsci.arch.ModelList((ma, mb))
+    assert model.reparam and ma.flat_params.data_ptr() == model.flat_params.data_ptr()
+    N = 31
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32)
+
+    def resid(out):
+        return hessian(out["u"], out["x"]) + jacobian(out["p"], out["y"]) * out["u"]
+
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"r": np.zeros((N, 1), np.float32)}, {"r": resid},
+                          ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    solver._materialize()
+    solver.engine.forward_backward([c.fused for c in solver._compiled.values()])
+    g = solver._train_grad().cpu().numpy().astype(np.float64)
+    x = torch.tensor(X[:, :1].astype(np.float64), requires_grad=True)
+    y = torch.tensor(X[:, 1:].astype(np.float64), requires_grad=True)
+    u = oa({"x": x, "y": y})["u"]
+    p = ob({"x": x, "y": y})["p"]
+    ux = torch.autograd.grad(u.sum(), x, create_graph=True)[0]
+    uxx = torch.autograd.grad(ux.sum(), x, create_graph=True)[0]
+    py = torch.autograd.grad(p.sum(), y, create_graph=True)[0]
+    loss = ((uxx + py * u) ** 2).mean()
+    for mem, om in ((ma, oa), (mb, ob)):
+        gr = torch.autograd.grad(loss, om.parameters(), allow_unused=True, retain_graph=True)
+        gref = np.concatenate([(torch.zeros_like(q) if gg is None else gg).numpy().ravel() for gg, q in zip(gr, om.parameters())])
+        off = mem._train_offset
+        assert rel(g[off:off + gref.size], gref) < 1e-4
+    assert solver._compiled["EQ"].fused.losses()["r"] == pytest.approx(float(loss.detach()), rel=5e-5)
+    before = model.flat_params.clone()
+    solver.train()
+    assert float((model.flat_params - before).abs().max()) > 1e-4
