@@ -576,3 +576,44 @@ def test_model_list_with_a_learnable_activation_member(tmp_path):
     before = model.flat_params.clone()
     solver.train()
     assert float((model.flat_params - before).abs().max()) > 1e-4
+
+
+def test_unsteady_navier_stokes_and_laplace_3d(tmp_path):
+    """NavierStokes(dim=2, time=True) (navier_stokes.py:70-151: first derivatives along t, x, y, second along x, y ->
+    the (3, 3) stream kernels) and Laplace(dim=3) (laplace.py:40-55), through the sympy path against the oracle."""
+    model = ppsci.arch.MLP(("t", "x", "y"), ("u", "v", "p"), 2, 24, "tanh")
+    net = T.make_net(3, [24, 24], 3, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 29
+    rng = np.random.default_rng(33)
+    X = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    eq = ppsci.equation.NavierStokes(0.02, 1.3, 2, True)
+    keys = ("continuity", "momentum_x", "momentum_y")
+    cst = _sup_constraint({"t": X[:, :1], "x": X[:, 1:2], "y": X[:, 2:]}, {k: np.zeros((N, 1), np.float32) for k in keys},
+                          eq.equations, ppsci.loss.MSELoss("sum"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    omodel = R.MLP(("t", "x", "y"), ("u", "v", "p"), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"t": X[:, :1].astype(np.float64), "x": X[:, 1:2].astype(np.float64), "y": X[:, 2:].astype(np.float64)},
+              exprs={k: R.lambdify(eq.equations[k], omodel) for k in keys}, label={k: np.zeros((N, 1)) for k in keys},
+              reduction="sum")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    got = solver._compiled["EQ"].fused.losses()
+    for k in keys:
+        assert got[k] == pytest.approx(losses[k], rel=5e-5)
+    assert rel(g, gref) < 5e-5
+    # 3-D Laplace: three second-order streams
+    m3 = ppsci.arch.MLP(("x", "y", "z"), ("u",), 2, 24, "silu")
+    net3 = T.make_net(3, [24, 24], 1, activation="silu", bias_scale=0.05)
+    set_model_weights(m3, net3)
+    lap = ppsci.equation.Laplace(dim=3)
+    c3 = _sup_constraint({"x": X[:, :1], "y": X[:, 1:2], "z": X[:, 2:]}, {"laplace": np.zeros((N, 1), np.float32)},
+                         lap.equations, ppsci.loss.MSELoss("mean"))
+    s3 = _solver(tmp_path, m3, {"EQ": c3})
+    g3 = _run(s3)
+    o3 = R.MLP(("x", "y", "z"), ("u",), net3.astype(np.float32).astype(np.float64))
+    oc3 = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:2].astype(np.float64), "z": X[:, 2:].astype(np.float64)},
+               exprs={"laplace": R.lambdify(lap.equations["laplace"], o3)}, label={"laplace": np.zeros((N, 1))}, reduction="mean")
+    t3, _, gref3, _ = R.loss_and_grads(o3, [oc3])
+    assert s3._compiled["EQ"].fused.losses()["laplace"] == pytest.approx(t3, rel=5e-5)
+    assert rel(g3, gref3) < 5e-5
