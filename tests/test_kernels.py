@@ -517,6 +517,41 @@ def test_learnable_activations_fwd_and_bwd(act, hidden, dout, n2, N):
     assert _rel(g[-nP:], gref[-nP:]) < 1e-5, _rel(g[-nP:], gref[-nP:])
 
 
+@pytest.mark.parametrize("width,N", [(128, 21), (256, 16)])
+def test_wide_nets_with_three_second_order_streams(width, N):
+    """(3, 3) stream set (unsteady 2-D Navier-Stokes, 3-D Laplace) on the feature-split kernels: S = 7."""
+    dirs = np.eye(3)
+    net = T.make_net(3, [width, width], 2, bias_scale=0.2)
+    rng = np.random.default_rng(41)
+    X = rng.uniform(-1, 1, (N, 3)).astype(np.float32).astype(np.float64)
+    emb = [0, 0, 0]
+    from paddlescience_amd import hotpath as hp
+
+    lay = hp.NetLayout(3, 2, width, 2, "tanh", False, emb, [0.0] * 3)
+    spec = hp.StreamSpec([list(map(float, r)) for r in dirs], 3)
+    desc = lay.desc(spec)
+    params = _t(T.flat_params(net))
+    inputs = [_t(X[:, j]) for j in range(3)]
+    U = _full((2 * spec.S, N), float("nan"))
+    st = _full((hp.stash_bytes(desc, N) // 4,), float("nan"))
+    hp.taylor_fwd(desc, params, inputs, U, st)
+    net32 = net.astype(np.float32).astype(np.float64)
+    ref, cache = T.taylor_forward(net32, X, dirs, 3, keep=True)
+    got = U.cpu().numpy().astype(np.float64)
+    for q in range(got.shape[0]):
+        assert _rel(got[q], ref.reshape(-1, N)[q]) < 8e-6
+    Ubar = rng.standard_normal((2, spec.S, N)).astype(np.float32).astype(np.float64)
+    rows = hp.bwd_partial_rows(desc, N)
+    P = params.numel()
+    partials = _full((rows, P), float("nan"))
+    ws = _full((max(4, hp.bwd_workspace_bytes(desc, N) // 4),), float("nan"))
+    hp.taylor_bwd(desc, params, inputs, _t(Ubar.reshape(-1, N)), st, ws, partials)
+    grad = _full((P,), float("nan"))
+    hp.reduce_rows(partials, rows, P, grad, False)
+    gW, gb = T.taylor_backward(net32, cache, Ubar)
+    assert _rel(grad.cpu().numpy().astype(np.float64), T.flat_grads(gW, gb)) < 1e-5
+
+
 def test_adam_step_matches_oracle():
     from oracle import ref_torch as R
     from paddlescience_amd import hotpath as hp
