@@ -31,7 +31,9 @@ fuse_derivative=True, equation/pde/*.py, loss/mse.py) with `paddle` replaced by 
 fixtures to 1e-10 (tests/test_golden_hotpath.py).  The SPINN / Helmholtz and FNO restatements at the end of
 this file are pinned the same way (tests/golden/make_spinn_golden.py -> spinn.npz, make_fno_golden.py ->
 fno.npz: the reference's arch/spinn.py, ModifiedMLP, equation/pde/helmholtz.py, arch/fno_block.py, tfnonet.py
-executed under the shim; tests/test_golden_spinn.py, tests/test_golden_fno.py).  What remains unpinned is
+executed under the shim; tests/test_golden_spinn.py, tests/test_golden_fno.py), and so are the MLP variants
+(weight_norm / random_weight / fourier / swish / stan), CausalMSELoss, ModelList and ParameterNode
+(tests/golden/make_variants_golden.py -> variants.npz, tests/test_golden_variants.py).  What remains unpinned is
 PaddlePaddle's own kernel arithmetic (covered by the fp32-vs-fp64 tolerance).
 """
 from __future__ import annotations
@@ -79,15 +81,20 @@ class MLP:
         for i, (w, b) in enumerate(zip(self.weights, self.biases)):
             if i == n_hidden:
                 out += self.act_beta  # self.acts is registered before self.last_fc (mlp.py:262-263, :274)
-            out += [w, self.weight_g[i], b] if (self.factor and i < n_hidden) else [w, b]
+            out += [w, self.weight_g[i], b] if self._factored(i) else [w, b]
         return out
+
+    def _factored(self, i) -> bool:
+        """weight_norm: hidden layers only; random_weight: also last_fc (mlp.py:239-249, :266-272)."""
+        n_hidden = len(self.weights) - 1
+        return bool(self.factor) and (i < n_hidden or (self.factor == "random_weight" and len(self.weight_g) > n_hidden))
 
     def _linear(self, i, y):
         w = self.weights[i]
-        if self.factor == "weight_norm" and i < len(self.weights) - 1:  # mlp.py:50-54
+        if self.factor == "weight_norm" and self._factored(i):  # mlp.py:50-54
             norm = torch.linalg.vector_norm(w, ord=2, dim=0, keepdim=True)
             w = self.weight_g[i] * w / norm
-        elif self.factor == "random_weight" and i < len(self.weights) - 1:  # mlp.py:91-92
+        elif self.factor == "random_weight" and self._factored(i):  # mlp.py:91-92
             w = self.weight_g[i] * w
         return y @ w + self.biases[i]
 
@@ -125,7 +132,7 @@ class MLP:
                 else:
                     skip = y
             y = self._act(y, i)
-        return y @ self.weights[-1] + self.biases[-1]
+        return self._linear(n_hidden, y)  # last_fc (factorised too under random_weight)
 
     def __call__(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:  # mlp.py:298-315
         if self.periods:

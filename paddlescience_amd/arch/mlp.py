@@ -150,7 +150,11 @@ class MLP(Arch):
             fin = hidden[0]
         if self._param_act:  # self.acts is registered between self.linears and self.last_fc (mlp.py:262-263, :274)
             shapes += [(f"acts.{l}.beta", () if self.activation == "swish" else (hidden[0],)) for l in range(len(hidden))]
-        shapes += [("last_fc.weight", (fin, len(self.output_keys))), ("last_fc.bias", (len(self.output_keys),))]
+        if self._linear_kind == L.LINEAR_RWF:  # mlp.py:266-272: with random_weight the last linear is factorised too
+            shapes += [("last_fc.weight_v", (fin, len(self.output_keys))), ("last_fc.weight_g", (len(self.output_keys),)),
+                       ("last_fc.bias", (len(self.output_keys),))]
+        else:
+            shapes += [("last_fc.weight", (fin, len(self.output_keys))), ("last_fc.bias", (len(self.output_keys),))]
         n_train = sum(int(np.prod(shp)) for _, shp in shapes)
         self._shapes = shapes
         self._n_hidden_linears, self._fourier_half = len(hidden), fourier_half
@@ -189,7 +193,11 @@ class MLP(Arch):
                                           f"linears.{l}.weight_g", f"linears.{l}.bias", w, b))
             nlin = 2 * (kl + len(hidden))  # kernel layout: the last linear follows the hidden ones ...
             w, b = kviews[nlin], kviews[nlin + 1]
-            self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], "last_fc.weight", None, "last_fc.bias", w, b))
+            if self._linear_kind == L.LINEAR_RWF:
+                self._records.append((L.LINEAR_RWF, w[2][0], w[2][1], "last_fc.weight_v", "last_fc.weight_g",
+                                      "last_fc.bias", w, b))
+            else:
+                self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], "last_fc.weight", None, "last_fc.bias", w, b))
             if self._param_act:  # ... and then one [H] parameter vector per hidden layer
                 none = (0, 0, ())
                 for l in range(len(hidden)):
@@ -217,7 +225,10 @@ class MLP(Arch):
         else:
             self.linears = [_FactoredLinear(byname[f"linears.{l}.weight_v"], byname[f"linears.{l}.weight_g"],
                                             byname[f"linears.{l}.bias"]) for l in range(nl)]
-        self.last_fc = _Linear(byname["last_fc.weight"], byname["last_fc.bias"])
+        if "last_fc.weight_v" in byname:
+            self.last_fc = _FactoredLinear(byname["last_fc.weight_v"], byname["last_fc.weight_g"], byname["last_fc.bias"])
+        else:
+            self.last_fc = _Linear(byname["last_fc.weight"], byname["last_fc.bias"])
         self.fourier_emb = _Kernel(byname["fourier_emb.kernel"]) if self._fourier_half else None
         if not self.reparam:
             self.kernel_params = flat

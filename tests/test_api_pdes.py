@@ -230,6 +230,8 @@ def test_factored_and_fourier_mlp_variants(tmp_path, variant):
         okw["fourier_kernel"] = B.astype(np.float32).astype(np.float64)
     if "factor" in okw:
         okw["weight_g"] = [rng.uniform(0.6, 1.6, H).astype(np.float32).astype(np.float64) for _ in range(nl)]
+        if okw["factor"] == "random_weight":  # last_fc is factorised too (mlp.py:266-272)
+            okw["weight_g"].append(rng.uniform(0.6, 1.6, 1).astype(np.float32).astype(np.float64))
     net32 = net.astype(np.float32).astype(np.float64)
     omodel = R.MLP(("t", "x"), ("u",), net32, **okw)
     # the model's trainable tensors are in the oracle's parameters() order
