@@ -469,7 +469,7 @@ def point_loss(kind, output_dict, label_dict, weight_dict=None, reduction="mean"
             n = x.shape[0]
             loss = torch.linalg.norm((x - y).reshape(n, -1), dim=1) / torch.linalg.norm(y.reshape(n, -1), dim=1)
             if w is not None:
-                loss = loss * w.reshape(n)
+                loss = loss * w  # l2.py:296-297: [N] * [N, 1] broadcasts to [N, N] (pinned by tests/golden/variants.npz)
         else:
             raise ValueError(kind)
         loss = loss.sum() if reduction == "sum" else loss.mean()

@@ -127,7 +127,8 @@ class CompiledConstraint:
             elif name.startswith(LABEL_PREFIX):
                 srcs.append(label[name[len(LABEL_PREFIX):]])
             elif name.startswith(WEIGHT_PREFIX):
-                srcs.append(weight[name[len(WEIGHT_PREFIX):]])
+                w = weight[name[len(WEIGHT_PREFIX):]]
+                srcs.append(self.loss.batch_weight(w) if hasattr(self.loss, "batch_weight") else w)
             elif name.startswith(CAUSAL_PREFIX):
                 srcs.append(None)  # written on the device every step (engine.FusedConstraint.forward)
             else:

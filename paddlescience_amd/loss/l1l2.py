@@ -70,6 +70,22 @@ class L2RelLoss(_PointLoss):
     term_kind = hp.LOSS_ABSREL
 
     def _point(self, x, y, w, area):
+        # l2.py:296-297: the [N] relative errors times the [N, 1] weights broadcast to [N, N]; its mean / sum is
+        # mean(err) * mean(w) / sum(err) * sum(w), which the fused path reproduces through `batch_weight`
         n = x.shape[0]
         loss = torch.linalg.norm((x - y).reshape(n, -1), dim=1) / torch.linalg.norm(y.reshape(n, -1), dim=1)
-        return loss * w.reshape(n) if w is not None else loss
+        return loss * w if w is not None else loss
+
+    def batch_weight(self, w):
+        """The per-point weight column the epilogue multiplies by, such that its reduction equals the reference's
+        reduction of the broadcast [N, N] product (see `_point`)."""
+        if isinstance(w, torch.Tensor):
+            if w.dim() < 2:
+                return w
+            return torch.full_like(w, 1.0) * (w.mean() if self.reduction == "mean" else w.sum())
+        import numpy as np
+
+        w = np.asarray(w)
+        if w.ndim < 2:
+            return w
+        return np.full_like(w, w.mean(dtype=np.float64) if self.reduction == "mean" else w.sum(dtype=np.float64))

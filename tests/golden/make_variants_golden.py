@@ -101,12 +101,12 @@ def main():
     def trainable(model):
         return [p for p in model.parameters() if p.requires_grad]
 
-    def allen_cahn_case(name, model, n, rng, loss_obj, sort_t=False, positive=()):
+    def allen_cahn_case(name, model, n, rng, loss_obj, sort_t=False, positive=(), scale=0.3):
         ps = trainable(model)
         names = [k for k, p in model.named_parameters() if p.requires_grad]
         for k, p in zip(names, ps):
             p._positive = any(tag in k for tag in positive)
-        flat = set_params(ps, rng)
+        flat = set_params(ps, rng, scale)
         X = rng.uniform([0, -1], [1, 1], (n, 2)).astype(np.float32).astype(np.float64)
         if sort_t:
             X[:, 0] = np.sort(X[:, 0])
@@ -141,6 +141,74 @@ def main():
                     positive=("beta",))
     allen_cahn_case("causal", MLP(("t", "x"), ("u",), None, (16, 16), "tanh"), 48, rng,
                     mse.CausalMSELoss(8, "mean", tol=1.5), sort_t=True)
+
+    for act in ("siren", "gelu", "sigmoid", "cos"):
+        allen_cahn_case(f"act_{act}", MLP(("t", "x"), ("u",), None, (20, 20, 20), act), 30, rng, mse.MSELoss("mean"),
+                        scale=0.03 if act == "siren" else 0.3)  # siren multiplies by w0 = 30 (activation.py Siren)
+
+    # ---- the other point losses (loss/l1.py, loss/mae.py, loss/l2.py) on an Allen-Cahn residual + a data term
+    F = sys.modules["paddle.nn.functional"]
+    F.l1_loss = lambda x, y, reduction="mean": ((x - y).abs() if reduction == "none" else torch.nn.functional.l1_loss(x, y, reduction=reduction))
+    _sum, _mean = torch.Tensor.sum, torch.Tensor.mean
+    torch.Tensor.sum = lambda self, axis=None, keepdim=False, **k: _sum(self) if axis is None and not k else _sum(self, dim=k.get("dim", axis), keepdim=keepdim)
+    paddle.linalg = type("linalg", (), {"norm": staticmethod(lambda x, p=2, axis=None: torch.linalg.norm(x, ord=p, dim=axis))})
+    paddle.norm = lambda x, p=2, axis=None: torch.linalg.norm(x, ord=p, dim=axis)
+    l1m, maem, l2m = (importlib.import_module(f"ppsci.loss.{m}") for m in ("l1", "mae", "l2"))
+    for lname, cls in (("l1", l1m.L1Loss), ("mae", maem.MAELoss), ("l2", l2m.L2Loss), ("l2rel", l2m.L2RelLoss)):
+        for red in ("mean", "sum"):
+            model = MLP(("t", "x"), ("u",), None, (16, 16), "tanh")
+            ps = trainable(model)
+            flat = set_params(ps, rng)
+            n = 37
+            X = rng.uniform([0, -1], [1, 1], (n, 2)).astype(np.float32).astype(np.float64)
+            data = {"t": torch.tensor(X[:, :1], requires_grad=True), "x": torch.tensor(X[:, 1:], requires_grad=True)}
+            eq = mods["allen_cahn"].AllenCahn(0.05)
+            od = model(data)
+            dd = dict(data)
+            dd.update(od)
+            od["allen_cahn"] = eq.equations["allen_cahn"](dd)
+            clear()
+            lab = {"allen_cahn": torch.tensor(rng.standard_normal((n, 1)).astype(np.float32).astype(np.float64) + 3.0),
+                   "u": torch.tensor(rng.standard_normal((n, 1)).astype(np.float32).astype(np.float64) + 2.0)}
+            wts = {k: torch.tensor(rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32).astype(np.float64)) for k in lab}
+            losses = cls(red, weight={"u": 0.7})(od, lab, wts)
+            total = losses["allen_cahn"] + losses["u"]
+            nm = f"loss_{lname}_{red}"
+            out[f"{nm}/X"], out[f"{nm}/params"] = X, flat
+            for k in lab:
+                out[f"{nm}/label/{k}"], out[f"{nm}/weight/{k}"] = lab[k].numpy()[:, 0], wts[k].numpy()[:, 0]
+                out[f"{nm}/loss/{k}"] = np.asarray(float(losses[k].detach()))
+            out[f"{nm}/grad"] = grads_flat(total, ps)
+            print(nm, float(total.detach()))
+
+    # ---- every function of SYMPY_TO_PADDLE (symbolic.py:79-108) in one residual
+    # (the dummy paddle module handed the map placeholders for the functions the shim had not defined)
+    for sf, tname in ((sp.asin, "asin"), (sp.acos, "acos"), (sp.atan, "atan"), (sp.atan2, "atan2"), (sp.asinh, "asinh"),
+                      (sp.acosh, "acosh"), (sp.atanh, "atanh"), (sp.erf, "erf"), (sp.loggamma, "lgamma")):
+        mods["symbolic"].SYMPY_TO_PADDLE[sf] = getattr(torch, tname)
+    model = MLP(("x", "y"), ("u",), None, (20, 20), "tanh")
+    ps = trainable(model)
+    flat = set_params(ps, rng)
+    n = 48
+    X = rng.uniform(0.1, 0.9, (n, 2)).astype(np.float32).astype(np.float64)
+    data = {"x": torch.tensor(X[:, :1], requires_grad=True), "y": torch.tensor(X[:, 1:], requires_grad=True)}
+    x, y = sp.symbols("x y")
+    u = sp.Function("u")(x, y)
+    expr = (sp.atan(u.diff(x)) + sp.erf(u) * sp.asinh(u.diff(y, 2)) + sp.atan2(u.diff(x, 2), 1 + x * x)
+            + sp.asin(u / 4) * sp.acos(x / 2) + sp.atanh(y / 2) * u + sp.acosh(2 + u * u)
+            + sp.loggamma(2 + y) * u.diff(y) + sp.floor(4 * x) * u + sp.ceiling(3 * y) * u.diff(x)
+            + sp.Max(u, u.diff(x), 0.1) + sp.Min(u.diff(y), x) + sp.Heaviside(x - 0.5) * u + sp.sign(y - 0.4) * u)
+    od = model(data)
+    dd = dict(data)
+    dd.update(od)
+    od["r"] = lambdify(expr, model, fuse_derivative=True)(dd)
+    clear()
+    losses = mse.MSELoss("mean")(od, {"r": torch.zeros(n, 1, dtype=D)}, None)
+    out["sympy_map/X"], out["sympy_map/params"] = X, flat
+    out["sympy_map/res"] = od["r"].detach().numpy()[:, 0]
+    out["sympy_map/loss"] = np.asarray(float(losses["r"].detach()))
+    out["sympy_map/grad"] = grads_flat(losses["r"], ps)
+    print("sympy_map", float(losses["r"].detach()))
 
     # ---- ModelList: two nets coupled in sympy residuals
     ml = importlib.import_module("ppsci.arch.model_list")
