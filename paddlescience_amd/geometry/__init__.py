@@ -2,10 +2,11 @@
 from .base import Geometry  # noqa: F401
 from .boolean import CSGDifference, CSGIntersection, CSGUnion, Disk  # noqa: F401
 from .pointcloud import PointCloud  # noqa: F401
+from .polygon import Polygon, Triangle  # noqa: F401
 from .shapes import Cuboid, Hypercube, Interval, Rectangle  # noqa: F401
 from .timedomain import TimeDomain, TimeXGeometry  # noqa: F401
 
-__all__ = ["Geometry", "Disk", "CSGUnion", "CSGDifference", "CSGIntersection", "PointCloud", "Interval", "Rectangle", "Cuboid", "Hypercube", "TimeDomain", "TimeXGeometry", "build_geometry"]
+__all__ = ["Geometry", "Disk", "CSGUnion", "CSGDifference", "CSGIntersection", "PointCloud", "Triangle", "Polygon", "Interval", "Rectangle", "Cuboid", "Hypercube", "TimeDomain", "TimeXGeometry", "build_geometry"]
 
 
 def build_geometry(cfg):

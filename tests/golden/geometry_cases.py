@@ -83,6 +83,29 @@ def run(ns) -> dict:
             out[f"{nm}.on_boundary"] = np.asarray(geo.on_boundary(q))
             out[f"{nm}.sdf"] = np.asarray(geo.sdf_func(q))
         out["diff.normal"] = np.asarray(shapes["diff"].boundary_normal(q[[0, 2, 4]]))
+    if hasattr(ns, "Triangle"):  # edge-chain shapes; one triangle given clockwise, one polygon given clockwise
+        tri = ns.Triangle((0.0, 0.0), (1.0, 0.0), (0.2, 0.8))
+        tri_cw = ns.Triangle((0.1, 0.1), (0.3, 1.2), (1.5, 0.4))
+        poly = ns.Polygon(((0, 0), (1, 0), (2, 1), (2, 2), (0, 2)))
+        poly_cw = ns.Polygon(((0.0, 0.0), (0.0, 1.5), (0.7, 0.6), (1.6, 1.4), (1.2, -0.3)))
+        edge_shapes = {"tri": tri, "tri_cw": tri_cw, "poly": poly, "poly_cw": poly_cw}
+        for i, (nm, geo) in enumerate(edge_shapes.items()):
+            case(f"{nm}.interior_rand", 90 + i, lambda geo=geo: geo.sample_interior(45))
+            case(f"{nm}.boundary_rand", 100 + i, lambda geo=geo: geo.random_boundary_points(33))
+            case(f"{nm}.boundary_even", 110 + i, lambda geo=geo: geo.uniform_boundary_points(37))
+            case(f"{nm}.random_points", 120 + i, lambda geo=geo: geo.random_points(29))
+            np.random.seed(130 + i)
+            q = (np.random.random((60, 2)) * 2.6 - 0.4).astype("float32")
+            q = np.concatenate([q, np.asarray(geo.uniform_boundary_points(9), dtype="float32")])
+            out[f"{nm}.is_inside"] = np.asarray(geo.is_inside(q))
+            out[f"{nm}.on_boundary"] = np.asarray(geo.on_boundary(q))
+            out[f"{nm}.sdf"] = np.asarray(geo.sdf_func(q))
+            out[f"{nm}.meta"] = np.asarray([geo.area, geo.perimeter, geo.diam, *np.ravel(geo.bbox)], dtype="float64")
+        case("tri.boundary_sample", 140, lambda: tri.sample_boundary(31))
+        mid = np.array([[0.5, 0.0], [0.6, 0.4], [0.1, 0.4], [0.3, 0.3]], dtype="float32")
+        out["tri.normal"] = np.asarray(tri.boundary_normal(mid))
+        case("tri_diff.interior", 141, lambda: (ns.Rectangle((0.0, 0.0), (1.0, 1.0)) - tri).sample_interior(27))
+        case("tri_time.interior", 142, lambda: ns.TimeXGeometry(ns.TimeDomain(0.0, 1.0, time_step=0.5), tri_cw).sample_interior(26))
     if hasattr(ns, "PointCloud"):
         rng = np.random.default_rng(5)
         pts = {"x": rng.uniform(0, 1, (40, 1)).astype("float32"), "y": rng.uniform(-1, 1, (40, 1)).astype("float32"),

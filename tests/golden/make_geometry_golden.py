@@ -27,6 +27,15 @@ def main():
     ns = types.SimpleNamespace(Interval=g1.Interval, Rectangle=g2.Rectangle, Cuboid=g3.Cuboid, Hypercube=gnd.Hypercube,
                                TimeDomain=td.TimeDomain, TimeXGeometry=td.TimeXGeometry, Disk=g2.Disk,
                                PointCloud=_ref_import.ref_module("ppsci.geometry.pointcloud").PointCloud)
+    ns.Triangle, ns.Polygon = g2.Triangle, g2.Polygon
+    for k in [k for k in sys.modules if k == "scipy" or k.startswith("scipy.")]:  # the real scipy for Polygon's pdist
+        del sys.modules[k]
+    sys.meta_path[:] = [f for f in sys.meta_path if type(f).__module__ != "_ref_import"]
+    import scipy.spatial.distance
+
+    g2.spatial = scipy.spatial
+    if not hasattr(np, "int"):  # Polygon.on_boundary (geometry_2d.py:549) still spells the removed alias
+        np.int = int
     cases = geometry_cases.run(ns)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **cases)
     print(f"wrote {len(cases)} arrays")
