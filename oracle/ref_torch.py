@@ -481,6 +481,33 @@ def point_loss(kind, output_dict, label_dict, weight_dict=None, reduction="mean"
     return losses
 
 
+def periodic_loss(kind, output_dict, label_dict, weight_dict=None, reduction="mean", weight=None):
+    """PeriodicMSELoss (mse.py:322-355), PeriodicL1Loss (l1.py:185-218), PeriodicL2Loss (l2.py:181-207): first half of
+    every output against its second half."""
+    losses = {}
+    for key in label_dict:
+        n = len(output_dict[key])
+        if n % 2 > 0:
+            raise ValueError(f"Length of output({n}) of key({key}) should be even.")
+        a, b = output_dict[key][:n // 2], output_dict[key][n // 2:]
+        loss = (a - b).abs() if kind == "periodic_l1" else (a - b) ** 2
+        if weight_dict and key in weight_dict:
+            loss = loss * weight_dict[key]
+        if "area" in output_dict:
+            loss = loss * output_dict["area"]
+        if kind == "periodic_l1":
+            loss = loss.sum(dim=1)
+        elif kind == "periodic_l2":
+            loss = loss.sum(dim=1).sqrt()
+        loss = loss.sum() if reduction == "sum" else loss.mean()
+        if isinstance(weight, (float, int)):
+            loss = loss * weight
+        elif isinstance(weight, dict) and key in weight:
+            loss = loss * weight[key]
+        losses[key] = loss
+    return losses
+
+
 def causal_mse_loss(output_dict, label_dict, weight_dict=None, reduction="mean", weight=None, n_chunks=1, tol=1.0):
     """CausalMSELoss.forward, mse.py:158-187."""
     losses = {}
@@ -536,6 +563,8 @@ def train_forward(
         if c.get("loss_kind", "mse") == "causal_mse":
             losses = causal_mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"),
                                      c["n_chunks"], c.get("tol", 1.0))
+        elif c.get("loss_kind", "mse").startswith("periodic_"):
+            losses = periodic_loss(c["loss_kind"], output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
         elif c.get("loss_kind", "mse") == "mse":
             losses = mse_loss(output_dict, label, wd, c.get("reduction", "mean"), c.get("loss_weight"))
         else:

@@ -74,8 +74,15 @@ class CompiledConstraint:
                                area="area" if "area" in input_keys else None,
                                scale=loss.term_scale(k, n_global) if loss is not None else 0.0,
                                kind=getattr(loss, "term_kind", 0) if loss is not None else 0,
-                               causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None))
+                               causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None,
+                               periodic=bool(getattr(loss, "periodic", False))))
         self.low = graph.lower(outputs, losses, extra_outputs)
+        if getattr(loss, "periodic", False):
+            if batch_size % 2:
+                raise ValueError(f"Length of output({batch_size}) should be even.")  # mse.py:326-329
+            if any(k in weight_keys for k in label_keys):
+                raise ValueError("Periodic*Loss with per-point weights: the reference multiplies its [n] pair terms by the "
+                                 "[2n] weight column, which does not broadcast (mse.py:335-336)")
         causal = getattr(loss, "causal", None)
         if causal and batch_size % int(causal["n_chunks"]) != 0:
             raise ValueError(f"CausalMSELoss: batch size {batch_size} is not a multiple of n_chunks "
@@ -108,11 +115,13 @@ class CompiledConstraint:
         if not nets:
             raise NotImplementedError("a constraint that evaluates no network has nothing to train")
         self.fused = FusedConstraint(name, nets, self.low.streams, self.low.program.build(), inputs, aux,
-                                     self.low.loss_keys, want_residual=want_values or bool(self.low.causal))
+                                     self.low.loss_keys, want_residual=want_values or bool(self.low.causal) or bool(self.low.periodic))
         if self.low.param_slots:
             from .equation.pde.base import EqParamStore
 
             self.fused.set_eq_params(EqParamStore.get())
+        if self.low.periodic:
+            self.fused.set_periodic(self.low.periodic)
         if self.low.causal:
             self.fused.set_causal(self.low.causal, int(causal["n_chunks"]), float(causal["tol"]))
         self.train = train

@@ -52,3 +52,40 @@ class InitialConstraint(_GeometricConstraint):
         n = dataloader_cfg["batch_size"] * dataloader_cfg["iters_per_epoch"]
         input = geom.sample_initial_interior(n, random, _crit(criteria), evenly, compute_sdf_derivatives)
         self._setup(output_expr, label_dict, geom, dataloader_cfg, loss, input, weight_dict, name)
+
+
+class PeriodicConstraint(Constraint):
+    """/root/reference/ppsci/constraint/periodic_constraint.py:60-166: boundary points and their images on the opposite
+    side along `periodic_key`, interleaved per iteration so that every batch is [half ; images of that half]; labels are
+    zeros (the Periodic*Loss compares the two halves of each output)."""
+
+    def __init__(self, output_expr: Dict[str, Callable], label_dict: Dict[str, Union[float, Callable]], geom,
+                 periodic_key: str, dataloader_cfg: Dict[str, Any], loss, random: str = "pseudo",
+                 criteria: Optional[Callable] = None, evenly: bool = False,
+                 weight_dict: Optional[Dict[str, Callable]] = None, name: str = "PeriodicBC"):
+        import numpy as np
+
+        from ..utils.misc import DEFAULT_DTYPE
+
+        self.input_keys = geom.dim_keys
+        self.output_keys = tuple(output_expr.keys())
+        self.output_expr = dict(output_expr)
+        bs, iters = dataloader_cfg["batch_size"], dataloader_cfg["iters_per_epoch"]
+        if bs % 2 > 0:
+            raise ValueError(f"batch_size({bs}) should be positive and even when using PeriodicConstraint")
+        if dataloader_cfg.get("shuffle", False):
+            raise ValueError("shuffle should be False when using PeriodicConstraint")
+        half = bs // 2
+        side = geom.sample_boundary(half * iters, random, _crit(criteria), evenly)
+        if "area" in side:
+            side["area"] *= iters
+        space = getattr(geom, "geometry", geom)  # TimeXGeometry: the component indexes the spatial keys
+        image = geom.periodic_point(side, space.dim_keys.index(periodic_key))
+        mixed = {k: np.vstack([part[k][i * half:(i + 1) * half] for i in range(iters) for part in (side, image)])
+                 for k in side}
+        n_rows = next(iter(mixed.values())).shape[0]
+        label = {k: np.full((n_rows, 1), 0, DEFAULT_DTYPE) for k in label_dict}
+        weight = None
+        if weight_dict is not None:
+            _, weight = prepare_label_weight(mixed, label_dict, weight_dict, geom.dim_keys)
+        Constraint.__init__(self, finish_dataset(dataloader_cfg, mixed, label, weight), dataloader_cfg, loss, name)

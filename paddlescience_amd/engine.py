@@ -97,6 +97,10 @@ class FusedConstraint:
         self.causal, self.n_chunks, self.tol = list(rows), n_chunks, tol
         self.chunk_scratch = torch.zeros((len(self.causal), n_chunks), dtype=torch.float32, device=self.U.device)
 
+    def set_periodic(self, rows: Sequence[tuple]) -> None:
+        """Periodic*Loss (loss/periodic.py): rows = (residual row, label aux); batch = [points ; periodic images]."""
+        self.periodic = list(rows)
+
     def forward(self, params: torch.Tensor, train: bool) -> None:
         for nt in self.nets:
             if nt["pre"] is not None:
@@ -113,10 +117,23 @@ class FusedConstraint:
             for j, (row, lab, w, ar, cw) in enumerate(self.causal):
                 hp.causal_weights(self.n_chunks, self.tol, self.resid[row], ax(lab), ax(w), ax(ar),
                                   self.chunk_scratch[j], self.aux[cw])
+        periodic = getattr(self, "periodic", None)
+        if periodic:
+            # first pass: values only; every point's label becomes its partner's value (a constant for the reverse
+            # sweep), so the per-point loss below has the pair loss's gradient and twice its value
+            hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, None, self.loss_partials,
+                        *self._eq_args(False))
+            h = self.n // 2
+            for row, lab in periodic:
+                self.aux[lab][:h].copy_(self.resid[row][h:])
+                self.aux[lab][h:].copy_(self.resid[row][:h])
         hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
                     self.loss_partials, *self._eq_args(train))
 
         hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)
+        if periodic:
+            for row, _ in periodic:
+                self.loss_terms[row:row + 1].mul_(0.5)
 
     def _eq_args(self, train: bool):
         st = getattr(self, "eq_store", None)

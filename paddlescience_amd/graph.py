@@ -321,6 +321,7 @@ class Lowered:
         self.input_names, self.aux_names, self.loss_keys = input_names, aux_names, loss_keys
         self.value_index = value_index  # output name -> program value index
         self.causal: List[tuple] = []
+        self.periodic: List[tuple] = []
         self.param_slots: List[int] = []  # slots of the learnable equation parameters the program reads
         self.nets: List[tuple] = []  # (model, StreamSpec, first U row, input indices) per network of the constraint
 
@@ -479,6 +480,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 val[id(n)] = prog.op(_UNARY_OPS[n.op], val[id(n.args[0])])
 
     loss_keys = []
+    periodic = []  # (residual row, label aux) -- Periodic*Loss: the label row receives the partner half's values
     causal = []  # (residual row, label aux, weight aux, area aux, causal-factor aux) -- CausalMSELoss
     for ls in losses:
         key = ls["key"]
@@ -491,6 +493,8 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             causal.append((len(loss_keys), lab, w, ar, cw))
             prog.n_aux = max(prog.n_aux, ar + 1)
             ar = cw
+        if ls.get("periodic"):
+            periodic.append((len(loss_keys), lab))
         prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0), ls.get("kind", 0))
         loss_keys.append(key)
     for name in extra_outputs:
@@ -499,6 +503,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     value_index = {k: val[id(v)] for k, v in outputs.items()}
     low = Lowered(model, streams, prog, input_names, aux_names, loss_keys, value_index)
     low.causal = causal
+    low.periodic = periodic
     low.param_slots = sorted(param_slots)
     # ---- stream programs of the input transforms: <= MAX_RES output rows per program, rows in (feature, stream) order
     pre = {}

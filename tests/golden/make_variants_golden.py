@@ -181,6 +181,32 @@ def main():
             out[f"{nm}/grad"] = grads_flat(total, ps)
             print(nm, float(total.detach()))
 
+    # ---- Periodic{MSE,L1,L2}Loss (mse.py:269-355, l1.py:123-218, l2.py:118-207): batch = [x = -1 side ; x = +1 side]
+    for lname, cls in (("mse", mse.PeriodicMSELoss), ("l1", l1m.PeriodicL1Loss), ("l2", l2m.PeriodicL2Loss)):
+        for red in ("mean", "sum"):
+            model = MLP(("t", "x"), ("u",), None, (16, 16), "tanh")
+            ps = trainable(model)
+            flat = set_params(ps, rng)
+            h = 19
+            tcol = rng.uniform(0, 1, (h, 1)).astype(np.float32).astype(np.float64)
+            X = np.concatenate([np.concatenate([tcol, np.full((h, 1), -1.0)], 1), np.concatenate([tcol, np.full((h, 1), 1.0)], 1)])
+            data = {"t": torch.tensor(X[:, :1], requires_grad=True), "x": torch.tensor(X[:, 1:], requires_grad=True)}
+            eq = mods["allen_cahn"].AllenCahn(0.05)
+            od = model(data)
+            dd = dict(data)
+            dd.update(od)
+            od["allen_cahn"] = eq.equations["allen_cahn"](dd)
+            clear()
+            lab = {k: torch.zeros(2 * h, 1, dtype=D) for k in ("u", "allen_cahn")}
+            losses = cls(red, weight={"u": 0.7})(od, lab, None)
+            total = losses["allen_cahn"] + losses["u"]
+            nm = f"periodic_{lname}_{red}"
+            out[f"{nm}/X"], out[f"{nm}/params"] = X, flat
+            for k in lab:
+                out[f"{nm}/loss/{k}"] = np.asarray(float(losses[k].detach()))
+            out[f"{nm}/grad"] = grads_flat(total, ps)
+            print(nm, float(total.detach()))
+
     # ---- every function of SYMPY_TO_PADDLE (symbolic.py:79-108) in one residual
     # (the dummy paddle module handed the map placeholders for the functions the shim had not defined)
     for sf, tname in ((sp.asin, "asin"), (sp.acos, "acos"), (sp.atan, "atan"), (sp.atan2, "atan2"), (sp.asinh, "asinh"),

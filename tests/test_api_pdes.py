@@ -619,3 +619,57 @@ def test_unsteady_navier_stokes_and_laplace_3d(tmp_path):
     t3, _, gref3, _ = R.loss_and_grads(o3, [oc3])
     assert s3._compiled["EQ"].fused.losses()["laplace"] == pytest.approx(t3, rel=5e-5)
     assert rel(g3, gref3) < 5e-5
+
+
+def test_periodic_constraint_batches_and_training_step(tmp_path):
+    """PeriodicConstraint (periodic_constraint.py:60-166) on a time x rectangle domain: every batch is [half ; images
+    of that half along the periodic key]; two training iterations (two different batches) against the oracle."""
+    geom = ppsci.geometry.TimeXGeometry(ppsci.geometry.TimeDomain(0.0, 1.0, time_step=0.125),
+                                        ppsci.geometry.Rectangle((-1.0, 0.0), (1.0, 2.0)))
+    model = ppsci.arch.MLP(("t", "x", "y"), ("u",), 2, 20, "tanh")
+    net = T.make_net(3, [20, 20], 1, bias_scale=0.05)
+    set_model_weights(model, net)
+    x, y, t = sp.symbols("x y t")
+    u = sp.Function("u")(t, x, y)
+    exprs = {"u": lambda out: out["u"], "u_x": u.diff(x)}
+    np.random.seed(7)
+    bs, iters = 16, 2
+    cst = ppsci.constraint.PeriodicConstraint(
+        exprs, {"u": 0, "u_x": 0}, geom, "x", {"dataset": "NamedArrayDataset", "batch_size": bs, "iters_per_epoch": iters,
+                                        "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}},
+        ppsci.loss.PeriodicMSELoss("mean", weight={"u_x": 0.5}), criteria=lambda t, x, y: np.isclose(x, -1.0), name="PBC")
+    data = cst.data_loader.dataset.input
+    assert data["x"].shape == (bs * iters, 1)
+    h = bs // 2
+    for i in range(iters):
+        lo, hi = data["x"][i * bs:i * bs + h], data["x"][i * bs + h:(i + 1) * bs]
+        assert np.all(lo == -1.0) and np.all(hi == 1.0)
+        for k in ("t", "y"):
+            assert np.array_equal(data[k][i * bs:i * bs + h], data[k][i * bs + h:(i + 1) * bs])
+    assert np.all(data["normal_x"][:h] == -1.0) and np.all(data["normal_x"][h:bs] == 1.0)
+    with pytest.raises(ValueError, match="even"):
+        ppsci.constraint.PeriodicConstraint(exprs, {"u": 0}, geom, "x", {"dataset": "IterableNamedArrayDataset", "batch_size": 7,
+                                                                          "iters_per_epoch": 1}, ppsci.loss.PeriodicMSELoss())
+
+    opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PBC": cst}, str(tmp_path), opt, epochs=1, iters_per_epoch=iters, log_freq=1)
+    solver.train()
+    omodel = R.MLP(("t", "x", "y"), ("u",), net.astype(np.float32).astype(np.float64))
+    oexprs = {"u": lambda d: d["u"], "u_x": R.lambdify(u.diff(x), omodel)}
+    p = np.concatenate([q.detach().numpy().ravel() for q in omodel.parameters()])
+    adam = R.Adam(p.size, 1e-3)
+    for i in range(iters):
+        off = 0
+        with torch.no_grad():
+            for q in omodel.parameters():
+                q.copy_(torch.tensor(p[off:off + q.numel()].reshape(q.shape)))
+                off += q.numel()
+        oc = dict(name="PBC", input={k: data[k][i * bs:(i + 1) * bs].astype(np.float64) for k in ("t", "x", "y")}, exprs=oexprs,
+                  label={k: np.zeros((bs, 1)) for k in ("u", "u_x")}, reduction="mean", loss_kind="periodic_mse",
+                  loss_weight={"u_x": 0.5})
+        total, losses, g, _ = R.loss_and_grads(omodel, [oc])
+        p = adam.step(p, g)
+    got = solver._compiled["PBC"].fused.losses()
+    for k in ("u", "u_x"):
+        assert got[k] == pytest.approx(losses[k], rel=5e-4), k
+    assert rel(model.flat_params.cpu().numpy()[:p.size], p) < 1e-5
