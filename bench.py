@@ -1,13 +1,24 @@
-"""bench.py -- collocation-points/sec of the PINN hot path (PDE residual + gradient + Adam).
+"""bench.py -- collocation-points/sec of the PINN hot path (PDE residual + gradient + Adam) on MI355X.
 
-Workload (BASELINE.json configs[1]): Allen-Cahn 1D+t, MLP 2->64x4->1 tanh, 100 000 collocation
-points per GPU, residual u_t - eps^2 u_xx + 5u^3 - 5u (eps = 0.01), MSE-mean, Adam.  Synthetic
-points `default_rng(42+rank).uniform([0,-1],[1,1])`, Xavier-uniform weights `default_rng(1234)`
-(SURVEY.md 8d).  A "step" = taylor_fwd + epilogue + taylor_bwd + gradient reduce (+ RCCL all-reduce
-of the flat gradient when N > 1) + fused Adam, inputs resident in HBM.
+PRIMARY LINE (`metric`, `value`, `roofline`, `cpu_baseline`): BASELINE.json configs[1] -- Allen-Cahn 1D+t, MLP
+2->64x4->1 tanh, 100 000 collocation points per GPU, residual u_t - eps^2 u_xx + 5u^3 - 5u (eps = 0.01), MSE-mean,
+Adam.  Synthetic points `default_rng(42+rank).uniform([0,-1],[1,1])`, Xavier-uniform weights `default_rng(1234)`
+(SURVEY.md 8d).  A "step" = taylor_fwd + epilogue + taylor_bwd + gradient reduce (+ RCCL all-reduce of the flat
+gradient when N > 1) + fused Adam, inputs resident in HBM.  One process per GPU
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`); per-GPU work is fixed => weak scaling.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`);
-per-GPU work is fixed => weak scaling.  Rank 0 prints ONE JSON line.
+The same JSON line also carries
+  * `parity`     -- the TIMED net (initial weights) on the first 2 048 points of the timed batch against
+                    tests/golden/bench_nets.npz, i.e. values produced by running the reference's own Python in fp64
+                    (tests/golden/make_bench_nets_golden.py): residual / gradient rel-L2, loss rel;
+  * `secondary`  -- (N = 1 only) the other BASELINE configs, each with points/s, its dominant kernel's roofline
+                    fraction and its own parity: cfg 1 Laplace2D 3x20 10 k points (+ its cpu_baseline), cfg 3 shard
+                    NavierStokes 5x128 125 k points, cfg 4 TFNO-2D 64x64 batch 16, cfg 5 SPINN Helmholtz3D 128^3;
+  * `strong_scaling` -- BASELINE configs[2] as the north star states it: 1 000 000 NavierStokes points sharded
+                    rank-strided over the N ranks (N = 1: all of them on one GPU), one SUM all-reduce of the flat
+                    gradient (66 819 floats = 267 KB) per step; `value` = 1e6 / step time, "scaling": "strong".
+Rank 0 prints ONE JSON line.  The oracle (oracle/) is used by the `cpu_baseline` legs and, as the CHECKER of the
+cfg 4 / cfg 5 parity entries, never inside a timed region.
 """
 from __future__ import annotations
 
@@ -26,20 +37,71 @@ if ROOT not in sys.path:
 
 HIDDEN, WIDTH, N_PER_GPU = 4, 64, 100_000
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (f32 in) peak == fp32 vector peak
+PEAK_HBM_TBPS = 8.0       # MI355X_MICROARCH.md: HBM3E
 EPS = 0.01
+N_FIX = 2048              # points of the reference-run fixtures (tests/golden/bench_nets.npz)
+NS_TOTAL = 1_000_000      # BASELINE configs[2]
+CPU_THREADS = 8  # measured on the GPU box (tools/cpu_threads.py): 8 threads is the fastest setting for this
+                 # graph of small ops; 32+ threads are slower, 256 threads 100x slower
 
 
-def build_constraint(dev, rank):
-    from oracle import taylor_np as T  # only for the seeded weight draw shared with the CPU baseline
+def bench_weights(d_in, hidden, d_out, seed=1234):
+    """W ~ U(+-sqrt(6/(in+out))), b = 0, default_rng(seed), layer by layer, W then b; flat fp32
+    vector in `parameters()` order.  (Same draw as oracle.taylor_np.make_net / tests/golden/make_bench_nets_golden.)"""
+    rng = np.random.default_rng(seed)
+    sizes = [d_in] + list(hidden) + [d_out]
+    out = []
+    for fi, fo in zip(sizes[:-1], sizes[1:]):
+        lim = np.sqrt(6.0 / (fi + fo))
+        out.append(rng.uniform(-lim, lim, size=(fi, fo)).astype(np.float32).ravel())
+        out.append(np.zeros(fo, np.float32))
+    return np.concatenate(out)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "bench_nets.npz"))
+
+
+def time_wall(fn, steps, warmup, barrier=None):
+    sync = barrier or torch.cuda.synchronize
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def time_events(fn, reps=20):
+    """Average duration of `fn`'s launches with HIP events on the launch stream (torch's current stream)."""
+    fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])) * 1e-3
+
+
+def main_kernel_only(on):
+    from paddlescience_amd import _lib
+
+    _lib.lib().ppsci_set_bwd_main_only(1 if on else 0)
+
+
+# ------------------------------------------------------------------------------------------ cfg 2 (primary)
+def allen_cahn_program(n_scale):
     from paddlescience_amd import _lib as L
     from paddlescience_amd import hotpath as hp
-    from paddlescience_amd.engine import Engine, FusedConstraint
 
-    net = T.make_net(2, [WIDTH] * HIDDEN, 1, seed=1234)
-    lay = hp.NetLayout(2, HIDDEN, WIDTH, 1, "tanh")
-    X = np.random.default_rng(42 + rank).uniform([0, -1], [1, 1], (N_PER_GPU, 2)).astype(np.float32)
-    xs = [torch.tensor(X[:, j].copy(), device=dev) for j in range(2)]  # (t, x)
-    streams = hp.StreamSpec([[0.0, 1.0], [1.0, 0.0]], 1)  # streams: u, u_x, u_t, u_xx
     pr = hp.Program(4, 2)
     u, ut, uxx = pr.ld_u(0), pr.ld_u(2), pr.ld_u(3)
     five = pr.const(5.0)
@@ -47,24 +109,45 @@ def build_constraint(dev, rank):
               pr.op(L.OP_ADD, pr.op(L.OP_SUB, ut, pr.op(L.OP_MUL, pr.const(EPS**2), uxx)),
                     pr.op(L.OP_MUL, pr.op(L.OP_MUL, pr.op(L.OP_MUL, five, u), u), u)),
               pr.op(L.OP_MUL, five, u))
-    return net, lay, X, xs, streams, pr, r
+    pr.residual(r, scale=1.0 / n_scale)
+    return pr.build()
 
 
-CPU_THREADS = 8  # measured on the GPU box (tools/cpu_threads.py): 8 threads is the fastest setting for this
-                 # graph of small ops; 32+ threads are slower, 256 threads 100x slower
+def allen_cahn_constraint(dev, X, n_scale, want_residual=False):
+    from paddlescience_amd import hotpath as hp
+    from paddlescience_amd.engine import FusedConstraint
+
+    lay = hp.NetLayout(2, HIDDEN, WIDTH, 1, "tanh")
+    xs = [torch.tensor(X[:, j].copy(), device=dev) for j in range(2)]  # (t, x)
+    streams = hp.StreamSpec([[0.0, 1.0], [1.0, 0.0]], 1)  # streams: u, u_x, u_t, u_xx
+    return lay, FusedConstraint("EQ", lay, streams, allen_cahn_program(n_scale), xs, [], ["allen_cahn"],
+                                want_residual=want_residual)
 
 
-def cpu_baseline(net, X, steps=10):
-    """The oracle's restatement of the reference algorithm (reverse-over-reverse autodiff, fp32,
-    torch-CPU), timed on the same batch: residual + MSE + backward + Adam."""
+def parity_allen_cahn(dev, flat, X):
+    """The timed net at its initial weights on the first N_FIX points of the timed batch vs the reference-run values."""
+    from paddlescience_amd.engine import Engine
+
+    G = gold()
+    assert np.array_equal(X[:N_FIX], G["allen_cahn_4x64/X"]), "bench batch no longer starts with the fixture's points"
+    lay, cst = allen_cahn_constraint(dev, X[:N_FIX], N_FIX, want_residual=True)
+    eng = Engine(lay, torch.tensor(flat, device=dev))
+    eng.forward_backward([cst])
+    torch.cuda.synchronize()
+    return {"reference": "tests/golden/bench_nets.npz (reference's own Python, fp64, torch-backed paddle shim)",
+            "points": N_FIX,
+            "residual_rel_l2": rel(cst.resid[0].cpu().numpy(), G["allen_cahn_4x64/res/allen_cahn"]),
+            "grad_rel_l2": rel(eng.grad.cpu().numpy(), G["allen_cahn_4x64/grad"]),
+            "loss_rel": abs(cst.losses()["allen_cahn"] / float(G["allen_cahn_4x64/total"]) - 1.0)}
+
+
+def cpu_steps(model, cst, n_params, steps, threads):
+    """Median wall time of `steps` full training steps (residual + MSE + backward + Adam) of the oracle's
+    restatement of the reference algorithm (reverse-over-reverse autodiff, fp32, torch-CPU)."""
     from oracle import ref_torch as R
 
-    torch.set_num_threads(min(CPU_THREADS, os.cpu_count()))
-    model = R.MLP(("t", "x"), ("u",), net, dtype=torch.float32)
-    n = X.shape[0]
-    cst = dict(name="EQ", input={"t": X[:, :1], "x": X[:, 1:]}, exprs={"allen_cahn": R.allen_cahn_fn(EPS)},
-               label={"allen_cahn": np.zeros((n, 1), np.float32)}, reduction="mean")
-    opt = R.Adam(sum(p.numel() for p in model.parameters()), 1e-3, dtype=np.float32)
+    torch.set_num_threads(threads)
+    opt = R.Adam(n_params, 1e-3, dtype=np.float32)
     flat = np.concatenate([p.detach().numpy().ravel() for p in model.parameters()])
     times = []
     for i in range(steps + 1):
@@ -79,15 +162,302 @@ def cpu_baseline(net, X, steps=10):
                 off += k
         if i > 0:
             times.append(time.perf_counter() - t0)
-    return n / float(np.median(times)), len(times)
+    return float(np.median(times))
 
 
+def oracle_net(d_in, hidden, d_out, flat):
+    from oracle import taylor_np as T
+
+    net = T.make_net(d_in, hidden, d_out)
+    off = 0
+    for i in range(len(net.weights)):
+        n = net.weights[i].size
+        net.weights[i] = flat[off:off + n].reshape(net.weights[i].shape).astype(np.float64)
+        off += n
+        n = net.biases[i].size
+        net.biases[i] = flat[off:off + n].astype(np.float64)
+        off += n
+    return net
+
+
+def cpu_baseline(kind, flat, X, steps=20):
+    """`kind` in {"allen_cahn", "laplace"}: the same batch the GPU was timed on; best-thread and 1-thread figures."""
+    from oracle import ref_torch as R
+
+    n = X.shape[0]
+    if kind == "allen_cahn":
+        net = oracle_net(2, [WIDTH] * HIDDEN, 1, flat)
+        model = R.MLP(("t", "x"), ("u",), net, dtype=torch.float32)
+        cst = dict(name="EQ", input={"t": X[:, :1], "x": X[:, 1:]}, exprs={"allen_cahn": R.allen_cahn_fn(EPS)},
+                   label={"allen_cahn": np.zeros((n, 1), np.float32)}, reduction="mean")
+    else:
+        net = oracle_net(2, [20] * 3, 1, flat)
+        model = R.MLP(("x", "y"), ("u",), net, dtype=torch.float32)
+        cst = dict(name="EQ", input={"x": X[:, :1], "y": X[:, 1:]},
+                   exprs={k: R.lambdify(e, model, dtype=torch.float32) for k, e in R.laplace_exprs(2).items()},
+                   label={"laplace": np.zeros((n, 1), np.float32)}, reduction="sum")
+    thr = min(CPU_THREADS, os.cpu_count())
+    t_best = cpu_steps(model, cst, flat.size, steps, thr)
+    t_one = cpu_steps(model, cst, flat.size, steps, 1)
+    return {"value": n / t_best, "unit": "points/s", "cores": thr, "kind": "port",
+            "value_1_thread": n / t_one,
+            "sample": f"the same {n}-point batch, median of {steps} full training steps (residual + MSE + backward + "
+                      "Adam) of the torch-CPU fp32 reverse-over-reverse restatement of the reference algorithm "
+                      f"(oracle/ref_torch.py); {thr} threads (the fastest setting) and 1 thread of {os.cpu_count()} "
+                      f"host cores; torch {torch.__version__}"}
+
+
+# ------------------------------------------------------------------------------------------ API-level configs
+def api_pinn(tag, inputs, outputs, hidden, eq, X, reduction, weight, tmp, batch=None):
+    import ppsci
+
+    n = X.shape[0]
+    model = ppsci.arch.MLP(inputs, outputs, len(hidden), hidden[0], "tanh")
+    flat = bench_weights(len(inputs), hidden, len(outputs))
+    model.flat_params.copy_(torch.tensor(flat).to(model.flat_params.device))
+    keys = list(eq.equations.keys())
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {k: X[:, j:j + 1] for j, k in enumerate(inputs)},
+                       "label": {k: np.zeros((n, 1), np.float32) for k in keys},
+                       "weight": None if weight is None else {k: np.full((n, 1), weight, np.float32) for k in keys}},
+           "batch_size": batch or n, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    pde = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss(reduction), eq.equations, name="EQ")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"EQ": pde}, os.path.join(tmp, tag), opt, epochs=1, iters_per_epoch=1)
+    return solver, opt, solver._compiled["EQ"], flat
+
+
+def api_parity(name, inputs, outputs, hidden, make_eq, reduction, weight, tmp):
+    """The config's net (same seeded weights) on the fixture's N_FIX points through the ppsci API vs reference-run values."""
+    G = gold()
+    X = G[f"{name}/X"]
+    eq = make_eq()
+    solver, _, cc, _ = api_pinn("par_" + name, inputs, outputs, hidden, eq, X, reduction, weight, tmp)
+    solver.engine.forward_backward([cc.fused])
+    losses = cc.fused.losses()
+    res = solver.predict({k: X[:, j:j + 1] for j, k in enumerate(inputs)}, eq.equations, batch_size=None, return_numpy=True)
+    keys = list(eq.equations.keys())
+    return {"points": N_FIX, "reference": "tests/golden/bench_nets.npz",
+            "residual_rel_l2": max(rel(res[k][:, 0], G[f"{name}/res/{k}"]) for k in keys),
+            "grad_rel_l2": rel(solver.engine.grad.cpu().numpy(), G[f"{name}/grad"]),
+            "loss_rel": max(abs(losses[k] / float(G[f"{name}/loss/{k}"]) - 1.0) for k in keys)}
+
+
+def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
+    def step():
+        solver.engine.forward_backward([cc.fused])
+        opt.step(solver.engine.grad)
+
+    t = time_wall(step, steps, warmup)
+    main_kernel_only(True)
+    t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))
+    main_kernel_only(False)
+    t_fwd = time_events(lambda: cc.fused.forward(solver.engine.params, True))
+    ach = 4.0 * p_mat * S * n / t_bwd / 1e12
+    return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
+            "matrix_tflops_step": 6.0 * p_mat * S * n / t / 1e12,
+            "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": t_bwd * 1e3,
+                         "fwd_plus_epilogue_ms": t_fwd * 1e3}}
+
+
+def secondary_laplace(tmp, steps, warmup, with_cpu):
+    import ppsci
+
+    X = np.random.default_rng(42).random((10_000, 2), dtype=np.float32)
+    solver, opt, cc, flat = api_pinn("lap", ("x", "y"), ("u",), [20] * 3, ppsci.equation.Laplace(2), X, "sum", None, tmp)
+    e = pinn_entry("cfg1 Laplace2D, MLP 2->20x3->1 tanh, 10 000 interior points, u_xx+u_yy, MSE-sum, Adam "
+                   "(BASELINE.json configs[0]); launch/latency-bound: 625 tiles on 1 024 wave slots",
+                   solver, opt, cc, 10_000, 2 * 20 + 2 * 400 + 20, 5, steps, warmup, "taylor_bwd_kernel<2, 2, 2, 0>")
+    e["parity"] = api_parity("laplace2d_3x20", ("x", "y"), ("u",), [20] * 3, lambda: ppsci.equation.Laplace(2), "sum",
+                             None, tmp)
+    if with_cpu:
+        e["cpu_baseline"] = cpu_baseline("laplace", flat, X)
+        e["speedup_vs_cpu_best_thread"] = e["value"] / e["cpu_baseline"]["value"]
+    return e
+
+
+def ns_setup(tmp, X, tag, batch=None):
+    import ppsci
+
+    eq = ppsci.equation.NavierStokes(0.01, 1.0, 2, False)
+    return api_pinn(tag, ("x", "y"), ("u", "v", "p"), [128] * 5, eq, X, "sum", 1e-4, tmp, batch)
+
+
+NS_PMAT = 2 * 128 + 4 * 128 * 128 + 128 * 3
+
+
+def secondary_ns(tmp, steps, warmup):
+    import ppsci
+
+    X = np.random.default_rng(42).uniform(-0.05, 0.05, (NS_TOTAL, 2)).astype(np.float32)[0::8]  # rank 0 of 8, strided
+    solver, opt, cc, _ = ns_setup(tmp, X, "ns")
+    e = pinn_entry("cfg3 shard: LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 125 000 points (rank 0 of 8 of the "
+                   "1 M-point cloud), continuity + momentum_x + momentum_y, weights 1e-4, MSE-sum, Adam",
+                   solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wide_kernel<8, 4, 2, 2, 0>")
+    e["parity"] = api_parity("ns2d_5x128", ("x", "y"), ("u", "v", "p"), [128] * 5,
+                             lambda: ppsci.equation.NavierStokes(0.01, 1.0, 2, False), "sum", 1e-4, tmp)
+    return e
+
+
+def strong_ns(tmp, world, rank, steps, warmup, barrier):
+    """BASELINE configs[2]: 1 M NavierStokes points, rank-strided shards, one SUM all-reduce of the flat gradient."""
+    # the whole cloud goes into the dataset; the (Distributed)BatchSampler hands this rank its strided shard
+    # X[rank::world] (/root/reference/ppsci/data/__init__.py:76-99), bound once and resident in HBM
+    X = np.random.default_rng(42).uniform(-0.05, 0.05, (NS_TOTAL, 2)).astype(np.float32)
+    n_local = NS_TOTAL // world
+    solver, opt, cc, _ = ns_setup(tmp, X, f"ns_strong_r{rank}", n_local)
+    eng = solver.engine
+    assert eng.world == world and cc.fused.n == n_local, (eng.world, world, cc.fused.n)
+
+    def step():
+        eng.forward_backward([cc.fused])
+        eng.allreduce()
+        opt.step(eng.grad)
+
+    t = time_wall(step, steps, warmup, barrier)
+    tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    t = float(tt[0])
+    return {"workload": "LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 1 000 000 collocation points sharded "
+                        "rank-strided over the ranks, SUM all-reduce of the flat gradient, Adam (BASELINE.json configs[2])",
+            "value": NS_TOTAL / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps, "n_gpus": world,
+            "scaling": "strong", "points_total": NS_TOTAL, "points_per_rank": n_local,
+            "allreduce_bytes": int(eng.grad.numel()) * 4, "comm_world_size": eng.world,
+            "matrix_tflops_per_gpu": 6.0 * NS_PMAT * 5 * n_local / t / 1e12}
+
+
+def secondary_tfno(steps, warmup, B=16, H=64, W=64):
+    """BASELINE configs[3] / SURVEY 8(d): TFNO2dNet in 3, hidden 32, lifting 256, projection 64, 4 layers, n_modes
+    (12, 12), group_norm, fft_norm forward; one training step = forward + MSE + backward + fused Adam."""
+    import ppsci
+    from paddlescience_amd.arch import fno
+
+    torch.manual_seed(0)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
+                                 lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm")
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, H, W)).astype(np.float32)).cuda()
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+
+    # parity (checker: the oracle's fp64 restatement of fno_block.py / tfnonet.py, pinned by tests/golden/fno.npz)
+    from oracle import ref_torch as R
+
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    xs, ys = x[:2].cpu().double(), y[:2].cpu().double()
+    yo = R.fno_forward(xs, P, 4, (12, 12), "group_norm")
+    lo = ((yo - ys) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    model.flat_grad.zero_()
+    yh = model.forward_tensor(x[:2])
+    lh = ((yh - y[:2]) ** 2).mean()
+    lh.backward()
+    gh = {n: p.grad.detach().cpu().numpy() for n, p in torch.nn.Module.named_parameters(model)}
+    parity = {"checker": "oracle/ref_torch.fno_forward fp64 (pinned by reference-run tests/golden/fno.npz), batch 2 of "
+                         "the timed batch, the timed model's weights",
+              "output_rel_l2": rel(yh.detach().cpu().numpy(), yo.detach().numpy()),
+              "grad_rel_l2": max(rel(gh[n], go[n].numpy()) for n in names),
+              "loss_rel": abs(float(lh.detach()) / float(lo.detach()) - 1.0)}
+
+    from paddlescience_amd.operator_engine import OperatorConstraint, OperatorEngine  # noqa: F401
+
+    def step():
+        model.flat_grad.zero_()
+        loss = ((model.forward_tensor(x) - y) ** 2).mean()
+        loss.backward()
+        opt.step(model.flat_grad)
+
+    t = time_wall(step, steps, warmup)
+    layer = fno.SpectralConv2d(32, 32, (12, 12), fft_norm="forward").cuda()
+    x_ft = torch.fft.rfftn(torch.randn(B, 32, H, W, device="cuda"), norm="forward", dim=(-2, -1))
+    t_k = time_events(lambda: fno.spectral_contract(x_ft, layer.weight_real, layer.weight_imag))
+    byts = 4.0 * (2 * 32 * 32 * 84 + 2 * 2 * B * 32 * 84)  # weights re+im, x_ft slice in, out slice out
+    ach = byts / t_k / 1e12
+    return {"config": "cfg4 TFNO-2D Darcy shape: 64x64 grid, batch 16, in 3, hidden 32, lifting 256, projection 64, "
+                      "4 layers, n_modes (12,12), group_norm; forward + MSE + backward + Adam",
+            "value": B * H * W / t, "unit": "grid-points/s", "samples_per_s": B / t, "ms_per_step": t * 1e3, "steps": steps,
+            "roofline": {"bound": "hbm", "kernel": "spectral_contract_kernel (84 modes x [16 x 64]x[64 x 64] real GEMM on "
+                                                   "v_mfma_f32_16x16x4_f32)", "achieved": ach, "peak": PEAK_HBM_TBPS,
+                         "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS, "kernel_ms": t_k * 1e3,
+                         "note": "1.4 MB of operands, 11 MFLOP: launch/latency-bound at this size"},
+            "parity": parity}
+
+
+def secondary_spinn(tmp, steps, warmup, nc=128):
+    import ppsci
+
+    np.random.seed(111)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), 32, 4, 64, "tanh")
+    eq = ppsci.equation.Helmholtz(3, 1.0)
+    eq.model = model
+    rng = np.random.default_rng(42)
+
+    def run(n, timed):
+        xs = [rng.uniform(-1, 1, (n, 1)).astype(np.float32) for _ in range(3)]
+        uc = rng.standard_normal((n, n, n, 1)).astype(np.float32)
+        data = {"x": xs[0], "y": xs[1], "z": xs[2], "uc": uc}
+        lab = {"helmholtz": uc}
+        pde = ppsci.constraint.SupervisedConstraint(
+            {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: data, "label": lambda d: lab}},
+            output_expr=eq.equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+        opt = ppsci.optimizer.Adam(1e-3)(model)
+        solver = ppsci.solver.Solver(model, {"PDE": pde}, os.path.join(tmp, f"spinn{n}"), opt, epochs=1, iters_per_epoch=1)
+        cc = solver._compiled["PDE"]
+        cc.bind(data, lab)
+        return solver, opt, cc, xs, uc
+
+    # parity on a 24^3 grid (checker: oracle fp64 restatement of spinn.py / helmholtz.py, pinned by tests/golden/spinn.npz)
+    from oracle import ref_torch as R
+
+    solver, opt, cc, xs, uc = run(24, False)
+    solver.engine.forward_backward([cc])
+    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, np.float64) for k, v in model.state_dict().items()}
+    nets = []
+    for b in range(3):
+        P = {k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"branch_nets.{b}.")}
+        nl = sum(1 for k in P if k.startswith("linears.") and k.endswith(".weight"))
+        nets.append(R.ModifiedMLP1(dict(wu=P["embed_u.0.weight"], bu=P["embed_u.0.bias"], wv=P["embed_v.0.weight"],
+                                        bv=P["embed_v.0.bias"], w=[P[f"linears.{l}.weight"] for l in range(nl)],
+                                        b=[P[f"linears.{l}.bias"] for l in range(nl)], wl=P["last_fc.weight"],
+                                        bl=P["last_fc.bias"]), "tanh"))
+    xt = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in xs]
+    uo, ro = R.spinn_helmholtz(nets, xt, 1.0)
+    lo = float(((ro - torch.tensor(uc[..., 0].astype(np.float64))) ** 2).mean().detach())
+    pred = solver.predict({"x": xs[0], "y": xs[1], "z": xs[2]}, batch_size=None, return_numpy=True)["u"]
+    parity = {"checker": "oracle/ref_torch.spinn_helmholtz fp64 (pinned by reference-run tests/golden/spinn.npz), 24^3 "
+                         "grid, the timed model's weights",
+              "u_rel_l2": rel(pred[..., 0], uo.detach().numpy()), "loss_rel": abs(cc.loss() / lo - 1.0)}
+
+    solver, opt, cc, xs, uc = run(nc, True)
+
+    def step():
+        solver.engine.forward_backward([cc])
+        opt.step(solver.engine.grad)
+
+    t = time_wall(step, steps, warmup)
+    t_g = time_events(lambda: cc.forward(True))
+    pts = nc ** 3
+    ach = pts * 4 / t_g / 1e12
+    return {"config": f"cfg5 SPINN Helmholtz3D: 3 x ModifiedMLP 1->64x4->32 tanh, {nc}^3 tensor-product grid, "
+                      "k^2 u + u_xx + u_yy + u_zz - f, MSE-mean, Adam",
+            "value": pts / t, "unit": "grid-points/s", "ms_per_step": t * 1e3, "steps": steps,
+            "roofline": {"bound": "hbm", "kernel": "3 x modmlp_fwd + spinn_grid_fwd_kernel (label read 4 B/grid point; the "
+                                                   "grid itself is never materialised)", "achieved": ach,
+                         "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS, "kernel_ms": t_g * 1e3,
+                         "note": "8.4 MB algorithmic read per step: latency-bound at this size"},
+            "parity": parity}
+
+
+# ------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg 1/3/4/5 entries (N = 1 only anyway)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 1 M-point NavierStokes strong-scaling entry")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,22 +467,24 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         torch.distributed.init_process_group("nccl", device_id=dev)
+        assert torch.distributed.get_world_size() == world == args.gpus, "one RCCL rank per GPU"
 
     from paddlescience_amd import hotpath as hp
-    from paddlescience_amd.engine import Engine, FusedConstraint
-    from oracle import taylor_np as T
-
-    net, lay, X, xs, streams, pr, r = build_constraint(dev, rank)
-    # MSE-mean over the GLOBAL batch (SURVEY.md 8e): the all-reduce is then a pure SUM
-    pr.residual(r, scale=1.0 / (N_PER_GPU * world))
-    cst = FusedConstraint("EQ", lay, streams, pr.build(), xs, [], ["allen_cahn"])
-    params = torch.tensor(T.flat_params(net), dtype=torch.float32, device=dev)
-    eng = Engine(lay, params)
+    from paddlescience_amd.engine import Engine
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    flat = bench_weights(2, [WIDTH] * HIDDEN, 1)
+    X = np.random.default_rng(42 + rank).uniform([0, -1], [1, 1], (N_PER_GPU, 2)).astype(np.float32)
+    parity = parity_allen_cahn(dev, flat, X) if rank == 0 else None
+    # MSE-mean over the GLOBAL batch (SURVEY.md 8e): the all-reduce is then a pure SUM
+    lay, cst = allen_cahn_constraint(dev, X, N_PER_GPU * world)
+    params = torch.tensor(flat, device=dev)
+    eng = Engine(lay, params)
+    assert eng.world == world
 
     for _ in range(args.warmup):
         eng.train_step([cst], 1e-3)
@@ -129,43 +501,45 @@ def main():
     loss = cst.losses()["allen_cahn"]
 
     # per-kernel timing of the dominant kernel (reverse sweep) with HIP events on the launch stream
-    def time_kernel(fn, reps=20):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        ev[0].record()
-        for i in range(reps):
-            fn()
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])) * 1e-3
-
-    from paddlescience_amd import _lib
-
-    t_fwd = time_kernel(lambda: hp.taylor_fwd(cst.desc, params, cst.inputs, cst.U, cst.stash))
-    _lib.lib().ppsci_set_bwd_main_only(1)  # time the dominant kernel alone (not its two small reduce kernels)
-    t_bwd = time_kernel(lambda: cst.backward(params))
-    _lib.lib().ppsci_set_bwd_main_only(0)
+    t_fwd = time_events(lambda: hp.taylor_fwd(cst.desc, params, cst.inputs, cst.U, cst.stash))
+    main_kernel_only(True)  # the dominant kernel alone (not the small reduction kernels behind it)
+    t_bwd = time_events(lambda: cst.backward(params))
+    main_kernel_only(False)
     # SURVEY.md 8(d) "R": residual evaluation only (forward streams + epilogue, no stash, no adjoints)
-    t_res = time_kernel(lambda: cst.forward(params, False))
+    t_res = time_events(lambda: cst.forward(params, False))
     p_mat = 2 * WIDTH + (HIDDEN - 1) * WIDTH * WIDTH + WIDTH  # matrix weights (P = 12 480)
-    S = streams.S
+    S = cst.streams.S
     flops_bwd = 4.0 * p_mat * S * N_PER_GPU   # reverse sweep: 2 GEMMs per layer  (F_T - F_R)
     flops_fwd = 2.0 * p_mat * S * N_PER_GPU   # F_R
     ach = flops_bwd / t_bwd / 1e12
 
-    # HBM traffic of the dominant kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KiB) collected by
-    # tools/profile_bench.sh in separate rocprofv3 --pmc passes of this same command and condensed by
-    # tools/summarize_profile.py into profiles/*_pmc_summary.json (a live bench run cannot read PMCs itself)
-    traffic = None
+    # HBM traffic of the dominant kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KiB) can only be read by
+    # rocprofv3 around the process, not from inside it: tools/profile_bench.sh collects them in separate --pmc passes of
+    # THIS command and tools/summarize_profile.py condenses them into profiles/*_bench_pmc_summary.json; the newest one
+    # is quoted here together with its file name (`traffic_source`), it is not measured by this run
+    traffic, traffic_src = None, None
     try:
         import glob
 
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_summary.json")))
         if files:
             for k, v in json.load(open(files[-1])).items():
-                if k.startswith("void taylor_bwd_kernel<4, 2, 1, 0"):
-                    traffic = v.get("hbm_bytes_per_launch")
+                if "taylor_bwd" in k and "<4, 2, 1, 0" in k:
+                    traffic, traffic_src = v.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
     except Exception:  # noqa: BLE001
         traffic = None
+
+    strong = None
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="ppsci_bench_")
+    if not args.no_strong:
+        try:
+            strong = strong_ns(tmp, world, rank, max(5, args.steps // 5), max(2, args.warmup // 3), barrier)
+        except Exception as e:  # noqa: BLE001
+            if world > 1:  # the other ranks are inside collectives: fail the job rather than hang it
+                raise
+            strong = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         out = {
@@ -187,16 +561,25 @@ def main():
                        "residual_only_points_per_s_per_gpu": N_PER_GPU / t_res},
             "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0>", "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "kernel_ms": t_bwd * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": t_bwd * 1e3,
                          "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12},
+            "parity": parity,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
-            v, k = cpu_baseline(net, X)
-            out["cpu_baseline"] = {"value": v, "unit": "points/s", "cores": min(CPU_THREADS, os.cpu_count()),
-                                   "kind": "port",
-                                   "sample": f"same 100k-point batch, median of {k} full training steps of the "
-                                             "torch-CPU fp32 reverse-over-reverse restatement (oracle/ref_torch.py), "
-                                             f"{min(CPU_THREADS, os.cpu_count())} threads of {os.cpu_count()} host cores"}
+            out["cpu_baseline"] = cpu_baseline("allen_cahn", flat, X)
+            out["speedup_vs_cpu_best_thread"] = out["value"] / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_secondary:
+            k, w = max(10, args.steps // 2), max(3, args.warmup // 2)
+            sec = []
+            for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),
+                       lambda: secondary_ns(tmp, k, w), lambda: secondary_tfno(k, w), lambda: secondary_spinn(tmp, k, w)):
+                try:
+                    sec.append(fn())
+                except Exception as e:  # noqa: BLE001 -- a secondary entry must not cost the primary line
+                    sec.append({"error": f"{type(e).__name__}: {e}"[:300]})
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

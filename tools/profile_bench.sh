@@ -4,7 +4,7 @@ TAG=${1:-r01}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python /root/repo/bench.py --steps 50 --warmup 10 --no-cpu-baseline"
+CMD="python /root/repo/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-secondary --no-strong"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o ac -- $CMD > $OUT/trace.log 2>&1
 # counters in their own runs (no tracing domains together with --pmc)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o ac -- $CMD > $OUT/pmc_fetch.log 2>&1
