@@ -149,6 +149,10 @@ void ppsci_set_bwd_main_only(int on);
  * the waves of a workgroup share one 16-point tile.  Default 8 (width > 64); 16 keeps width <= 128 on the
  * single-wave kernels; width > 128 always uses the wide kernels. */
 void ppsci_set_wide_min_nb(int nb);
+/* Testing knob: 1 (default) lets ppsci_taylor_bwd accumulate the hidden-weight gradient per WORKGROUP in LDS when the
+ * net allows it (padded width <= 64, fragments and accumulators fit LDS); 0 forces the per-tile streaming path that
+ * wider / deeper nets use, so that both are covered by the same tests. */
+void ppsci_set_bwd_accum(int on);
 /* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
 int ppsci_is_device_build(void);
 

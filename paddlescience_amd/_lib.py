@@ -75,6 +75,7 @@ _SYMBOLS = {
     "ppsci_set_max_grid": (None, [C.c_int]),
     "ppsci_set_bwd_main_only": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),
+    "ppsci_set_bwd_accum": (None, [C.c_int]),
     "ppsci_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
     "ppsci_stash_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
     "ppsci_bwd_partial_rows": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),

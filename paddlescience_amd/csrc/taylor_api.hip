@@ -76,15 +76,19 @@ extern "C" int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_poi
 
 static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.n_hidden - 1) * a.q.HP * a.q.HP; }
 
+// slots of per-tile (or, accumulating kernels, per-workgroup) hidden-weight gradient blocks in the workspace
+static long long bwd_wpart_slots(const BwdArgs& a, int grid) { return a.accum ? grid : (long long)a.ntiles + 1; }
+
 extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_points) {
   BwdArgs a;
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
   int grid = 0;
   if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
-  const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
-  // per-tile hidden-weight blocks (+ the spare slot) | chunk sums | per-workgroup small-parameter rows | their sum
-  const long long fl = ((long long)a.ntiles + 1 + chunks) * bwd_per_tile_floats(a) +
-                       ((long long)grid + 1) * ppsci_small_params(a.d, a.q);
+  const long long slots = bwd_wpart_slots(a, grid);
+  const long long chunks = slots < PPSCI_WRED_CHUNKS ? slots : PPSCI_WRED_CHUNKS;
+  // hidden-weight blocks per tile (+ the spare slot) or per workgroup | chunk sums | per-workgroup small-parameter
+  // rows | their sum
+  const long long fl = (slots + chunks) * bwd_per_tile_floats(a) + ((long long)grid + 1) * ppsci_small_params(a.d, a.q);
   return fl * 4 + 16;
 }
 
@@ -118,10 +122,11 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   a.stash = (const f32x4*)stash;
   int grid = 0;
   if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return PPSCI_E_UNSUPPORTED;
-  const long long chunks = a.ntiles < PPSCI_WRED_CHUNKS ? a.ntiles : PPSCI_WRED_CHUNKS;
+  const long long slots = bwd_wpart_slots(a, grid);
+  const long long chunks = slots < PPSCI_WRED_CHUNKS ? slots : PPSCI_WRED_CHUNKS;
   const int psmall = ppsci_small_params(a.d, a.q);
   float* wpart = (float*)workspace;
-  float* tmp = wpart + ((long long)a.ntiles + 1) * bwd_per_tile_floats(a);
+  float* tmp = wpart + slots * bwd_per_tile_floats(a);
   float* small_rows = tmp + chunks * bwd_per_tile_floats(a);
   float* small_sum = small_rows + (long long)grid * psmall;
   a.partials = small_rows;
@@ -131,5 +136,6 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   // W0 / biases / W_last: fixed-order sum over the workgroups' compact rows (a few hundred KB, not rows x P)
   rc = ppsci_reduce_rows(small_rows, grid, psmall, small_sum, 0, stream);
   if (rc != PPSCI_OK) return rc;
-  return ppsci_wgrad_reduce(a.d, a.q, a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
+  // hidden-to-hidden matrices: fixed-order tree sum over the tiles' (or the workgroups') blocks
+  return ppsci_wgrad_reduce(a.d, a.q, a.accum ? grid : a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
 }

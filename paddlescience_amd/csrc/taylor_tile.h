@@ -271,6 +271,7 @@ struct BwdArgs {
   int iters;
   int resident;
   int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
+  int accum;     // 1: hidden-weight gradient blocks accumulated per WORKGROUP (wpart has one slot per workgroup)
 };
 
 // Parameters that are NOT hidden-to-hidden matrices, in the compact order the reverse kernels flush their LDS
@@ -315,9 +316,13 @@ static inline int ppsci_fwd_small_floats(const ppsci_mlp_desc& d, const ppsci_de
   // W0s[d0*HP] + Bs[L*HP] + WLs[m*HP] + BLs[4*ceil(m/4)]
   return (q.d0 + d.n_hidden + d.d_out) * q.HP + ((d.d_out + 3) / 4) * 4;
 }
+// per-wave accumulators of the small tensors in the reverse kernel: gW0[d0*HP] gB[L*HP] (gP[L*HP]) gWL[m*HP] gBL[4*ceil(m/4)]
+__host__ __device__ static inline int ppsci_bwd_nacc_small(const ppsci_mlp_desc& d, const ppsci_derived& q) {
+  return (q.d0 + d.n_hidden + d.d_out + (ppsci_act_has_param(d.activation) ? d.n_hidden : 0)) * q.HP + ((d.d_out + 3) / 4) * 4;
+}
 static inline int ppsci_bwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q, int S) {
-  // WLs[m*HP] gW0[d0*HP] gB[L*HP] gWL[m*HP] gBL[4*ceil(m/4)] scratch[WAVES*S*SCR] tile inputs x[WAVES*d_raw*16]
-  return (2 * d.d_out + q.d0 + d.n_hidden) * q.HP + ((d.d_out + 3) / 4) * 4 +
-         (ppsci_act_has_param(d.activation) ? d.n_hidden * q.HP : 0) +  // gP: activation-parameter gradients
-         PPSCI_BWD_WAVES * (S * PPSCI_SCR_FLOATS + d.d_raw * PPSCI_TILE) + PPSCI_BWD_TINP_FLOATS;
+  // WLs[m*HP] | per wave: small-tensor accumulators | per wave: transpose scratch [S*SCR] | per wave: tile inputs
+  // x[d_raw*16] | row-pointer table
+  return d.d_out * q.HP + PPSCI_BWD_WAVES * (ppsci_bwd_nacc_small(d, q) + S * PPSCI_SCR_FLOATS + d.d_raw * PPSCI_TILE) +
+         PPSCI_BWD_TINP_FLOATS;
 }

@@ -569,3 +569,52 @@ def test_adam_step_matches_oracle():
         hp.adam_step(p, _t(g), m, v, 1e-3, t)
         q = ref.step(q, g.astype(np.float64))
     np.testing.assert_allclose(p.cpu().numpy(), q, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hidden,dout,n2,N,grid", [
+    ([64, 64, 64, 64], 1, 1, 16 * 11 + 3, 2),   # NB = 4: 12 tiles on 2 workgroups -> 2 rounds, the second one ragged
+    ([20, 20, 20], 1, 2, 16 * 9 + 1, 1),        # NB = 2: two accumulator copies (waves 0-1 / 2-3), 3 rounds
+    ([40, 40], 3, 2, 70, 0),                    # NB = 4, one hidden matrix, three outputs, automatic grid
+])
+def test_bwd_workgroup_accumulation_matches_streaming_and_oracle(hidden, dout, n2, N, grid):
+    """ppsci_taylor_bwd accumulates the hidden-weight gradient per workgroup in LDS (rotated feature blocks, slot
+    barriers) where the net allows it; `ppsci_set_bwd_accum(0)` forces the per-tile streaming path of wider nets.
+    Both must reproduce the oracle, on rounds in which some waves of a workgroup have no tile as well."""
+    from paddlescience_amd import _lib
+
+    dirs = np.eye(2) if n2 == 2 else np.array([[0.0, 1.0], [1.0, 0.0]])
+    net = T.make_net(2, hidden, dout, bias_scale=0.2)
+    rng = np.random.default_rng(11)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    Ubar = rng.standard_normal((dout, 1 + 2 + n2, N)).astype(np.float32).astype(np.float64)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+    ref = T.flat_grads(*T.taylor_backward(net32, cache, Ubar))
+    got = {}
+    _lib.lib().ppsci_set_max_grid(grid)
+    try:
+        for mode in (1, 0):
+            _lib.lib().ppsci_set_bwd_accum(mode)
+            got[mode] = _run_bwd(net, X, dirs, n2, Ubar)
+    finally:
+        _lib.lib().ppsci_set_bwd_accum(1)
+        _lib.lib().ppsci_set_max_grid(0)
+    assert _rel(got[1], ref) < 5e-6 and _rel(got[0], ref) < 5e-6
+    assert _rel(got[1], got[0]) < 2e-6
+
+
+@pytest.mark.parametrize("hidden,dout,n2,N", [([64, 64, 64, 64], 1, 1, 20_000), ([20, 20, 20], 1, 2, 10_000),
+                                              ([128] * 5, 3, 2, 4_000)])
+def test_bwd_is_bitwise_reproducible(hidden, dout, n2, N, dev):
+    """No float atomics across waves: two launches on the same inputs give bit-identical gradients (on the GPU this
+    is also the race detector for the slot-barrier scheme)."""
+    if dev != "gpu":
+        pytest.skip("run-to-run reproducibility is a property of the hardware scheduling: GPU only")
+    dirs = np.eye(2) if n2 == 2 else np.array([[0.0, 1.0], [1.0, 0.0]])
+    net = T.make_net(2, hidden, dout, bias_scale=0.2)
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    Ubar = (rng.standard_normal((dout, 1 + 2 + n2, N)) / N).astype(np.float32).astype(np.float64)
+    runs = [_run_bwd(net, X, dirs, n2, Ubar) for _ in range(4)]
+    for r in runs[1:]:
+        assert np.array_equal(r, runs[0])

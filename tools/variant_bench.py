@@ -58,29 +58,33 @@ def main():
             gp = torch.zeros((rows, lay.n_params), device=dev)
             f_med, f_min = timeit(lambda: hp.taylor_fwd(desc, params, xs, U, stash))
             fn_med, fn_min = timeit(lambda: hp.taylor_fwd(desc, params, xs, U, None))
-            ws = torch.zeros(max(4, hp.bwd_workspace_bytes(desc, N) // 4), device=dev)
-            b_med, b_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
-            L._lib.ppsci_set_bwd_main_only(1)
-            m_med, m_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
-            L._lib.ppsci_set_bwd_main_only(0)
-            try:
-                import ctypes
-                raw = ctypes.CDLL(path)
-                buf = (ctypes.c_ulonglong * 8)()
-                raw.ppsci_bwd_read_phase_timers(buf, 1)
+            for accum in (1, 0):
+                L._lib.ppsci_set_bwd_accum(accum)
+                ws = torch.zeros(max(4, hp.bwd_workspace_bytes(desc, N) // 4), device=dev)
+                b_med, b_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
                 L._lib.ppsci_set_bwd_main_only(1)
-                hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp)
-                torch.cuda.synchronize()
+                m_med, m_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
                 L._lib.ppsci_set_bwd_main_only(0)
-                raw.ppsci_bwd_read_phase_timers(buf, 1)
-                tot = float(sum(buf)) or 1.0
-                print(json.dumps({"variant": name, "phase_cycles_per_tile": [round(v / ((N + 15) // 16)) for v in buf],
-                                  "phase_pct": [round(100.0 * v / tot, 1) for v in buf]}), flush=True)
-            except AttributeError:
-                pass
-            print(json.dumps({"variant": name, "shape": label, "rows": rows, "fwd_ms": round(f_med, 4),
-                              "fwd_nostash_ms": round(fn_med, 4), "bwd_ms": round(b_med, 4),
-                              "bwd_min_ms": round(b_min, 4), "bwd_main_ms": round(m_med, 4)}), flush=True)
+                try:
+                    import ctypes
+                    raw = ctypes.CDLL(path)
+                    buf = (ctypes.c_ulonglong * 8)()
+                    raw.ppsci_bwd_read_phase_timers(buf, 1)
+                    L._lib.ppsci_set_bwd_main_only(1)
+                    hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp)
+                    torch.cuda.synchronize()
+                    L._lib.ppsci_set_bwd_main_only(0)
+                    raw.ppsci_bwd_read_phase_timers(buf, 1)
+                    tot = float(sum(buf)) or 1.0
+                    print(json.dumps({"variant": name, "accum": accum,
+                                      "phase_cycles_per_tile": [round(v / ((N + 15) // 16)) for v in buf],
+                                      "phase_pct": [round(100.0 * v / tot, 1) for v in buf]}), flush=True)
+                except AttributeError:
+                    pass
+                print(json.dumps({"variant": name, "accum": accum, "shape": label, "rows": rows, "fwd_ms": round(f_med, 4),
+                                  "fwd_nostash_ms": round(fn_med, 4), "bwd_ms": round(b_med, 4),
+                                  "bwd_min_ms": round(b_min, 4), "bwd_main_ms": round(m_med, 4)}), flush=True)
+            L._lib.ppsci_set_bwd_accum(1)
           except Exception as e:  # noqa: BLE001
             print(json.dumps({"variant": name, "shape": label, "error": str(e)[:100]}), flush=True)
 
