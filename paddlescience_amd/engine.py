@@ -158,20 +158,25 @@ class FusedConstraint:
 class StepGraph:
     """Capture-once / replay of a fixed launch sequence (every argument a persistent device buffer) as a HIP graph,
     through torch.cuda.CUDAGraph on the launch stream.  First call with a key: eager (also the warm-up a capture
-    needs); second: capture + replay; later: replay.  A failed capture falls back to eager launches for good."""
+    needs); second: capture + replay; later: replay.  A failed capture is LOGGED (a silent fallback would hide a
+    performance regression) and the step runs eagerly from then on.  At most `max_graphs` captured graphs are kept
+    (least recently used first out): a key that changes every iteration must not grow the table without bound."""
 
-    def __init__(self, enabled: bool):
+    def __init__(self, enabled: bool, max_graphs: int = 16):
         self.enabled = enabled
+        self.max_graphs = max_graphs
         self._graphs: Dict[tuple, object] = {}
 
     def run(self, key: tuple, eager) -> None:
         if not self.enabled:
             return eager()
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
             eager()
             self._graphs[key] = False
+            self._evict()
             return
+        self._graphs[key] = g  # most recently used last
         if g is False:
             try:
                 torch.cuda.synchronize()
@@ -180,12 +185,21 @@ class StepGraph:
                     eager()
                 self._graphs[key] = graph
                 graph.replay()
-            except Exception:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+                from .utils import logger
+
+                logger.warning(f"HIP-graph capture of the training step failed ({type(e).__name__}: {e}); the step is "
+                               "launched kernel by kernel from now on (PPSCI_HIP_GRAPH=0 silences this)")
                 self.enabled = False
+                self._graphs.clear()
                 torch.cuda.synchronize()
                 eager()
             return
         g.replay()
+
+    def _evict(self) -> None:
+        while len(self._graphs) > self.max_graphs:
+            self._graphs.pop(next(iter(self._graphs)))
 
     def clear(self) -> None:
         self._graphs.clear()

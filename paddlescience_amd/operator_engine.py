@@ -21,7 +21,9 @@ def _to_dev(d: Optional[dict], device) -> Dict[str, torch.Tensor]:
         if isinstance(v, torch.Tensor):
             out[k] = v.to(device=device, dtype=torch.float32)
         elif isinstance(v, (int, float)):
-            out[k] = v
+            # a Python scalar becomes a 0-d device tensor: bind() can then copy it in place like every other entry, and
+            # the captured step keeps one graph instead of re-capturing (and leaking one) per iteration
+            out[k] = torch.tensor(float(v), dtype=torch.float32, device=device)
         else:
             out[k] = torch.as_tensor(np.asarray(v, dtype=np.float32)).to(device)
     return out

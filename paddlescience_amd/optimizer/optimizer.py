@@ -13,6 +13,17 @@ from .. import hotpath as hp
 from . import lr_scheduler
 
 
+def _put_scheduler(d: dict, lr) -> None:
+    if hasattr(lr, "state_dict"):
+        st = lr.state_dict()
+        d["lr_last_epoch"], d["lr_last_lr"] = int(st["last_epoch"]), float(st["last_lr"])
+
+
+def _get_scheduler(state: dict, lr) -> None:
+    if hasattr(lr, "set_state_dict") and "lr_last_epoch" in state:
+        lr.set_state_dict({"last_epoch": int(state["lr_last_epoch"]), "last_lr": float(state["lr_last_lr"])})
+
+
 class _AdamState:
     def __init__(self, model, learning_rate, beta1, beta2, epsilon):
         self.model = model
@@ -52,12 +63,23 @@ class _AdamState:
         pass  # the flat gradient is overwritten by every reduce_rows
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t}
+        """Everything a resumed run needs to continue bit-for-bit (paddle's optimizer.state_dict() carries the
+        moments, the beta powers and the 'LR_Scheduler' entry): moments, step count, the moments of the learnable
+        equation parameters and the scheduler's position."""
+        d = {"m": self.m, "v": self.v, "t": self.t}
+        if self.eq_store is not None:
+            d["eq_m"], d["eq_v"] = self.eq_m, self.eq_v
+        _put_scheduler(d, self._lr)
+        return d
 
     def set_state_dict(self, state):
-        self.m.copy_(torch.as_tensor(state["m"]))
-        self.v.copy_(torch.as_tensor(state["v"]))
+        self.m.copy_(torch.as_tensor(state["m"]).to(self.m.device))
+        self.v.copy_(torch.as_tensor(state["v"]).to(self.v.device))
         self.t = int(state["t"])
+        if self.eq_store is not None and "eq_m" in state:
+            self.eq_m.copy_(torch.as_tensor(state["eq_m"]).to(self.eq_m.device))
+            self.eq_v.copy_(torch.as_tensor(state["eq_v"]).to(self.eq_v.device))
+        _get_scheduler(state, self._lr)
 
 
 class Adam:
@@ -128,6 +150,7 @@ class _FusedState:
         # checkpoint files use the Adam field names (utils/save_load.py)
         d["m"] = self.states[0] if self.states else torch.zeros(1)
         d["v"] = self.states[1] if len(self.states) > 1 else torch.zeros(1)
+        _put_scheduler(d, self._lr)
         return d
 
     def set_state_dict(self, state):
@@ -136,6 +159,7 @@ class _FusedState:
             if key is not None and key in state:
                 t.copy_(torch.as_tensor(state[key]).to(t.device))
         self.t = int(state.get("t", 0))
+        _get_scheduler(state, self._lr)
 
 
 class _SGDState(_FusedState):
@@ -280,7 +304,7 @@ class _LBFGSState:
         return {"m": torch.zeros(1), "v": torch.zeros(1), "t": self.t}
 
     def set_state_dict(self, state):
-        self.t = int(state.get("t", 0))
+        self.t = int(state.get("t", 0))  # the curvature history is rebuilt (paddle's LBFGS state is not portable either)
 
 
 class LBFGS:

@@ -28,6 +28,12 @@ from ..loss import mtl
 from ..utils import logger, misc, save_load
 
 
+def _metric_value(v):
+    """A scalar metric as a float; `keep_batch=True` metrics (one value per sample) are reported by their mean."""
+    t = torch.as_tensor(v).detach().float()
+    return float(t) if t.numel() == 1 else float(t.mean())
+
+
 def _is_full_static_batch(cst) -> bool:
     ds = getattr(cst.data_loader, "dataset", cst.data_loader)
     if getattr(ds, "is_iterable", False):
@@ -121,7 +127,8 @@ class Solver:
         if pretrained_model_path is not None:
             save_load.load_pretrain(self.model, pretrained_model_path, self.equation)
         if checkpoint_path is not None:
-            self.best_metric = save_load.load_checkpoint(checkpoint_path, self.model, self.optimizer, self.equation)
+            self.best_metric = save_load.load_checkpoint(checkpoint_path, self.model, self.optimizer, self.equation,
+                                                           aggregator=self.loss_aggregator)
 
         if self.world_size > 1:
             # DataParallel wrap of the reference (solver.py:388-412): replicate rank 0's parameters
@@ -215,8 +222,10 @@ class Solver:
             bsz = len(next(iter(inp.values())))
         else:
             bsz = cst.data_loader.batch_sampler.batch_size
-            if cst.data_loader.batch_sampler.drop_last is False and len(ds) % bsz != 0 and len(cst.data_loader) > 1:
-                raise NotImplementedError(f"constraint {name}: ragged last batch ({len(ds)} % {bsz} != 0); use drop_last")
+            per_rank = cst.data_loader.batch_sampler.num_samples  # ceil(n / world): what THIS rank's sampler yields
+            if cst.data_loader.batch_sampler.drop_last is False and per_rank % bsz != 0 and len(cst.data_loader) > 1:
+                raise NotImplementedError(f"constraint {name}: ragged last batch ({per_rank} % {bsz} != 0 samples per "
+                                          "rank); use drop_last")
             if len(cst.data_loader) == 1:
                 bsz = cst.data_loader.batch_sampler.num_samples
         cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
@@ -316,11 +325,11 @@ class Solver:
                     self.best_metric["metric"] = cur_metric
                     self.best_metric["epoch"] = epoch_id
                     save_load.save_checkpoint(self.model, self.optimizer, self.best_metric, None, self.output_dir,
-                                              "best_model", self.equation)
+                                              "best_model", self.equation, aggregator=self.loss_aggregator)
                 logger.info(f"[Eval][Epoch {epoch_id}][best metric: {self.best_metric['metric']}]")
             if self.save_freq > 0 and epoch_id % self.save_freq == 0:
                 save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
-                                          self.output_dir, f"epoch_{epoch_id}", self.equation)
+                                          self.output_dir, f"epoch_{epoch_id}", self.equation, aggregator=self.loss_aggregator)
             # "always save the latest model for convenient resume training" (solver.py of the reference, every epoch).
             # With iters_per_epoch = 1 (laplace2d.yaml) an epoch is 30 us of GPU work and the three files cost
             # 0.5 ms, so `latest` is refreshed at most every `latest_save_interval` seconds and at the last epoch.
@@ -329,7 +338,7 @@ class Solver:
                 self._latest_saved_at = now
                 save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
                                           self.output_dir, "latest", self.equation,
-                                          print_log=(epoch_id == self.epochs))
+                                          print_log=(epoch_id == self.epochs), aggregator=self.loss_aggregator)
 
     # ------------------------------------------------------------------ per-loss gradient weighting (GradNorm / NTK)
     def _loss_key_order(self):
@@ -469,18 +478,29 @@ class Solver:
                     labs.setdefault(k, []).append(torch.as_tensor(np.asarray(lab[k], dtype=np.float32)).to(self.device).view(-1, 1))
                     loss_sum[k] = loss_sum.get(k, 0.0) + lv[k]
                 nb += 1
-            all_out = {k: misc.all_gather(torch.cat(v, 0)) for k, v in outs.items()}
-            all_lab = {k: misc.all_gather(torch.cat(v, 0)) for k, v in labs.items()}
+            n_total = len(ds) if hasattr(ds, "__len__") and not getattr(ds, "is_iterable", False) else None
+            all_out = {k: self._gather_eval(torch.cat(v, 0), n_total) for k, v in outs.items()}
+            all_lab = {k: self._gather_eval(torch.cat(v, 0), n_total) for k, v in labs.items()}
             group[vname] = {}
             for mname, metric in (val.metric or {}).items():
                 res = metric(all_out, all_lab)
                 for k, v in res.items():
-                    group[vname][f"{mname}.{k}"] = float(v)
+                    group[vname][f"{mname}.{k}"] = _metric_value(v)
             msg = ", ".join(f"{k}: {v:.5f}" for k, v in group[vname].items())
             logger.info(f"[Eval][Epoch {epoch_id}][{vname}] loss: {sum(loss_sum.values()) / max(nb, 1):.5f}, {msg}")
             if group[vname] and target == float("inf"):
                 target = float(next(iter(group[vname].values())))  # first metric of the first validator
         return target, group
+
+    def _gather_eval(self, local: torch.Tensor, n_total: Optional[int]) -> torch.Tensor:
+        """All ranks' shards in DATASET order, without the sampler's wrap-around padding (eval.py:154-161 truncates
+        to num_samples): rank r holds samples r, r + W, r + 2W, ... of the padded index list."""
+        if self.world_size == 1:
+            return local
+        full = misc.all_gather(local)  # rank-major: [rank 0's shard ; rank 1's shard ; ...]
+        nl = local.shape[0]
+        full = full.view(self.world_size, nl, *local.shape[1:]).transpose(0, 1).reshape(nl * self.world_size, *local.shape[1:])
+        return full if n_total is None else full[:n_total]
 
     def _eval_operator(self, epoch_id: int):
         """eval.py _eval_by_dataset for models evaluated through torch (FNO): whole-dataset metrics."""
@@ -505,12 +525,14 @@ class Solver:
                         outs.setdefault(k, []).append(vals[k])
                     for k in lab_d:
                         labs.setdefault(k, []).append(lab_d[k])
-            all_out = {k: misc.all_gather(torch.cat(v, 0)) for k, v in outs.items()}
-            all_lab = {k: misc.all_gather(torch.cat(v, 0)) for k, v in labs.items()}
+            ds = getattr(val.data_loader, "dataset", val.data_loader)
+            n_total = len(ds) if hasattr(ds, "__len__") and not getattr(ds, "is_iterable", False) else None
+            all_out = {k: self._gather_eval(torch.cat(v, 0), n_total) for k, v in outs.items()}
+            all_lab = {k: self._gather_eval(torch.cat(v, 0), n_total) for k, v in labs.items()}
             group[vname] = {}
             for mname, metric in (val.metric or {}).items():
                 for k, v in metric(all_out, all_lab).items():
-                    group[vname][f"{mname}.{k}"] = float(v)
+                    group[vname][f"{mname}.{k}"] = _metric_value(v)
             msg = ", ".join(f"{k}: {v:.5f}" for k, v in group[vname].items())
             logger.info(f"[Eval][Epoch {epoch_id}][{vname}] loss: {loss_sum / max(nb, 1):.5f}, {msg}")
             if group[vname] and target == float("inf"):

@@ -105,6 +105,23 @@ def _load_equation(path: str, equation) -> None:
     logger.message(f"Finish loading equation parameters from: {path}.pdeqn")
 
 
+def _set_model_state(model, path: str) -> None:
+    """paddle's set_state_dict warns about missing / unexpected keys; a file none of whose keys matches a parameter
+    (e.g. a plain-MLP file loaded into a weight_norm / ModelList model) would silently leave the model at its random
+    initialisation: that raises."""
+    state = _load_pdparams(path)
+    result = model.set_state_dict(state)
+    if not isinstance(result, tuple) or len(result) != 2:
+        return
+    missing, unexpected = result
+    if missing:
+        logger.warning(f"{path}: {len(missing)} parameter(s) not found in the file and left unchanged: {list(missing)[:8]}")
+    if unexpected:
+        logger.warning(f"{path}: {len(unexpected)} key(s) in the file match no parameter: {list(unexpected)[:8]}")
+    if state and len(unexpected) == len(state):
+        raise ValueError(f"{path}: no key of the file matches a parameter of the model")
+
+
 def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None, grad_scaler=None,
                     output_dir: Optional[str] = None, prefix: str = "model", equation=None, print_log: bool = True,
                     ema_model=None, aggregator=None):
@@ -118,9 +135,14 @@ def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None,
     path = os.path.join(ckpt_dir, prefix)
     _save_pdparams(path + ".pdparams", _state_arrays(model))
     if optimizer is not None:
-        st = optimizer.state_dict()
-        _save_npz(path + ".pdopt", {"m": st["m"].detach().cpu().numpy(), "v": st["v"].detach().cpu().numpy(),
-                                    "t": np.asarray(st["t"])})
+        # the optimizer's WHOLE state (paddle.save(optimizer.state_dict()), save_load.py:246): every moment / buffer
+        # tensor, the step count, the moments of learnable equation parameters and the LR scheduler's position
+        arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                  for k, v in optimizer.state_dict().items()}
+        if aggregator is not None and getattr(aggregator, "should_persist", False):
+            for k, v in aggregator.state_dict().items():  # GradNorm / NTK weights (save_load.py:277-279, .pdagg)
+                arrays["agg_" + k] = np.asarray(v)
+        _save_npz(path + ".pdopt", arrays)
     if equation is not None and sum(len(eq.learnable_parameters) for eq in equation.values()) > 0:
         # save_load.py:267-276: {equation name: ParameterList state dict}
         with open(path + ".pdeqn", "wb") as f:
@@ -137,10 +159,14 @@ def load_checkpoint(path: str, model, optimizer=None, equation=None, grad_scaler
                     ) -> Dict[str, float]:
     if not os.path.exists(f"{path}.pdparams"):
         raise FileNotFoundError(f"{path}.pdparams not exist.")
-    model.set_state_dict(_load_pdparams(f"{path}.pdparams"))
+    _set_model_state(model, f"{path}.pdparams")
     if optimizer is not None and os.path.exists(f"{path}.pdopt"):
         st = _load_npz(f"{path}.pdopt")
-        optimizer.set_state_dict({"m": st["m"], "v": st["v"], "t": int(st["t"])})
+        optimizer.set_state_dict({k: (v.item() if v.ndim == 0 else v) for k, v in st.items() if not k.startswith("agg_")})
+        if aggregator is not None and getattr(aggregator, "should_persist", False):
+            agg = {k[4:]: v for k, v in st.items() if k.startswith("agg_")}
+            if agg:
+                aggregator.set_state_dict(agg)
     _load_equation(path, equation)
     with open(f"{path}.pdstates") as f:
         metric = json.load(f)
@@ -154,6 +180,6 @@ def load_pretrain(model, path: str, equation=None):
     path = path[:-len(".pdparams")] if path.endswith(".pdparams") else path
     if not os.path.exists(f"{path}.pdparams"):
         raise FileNotFoundError(f"{path}.pdparams not exist.")
-    model.set_state_dict(_load_pdparams(f"{path}.pdparams"))
+    _set_model_state(model, f"{path}.pdparams")
     logger.message(f"Finish loading pretrained model from: {path}.pdparams")
     _load_equation(path, equation)

@@ -108,6 +108,8 @@ def main():
         return main_spinn(outdir)
     if reduction == "viv":
         return main_viv(outdir)
+    if reduction == "periodic":
+        return main_periodic(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -123,6 +125,55 @@ def main():
     if not dist.is_initialized() or dist.get_rank() == 0:
         np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
                  loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_periodic(outdir):
+    """PeriodicConstraint + PeriodicMSELoss next to a supervised constraint with a validator: the batch
+    [boundary points ; their images] is sharded rank-strided, so every rank pairs the halves of its own shard
+    (needs an even per-rank half); eval gathers the ranks' shards back into dataset order without the sampler's
+    wrap-around padding (9 validation samples on 2 ranks)."""
+    import sympy as sp
+
+    import ppsci
+    from oracle import taylor_np as T
+    from paddlescience_amd import device
+    from tests.common import set_model_weights
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    geom = ppsci.geometry.Rectangle((-1.0, 0.0), (1.0, 2.0))
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 2, 16, "tanh")
+    set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
+    x, y = sp.symbols("x y")
+    u = sp.Function("u")(x, y)
+    np.random.seed(7)
+    pbc = ppsci.constraint.PeriodicConstraint(
+        {"u": lambda out: out["u"], "u_x": u.diff(x)}, {"u": 0, "u_x": 0}, geom, "x",
+        {"dataset": "NamedArrayDataset", "batch_size": 16, "iters_per_epoch": 1,
+         "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": False}},
+        ppsci.loss.PeriodicMSELoss("mean", weight={"u_x": 0.5}), criteria=lambda x, y: np.isclose(x, -1.0), name="PBC")
+    rng = np.random.default_rng(5)
+    Xv = rng.uniform([-1, 0], [1, 2], (9, 2)).astype(np.float32)
+    lv = rng.standard_normal((9, 1)).astype(np.float32)
+    val = ppsci.validate.SupervisedValidator(
+        {"dataset": {"name": "NamedArrayDataset", "input": {"x": Xv[:, :1], "y": Xv[:, 1:]}, "label": {"u": lv}},
+         "batch_size": 5, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": False}},
+        ppsci.loss.MSELoss("mean"), {"u": lambda out: out["u"]}, metric={"MSE": ppsci.metric.MSE()}, name="V")
+    opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PBC": pbc}, outdir, opt, epochs=3, iters_per_epoch=1, log_freq=1,
+                                 validator={"V": val})
+    solver.train()
+    target, group = solver.eval()
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(),
+                 pred=np.asarray([target]), loss=np.asarray(solver.last_losses["loss"]))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

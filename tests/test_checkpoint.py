@@ -92,3 +92,49 @@ def test_equation_parameters_round_trip(tmp_path, dev):
     save_load.load_checkpoint(path, model, None, eq)
     assert eq["VIV"].k1.item() == 4.0 and eq["VIV"].k2.item() == -1.0
     EqParamStore.reset()
+
+
+def _laplace_solver(tmp, epochs, checkpoint_path=None, opt_name="Adam"):
+    ppsci.utils.misc.set_random_seed(3)
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 2, 16, "tanh")
+    net = T.make_net(2, [16, 16], 1, seed=9, bias_scale=0.1)
+    set_model_weights(model, net)
+    X = np.random.default_rng(0).uniform(0, 1, (64, 2)).astype(np.float32)
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": {"x": X[:, :1], "y": X[:, 1:]},
+                       "label": {"laplace": np.zeros((64, 1), np.float32)}}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), ppsci.equation.Laplace(2).equations, name="EQ")
+    sch = ppsci.optimizer.lr_scheduler.ExponentialDecay(4, 3, 1e-2, 0.5, 4, warmup_epoch=1)()
+    if opt_name == "Adam":
+        opt = ppsci.optimizer.Adam(sch)(model)
+    else:
+        opt = ppsci.optimizer.RMSProp(sch, momentum=0.9)(model)
+    return ppsci.solver.Solver(model, {"EQ": cst}, str(tmp), opt, sch, epochs=epochs, iters_per_epoch=3, save_freq=1,
+                               checkpoint_path=checkpoint_path), model, opt, sch
+
+
+@pytest.mark.parametrize("opt_name", ["Adam", "RMSProp"])
+def test_resumed_run_equals_uninterrupted_run(tmp_path, dev, opt_name):
+    """The checkpoint carries the optimizer's whole state (every moment buffer, step count) AND the LR scheduler's
+    position (paddle: optimizer.state_dict()['LR_Scheduler']): 2 epochs + resume + 2 epochs == 4 epochs, bitwise."""
+    full, m_full, _, sch_full = _laplace_solver(tmp_path / "full", 4, opt_name=opt_name)
+    full.train()
+    part, _, _, _ = _laplace_solver(tmp_path / "part", 2, opt_name=opt_name)
+    part.train()
+    ck = os.path.join(str(tmp_path / "part"), "checkpoints", "epoch_2")
+    res, m_res, opt_res, sch_res = _laplace_solver(tmp_path / "part", 4, checkpoint_path=ck, opt_name=opt_name)
+    assert sch_res.last_epoch == 6 and opt_res.t == 6  # 2 epochs x 3 iterations: warm-up is not replayed
+    res.train()
+    assert sch_res.last_epoch == sch_full.last_epoch and sch_res.get_lr() == sch_full.get_lr()
+    np.testing.assert_array_equal(m_res.flat_params.cpu().numpy(), m_full.flat_params.cpu().numpy())
+
+
+def test_loading_a_file_with_foreign_keys_raises_instead_of_keeping_random_weights(tmp_path, dev):
+    plain = _model()
+    save_load.save_checkpoint(plain, None, {"metric": 1.0, "epoch": 1}, None, str(tmp_path), "plain")
+    wn = _model(weight_norm=True)
+    path = os.path.join(str(tmp_path), "checkpoints", "plain")
+    # biases and last_fc match, weight_v / weight_g are reported missing: loads with a warning
+    save_load.load_pretrain(wn, path)
+    other = ppsci.arch.ModelList((_model(), ppsci.arch.MLP(("x", "y"), ("v",), 3, 16, "tanh")))
+    with pytest.raises(ValueError, match="no key of the file"):
+        save_load.load_pretrain(other, path)

@@ -64,6 +64,17 @@ def test_two_ranks_reproduce_single_rank_factored_layers_and_equation_parameters
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
 
 
+def test_two_ranks_reproduce_single_rank_periodic_constraint_and_eval_gather(tmp_path):
+    """PeriodicConstraint under data parallelism (each rank pairs the halves of its rank-strided shard) and the
+    validator metric over a dataset whose size is not a multiple of the world size (the gathered shards are put back
+    into dataset order and trimmed to len(dataset), eval.py:154-161)."""
+    d = str(tmp_path)
+    one = _run(d, 1, "periodic")
+    two = _run(d, 2, "periodic")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5)
+
+
 def test_iterable_dataset_refuses_world_size_gt_1():
     """data/__init__.py:62-66."""
     import ppsci.data as D
