@@ -43,7 +43,10 @@ enum { PPSCI_ACT_TANH = 0, PPSCI_ACT_SILU = 1, PPSCI_ACT_SIN = 2, PPSCI_ACT_SIGM
        /* activations with a trainable per-feature parameter p (one [width] vector per hidden layer, stored behind the
         * last bias in the parameter buffer): Swish x*sigmoid(p x) (activation.py:49-58, its scalar beta broadcast by
         * the caller) and Stan tanh(x)*(1 + p x) (activation.py:28-46) */
-       PPSCI_ACT_SWISH = 6, PPSCI_ACT_STAN = 7 };
+       PPSCI_ACT_SWISH = 6, PPSCI_ACT_STAN = 7,
+       /* the rest of act_func_dict (activation.py:139-154): nn.ReLU, nn.LeakyReLU() (slope 0.01), nn.ELU() (alpha 1),
+        * nn.SELU, nn.Identity -- their second and higher derivatives vanish (elu / selu: c e^z below zero) */
+       PPSCI_ACT_RELU = 8, PPSCI_ACT_LEAKY_RELU = 9, PPSCI_ACT_ELU = 10, PPSCI_ACT_SELU = 11, PPSCI_ACT_IDENTITY = 12 };
 enum { PPSCI_EMBED_NONE = 0, PPSCI_EMBED_PERIOD = 1,
        /* inputs[j] is an [S, N] block holding this network input AND its derivative streams (value, first
         * derivatives along the n1 directions, second along the first n2): a registered input transform
@@ -67,6 +70,7 @@ typedef struct ppsci_mlp_desc {
   int32_t skip_connection;       /* mlp.py:286-291 quirk: pre-activation doubled on even i>=2 */
   int32_t n1;                    /* first-order directions                                   */
   int32_t n2;                    /* second-order streams, along dirs[0..n2-1]; n2 <= n1      */
+                                 /* stream order: value | n1 first | n2 second | n3 third | n4 fourth; S = 1+n1+n2+n3+n4 */
   int32_t embed[PPSCI_MAX_IN];   /* PPSCI_EMBED_* per raw input (PeriodEmbedding mlp.py:95-114) */
   float omega[PPSCI_MAX_IN];     /* 2*pi/period for PERIOD inputs                            */
   float dirs[PPSCI_MAX_DIRS][PPSCI_MAX_IN];
@@ -75,6 +79,9 @@ typedef struct ppsci_mlp_desc {
                                     hidden layer 0: matrix [B, B] ([d0, 2*fourier_half], 2*fourier_half == width),
                                     zero bias, cos on features < fourier_half and sin on the rest; n_hidden counts
                                     it; the skip quirk / act_scale apply to the layers after it; tanh nets only */
+  int32_t n3;                    /* third-order streams, along dirs[0..n3-1]; n3 <= n2 (DerivativeNode of any order,
+                                    utils/symbolic.py:310-333: u_xxx of KdV-type residuals)                          */
+  int32_t n4;                    /* fourth-order streams, along dirs[0..n4-1]; n4 <= n3 (Biharmonic, euler_beam.py)  */
 } ppsci_mlp_desc;
 
 /* Epilogue program: the pointwise part of a constraint -- the sympy operator tree that

@@ -117,6 +117,17 @@ class MLP:
             return torch.sigmoid(y)
         if self.activation == "gelu":
             return torch.nn.functional.gelu(y)  # nn.GELU() default: exact erf form
+        F = torch.nn.functional  # activation.py:139-154: nn.ReLU(), nn.LeakyReLU() (0.01), nn.ELU() (alpha 1), nn.SELU()
+        if self.activation == "relu":
+            return F.relu(y)
+        if self.activation == "leaky_relu":
+            return F.leaky_relu(y, 0.01)
+        if self.activation == "elu":
+            return F.elu(y, 1.0)
+        if self.activation == "selu":
+            return F.selu(y)
+        if self.activation == "identity":
+            return y
         raise ValueError(self.activation)
 
     def forward_tensor(self, x):  # mlp.py:281-296

@@ -13,7 +13,8 @@ from typing import List, Optional, Sequence
 
 MAX_IN, MAX_DIRS, MAX_OUT, MAX_HIDDEN, MAX_PROG, MAX_RES, MAX_AUX = 8, 4, 8, 16, 128, 8, 16
 
-ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5, "swish": 6, "stan": 7}
+ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5, "swish": 6, "stan": 7, "relu": 8, "leaky_relu": 9,
+       "elu": 10, "selu": 11, "identity": 12}
 PARAM_ACTS = ("swish", "stan")  # a trainable per-feature parameter vector per hidden layer (behind the last bias)
 SIREN_W0 = 30.0  # activation.py:98
 LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER, LINEAR_BROADCAST = range(5)
@@ -31,7 +32,7 @@ class MlpDesc(C.Structure):
         ("d_raw", C.c_int32), ("n_hidden", C.c_int32), ("width", C.c_int32), ("d_out", C.c_int32),
         ("activation", C.c_int32), ("skip_connection", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
         ("embed", C.c_int32 * MAX_IN), ("omega", C.c_float * MAX_IN), ("dirs", (C.c_float * MAX_IN) * MAX_DIRS),
-        ("act_scale", C.c_float), ("fourier_half", C.c_int32),
+        ("act_scale", C.c_float), ("fourier_half", C.c_int32), ("n3", C.c_int32), ("n4", C.c_int32),
     ]
 
 
@@ -173,8 +174,9 @@ def ptr_array(ptrs: Sequence[int]):
 
 def make_mlp_desc(d_raw: int, n_hidden: int, width: int, d_out: int, activation: str, skip_connection: bool,
                   dirs: Sequence[Sequence[float]], n2: int, embed: Optional[Sequence[int]] = None,
-                  omega: Optional[Sequence[float]] = None, fourier_half: int = 0) -> MlpDesc:
+                  omega: Optional[Sequence[float]] = None, fourier_half: int = 0, n3: int = 0, n4: int = 0) -> MlpDesc:
     d = MlpDesc()
+    d.n3, d.n4 = int(n3), int(n4)
     d.fourier_half = int(fourier_half)
     d.d_raw, d.n_hidden, d.width, d.d_out = d_raw, n_hidden, width, d_out
     if activation == "siren":  # sin(30 z): the sin kernels with the pre-activation multiplier

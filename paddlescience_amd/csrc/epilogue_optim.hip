@@ -369,7 +369,7 @@ extern "C" int64_t ppsci_stash_bytes(const ppsci_mlp_desc* d, int64_t n_points) 
   ppsci_derived q;
   if (!d || n_points <= 0 || ppsci_derive(d, &q) != PPSCI_OK) return 0;
   const int64_t ntiles = (n_points + PPSCI_TILE - 1) / PPSCI_TILE;
-  const int64_t S = 1 + d->n1 + d->n2;
+  const int64_t S = 1 + d->n1 + d->n2 + d->n3 + d->n4;
   return ntiles * d->n_hidden * S * q.NB * 64 * 16;
 }
 

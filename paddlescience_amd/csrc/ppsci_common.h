@@ -84,6 +84,7 @@ static inline int ppsci_derive(const ppsci_mlp_desc* d, ppsci_derived* q) {
   if (d->n_hidden < 1 || d->n_hidden > PPSCI_MAX_HIDDEN) return PPSCI_E_INVALID;
   if (d->width < 1 || d->d_out < 1 || d->d_out > PPSCI_MAX_OUT) return PPSCI_E_INVALID;
   if (d->n1 < 0 || d->n1 > PPSCI_MAX_DIRS || d->n2 < 0 || d->n2 > d->n1) return PPSCI_E_INVALID;
+  if (d->n3 < 0 || d->n3 > d->n2 || d->n4 < 0 || d->n4 > d->n3) return PPSCI_E_INVALID;
   int d0 = 0;
   for (int j = 0; j < d->d_raw; ++j) d0 += (d->embed[j] == PPSCI_EMBED_PERIOD) ? 2 : 1;
   q->d0 = d0;

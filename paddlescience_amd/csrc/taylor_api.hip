@@ -39,6 +39,11 @@ static int run_fwd_act(FwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_GELU: return ppsci_fwd_run_gelu(a, stream, launch, grid);
     case PPSCI_ACT_SWISH: return ppsci_fwd_run_swish(a, stream, launch, grid);
     case PPSCI_ACT_STAN: return ppsci_fwd_run_stan(a, stream, launch, grid);
+    case PPSCI_ACT_RELU: return ppsci_fwd_run_relu(a, stream, launch, grid);
+    case PPSCI_ACT_LEAKY_RELU: return ppsci_fwd_run_leaky_relu(a, stream, launch, grid);
+    case PPSCI_ACT_ELU: return ppsci_fwd_run_elu(a, stream, launch, grid);
+    case PPSCI_ACT_SELU: return ppsci_fwd_run_selu(a, stream, launch, grid);
+    case PPSCI_ACT_IDENTITY: return ppsci_fwd_run_identity(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }
@@ -60,6 +65,11 @@ static int run_bwd_act(BwdArgs& a, void* stream, int launch, int* grid) {
     case PPSCI_ACT_GELU: return ppsci_bwd_run_gelu(a, stream, launch, grid);
     case PPSCI_ACT_SWISH: return ppsci_bwd_run_swish(a, stream, launch, grid);
     case PPSCI_ACT_STAN: return ppsci_bwd_run_stan(a, stream, launch, grid);
+    case PPSCI_ACT_RELU: return ppsci_bwd_run_relu(a, stream, launch, grid);
+    case PPSCI_ACT_LEAKY_RELU: return ppsci_bwd_run_leaky_relu(a, stream, launch, grid);
+    case PPSCI_ACT_ELU: return ppsci_bwd_run_elu(a, stream, launch, grid);
+    case PPSCI_ACT_SELU: return ppsci_bwd_run_selu(a, stream, launch, grid);
+    case PPSCI_ACT_IDENTITY: return ppsci_bwd_run_identity(a, stream, launch, grid);
     default: ppsci_set_error("unknown activation %d", a.d.activation); return PPSCI_E_UNSUPPORTED;
   }
 }

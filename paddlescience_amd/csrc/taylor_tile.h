@@ -85,6 +85,30 @@ __device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, flo
     d1 = Phi + z * phi;
     d2 = phi * (2.f - z * z);
     d3 = phi * z * (z * z - 4.f);
+  } else if (ACT == PPSCI_ACT_RELU) {  // nn.ReLU (activation.py:141)
+    s = z > 0.f ? z : 0.f;
+    d1 = z > 0.f ? 1.f : 0.f;
+    d2 = 0.f;
+    d3 = 0.f;
+  } else if (ACT == PPSCI_ACT_LEAKY_RELU) {  // nn.LeakyReLU(), negative_slope = 0.01 (activation.py:144)
+    s = z > 0.f ? z : 0.01f * z;
+    d1 = z > 0.f ? 1.f : 0.01f;
+    d2 = 0.f;
+    d3 = 0.f;
+  } else if (ACT == PPSCI_ACT_ELU || ACT == PPSCI_ACT_SELU) {
+    // nn.ELU(): alpha = 1 (activation.py:140); nn.SELU(): scale * (max(0,x) + min(0, alpha (e^x - 1))) (:142)
+    const float scale = ACT == PPSCI_ACT_SELU ? 1.0507009873554804934193349852946f : 1.f;
+    const float alpha = ACT == PPSCI_ACT_SELU ? 1.6732632423543772848170429916717f : 1.f;
+    const float e = scale * alpha * expf(z);
+    s = z > 0.f ? scale * z : e - scale * alpha;
+    d1 = z > 0.f ? scale : e;
+    d2 = z > 0.f ? 0.f : e;
+    d3 = d2;
+  } else if (ACT == PPSCI_ACT_IDENTITY) {  // nn.Identity (activation.py:151)
+    s = z;
+    d1 = 1.f;
+    d2 = 0.f;
+    d3 = 0.f;
   } else {
     s = sinf(z);
     float c = cosf(z);
@@ -150,6 +174,57 @@ __device__ __forceinline__ void ppsci_act_from_stash(float v, float& s, float& d
     d3 = d1 * (6.f * s * s - 2.f);
   } else {
     ppsci_act_eval<ACT>(v, s, d1, d2, d3);
+  }
+}
+
+// Derivatives 1..5 of the activation for the third / fourth-order Taylor streams (Faa di Bruno needs sigma^(4) in the
+// forward sweep and sigma^(5) in the reverse one).  `v` is what the stash holds: tanh(z) for tanh nets when
+// FROM_STASH, z otherwise.  tanh: polynomials in s; sigmoid family: polynomials in g1 = g(1-g); gelu: Hermite-type
+// polynomials times the Gaussian.
+template <int ACT, bool FROM_STASH>
+__device__ __forceinline__ void ppsci_act_eval5(float v, float& s, float (&d)[5]) {
+  if (ACT == PPSCI_ACT_TANH) {
+    s = FROM_STASH ? v : ppsci_tanh(v);
+    const float s2 = s * s;
+    d[0] = 1.f - s2;
+    d[1] = -2.f * s * d[0];
+    d[2] = d[0] * (6.f * s2 - 2.f);
+    d[3] = d[0] * s * (16.f - 24.f * s2);
+    d[4] = d[0] * (16.f + s2 * (-120.f + 120.f * s2));
+  } else if (ACT == PPSCI_ACT_SILU || ACT == PPSCI_ACT_SIGMOID) {
+    const float g = 1.f / (1.f + expf(-v));
+    const float g1 = g * (1.f - g), t = 1.f - 2.f * g;
+    const float g2 = g1 * t, g3 = g1 * (1.f - 6.f * g1), g4 = g2 * (1.f - 12.f * g1);
+    const float g5 = g1 * (1.f + g1 * (-30.f + 120.f * g1));
+    if (ACT == PPSCI_ACT_SIGMOID) {
+      s = g;
+      d[0] = g1, d[1] = g2, d[2] = g3, d[3] = g4, d[4] = g5;
+    } else {  // z g(z): k g^(k-1) + z g^(k)
+      s = v * g;
+      d[0] = g + v * g1, d[1] = 2.f * g1 + v * g2, d[2] = 3.f * g2 + v * g3, d[3] = 4.f * g3 + v * g4, d[4] = 5.f * g4 + v * g5;
+    }
+  } else if (ACT == PPSCI_ACT_GELU) {
+    const float phi = 0.3989422804014327f * expf(-0.5f * v * v);
+    const float Phi = 0.5f * (1.f + erff(v * 0.7071067811865476f));
+    const float z2 = v * v;
+    s = v * Phi;
+    d[0] = Phi + v * phi;
+    d[1] = phi * (2.f - z2);
+    d[2] = phi * v * (z2 - 4.f);
+    d[3] = phi * (-4.f + z2 * (7.f - z2));
+    d[4] = phi * v * (18.f + z2 * (-11.f + z2));
+  } else if (ACT == PPSCI_ACT_COS) {
+    const float sn = sinf(v), cs = cosf(v);
+    s = cs;
+    d[0] = -sn, d[1] = -cs, d[2] = sn, d[3] = cs, d[4] = -sn;
+  } else if (ACT == PPSCI_ACT_SIN) {
+    const float sn = sinf(v), cs = cosf(v);
+    s = sn;
+    d[0] = cs, d[1] = -sn, d[2] = -cs, d[3] = sn, d[4] = cs;
+  } else {  // piecewise-linear / exponential-linear family: one evaluation serves every order
+    float d1, d2, d3;
+    ppsci_act_eval<ACT>(v, s, d1, d2, d3);
+    d[0] = d1, d[1] = d2, d[2] = d3, d[3] = d3, d[4] = d3;  // elu / selu: c e^z below 0; relu-type: 0
   }
 }
 
@@ -299,7 +374,17 @@ int ppsci_fwd_run_swish(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_stan(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_cos(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fwd_run_sigmoid(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_relu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_leaky_relu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_elu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_selu(FwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fwd_run_identity(FwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_tanh(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_relu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_leaky_relu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_elu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_selu(BwdArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_bwd_run_identity(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_tanh_fourier(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_silu(BwdArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_bwd_run_sin(BwdArgs& a, void* stream, int launch, int* grid_out);
@@ -311,7 +396,7 @@ int ppsci_bwd_run_sigmoid(BwdArgs& a, void* stream, int launch, int* grid_out);
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
 // LDS carve sizes (floats)
-#define PPSCI_BWD_TINP_FLOATS (2 * (PPSCI_MAX_OUT * (1 + 2 * PPSCI_MAX_DIRS) + PPSCI_MAX_IN))  // 64-bit row pointers
+#define PPSCI_BWD_TINP_FLOATS (2 * (PPSCI_MAX_OUT * (1 + 4 * PPSCI_MAX_DIRS) + PPSCI_MAX_IN))  // 64-bit row pointers
 static inline int ppsci_fwd_small_floats(const ppsci_mlp_desc& d, const ppsci_derived& q) {
   // W0s[d0*HP] + Bs[L*HP] + WLs[m*HP] + BLs[4*ceil(m/4)]
   return (q.d0 + d.n_hidden + d.d_out) * q.HP + ((d.d_out + 3) / 4) * 4;

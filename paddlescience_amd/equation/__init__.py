@@ -1,9 +1,9 @@
 """ppsci.equation (/root/reference/ppsci/equation/__init__.py:55-76)."""
 import copy
 
-from .pde import PDE, AllenCahn, Helmholtz, Laplace, NavierStokes, Poisson, Vibration  # noqa: F401
+from .pde import PDE, AllenCahn, Biharmonic, Helmholtz, Laplace, NavierStokes, Poisson, Vibration  # noqa: F401
 
-__all__ = ["PDE", "AllenCahn", "Helmholtz", "Laplace", "NavierStokes", "Poisson", "Vibration", "build_equation"]
+__all__ = ["PDE", "AllenCahn", "Biharmonic", "Helmholtz", "Laplace", "NavierStokes", "Poisson", "Vibration", "build_equation"]
 
 
 def build_equation(cfg):

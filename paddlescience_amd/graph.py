@@ -195,13 +195,20 @@ def net_raw_vars(model) -> Tuple[str, ...]:
 
 
 def directional(e: Sym, d, order: int) -> Sym:
-    """order-th derivative of e along direction d: a variable name, or a pair (a, b) for the direction a + b."""
+    """order-th derivative of e along direction d: a variable name, a pair (a, b) for the direction a + b, or a triple
+    (a, b, -1.0) for a - b."""
     if isinstance(d, tuple):
-        a, b = d
-        if order == 1:
-            return diff(e, a) + diff(e, b)
-        ea = diff(e, a)
-        return diff(ea, a) + 2.0 * diff(ea, b) + diff(diff(e, b), b)
+        a, b = d[0], d[1]
+        sgn = float(d[2]) if len(d) > 2 else 1.0
+        if order <= 2 and sgn == 1.0:
+            if order == 1:
+                return diff(e, a) + diff(e, b)
+            ea = diff(e, a)
+            return diff(ea, a) + 2.0 * diff(ea, b) + diff(diff(e, b), b)
+        out = e
+        for _ in range(order):
+            out = diff(out, a) + sgn * diff(out, b)
+        return out
     out = e
     for _ in range(order):
         out = diff(out, d)
@@ -220,10 +227,10 @@ def diff(e: Sym, var: str) -> Sym:
     if k == "net":
         if var not in net_raw_vars(e.model):
             return Sym.const(0.0)
-        if len(e.dirs) >= 2:
+        if len(e.dirs) >= 4:
             raise NotImplementedError(
                 f"derivative order {len(e.dirs) + 1} of a network output ({e!r} w.r.t. {var}) is beyond the fused "
-                "HIP kernels (orders 0..2)")
+                "HIP kernels (orders 0..4)")
         return Sym.net(e.model, e.comp, e.dirs + (var,))
     op, a = e.op, e.args
     if op == "detach":
@@ -308,8 +315,10 @@ def _walk(roots: Iterable[Sym]) -> List[Sym]:
     return order
 
 
-# (n1, n2) combinations the kernels are instantiated for (taylor_fwd.inc / taylor_bwd.inc)
-_INSTANTIATED = [(0, 0), (1, 1), (2, 0), (2, 1), (2, 2), (3, 3)]
+# (n1, n2, n3, n4) combinations the kernels are instantiated for (taylor_fwd.inc / taylor_bwd.inc): first-order
+# directions, and how many of the FIRST of them also carry second / third / fourth-order streams
+_INSTANTIATED = [(0, 0, 0, 0), (1, 1, 0, 0), (2, 0, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (3, 3, 0, 0),
+                 (1, 1, 1, 0), (1, 1, 1, 1), (2, 2, 2, 2), (4, 4, 4, 4)]
 
 
 class Lowered:
@@ -338,52 +347,63 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     model = model_list[0] if model_list else None
 
     # ---- derivative set -> stream specification
-    firsts, seconds, mixed = set(), set(), set()
+    # order[d] = highest pure derivative order needed along direction d (a variable, (a, b) = a + b, (a, b, -1) = a - b)
+    order: Dict[object, int] = {}
+    mixed, mixed4 = set(), set()
+
+    def need(d, k):
+        order[d] = max(order.get(d, 0), k)
+
     for n in nodes:
-        if n.kind != "net":
+        if n.kind != "net" or not n.dirs:
             continue
-        if len(n.dirs) == 1:
-            firsts.add(n.dirs[0])
-        elif len(n.dirs) == 2:
+        vs = sorted(set(n.dirs))
+        k = len(n.dirs)
+        if len(vs) == 1:
+            need(vs[0], k)
+        elif k == 2:
             a, b = n.dirs
-            if a == b:
-                seconds.add(a)
-            else:
-                mixed.add((a, b))
-                seconds.update((a, b))
+            mixed.add((a, b))
+            need(a, 2), need(b, 2), need((a, b), 2)
+        elif k == 4 and len(vs) == 2 and n.dirs.count(vs[0]) == 2:
+            a, b = vs  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
+            mixed4.add((a, b))
+            need(a, 4), need(b, 4), need((a, b), 4), need((a, b, -1.0), 4)
+        else:
+            raise NotImplementedError(
+                f"mixed derivative {n!r}: beyond pure derivatives the fused HIP kernels carry u_ab and u_aabb")
     in_keys: List[str] = []  # union of the members' inputs: the constraint's input arrays
     for mm in model_list:
         in_keys += [k for k in net_raw_vars(mm) if k not in in_keys]
-    order_second = [v for v in in_keys if v in seconds]
-    order_first = [v for v in in_keys if v in firsts and v not in seconds]
-    dir_names: List[object] = list(order_second) + sorted(mixed) + order_first
-    n2 = len(order_second) + len(mixed)
+
+    def rank(d):  # variables in input order first, then the combined directions
+        return (0, in_keys.index(d)) if isinstance(d, str) else (1, repr(d))
+
+    dir_names: List[object] = sorted(order, key=lambda d: (-order[d], rank(d)))  # higher orders first: prefix property
     n1 = len(dir_names)
+    n2 = sum(1 for d in dir_names if order[d] >= 2)
+    n3 = sum(1 for d in dir_names if order[d] >= 3)
+    n4 = sum(1 for d in dir_names if order[d] >= 4)
     choice = None
-    for (a, b) in _INSTANTIATED:
-        if a >= n1 and b >= n2 and (choice is None or (a, b) < choice):
-            choice = (a, b)
+    for c in _INSTANTIATED:
+        if c[0] >= n1 and c[1] >= n2 and c[2] >= n3 and c[3] >= n4 and (choice is None or (c[2:], c[:2]) < (choice[2:], choice[:2])):
+            choice = c
     if choice is None:
-        raise NotImplementedError(f"derivative set with {n1} directions / {n2} second-order streams exceeds the "
-                                  f"instantiated kernels {_INSTANTIATED}")
-    # second-order streams are the first n2 directions: keep that prefix, pad with zero directions after it
+        raise NotImplementedError(f"derivative set with {n1} directions / {n2} second / {n3} third / {n4} fourth-order "
+                                  f"streams exceeds the instantiated kernels {_INSTANTIATED}")
     dirs_vec: List[List[float]] = []
     for d in dir_names:
         v = [0.0] * len(in_keys)
         if isinstance(d, tuple):
             v[in_keys.index(d[0])] = 1.0
-            v[in_keys.index(d[1])] = 1.0
+            v[in_keys.index(d[1])] = float(d[2]) if len(d) > 2 else 1.0
         else:
             v[in_keys.index(d)] = 1.0
         dirs_vec.append(v)
-    n1p, n2p = choice
-    if n2p > n2:
-        # more second-order streams requested than needed: they must come from the FIRST directions, so
-        # move first-order-only directions in front of the zero padding (their second streams are unused)
-        pass
-    while len(dirs_vec) < n1p:
+    n1p, n2p, n3p, n4p = choice
+    while len(dirs_vec) < n1p:  # padding directions are zero vectors: their streams vanish identically
         dirs_vec.append([0.0] * len(in_keys))
-    streams = hp.StreamSpec(dirs_vec, n2p)
+    streams = hp.StreamSpec(dirs_vec, n2p, n3p, n4p)
     S = streams.S
     dir_index = {d: i for i, d in enumerate(dir_names)}
 
@@ -405,13 +425,14 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             for k in mm.input_keys:
                 phi = feats[k]
                 rows_k = [phi] + [Sym.const(0.0) if d is None else directional(phi, d, 1) for d in padded]
-                rows_k += [Sym.const(0.0) if d is None else directional(phi, d, 2) for d in padded[:n2p]]
+                for kk, npk in ((2, n2p), (3, n3p), (4, n4p)):
+                    rows_k += [Sym.const(0.0) if d is None else directional(phi, d, kk) for d in padded[:npk]]
                 blocks.append(rows_k)
             pre_nets[id(mm)] = blocks
-            spec = hp.StreamSpec([[0.0] * len(mm.input_keys) for _ in range(n1p)], n2p)
+            spec = hp.StreamSpec([[0.0] * len(mm.input_keys) for _ in range(n1p)], n2p, n3p, n4p)
         else:
             idx = [in_keys.index(k) for k in mm.input_keys]
-            spec = hp.StreamSpec([[v[j] for j in idx] for v in dirs_vec], n2p)
+            spec = hp.StreamSpec([[v[j] for j in idx] for v in dirs_vec], n2p, n3p, n4p)
         nets.append((mm, spec, rows, idx))
         row0[id(mm)] = rows
         rows += len(mm.output_keys) * S
@@ -464,15 +485,27 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             elif len(n.dirs) == 1:
                 val[id(n)] = prog.ld_u(c * S + 1 + dir_index[n.dirs[0]])
             else:
-                a, b = n.dirs
-                if a == b:
-                    val[id(n)] = prog.ld_u(c * S + 1 + n1p + dir_index[a])
-                else:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
-                    sab = prog.ld_u(c * S + 1 + n1p + dir_index[(a, b)])
-                    sa = prog.ld_u(c * S + 1 + n1p + dir_index[a])
-                    sb = prog.ld_u(c * S + 1 + n1p + dir_index[b])
+                base = {2: 1 + n1p, 3: 1 + n1p + n2p, 4: 1 + n1p + n2p + n3p}[len(n.dirs)]
+                vs = sorted(set(n.dirs))
+                if len(vs) == 1:
+                    val[id(n)] = prog.ld_u(c * S + base + dir_index[vs[0]])
+                elif len(n.dirs) == 2:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
+                    a, b = n.dirs
+                    sab = prog.ld_u(c * S + base + dir_index[(a, b)])
+                    sa = prog.ld_u(c * S + base + dir_index[a])
+                    sb = prog.ld_u(c * S + base + dir_index[b])
                     t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, sab, sa), sb)
                     val[id(n)] = prog.op(L.OP_MUL, prog.const(0.5), t)
+                else:  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
+                    a, b = vs
+                    sp_ = prog.ld_u(c * S + base + dir_index[(a, b)])
+                    sm_ = prog.ld_u(c * S + base + dir_index[(a, b, -1.0)])
+                    sa = prog.ld_u(c * S + base + dir_index[a])
+                    sb = prog.ld_u(c * S + base + dir_index[b])
+                    two = prog.const(2.0)
+                    t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, prog.op(L.OP_ADD, sp_, sm_), prog.op(L.OP_MUL, two, sa)),
+                                prog.op(L.OP_MUL, two, sb))
+                    val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 12.0), t)
         else:
             if n.op in _BINARY_OPS:
                 val[id(n)] = prog.op(_BINARY_OPS[n.op], val[id(n.args[0])], val[id(n.args[1])])

@@ -47,10 +47,12 @@ class StreamSpec:
 
     dirs: List[List[float]]
     n2: int
+    n3: int = 0  # third-order streams along dirs[:n3]  (n3 <= n2)
+    n4: int = 0  # fourth-order streams along dirs[:n4] (n4 <= n3)
 
     @property
     def S(self) -> int:
-        return 1 + len(self.dirs) + self.n2
+        return 1 + len(self.dirs) + self.n2 + self.n3 + self.n4
 
 
 @dataclass
@@ -70,7 +72,7 @@ class NetLayout:
     def desc(self, streams: StreamSpec) -> L.MlpDesc:
         return L.make_mlp_desc(self.d_raw, self.n_hidden, self.width, self.d_out, self.activation,
                                self.skip_connection, streams.dirs, streams.n2, self.embed, self.omega,
-                               self.fourier_half)
+                               self.fourier_half, getattr(streams, "n3", 0), getattr(streams, "n4", 0))
 
     @property
     def d0(self) -> int:
@@ -120,7 +122,7 @@ def taylor_fwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Ten
     n = inputs[0].numel() if n is None else n
     _require_device(params)
     _chk_f32(params, U, *inputs)
-    assert U.numel() == desc.d_out * (1 + desc.n1 + desc.n2) * n
+    assert U.numel() == desc.d_out * (1 + desc.n1 + desc.n2 + desc.n3 + desc.n4) * n
     ptrs = L.ptr_array([t.data_ptr() for t in inputs])
     L.check(L.lib().ppsci_taylor_fwd(C.byref(desc), _p(params), n, ptrs, _p(U), _p(stash), _stream_ptr(params)))
 

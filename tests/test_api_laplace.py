@@ -151,3 +151,55 @@ def test_update_freq_accumulates_gradients(tmp_path):
     got = model.flat_params.cpu().numpy().astype(np.float64)
     assert np.abs(got - p).max() < 5e-6
     assert optimizer.t == 3
+
+
+def test_expression_solver_surface(tmp_path):
+    """ppsci.utils.expression.ExpressionSolver (expression.py:60-222): train_forward / eval_forward / visu_forward with
+    the reference's arguments and return structure, against the oracle's restatement of the same loop."""
+    from ppsci.utils.expression import ExpressionSolver
+
+    net = T.make_net(2, [20, 20, 20], 1, bias_scale=0.1)
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 3, 20, "tanh")
+    set_model_weights(model, net)
+    eq = ppsci.equation.Laplace(2)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (40, 2)).astype(np.float32)
+    Xb = rng.uniform(0, 1, (12, 2)).astype(np.float32)
+    lab_b = rng.standard_normal((12, 1)).astype(np.float32)
+    inputs = ({"x": X[:, :1], "y": X[:, 1:]}, {"x": Xb[:, :1], "y": Xb[:, 1:]})
+    labels = ({"laplace": np.zeros((40, 1), np.float32)}, {"u": lab_b})
+    weights = ({}, {})
+    exprs = (eq.equations, {"u": lambda out: out["u"]})
+
+    class C:
+        def __init__(self, loss):
+            self.loss = loss
+
+    csts = {"EQ": C(ppsci.loss.MSELoss("sum")), "BC": C(ppsci.loss.MSELoss("mean"))}
+    es = ExpressionSolver()
+    with pytest.raises(NotImplementedError):
+        es.forward()
+    losses_all, losses_cst = es.train_forward(exprs, inputs, model, csts, labels, weights)
+    grad = es.backward()
+    omodel = R.MLP(("x", "y"), ("u",), net.astype(np.float32).astype(np.float64))
+    ocs = [dict(name="EQ", input={k: v.astype(np.float64) for k, v in inputs[0].items()},
+                exprs={k: R.lambdify(e, omodel) for k, e in R.laplace_exprs(2).items()},
+                label={"laplace": np.zeros((40, 1))}, reduction="sum"),
+           dict(name="BC", input={k: v.astype(np.float64) for k, v in inputs[1].items()}, exprs={"u": lambda d: d["u"]},
+                label={"u": lab_b.astype(np.float64)}, reduction="mean")]
+    total, olosses, og, outs = R.loss_and_grads(omodel, ocs)
+    assert set(losses_all) == {"laplace", "u"} and set(losses_cst) == {"EQ", "BC"}
+    assert float(losses_all["laplace"]) == pytest.approx(olosses["laplace"], rel=3e-5)
+    assert float(losses_all["u"]) == pytest.approx(olosses["u"], rel=3e-5)
+    assert losses_cst["EQ"] == pytest.approx(olosses["laplace"], rel=3e-5)
+    assert rel(grad.cpu().numpy(), og) < 5e-5
+    # second call, same signature: the compiled constraint is reused with the new batch
+    inputs2 = ({"x": X[::-1, :1].copy(), "y": X[::-1, 1:].copy()}, inputs[1])
+    l2, _ = es.train_forward(exprs, inputs2, model, csts, labels, weights)
+    assert float(l2["laplace"]) == pytest.approx(float(losses_all["laplace"]), rel=1e-5) and len(es._cache) == 2
+    out, vloss = es.eval_forward(exprs[1], inputs[1], model, C(ppsci.loss.MSELoss("mean")), labels[1], {})
+    assert rel(out["u"].cpu().numpy(), outs[1]["u"].detach().numpy()) < 5e-6
+    assert float(vloss["u"]) == pytest.approx(olosses["u"], rel=3e-5)
+    vis = es.visu_forward(eq.equations, inputs[0], model)
+    assert rel(vis["laplace"].cpu().numpy(), outs[0]["laplace"].detach().numpy()) < 1e-5
+    assert set(es.visu_forward(None, inputs[0], model)) == {"u"}

@@ -278,8 +278,10 @@ def test_autodiff_errors_follow_reference():
         jacobian(out["u"], x, i=1)
     with pytest.raises(ValueError):
         hessian(out["u"], x, component=0)
+    third = jacobian(hessian(out["u"], x), x)  # orders 3 and 4 are carried by the kernels' higher-order streams
+    assert repr(third) == "u__x__x__x" and repr(jacobian(third, x)) == "u__x__x__x__x"
     with pytest.raises(NotImplementedError):
-        jacobian(hessian(out["u"], x), x)  # third order
+        jacobian(jacobian(third, x), x)  # fifth order
     with pytest.raises(TypeError):
         jacobian(out["u"], torch.zeros(3, 1))
     ppsci.autodiff.clear()
