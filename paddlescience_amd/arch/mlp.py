@@ -100,8 +100,15 @@ class MLP(Arch):
             raise ValueError(f"hidden_size should be list of int or int, but got {type(hidden_size)}")
         if weight_norm:
             random_weight = None  # mlp.py:239-249: weight_norm is tested first
-        if input_dim is not None or output_dim is not None:
-            raise NotImplementedError("input_dim / output_dim overrides are not supported on the HIP path")
+        # mlp.py:217-218, :264-272: input_dim / output_dim replace len(input_keys) / len(output_keys) as the first / last
+        # layer's width, for keys that carry multi-column tensors.  Here every key is one [N] column of the SoA batch
+        # (base.py:78-148 concat / split), so only the values that agree with the key counts are meaningful.
+        if input_dim is not None and int(input_dim) != len(self.input_keys):
+            raise NotImplementedError(f"input_dim={input_dim} with {len(self.input_keys)} input key(s): multi-column "
+                                      "inputs are not supported on the HIP path (give one key per column)")
+        if output_dim is not None and int(output_dim) != len(self.output_keys):
+            raise NotImplementedError(f"output_dim={output_dim} with {len(self.output_keys)} output key(s): multi-column "
+                                      "outputs are not supported on the HIP path (give one key per column)")
         if len(set(hidden)) != 1:
             raise NotImplementedError("the fused HIP kernels need one width for all hidden layers")
         self.activation = act_mod.get_activation(activation)

@@ -1,5 +1,6 @@
 from . import lr_scheduler  # noqa: F401
-from .optimizer import LBFGS, SGD, Adam, AdamW, Momentum, OptimizerList, RMSProp  # noqa: F401
+from .optimizer import (LBFGS, SGD, Adam, AdamW, ClipGradByGlobalNorm, ClipGradByNorm, ClipGradByValue, Momentum,  # noqa: F401
+                        OptimizerList, RMSProp)
 
 __all__ = ["Adam", "AdamW", "SGD", "Momentum", "RMSProp", "LBFGS", "OptimizerList", "lr_scheduler", "build_optimizer",
            "build_lr_scheduler"]

@@ -2,7 +2,8 @@
 (/root/reference/ppsci/optimizer/optimizer.py:39-495).  Adam (:179-248): a factory called with the
 model(s); the returned object owns the Adam moments and performs the fused HIP update on the model's
 flat parameter buffer (paddle.optimizer.Adam semantics, beta1=0.9 beta2=0.999 epsilon=1e-8).
-weight_decay / grad_clip / amsgrad / lazy_mode of the reference signature are rejected when set."""
+`weight_decay` (a float: paddle's L2Decay(coeff), added to the gradient) and `grad_clip` (the ClipGradBy* classes below,
+stand-ins for paddle.nn.ClipGradBy*) are honoured; amsgrad / lazy_mode of the reference signature are rejected when set."""
 from __future__ import annotations
 
 from typing import Optional, Union
@@ -24,7 +25,57 @@ def _get_scheduler(state: dict, lr) -> None:
         lr.set_state_dict({"last_epoch": int(state["lr_last_epoch"]), "last_lr": float(state["lr_last_lr"])})
 
 
+class ClipGradByValue:
+    """paddle.nn.ClipGradByValue(max, min=None): g <- clip(g, min, max), min defaults to -max."""
+
+    def __init__(self, max: float, min: Optional[float] = None):  # noqa: A002
+        self.max, self.min = float(max), float(-max if min is None else min)
+
+    def __call__(self, model, grad: torch.Tensor) -> torch.Tensor:
+        return grad.clamp_(self.min, self.max)
+
+
+class ClipGradByNorm:
+    """paddle.nn.ClipGradByNorm(clip_norm): every parameter TENSOR's gradient is rescaled to at most clip_norm."""
+
+    def __init__(self, clip_norm: float):
+        self.clip_norm = float(clip_norm)
+
+    def __call__(self, model, grad: torch.Tensor) -> torch.Tensor:
+        base = model.flat_params.storage_offset()
+        for p in model.parameters():  # views of the flat buffer: the gradient has the same layout
+            o = p.storage_offset() - base
+            g = grad[o:o + p.numel()]
+            nrm = torch.linalg.vector_norm(g)
+            g.mul_(torch.clamp(self.clip_norm / torch.clamp(nrm, min=1e-30), max=1.0))
+        return grad
+
+
+class ClipGradByGlobalNorm:
+    """paddle.nn.ClipGradByGlobalNorm(clip_norm): g <- g * clip_norm / max(||g||_2 over all parameters, clip_norm)."""
+
+    def __init__(self, clip_norm: float):
+        self.clip_norm = float(clip_norm)
+
+    def __call__(self, model, grad: torch.Tensor) -> torch.Tensor:
+        nrm = torch.linalg.vector_norm(grad)
+        return grad.mul_(self.clip_norm / torch.clamp(nrm, min=self.clip_norm))
+
+
+def _clip(grad_clip, model, grad: torch.Tensor, grad_scale: float) -> torch.Tensor:
+    """Clipping acts on the gradient the optimizer would see (after the data-parallel / accumulation scale)."""
+    if grad_clip is None:
+        return grad
+    if grad_scale != 1.0:
+        grad = grad * grad_scale
+    else:
+        grad = grad.clone()
+    return grad_clip(model, grad)
+
+
 class _AdamState:
+    l2, grad_clip = 0.0, None
+
     def __init__(self, model, learning_rate, beta1, beta2, epsilon):
         self.model = model
         self._lr = learning_rate
@@ -43,8 +94,18 @@ class _AdamState:
 
     def step(self, grad: torch.Tensor, grad_scale: float = 1.0):
         self.t += 1
-        hp.adam_step(self.model.flat_params, grad, self.m, self.v, self.get_lr(), self.t, self.beta1, self.beta2,
-                     self.epsilon, grad_scale)
+        if self.grad_clip is not None:
+            grad, grad_scale = _clip(self.grad_clip, self.model, grad, grad_scale), 1.0
+        if self.l2 != 0.0:
+            # paddle Adam(weight_decay=c): L2Decay, g += c * p before the moments -- the fused kernel's l2 term with
+            # the decoupled-decay factor of its AdamW branch set to 1
+            c2 = (1.0 - self.beta2 ** self.t) ** 0.5
+            lr_t = self.get_lr() * c2 / (1.0 - self.beta1 ** self.t)
+            hp.optim_step(hp.OPT_ADAMW, self.model.flat_params, grad, [self.m, self.v],
+                          [lr_t, grad_scale, self.l2, self.beta1, self.epsilon * c2, 1.0, self.beta2])
+        else:
+            hp.adam_step(self.model.flat_params, grad, self.m, self.v, self.get_lr(), self.t, self.beta1, self.beta2,
+                         self.epsilon, grad_scale)
 
         if self.eq_store is not None:  # the learnable equation parameters: same rule, their own moments
             hp.adam_step(self.eq_store.values, self.eq_store.grad, self.eq_m, self.eq_v, self.get_lr(), self.t,
@@ -86,9 +147,10 @@ class Adam:
     def __init__(self, learning_rate: Union[float, "lr_scheduler._Scheduler"] = 1e-3, beta1: float = 0.9,
                  beta2: float = 0.999, epsilon: float = 1e-8, weight_decay=None, grad_clip=None, lazy_mode: bool = False,
                  amsgrad: bool = False):
-        if weight_decay is not None or grad_clip is not None or lazy_mode or amsgrad:
-            raise NotImplementedError("weight_decay / grad_clip / lazy_mode / amsgrad have no fused HIP kernel yet")
+        if lazy_mode or amsgrad:
+            raise NotImplementedError("lazy_mode / amsgrad have no fused HIP kernel yet")
         self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+        self.l2, self.grad_clip = _l2(weight_decay), grad_clip
 
     def __call__(self, model_list) -> _AdamState:
         """`Adam(lr)(model)` or, for inverse problems, `Adam(lr)((model,) + tuple(equation.values()))`
@@ -101,6 +163,7 @@ class Adam:
                 raise NotImplementedError("one network per optimizer on the fused HIP path")
             model_list = nets[0]
         st = _AdamState(model_list, self.learning_rate, self.beta1, self.beta2, self.epsilon)
+        st.l2, st.grad_clip = self.l2, self.grad_clip
         if any(e.learnable_parameters for e in eqs):
             st.attach_equation_parameters()
         return st
@@ -127,6 +190,12 @@ class _FusedState:
 
     kind = hp.OPT_SGD
     n_states = 0
+    grad_clip = None
+
+    def _pre(self, grad, grad_scale):
+        if self.grad_clip is None:
+            return grad, grad_scale
+        return _clip(self.grad_clip, self.model, grad, grad_scale), 1.0
 
     def __init__(self, model, learning_rate):
         self.model = model
@@ -169,6 +238,7 @@ class _SGDState(_FusedState):
 
     def step(self, grad, grad_scale: float = 1.0):
         self.t += 1
+        grad, grad_scale = self._pre(grad, grad_scale)
         hp.optim_step(hp.OPT_SGD, self.model.flat_params, grad, [], [self.get_lr(), grad_scale, self.l2])
 
 
@@ -181,6 +251,7 @@ class _MomentumState(_FusedState):
 
     def step(self, grad, grad_scale: float = 1.0):
         self.t += 1
+        grad, grad_scale = self._pre(grad, grad_scale)
         hp.optim_step(hp.OPT_MOMENTUM, self.model.flat_params, grad, self.states,
                       [self.get_lr(), grad_scale, self.l2, self.momentum], self.nesterov)
 
@@ -194,6 +265,7 @@ class _RMSPropState(_FusedState):
 
     def step(self, grad, grad_scale: float = 1.0):
         self.t += 1
+        grad, grad_scale = self._pre(grad, grad_scale)
         hp.optim_step(hp.OPT_RMSPROP, self.model.flat_params, grad, self.states,
                       [self.get_lr(), grad_scale, self.l2, self.rho, self.epsilon, self.momentum], self.centered)
 
@@ -215,6 +287,7 @@ class _AdamWState(_FusedState):
 
     def step(self, grad, grad_scale: float = 1.0):
         self.t += 1
+        grad, grad_scale = self._pre(grad, grad_scale)
         lr = self.get_lr()
         c2 = (1.0 - self.beta2 ** self.t) ** 0.5
         lr_t = lr * c2 / (1.0 - self.beta1 ** self.t)
@@ -224,46 +297,53 @@ class _AdamWState(_FusedState):
 
 class SGD:
     def __init__(self, learning_rate=0.001, weight_decay=None, grad_clip=None):
-        if grad_clip is not None:
-            raise NotImplementedError("grad_clip has no fused HIP kernel yet")
-        self.learning_rate, self.l2 = learning_rate, _l2(weight_decay)
+        self.learning_rate, self.l2, self.grad_clip = learning_rate, _l2(weight_decay), grad_clip
 
     def __call__(self, model_list):
-        return _SGDState(_single(model_list), self.learning_rate, self.l2)
+        st = _SGDState(_single(model_list), self.learning_rate, self.l2)
+        st.grad_clip = self.grad_clip
+        return st
 
 
 class Momentum:
     def __init__(self, learning_rate, momentum: float, weight_decay=None, grad_clip=None, use_nesterov: bool = False,
                  no_weight_decay_name: Optional[str] = None):
-        if grad_clip is not None or no_weight_decay_name:
-            raise NotImplementedError("grad_clip / no_weight_decay_name have no fused HIP kernel yet")
+        if no_weight_decay_name:
+            raise NotImplementedError("no_weight_decay_name (per-parameter decay masks) has no fused HIP kernel yet")
         self.learning_rate, self.momentum, self.l2, self.nesterov = learning_rate, momentum, _l2(weight_decay), use_nesterov
+        self.grad_clip = grad_clip
 
     def __call__(self, model_list):
-        return _MomentumState(_single(model_list), self.learning_rate, self.momentum, self.l2, self.nesterov)
+        st = _MomentumState(_single(model_list), self.learning_rate, self.momentum, self.l2, self.nesterov)
+        st.grad_clip = self.grad_clip
+        return st
 
 
 class RMSProp:
     def __init__(self, learning_rate, rho: float = 0.95, epsilon: float = 1e-6, momentum: float = 0.0, weight_decay=None,
                  grad_clip=None, centered: bool = False):
-        if grad_clip is not None:
-            raise NotImplementedError("grad_clip has no fused HIP kernel yet")
         self.args = (learning_rate, rho, epsilon, momentum, _l2(weight_decay), centered)
+        self.grad_clip = grad_clip
 
     def __call__(self, model_list):
-        return _RMSPropState(_single(model_list), *self.args)
+        st = _RMSPropState(_single(model_list), *self.args)
+        st.grad_clip = self.grad_clip
+        return st
 
 
 class AdamW:
     def __init__(self, learning_rate=0.001, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-8,
                  weight_decay: float = 0.001, grad_clip=None, no_weight_decay_name: Optional[str] = None,
                  one_dim_param_no_weight_decay: bool = False, amsgrad: bool = False):
-        if grad_clip is not None or no_weight_decay_name or one_dim_param_no_weight_decay or amsgrad:
-            raise NotImplementedError("grad_clip / per-parameter weight-decay masks / amsgrad have no fused HIP kernel yet")
+        if no_weight_decay_name or one_dim_param_no_weight_decay or amsgrad:
+            raise NotImplementedError("per-parameter weight-decay masks / amsgrad have no fused HIP kernel yet")
         self.args = (learning_rate, beta1, beta2, epsilon, weight_decay)
+        self.grad_clip = grad_clip
 
     def __call__(self, model_list):
-        return _AdamWState(_single(model_list), *self.args)
+        st = _AdamWState(_single(model_list), *self.args)
+        st.grad_clip = self.grad_clip
+        return st
 
 
 class _LBFGSState:
@@ -318,5 +398,58 @@ class LBFGS:
 
 
 class OptimizerList:
+    """optimizer.py:498-559: several optimizers, one per model.  On the flat-buffer path the models are the members of
+    ONE ppsci.arch.ModelList (whose parameters live in one buffer): `step(grad)` hands every optimizer its member's
+    slice of the flat gradient.  LBFGS is refused like in the reference."""
+
     def __init__(self, optimizer_list):
-        raise NotImplementedError("OptimizerList (several optimizers over model groups) is not supported on the flat-buffer path")
+        self._opt_list = tuple(optimizer_list)
+        if any(getattr(o, "is_lbfgs", False) for o in self._opt_list):
+            raise ValueError("LBFGS is not supported in OptimizerList yet.")
+
+    def _slice(self, opt, grad: torch.Tensor) -> torch.Tensor:
+        m = opt.model
+        n = m.flat_params.numel()
+        if hasattr(m, "_train_offset"):
+            return grad[m._train_offset:m._train_offset + n]
+        if len(self._opt_list) == 1 and grad.numel() == n:
+            return grad
+        raise NotImplementedError("OptimizerList: the optimizers' models must be members of one ModelList")
+
+    def step(self, grad: torch.Tensor, grad_scale: float = 1.0):
+        for opt in self._opt_list:
+            opt.step(self._slice(opt, grad), grad_scale)
+
+    def clear_grad(self):
+        for opt in self._opt_list:
+            opt.clear_grad()
+
+    def get_lr(self) -> float:
+        """Return learning rate of first optimizer"""
+        return self._opt_list[0].get_lr()
+
+    @property
+    def t(self) -> int:
+        return self._opt_list[0].t
+
+    def set_state_dict(self, state_dicts):
+        if isinstance(state_dicts, dict):  # checkpoint form: keys prefixed "opt<i>."
+            state_dicts = [{k.split(".", 1)[1]: v for k, v in state_dicts.items() if k.startswith(f"opt{i}.")}
+                           for i in range(len(self._opt_list))]
+        for i, opt in enumerate(self._opt_list):
+            opt.set_state_dict(state_dicts[i])
+
+    def state_dict(self):
+        return [opt.state_dict() for opt in self._opt_list]
+
+    def __len__(self) -> int:
+        return len(self._opt_list)
+
+    def __getitem__(self, idx):
+        return self._opt_list[idx]
+
+    def __setitem__(self, idx, opt):
+        raise NotImplementedError("Can not modify any item in OptimizerList.")
+
+    def __iter__(self):
+        yield from iter(self._opt_list)

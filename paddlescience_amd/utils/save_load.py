@@ -137,8 +137,10 @@ def save_checkpoint(model, optimizer, metric: Optional[Dict[str, float]] = None,
     if optimizer is not None:
         # the optimizer's WHOLE state (paddle.save(optimizer.state_dict()), save_load.py:246): every moment / buffer
         # tensor, the step count, the moments of learnable equation parameters and the LR scheduler's position
-        arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-                  for k, v in optimizer.state_dict().items()}
+        st = optimizer.state_dict()
+        if isinstance(st, list):  # OptimizerList: one state dict per optimizer
+            st = {f"opt{i}.{k}": v for i, d in enumerate(st) for k, v in d.items()}
+        arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in st.items()}
         if aggregator is not None and getattr(aggregator, "should_persist", False):
             for k, v in aggregator.state_dict().items():  # GradNorm / NTK weights (save_load.py:277-279, .pdagg)
                 arrays["agg_" + k] = np.asarray(v)

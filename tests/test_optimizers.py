@@ -101,3 +101,57 @@ def test_remaining_lr_schedules_closed_forms():
     lst = S.SchedulerList((S.ConstLR(1, 1, 0.3)(), S.ConstLR(1, 1, 0.7)()))
     lst.step()
     assert lst.get_lr() == pytest.approx(0.3)
+
+
+def test_adam_weight_decay_grad_clip_and_optimizer_list(dev):
+    """Adam(weight_decay=c) is paddle's L2Decay (g += c p before the moments); grad_clip follows paddle.nn.ClipGradBy*;
+    OptimizerList steps every member of a ModelList with its own optimizer on its slice of the flat gradient."""
+    import ppsci
+    from ppsci.optimizer import ClipGradByGlobalNorm, ClipGradByNorm, ClipGradByValue
+
+    rng = np.random.default_rng(0)
+
+    def adam_ref(p, g, lr, t=1, b1=0.9, b2=0.999, eps=1e-8):
+        m, v = (1 - b1) * g, (1 - b2) * g * g
+        return p - lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t) * m / (np.sqrt(v) + eps * np.sqrt(1 - b2 ** t))
+
+    model = ppsci.arch.MLP(("x",), ("u",), 2, 16, "tanh")
+    p0 = model.flat_params.cpu().numpy().astype(np.float64)
+    g = rng.standard_normal(p0.size).astype(np.float32)
+    gt = torch.tensor(g).to(model.flat_params.device)
+    opt = ppsci.optimizer.Adam(1e-2, weight_decay=0.1)(model)
+    opt.step(gt)
+    np.testing.assert_allclose(model.flat_params.cpu().numpy(), adam_ref(p0, g + 0.1 * p0, 1e-2), rtol=2e-5, atol=1e-7)
+
+    for clip, fn in [(ClipGradByValue(0.3), lambda a: np.clip(a, -0.3, 0.3)),
+                     (ClipGradByGlobalNorm(0.5), lambda a: a * 0.5 / max(np.linalg.norm(a), 0.5))]:
+        model = ppsci.arch.MLP(("x",), ("u",), 2, 16, "tanh")
+        p0 = model.flat_params.cpu().numpy().astype(np.float64)
+        ppsci.optimizer.Adam(1e-2, grad_clip=clip)(model).step(gt)
+        np.testing.assert_allclose(model.flat_params.cpu().numpy(), adam_ref(p0, fn(g.astype(np.float64)), 1e-2),
+                                   rtol=2e-5, atol=1e-7)
+        assert np.array_equal(gt.cpu().numpy(), g)  # the caller's gradient buffer is left alone
+    model = ppsci.arch.MLP(("x",), ("u",), 2, 16, "tanh")
+    p0 = model.flat_params.cpu().numpy().astype(np.float64)
+    ppsci.optimizer.SGD(0.5, grad_clip=ClipGradByNorm(0.1))(model).step(gt)
+    want, off = p0.copy(), 0
+    for q in model.parameters():
+        n = q.numel()
+        gq = g[off:off + n].astype(np.float64)
+        want[off:off + n] -= 0.5 * gq * min(1.0, 0.1 / np.linalg.norm(gq))
+        off += n
+    np.testing.assert_allclose(model.flat_params.cpu().numpy(), want, rtol=2e-5, atol=1e-7)
+
+    m1 = ppsci.arch.MLP(("x",), ("u",), 2, 16, "tanh")
+    m2 = ppsci.arch.MLP(("x",), ("v",), 1, 8, "tanh")
+    o1, o2 = ppsci.optimizer.SGD(0.1)(m1), ppsci.optimizer.SGD(1.0)(m2)
+    both = ppsci.arch.ModelList((m1, m2))
+    opts = ppsci.optimizer.OptimizerList((o1, o2))
+    assert len(opts) == 2 and opts[1] is o2 and opts.get_lr() == 0.1
+    gb = torch.ones_like(both.flat_params)
+    a0, b0 = m1.flat_params.clone(), m2.flat_params.clone()
+    opts.step(gb)
+    np.testing.assert_allclose((a0 - m1.flat_params).cpu().numpy(), 0.1, rtol=1e-5)
+    np.testing.assert_allclose((b0 - m2.flat_params).cpu().numpy(), 1.0, rtol=1e-5)
+    with pytest.raises(ValueError):
+        ppsci.optimizer.OptimizerList((o1, ppsci.optimizer.LBFGS()(m2)))
