@@ -348,7 +348,7 @@ static int g_wide_min_nb = 8;
 extern "C" void ppsci_set_wide_min_nb(int nb) { g_wide_min_nb = nb; }
 extern "C" int ppsci_get_wide_min_nb(void) { return g_wide_min_nb; }
 static int g_bwd_accum = 1;
-extern "C" void ppsci_set_bwd_accum(int on) { g_bwd_accum = on ? 1 : 0; }
+extern "C" void ppsci_set_bwd_accum(int on) { g_bwd_accum = on; }
 extern "C" int ppsci_get_bwd_accum(void) { return g_bwd_accum; }
 
 extern "C" int ppsci_is_device_build(void) {

@@ -147,5 +147,5 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   rc = ppsci_reduce_rows(small_rows, grid, psmall, small_sum, 0, stream);
   if (rc != PPSCI_OK) return rc;
   // hidden-to-hidden matrices: fixed-order tree sum over the tiles' (or the workgroups') blocks
-  return ppsci_wgrad_reduce(a.d, a.q, a.accum ? grid : a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
+  return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
 }

@@ -6,7 +6,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "paddlescience_amd", "csrc")
-OUT = os.path.join(ROOT, "tests", "_emu_build")
+EXTRA = os.environ.get("PPSCI_EMU_EXTRA_FLAGS", "").split()  # experiment builds (e.g. -DPPSCI_WAVE_ACC) get their own directory
+OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "_".join(f.lstrip("-D") for f in EXTRA) if EXTRA else ""))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
            "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "spinn.hip", "epilogue_optim.hip"]
@@ -25,7 +26,7 @@ def build() -> str:
     lib = os.path.join(OUT, "libppsci_emu.so")
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "ppsci_hip.h"),
                                                        os.path.join(ROOT, "tests", "emu", "hip_emu.h")]
-    flags = ["-x", "c++", "-DPPSCI_EMU", "-DPPSCI_NUM_CU=4", "-O1", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+    flags = EXTRA + ["-x", "c++", "-DPPSCI_EMU", "-DPPSCI_NUM_CU=4", "-O1", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
              "-I", os.path.join(ROOT, "tests", "emu")]
 
     def one(src):

@@ -19,6 +19,9 @@ VARIANTS = {
     "noatomic": ["-DPPSCI_ABL_NOATOMIC"],
     "not2n": ["-DPPSCI_ABL_NOT2N"],
     "norowsum": ["-DPPSCI_ABL_NOROWSUM"],
+    "nobar": ["-DPPSCI_ABL_NOBAR"],
+    "norot": ["-DPPSCI_ABL_NOROT"],
+    "nobar_norot": ["-DPPSCI_ABL_NOBAR", "-DPPSCI_ABL_NOROT"],
 }
 
 
@@ -37,7 +40,8 @@ def build_variant(name, extra):
 
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(one, G.SOURCES))
-    lib = os.path.join(ROOT, "build", "variants", name + ".so")
+    os.makedirs(os.path.join(ROOT, "variants_out"), exist_ok=True)
+    lib = os.path.join(ROOT, "variants_out", name + ".so")  # travels with gpurun (build/ does not)
     subprocess.check_call([G.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return lib
 

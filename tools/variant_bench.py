@@ -36,7 +36,7 @@ def main():
                    ("NS 5x128 S5 125k", 2, 5, 128, 3, [[1.0, 0.0], [0.0, 1.0]], 2, 125_000)]
     if "--wide" in sys.argv:  # width 256 (feature-split kernels): one tile per CU, half a wave of tiles, full load
         shapes = [(f"AC 4x256 S4 {n}", 2, 4, 256, 1, [[0.0, 1.0], [1.0, 0.0]], 1, n) for n in (4096, 100_000)]
-    libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "*.so")))
+    libs = sorted(glob.glob(os.path.join(ROOT, "variants_out", "*.so")))
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     if only:
         libs = [p for p in libs if os.path.basename(p)[:-3] in only[0].split(",")]
@@ -58,10 +58,12 @@ def main():
             gp = torch.zeros((rows, lay.n_params), device=dev)
             f_med, f_min = timeit(lambda: hp.taylor_fwd(desc, params, xs, U, stash))
             fn_med, fn_min = timeit(lambda: hp.taylor_fwd(desc, params, xs, U, None))
+            grads = {}
             for accum in (1, 0):
                 L._lib.ppsci_set_bwd_accum(accum)
-                ws = torch.zeros(max(4, hp.bwd_workspace_bytes(desc, N) // 4), device=dev)
+                ws = torch.full((max(4, hp.bwd_workspace_bytes(desc, N) // 4),), float("nan"), device=dev)
                 b_med, b_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
+                grads[accum] = gp.clone()
                 L._lib.ppsci_set_bwd_main_only(1)
                 m_med, m_min = timeit(lambda: hp.taylor_bwd(desc, params, xs, Ubar, stash, ws, gp))
                 L._lib.ppsci_set_bwd_main_only(0)
@@ -85,6 +87,8 @@ def main():
                                   "fwd_nostash_ms": round(fn_med, 4), "bwd_ms": round(b_med, 4),
                                   "bwd_min_ms": round(b_min, 4), "bwd_main_ms": round(m_med, 4)}), flush=True)
             L._lib.ppsci_set_bwd_accum(1)
+            print(json.dumps({"variant": name, "grad_rel_diff_between_modes":
+                              float((grads[1] - grads[0]).norm() / grads[1].norm())}), flush=True)
           except Exception as e:  # noqa: BLE001
             print(json.dumps({"variant": name, "shape": label, "error": str(e)[:100]}), flush=True)
 
