@@ -1,17 +1,17 @@
-"""TFNO-2D on Darcy flow, after /root/reference/examples/neuraloperator/train_tfno.py (+ conf/tfno_darcyflow_pretrain.yaml).
+"""TFNO-2D on Darcy flow, after /root/reference/examples/neuraloperator/train_tfno.py (+ conf/tfno_darcyflow_pretrain.yaml):
+DarcyFlowDataset (positional-encoding channels, unit-Gaussian output encoding) -> TFNO2dNet -> LpLoss_train / H1Loss_train,
+validated at 16x16 and 32x32 with the H1 / L2 metrics.
 
-The reference reads `darcy_train_16.npy` / `darcy_test_{16,32}.npy`; there is no network here, so when
-`data_dir` does not hold them a synthetic stand-in of the same shapes is generated (smoothed random
-permeability field a(x) -> a few Jacobi sweeps of -div(a grad u) = 1), enough to exercise the whole path:
-positional-encoding channels, TFNO2dNet through the HIP spectral kernel, FunctionalLoss, validators.
+The reference reads `darcy_train_16.npy` / `darcy_test_{16,32}.npy`; there is no network here, so when `data_dir` does not
+hold them, files of the same format with a synthetic stand-in are written first (smoothed random two-phase permeability
+a(x) -> a few Jacobi sweeps of -div(a grad u) = 1): enough to exercise the whole path.
 
-    python examples/tfno_darcyflow.py epochs=5 resolution=16
+    python examples/tfno_darcyflow.py epochs=5
 """
 import os
 import sys
 
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ppsci  # noqa: E402
@@ -30,58 +30,48 @@ def synthetic_darcy(n, res, seed):
     for _ in range(200):  # Jacobi sweeps, zero Dirichlet boundary
         up = np.pad(u, ((0, 0), (1, 1), (1, 1)))
         u = (up[:, :-2, 1:-1] + up[:, 2:, 1:-1] + up[:, 1:-1, :-2] + up[:, 1:-1, 2:] + h2 / a) / 4.0
-    return a[:, None], u[:, None].astype(np.float32)
+    return a, u.astype(np.float32)
 
 
-def with_grid(a):
-    """Positional encoding of the reference dataset (ppsci/data/dataset/darcyflow_dataset.py): x- and y-coordinate
-    channels appended to the permeability."""
-    n, _, h, w = a.shape
-    gy, gx = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
-    return np.concatenate([a, np.broadcast_to(gx, (n, 1, h, w)), np.broadcast_to(gy, (n, 1, h, w))], 1).astype(np.float32)
-
-
-def lp_loss(output_dict, label_dict, weight_dict=None):
-    """metric.LpLoss_train(d=2, p=2) of the reference example: relative L2 per sample, summed over the batch."""
-    d = (output_dict["y"] - label_dict["y"]).flatten(1)
-    return {"l2": (torch.linalg.norm(d, dim=1) / torch.linalg.norm(label_dict["y"].flatten(1), dim=1)).sum()}
-
-
-def lp_metric(output_dict, label_dict):
-    d = (output_dict["y"] - label_dict["y"]).flatten(1)
-    return {"y": (torch.linalg.norm(d, dim=1) / torch.linalg.norm(label_dict["y"].flatten(1), dim=1)).mean()}
+def ensure_data(data_dir, n_train, n_test):
+    os.makedirs(data_dir, exist_ok=True)
+    for name, n, res, seed in (("darcy_train_16", n_train, 16, 1), ("darcy_test_16", n_test, 16, 2), ("darcy_test_32", n_test, 32, 3)):
+        f = os.path.join(data_dir, name + ".npy")
+        if not os.path.exists(f):
+            logger.warning(f"{f} not found: writing a synthetic Darcy-like stand-in of the same format")
+            a, u = synthetic_darcy(n, res, seed)
+            np.save(f, {"x": a, "y": u}, allow_pickle=True)
 
 
 if __name__ == "__main__":
-    cfg = parse(dict(seed=666, output_dir="./output_tfno", data_dir="./datasets/darcyflow", epochs=10, resolution=16,
-                     n_train=256, n_test=64, batch_size=16, n_modes=16, hidden_channels=32, lifting_channels=256,
-                     projection_channels=64, n_layers=4, norm="group_norm", learning_rate=5e-3, log_freq=8))
+    cfg = parse(dict(seed=666, output_dir="./output_tfno", data_dir="./datasets/darcyflow", epochs=10, n_train=256, n_test=64,
+                     batch_size=16, n_modes=16, hidden_channels=32, lifting_channels=256, projection_channels=64, n_layers=4,
+                     norm="group_norm", learning_rate=5e-3, log_freq=8, training_loss="h1"))
     ppsci.utils.misc.set_random_seed(cfg["seed"])
     logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
-    res = cfg["resolution"]
-    f = os.path.join(cfg["data_dir"], f"darcy_train_{res}.npy")
-    if os.path.exists(f):
-        raw = np.load(f, allow_pickle=True).item()
-        a_tr, u_tr = np.asarray(raw["x"], np.float32)[:, None], np.asarray(raw["y"], np.float32)[:, None]
-        raw = np.load(os.path.join(cfg["data_dir"], f"darcy_test_{res}.npy"), allow_pickle=True).item()
-        a_te, u_te = np.asarray(raw["x"], np.float32)[:, None], np.asarray(raw["y"], np.float32)[:, None]
-    else:
-        logger.warning(f"{f} not found: using synthetic Darcy-like fields")
-        a_tr, u_tr = synthetic_darcy(cfg["n_train"], res, 1)
-        a_te, u_te = synthetic_darcy(cfg["n_test"], res, 2)
-    mu, sd = u_tr.mean(), u_tr.std() + 1e-8  # UnitGaussianNormalizer of the reference (encode_output)
-    train_cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": with_grid(a_tr)}, "label": {"y": (u_tr - mu) / sd}},
-                 "batch_size": cfg["batch_size"], "sampler": {"name": "BatchSampler", "shuffle": True, "drop_last": True}}
-    test_cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": with_grid(a_te)}, "label": {"y": (u_te - mu) / sd}},
-                "batch_size": cfg["batch_size"], "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": False}}
+    ensure_data(cfg["data_dir"], cfg["n_train"], cfg["n_test"])
+
+    def loader(split, shuffle):
+        return {"dataset": {"name": "DarcyFlowDataset", "data_dir": cfg["data_dir"], "input_keys": ("x",), "label_keys": ("y",),
+                            "train_resolution": 16, "test_resolutions": [16, 32], "grid_boundaries": [[0, 1], [0, 1]],
+                            "encode_input": False, "encode_output": True, "encoding": "channel-wise", "channel_dim": 1,
+                            "data_split": split},
+                "sampler": {"name": "BatchSampler", "drop_last": False, "shuffle": shuffle}, "batch_size": cfg["batch_size"]}
+
+    train_loss = ppsci.loss.LpLoss_train(d=2, p=2) if cfg["training_loss"] == "l2" else ppsci.loss.H1Loss_train(d=2)
+    sup = ppsci.constraint.SupervisedConstraint(loader("train", True), loss=ppsci.loss.FunctionalLoss(train_loss), name="Sup")
+    metric = {"h1": ppsci.metric.FunctionalMetric(ppsci.loss.H1Loss(d=2)), "l2": ppsci.metric.FunctionalMetric(ppsci.loss.LpLoss(d=2, p=2))}
+    validator = {
+        "Sup_Validator_16x16": ppsci.validate.SupervisedValidator(loader("test_16x16", False), ppsci.loss.FunctionalLoss(train_loss),
+                                                                  metric=metric, name="Sup_Validator_16x16"),
+        "Sup_Validator_32x32": ppsci.validate.SupervisedValidator(loader("test_32x32", False), ppsci.loss.FunctionalLoss(train_loss),
+                                                                  metric=metric, name="Sup_Validator_32x32"),
+    }
     model = ppsci.arch.TFNO2dNet(("x",), ("y",), cfg["n_modes"], cfg["n_modes"], cfg["hidden_channels"], 3, 1,
                                  cfg["lifting_channels"], cfg["projection_channels"], cfg["n_layers"], norm=cfg["norm"])
-    sup = ppsci.constraint.SupervisedConstraint(train_cfg, ppsci.loss.FunctionalLoss(lp_loss), name="Sup")
-    val = ppsci.validate.SupervisedValidator(test_cfg, ppsci.loss.FunctionalLoss(lp_loss),
-                                             metric={"l2": ppsci.metric.FunctionalMetric(lp_metric)}, name="Sup_Validator")
     opt = ppsci.optimizer.Adam(cfg["learning_rate"])(model)
     solver = ppsci.solver.Solver(model, {sup.name: sup}, cfg["output_dir"], opt, epochs=cfg["epochs"],
                                  iters_per_epoch=len(sup.data_loader), log_freq=cfg["log_freq"], eval_during_train=True,
-                                 eval_freq=max(1, cfg["epochs"] // 2), validator={val.name: val})
+                                 eval_freq=max(1, cfg["epochs"] // 2), validator=validator)
     solver.train()
     solver.eval()

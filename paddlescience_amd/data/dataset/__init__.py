@@ -1,8 +1,9 @@
 import copy
 
 from .array_dataset import ContinuousNamedArrayDataset, IterableNamedArrayDataset, NamedArrayDataset  # noqa: F401
+from .darcyflow_dataset import DarcyFlowDataset  # noqa: F401
 
-__all__ = ["NamedArrayDataset", "IterableNamedArrayDataset", "ContinuousNamedArrayDataset", "build_dataset"]
+__all__ = ["NamedArrayDataset", "IterableNamedArrayDataset", "ContinuousNamedArrayDataset", "DarcyFlowDataset", "build_dataset"]
 
 
 def build_dataset(cfg):

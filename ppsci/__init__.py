@@ -11,6 +11,8 @@ for _name in ("arch", "autodiff", "constraint", "data", "equation", "functional"
               "utils", "validate"):
     sys.modules[f"ppsci.{_name}"] = getattr(_impl, _name)
 sys.modules["ppsci.loss.mtl"] = _impl.loss.mtl
+sys.modules["ppsci.data.dataset"] = _impl.data.dataset
+sys.modules["ppsci.data.dataset.darcyflow_dataset"] = _impl.data.dataset.darcyflow_dataset
 sys.modules["ppsci.optimizer.lr_scheduler"] = _impl.optimizer.lr_scheduler
 sys.modules["ppsci.utils.misc"] = _impl.utils.misc
 sys.modules["ppsci.utils.logger"] = _impl.utils.logger

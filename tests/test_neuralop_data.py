@@ -1,0 +1,109 @@
+"""Operator-learning data path against tests/golden/neuralop.npz -- produced by executing the REFERENCE's own
+ppsci/data/dataset/darcyflow_dataset.py and examples/neuraloperator/metric.py under the torch-backed paddle shim
+(tests/golden/make_neuralop_golden.py): DarcyFlowDataset items of every split (positional-encoding channels, unit-Gaussian
+encoders), PositionalEmbedding2D, LpLoss / H1Loss and their training variants."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ppsci
+from ppsci.data.dataset.darcyflow_dataset import DarcyFlowDataset, PositionalEmbedding2D
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "neuralop.npz"))
+
+
+@pytest.fixture()
+def darcy_dir(tmp_path):
+    for k in ("train_16", "test_16", "test_32"):
+        np.save(tmp_path / f"darcy_{k}.npy", {"x": G[f"raw/{k}/x"], "y": G[f"raw/{k}/y"]}, allow_pickle=True)
+    return str(tmp_path)
+
+
+@pytest.mark.parametrize("tag,kw", [("default", {}), ("enc_in", dict(encode_input=True))])
+def test_darcy_flow_dataset_matches_reference_run(darcy_dir, tag, kw):
+    for split in ("train", "test_16x16", "test_32x32"):
+        ds = DarcyFlowDataset(("x",), ("y",), darcy_dir, test_resolutions=[16, 32], train_resolution=16, data_split=split, **kw)
+        assert len(ds) == int(G[f"{tag}/{split}/len"])
+        for i in (0, len(ds) - 1):
+            inp, lab, w = ds[i]
+            assert inp["x"].dtype == np.float32 and inp["x"].shape == G[f"{tag}/{split}/{i}/x"].shape
+            np.testing.assert_allclose(inp["x"], G[f"{tag}/{split}/{i}/x"], rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(lab["y"], G[f"{tag}/{split}/{i}/y"], rtol=2e-5, atol=2e-6)
+        # batch-index path of this framework: a whole batch in one call equals the stacked items
+        idx = np.arange(min(3, len(ds)))
+        inp, lab, _ = ds[idx]
+        np.testing.assert_array_equal(inp["x"][2 if len(idx) > 2 else 0], ds[int(idx[-1])][0]["x"])
+    np.testing.assert_allclose(ds.output_encoder.mean, G[f"{tag}/out_mean"], rtol=1e-6)
+    np.testing.assert_allclose(ds.output_encoder.std, G[f"{tag}/out_std"], rtol=1e-5)
+    z = G["raw/test_16/y"][:2, None]
+    np.testing.assert_allclose(ds.output_encoder.decode(ds.output_encoder.encode(z.copy())), G[f"{tag}/decode"], rtol=1e-5, atol=1e-7)
+    if "encode_input" in kw:
+        np.testing.assert_allclose(ds.input_encoder.mean, G[f"{tag}/in_mean"], rtol=1e-6)
+        np.testing.assert_allclose(ds.input_encoder.std, G[f"{tag}/in_std"], rtol=1e-5)
+    with pytest.raises(ValueError):
+        DarcyFlowDataset(("x",), ("y",), darcy_dir, test_resolutions=[16, 64])
+
+
+def test_positional_embedding_2d():
+    pe = PositionalEmbedding2D([[0, 1], [-1, 1]])
+    out = pe(np.arange(60, dtype=np.float32).reshape(3, 5, 4))
+    np.testing.assert_array_equal(out, G["posenc/3x5x4"])
+    assert pe(np.zeros((2, 3, 5, 4), np.float32)).shape == (2, 5, 5, 4)
+
+
+def test_lp_and_h1_losses_match_reference_run():
+    x, y = torch.tensor(G["metric/x"]), torch.tensor(G["metric/y"])
+    L = ppsci.loss
+    cases = {"lp_d2": L.LpLoss(d=2, p=2), "lp_d2_p1_mean": L.LpLoss(d=2, p=1, reductions="mean"),
+             "lp_train_d2": L.LpLoss_train(d=2, p=2), "h1_d2": L.H1Loss(d=2),
+             "h1_d2_fix": L.H1Loss(d=2, L=1.0, fix_x_bnd=True, fix_y_bnd=True), "h1_train_d2": L.H1Loss_train(d=2)}
+    for name, fn in cases.items():
+        res = fn({"y": x}, {"y": y})
+        for k, v in res.items():
+            np.testing.assert_allclose(v.numpy(), G[f"metric/{name}/{k}"], rtol=1e-12, err_msg=f"{name}/{k}")
+    np.testing.assert_allclose(cases["lp_d2"].abs(x, y).numpy(), G["metric/lp_d2/abs"], rtol=1e-12)
+    np.testing.assert_allclose(cases["h1_d2_fix"].abs(x, y).numpy(), G["metric/h1_d2_fix/abs"], rtol=1e-12)
+    # differentiable (the FNO engine takes dL/d(output) from it)
+    xr = x.clone().requires_grad_(True)
+    cases["h1_train_d2"]({"y": xr}, {"y": y})["y"].sum().backward()
+    assert torch.isfinite(xr.grad).all() and float(xr.grad.abs().sum()) > 0
+
+
+def test_tfno_trains_on_the_darcy_dataset_end_to_end(darcy_dir, tmp_path):
+    """examples/tfno_darcyflow.py in small: DarcyFlowDataset by name -> SupervisedConstraint(FunctionalLoss(H1Loss_train))
+    -> TFNO2dNet -> Solver.train / eval with the H1 / L2 validators at both test resolutions (CPU: emulator kernels)."""
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    try:
+        ppsci.utils.misc.set_random_seed(3)
+
+        def loader(split, shuffle):
+            return {"dataset": {"name": "DarcyFlowDataset", "data_dir": darcy_dir, "input_keys": ("x",), "label_keys": ("y",),
+                                "train_resolution": 16, "test_resolutions": [16, 32], "data_split": split},
+                    "sampler": {"name": "BatchSampler", "drop_last": False, "shuffle": shuffle}, "batch_size": 3}
+
+        loss = ppsci.loss.FunctionalLoss(ppsci.loss.H1Loss_train(d=2))
+        sup = ppsci.constraint.SupervisedConstraint(loader("train", True), loss=loss, name="Sup")
+        metric = {"h1": ppsci.metric.FunctionalMetric(ppsci.loss.H1Loss(d=2)),
+                  "l2": ppsci.metric.FunctionalMetric(ppsci.loss.LpLoss(d=2, p=2))}
+        val = {n: ppsci.validate.SupervisedValidator(loader(s, False), loss, metric=metric, name=n)
+               for n, s in (("V16", "test_16x16"), ("V32", "test_32x32"))}
+        model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, 8, 3, 1, 16, 16, 2, norm="group_norm")
+        opt = ppsci.optimizer.Adam(2e-3)(model)
+        solver = ppsci.solver.Solver(model, {"Sup": sup}, str(tmp_path / "out"), opt, epochs=3, iters_per_epoch=len(sup.data_loader),
+                                     log_freq=1, validator=val)
+        first = None
+        solver.train()
+        target, group = solver.eval()
+        assert set(group) == {"V16", "V32"} and all(np.isfinite(v) for g in group.values() for v in g.values())
+        assert set(group["V16"]) == {"h1.h1", "l2.l2"}
+    finally:
+        from paddlescience_amd import _lib
+
+        _lib._inject_for_tests(None)
+        device.set_device(None)
