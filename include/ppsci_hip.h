@@ -275,6 +275,55 @@ int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const float* x_ft, c
 /* gx_ft = gout . conj(w)^T on the kept modes (NULL to skip); gw = sum_b conj(x) gout (both NULL to skip). */
 int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                               const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, void* stream);
+/* The same backward WITHOUT an autograd graph around the FFTs: ghat_ft = rfftn(dL/dy) with the forward transforms'
+ * norm.  Then dL/dx = irfftn(gx_ft) and the weight gradients carry wscale * c(my) (c = 1 on the DC / Nyquist column, 2
+ * elsewhere: the Hermitian half-spectrum; wscale = H*W for norm "forward", 1/(H*W) for "backward", 1 for "ortho").
+ * w_full = W, the width of the real grid. */
+int ppsci_spectral_conv2d_bwd_real(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                                   const float* ghat_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale,
+                                   int w_full, void* stream);
+
+/* Variants for callers that run the FFTs as raw, unscaled hipFFT calls (ppsci_fft2d_*): the result is multiplied by
+ * `scale` / `xscale` (1/(H*W): the product of the two transforms' normalisation factors, whatever `fft_norm` is), and the
+ * whole output spectrum is cleared first when zero_fill != 0 (hipFFT's C2R destroys its input, so the zeros outside the
+ * kept modes do not survive a step). */
+int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                                     float* out_ft, float scale, int zero_fill, void* stream);
+int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                          const float* w_im, const float* ghat_ft, float* gx_ft, float* gw_re, float* gw_im,
+                                          float wscale, int w_full, float xscale, int zero_fill, void* stream);
+/* Batched 2-D real FFTs on hipFFT, on `stream`, unscaled (csrc/fft.hip): rfftn / irfftn of fno_block.py:718-720, :791.
+ * r2c: [batch, H, W] -> [batch, H, W/2+1, 2]; c2r: the reverse, DESTROYING its input. */
+int ppsci_fft2d_r2c(int batch, int H, int W, const float* in, float* out, void* stream);
+int ppsci_fft2d_c2r(int batch, int H, int W, float* in, float* out, void* stream);
+
+/* ---- the rest of an FNO block / channel MLP, forward and hand-written backward (csrc/fno.hip) ---------------------
+ * 1x1 convolutions (fno_block.MLP fno_block.py:263-320, linear skip :190-226) as MFMA GEMMs over [B, C, P] (NCHW,
+ * P = H*W, a multiple of 4), and the block tail of forward_with_postactivation (fno_block.py:1191-1220):
+ * GroupNorm(1 group) + spectral bias + skip + GELU.
+ *
+ * ppsci_pw_conv: out[b,o,p] = sum_i Weff[o,i] x[b,i,p] (+ bias[o]) (* GELU'(zmul[b,o,p])) (+ out if accumulate);
+ *   act (optional) = GELU(out).  W is the torch / paddle Conv2D weight [Co, Ci] (row-major); transpose != 0 uses it
+ *   as [Ci x Co]: the data gradient gx[b,i,p] = sum_o W[o,i] gy[b,o,p] (then Cin = Co, Cout = Ci of the layer). */
+int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* W, int transpose, const float* bias,
+                  const float* zmul, int accumulate, float* out, float* act, void* stream);
+/* gW[o,i] = sum_{b,p} gy[b,o,p] x[b,i,p], gb[o] = sum_{b,p} gy[b,o,p] as per-chunk partial rows: partials
+ * [ppsci_pw_conv_wgrad_chunks(B, P)][Co*Ci] and partials_b [chunks][Co] (or NULL); P a multiple of 16.  Sum each with
+ * ppsci_reduce_rows (fixed order). */
+int64_t ppsci_pw_conv_wgrad_chunks(int B, int P);
+int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials, float* partials_b,
+                        void* stream);
+/* Block tail.  forward: u = v + sbias[c]; norm: u = (u - mean_b) rstd_b gamma[c] + beta[c] (statistics over C*P per
+ * sample, eps inside the square root); t = u + skip; y = gelu ? GELU(t) : t (y may be NULL).  rows: [B*C*4] floats of
+ * scratch, stats: [4*B] floats (kept for the backward).
+ * backward: gt = gout * GELU'(t) (the skip branch's gradient), gv = dL/dv, ggamma / gbeta / gsbias = the [C] parameter
+ * gradients (each may be NULL). */
+int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                       const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
+                       float* y, void* stream);
+int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
+                       const float* t, const float* gout, float* rows, float* stats, float* gt, float* gv, float* ggamma,
+                       float* gbeta, float* gsbias, void* stream);
 
 /* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
  * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it

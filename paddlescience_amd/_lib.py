@@ -96,6 +96,26 @@ _SYMBOLS = {
                                             C.c_void_p]),
     "ppsci_spectral_conv2d_bwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_spectral_conv2d_bwd_real": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "ppsci_spectral_conv2d_fwd_scaled": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_float, C.c_int, C.c_void_p]),
+    "ppsci_spectral_conv2d_bwd_real_scaled": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                                        C.c_float, C.c_int, C.c_void_p]),
+    "ppsci_fft2d_r2c": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_fft2d_c2r": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pw_conv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pw_conv_wgrad_chunks": (C.c_int64, [C.c_int, C.c_int]),
+    "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "ppsci_fno_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "ppsci_fno_tail_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_modmlp_param_count": (C.c_int64, [C.POINTER(ModMlpDesc)]),
     "ppsci_modmlp_stash_floats": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
     "ppsci_modmlp_fwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

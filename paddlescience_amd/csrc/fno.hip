@@ -1,0 +1,482 @@
+// fno.hip -- the non-spectral part of an FNO block and of the lifting / projection channel MLPs, forward AND
+// hand-written backward, so that a TFNO training step runs no library GEMM / normalisation / activation kernels and
+// no autograd graph:
+//
+//   fno_block.MLP (1x1 convolutions)           /root/reference/ppsci/arch/fno_block.py:263-320
+//   FNOBlocks skip connection (linear, 1x1)    /root/reference/ppsci/arch/fno_block.py:190-226
+//   forward_with_postactivation                /root/reference/ppsci/arch/fno_block.py:1191-1220
+//                                              x <- act( norm(SpectralConv(x)) + skip(x) ), GroupNorm(1 group)
+//
+// Data layout: NCHW as the reference ([B, C, P] with P = H*W contiguous).
+//
+// * ppsci_pw_conv:   out[b,o,p] = sum_i W[o,i] x[b,i,p] (+ bias[o]) -- one 1x1 convolution = one GEMM per sample,
+//   [Co x Ci] . [Ci x P], on v_mfma_f32_16x16x4_f32.  A wave owns 64 consecutive pixels: its B operands are float4
+//   loads (lane (g,c) reads pixels 4c..4c+3 of channel row k+g: 256 contiguous bytes per row), one float4 = the
+//   same k-step of four 16-pixel MFMA column tiles; the A operands (weights) sit in LDS in fragment order.  The
+//   epilogue adds the bias and optionally applies GELU (writing both the pre-activation and the activation), or
+//   multiplies with GELU'(z) of the producing layer (data gradient of the previous activation), or accumulates.
+//   With `transpose` the same kernel computes the data gradient gx[b,i,p] = sum_o W[o,i] gy[b,o,p].
+// * ppsci_pw_conv_wgrad: gW[o,i] = sum_{b,p} gy[b,o,p] x[b,i,p], gb[o] = sum gy -- contraction over pixels: both
+//   operands are float4 loads along pixels; per-chunk partial blocks, summed in a fixed order by ppsci_reduce_rows.
+// * ppsci_gn_*: GroupNorm with one group (per-sample statistics over C*P) fused with the spectral bias, the affine
+//   map, the skip addition and GELU; backward with per-row sums, a tiny fixed-order finalisation and one apply pass.
+// All reductions have a fixed order (no float atomics): bit-reproducible.
+#include "ppsci_common.h"
+
+#ifndef PPSCI_EMU
+#include <hip/hip_runtime.h>
+#endif
+#include <math.h>
+#include <string.h>
+
+extern "C" void ppsci_set_error(const char* fmt, ...);
+
+__device__ __forceinline__ float fno_gelu(float t) { return 0.5f * t * (1.f + erff(t * 0.7071067811865476f)); }
+__device__ __forceinline__ float fno_gelu_grad(float t) {
+  return 0.5f * (1.f + erff(t * 0.7071067811865476f)) + t * 0.3989422804014327f * expf(-0.5f * t * t);
+}
+
+// ------------------------------------------------------------------------------------------ 1x1 convolution
+struct PwArgs {
+  const float* x;      // [B, Cin, P]
+  const float* W;      // [Co, Ci] row-major (torch Conv2d weight [Co, Ci, 1, 1]); transpose: used as [Ci x Co]
+  const float* bias;   // [Cout] or null
+  const float* zmul;   // [B, Cout, P] or null: out *= GELU'(zmul)
+  float* out;          // [B, Cout, P]: pre-activation (or the plain result)
+  float* act;          // [B, Cout, P] or null: GELU(out)
+  int B, Cin, Cout, P, ldw, transpose, accumulate;
+  int kq;              // ceil(Cin / 16)
+  int nob;             // ceil(Cout / 16)
+};
+
+#define PW_WAVES 4
+#define PW_OC 4  // output-channel blocks (of 16) per accumulation pass
+
+__global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
+  PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  // stage W as A-operand fragments: comp r of lane (g,c) for (ob, q): Weff[o = 16ob + c][k = 16q + 4r + g]
+  for (int idx = tid; idx < a.nob * a.kq * 64; idx += blockDim.x) {
+    const int l = idx & 63, q = (idx >> 6) % a.kq, ob = (idx >> 6) / a.kq;
+    const int o = 16 * ob + (l & 15);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * q + 4 * r + (l >> 4);
+      float w = 0.f;
+      if (o < a.Cout && k < a.Cin) w = a.transpose ? a.W[(long long)k * a.ldw + o] : a.W[(long long)o * a.ldw + k];
+      v[r] = w;
+    }
+    *(f32x4*)&smem[(long long)idx * 4] = v;
+  }
+  __syncthreads();
+  const long long chunks_per_b = (a.P + 63) / 64;
+  const long long nchunk = (long long)a.B * chunks_per_b;
+  for (long long ch = (long long)blockIdx.x * PW_WAVES + wave; ch < nchunk; ch += (long long)gridDim.x * PW_WAVES) {
+    const int b = (int)(ch / chunks_per_b);
+    const int p0 = (int)(ch - (long long)b * chunks_per_b) * 64 + 4 * c;  // this lane's 4 pixels
+    const bool pok = p0 + 3 < a.P;  // P is a multiple of 4 (checked on the host): all four or none
+    const float* xb = a.x + (long long)b * a.Cin * a.P;
+    for (int ob0 = 0; ob0 < a.nob; ob0 += PW_OC) {
+      f32x4 acc[PW_OC][4];
+#pragma unroll
+      for (int j = 0; j < PW_OC; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < a.kq; ++q) {
+        f32x4 xv[4];  // k-step r: channel 16q + 4r + g, pixels p0..p0+3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * q + 4 * r + g;
+          xv[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < PW_OC; ++j) {
+          if (ob0 + j < a.nob) {
+            const f32x4 w4 = *(const f32x4*)&smem[((long long)((ob0 + j) * a.kq + q) * 64 + lane) * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xv[r][t], acc[j][t], 0, 0, 0);
+          }
+        }
+      }
+      // D_t[row = 4g + rr][col = c]: channel 16(ob0+j) + 4g + rr, pixel p0 + t
+#pragma unroll
+      for (int j = 0; j < PW_OC; ++j) {
+        if (ob0 + j >= a.nob) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int o = 16 * (ob0 + j) + 4 * g + rr;
+          if (o >= a.Cout || !pok) continue;
+          const long long off = ((long long)b * a.Cout + o) * a.P + p0;
+          f32x4 v = (f32x4){acc[j][0][rr], acc[j][1][rr], acc[j][2][rr], acc[j][3][rr]};
+          if (a.bias) v += a.bias[o];
+          if (a.zmul) {
+            const f32x4 z = *(const f32x4*)&a.zmul[off];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] *= fno_gelu_grad(z[t]);
+          }
+          if (a.accumulate) v += *(const f32x4*)&a.out[off];
+          *(f32x4*)&a.out[off] = v;
+          if (a.act) {
+            f32x4 y;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y[t] = fno_gelu(v[t]);
+            *(f32x4*)&a.act[off] = y;
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* W, int transpose,
+                             const float* bias, const float* zmul, int accumulate, float* out, float* act, void* stream) {
+  if (B < 1 || Cin < 1 || Cout < 1 || P < 4 || (P & 3) || !x || !W || !out) {
+    ppsci_set_error("pw_conv: invalid argument (P must be a positive multiple of 4)");
+    return PPSCI_E_INVALID;
+  }
+  PwArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x, a.W = W, a.bias = bias, a.zmul = zmul, a.out = out, a.act = act;
+  a.B = B, a.Cin = Cin, a.Cout = Cout, a.P = P, a.transpose = transpose, a.accumulate = accumulate;
+  a.ldw = transpose ? Cout : Cin;  // W is [Co, Ci] = [rows, ldw]; transposed use: rows = Cin(of this call), ld = Cout
+  a.kq = (Cin + 15) / 16, a.nob = (Cout + 15) / 16;
+  const long long lds = (long long)a.nob * a.kq * 64 * 16;
+  if (lds > PPSCI_LDS_LIMIT_BYTES) {
+    ppsci_set_error("pw_conv: %d x %d weights do not fit LDS", Cout, Cin);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  if (PPSCI_SET_MAX_LDS(pw_conv_kernel, (int)lds) != 0) {
+    ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  const long long nchunk = (long long)B * ((P + 63) / 64);
+  long long grid = (nchunk + PW_WAVES - 1) / PW_WAVES;
+  if (grid > 4 * PPSCI_NUM_CU) grid = 4 * PPSCI_NUM_CU;
+  PPSCI_LAUNCH(pw_conv_kernel, PwArgs, (int)grid, 64 * PW_WAVES, (int)lds, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("pw_conv: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct PwWArgs {
+  const float* x;   // [B, Ci, P]
+  const float* gy;  // [B, Co, P]
+  float* part;      // [nchunk][Co*Ci]: per-chunk partial of gW (row-major [Co, Ci])
+  float* part_b;    // [nchunk][Co] or null: per-chunk partial of gb
+  int B, Ci, Co, P, nib, nob, cpix, chunks_per_b;
+};
+
+// one wave per (pixel chunk, out block, in block); cpix pixels of one sample per chunk (a multiple of 16)
+__global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  int id = blockIdx.x;
+  const int ib = id % a.nib;
+  id /= a.nib;
+  const int ob = id % a.nob;
+  const int ch = id / a.nob;
+  const int b = ch / a.chunks_per_b;
+  const int p0 = (ch - b * a.chunks_per_b) * a.cpix;
+  const int o = 16 * ob + c, i = 16 * ib + c;
+  const float* gr = a.gy + ((long long)b * a.Co + (o < a.Co ? o : 0)) * a.P;
+  const float* xr = a.x + ((long long)b * a.Ci + (i < a.Ci ? i : 0)) * a.P;
+  const float mo = o < a.Co ? 1.f : 0.f, mi = i < a.Ci ? 1.f : 0.f;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
+  for (int p = p0; p < pend; p += 16) {
+    // k-step r <-> pixel p + 4g + r for both operands
+    const f32x4 gv = *(const f32x4*)&gr[p + 4 * g] * mo;
+    const f32x4 xv = *(const f32x4*)&xr[p + 4 * g] * mi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[r], xv[r], acc, 0, 0, 0);
+    bsum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+  }
+  float* prow = a.part + (long long)ch * ((long long)a.Co * a.Ci);
+  // D[row = 4g + rr][col = c] = gW[o = 16ob + 4g + rr][i = 16ib + c]
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int oo = 16 * ob + 4 * g + rr;
+    if (oo < a.Co && i < a.Ci) prow[(long long)oo * a.Ci + i] = acc[rr];
+  }
+  if (ib == 0 && a.part_b) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (g == 0 && o < a.Co) a.part_b[(long long)ch * a.Co + o] = bsum;
+  }
+}
+
+extern "C" int64_t ppsci_pw_conv_wgrad_chunks(int B, int P) {
+  const int cpix = P >= 1024 ? 1024 : P;
+  return (int64_t)B * ((P + cpix - 1) / cpix);
+}
+
+// part_w: [chunks][Co*Ci], part_b: [chunks][Co] (or null); sum each with ppsci_reduce_rows(part, chunks, cols, out)
+extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials,
+                                   float* partials_b, void* stream) {
+  if (B < 1 || Ci < 1 || Co < 1 || P < 16 || (P & 15) || !x || !gy || !partials) {
+    ppsci_set_error("pw_conv_wgrad: invalid argument (P must be a positive multiple of 16)");
+    return PPSCI_E_INVALID;
+  }
+  PwWArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x, a.gy = gy, a.part = partials, a.part_b = partials_b;
+  a.B = B, a.Ci = Ci, a.Co = Co, a.P = P;
+  a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
+  a.cpix = P >= 1024 ? 1024 : P;
+  a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
+  const long long grid = (long long)B * a.chunks_per_b * a.nob * a.nib;
+  PPSCI_LAUNCH(pw_wgrad_kernel, PwWArgs, (int)grid, 64, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("pw_conv_wgrad: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm(1 group) block tail
+// forward:  u = v + sbias[c];  xh = (u - mean_b) * rstd_b;  t = xh * gamma[c] + beta[c] + skip;  y = gelu ? GELU(t) : t
+// (norm == 0: t = u + skip)
+struct GnArgs {
+  const float* v;      // [B, C, P] spectral convolution output (before its bias)
+  const float* sbias;  // [C] spectral bias
+  const float* gamma;  // [C] (norm only)
+  const float* beta;   // [C]
+  const float* skip;   // [B, C, P] or null
+  float* t;            // [B, C, P] pre-activation
+  float* y;            // [B, C, P] or null (== t when there is no activation)
+  float* rows;         // [B*C][4]: per-row sums (forward: sum u, sum u^2; backward: sum gt, sum gt*xh, sum xh)
+  float* stats;        // [B][2]: mean, rstd
+  const float* gout;   // backward: dL/dy
+  float* gt;           // backward: dL/dt (also the gradient of the skip branch)
+  float* gv;           // backward: dL/dv
+  float* ggamma;       // backward: [C] dL/dgamma (norm only), [C] dL/dbeta (norm only), [C] dL/d(spectral bias);
+  float* gbeta;        //           each may be null
+  float* gsbias;
+  int B, C, P, norm, gelu;
+  float eps;
+};
+
+__device__ __forceinline__ float fno_block_sum(float v, float* red) {
+  // sum over the 256 threads of the workgroup, fixed order; result in every thread
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup (256 threads) per (b, c) row
+__global__ void __launch_bounds__(256) gn_rowstats_kernel(GnArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, c = row % a.C;
+  const float* vr = a.v + (long long)row * a.P;
+  const float sb = a.sbias ? a.sbias[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
+    const f32x4 u = *(const f32x4*)&vr[p] + sb;
+    s1 += (u[0] + u[1]) + (u[2] + u[3]);
+    s2 += (u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]);
+  }
+  s1 = fno_block_sum(s1, red);
+  s2 = fno_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    a.rows[(long long)row * 4 + 0] = s1;
+    a.rows[(long long)row * 4 + 1] = s2;
+  }
+}
+
+// one thread per sample: mean / rstd from the row sums, in double, fixed order over the channels
+__global__ void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < a.C; ++c) {
+    s1 += (double)a.rows[((long long)b * a.C + c) * 4 + 0];
+    s2 += (double)a.rows[((long long)b * a.C + c) * 4 + 1];
+  }
+  const double n = (double)a.C * a.P, mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  a.stats[2 * b + 0] = (float)mean;
+  a.stats[2 * b + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
+  const long long n4 = (long long)a.B * a.C * a.P / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4, row = e / a.P;
+    const int c = (int)(row % a.C), b = (int)(row / a.C);
+    f32x4 u = *(const f32x4*)&a.v[e] + (a.sbias ? a.sbias[c] : 0.f);
+    if (a.norm) {
+      const float mean = a.stats[2 * b], rstd = a.stats[2 * b + 1];
+      u = (u - mean) * (rstd * a.gamma[c]) + a.beta[c];
+    }
+    if (a.skip) u += *(const f32x4*)&a.skip[e];
+    *(f32x4*)&a.t[e] = u;
+    if (a.y) {
+      f32x4 y = u;
+      if (a.gelu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = fno_gelu(u[k]);
+      }
+      *(f32x4*)&a.y[e] = y;
+    }
+  }
+}
+
+// backward pass 1: gt = gout * GELU'(t); row sums of gt, gt * xh, xh
+__global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, c = row % a.C, b = row / a.C;
+  const long long base = (long long)row * a.P;
+  const float sb = a.sbias ? a.sbias[c] : 0.f;
+  const float mean = a.norm ? a.stats[2 * b] : 0.f, rstd = a.norm ? a.stats[2 * b + 1] : 1.f;
+  float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+  for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
+    f32x4 g4 = *(const f32x4*)&a.gout[base + p];
+    if (a.gelu) {
+      const f32x4 t4 = *(const f32x4*)&a.t[base + p];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g4[k] *= fno_gelu_grad(t4[k]);
+    }
+    *(f32x4*)&a.gt[base + p] = g4;
+    const f32x4 xh = (*(const f32x4*)&a.v[base + p] + sb - mean) * rstd;
+    r1 += (g4[0] + g4[1]) + (g4[2] + g4[3]);
+    r2 += (g4[0] * xh[0] + g4[1] * xh[1]) + (g4[2] * xh[2] + g4[3] * xh[3]);
+    r3 += (xh[0] + xh[1]) + (xh[2] + xh[3]);
+  }
+  r1 = fno_block_sum(r1, red);
+  r2 = fno_block_sum(r2, red);
+  r3 = fno_block_sum(r3, red);
+  if (threadIdx.x == 0) {
+    a.rows[(long long)row * 4 + 0] = r1;
+    a.rows[(long long)row * 4 + 1] = r2;
+    a.rows[(long long)row * 4 + 2] = r3;
+  }
+}
+
+// backward finalisation (one workgroup): per-sample s1 = sum_c gamma r1, s2 = sum_c gamma r2 (stored behind the
+// statistics: stats[2B + 2b], stats[2B + 2b + 1]); per-channel dgamma, dbeta, dsbias
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(GnArgs a) {
+  const double n = (double)a.C * a.P;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < a.C; ++c) {
+      const double gm = a.norm ? (double)a.gamma[c] : 1.0;
+      s1 += gm * (double)a.rows[((long long)b * a.C + c) * 4 + 0];
+      s2 += gm * (double)a.rows[((long long)b * a.C + c) * 4 + 1];
+    }
+    a.stats[2 * a.B + 2 * b + 0] = (float)(s1 / n);
+    a.stats[2 * a.B + 2 * b + 1] = (float)(s2 / n);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    double dg = 0.0, db = 0.0, dsb = 0.0;
+    for (int b = 0; b < a.B; ++b) {
+      const double r1 = a.rows[((long long)b * a.C + c) * 4 + 0], r2 = a.rows[((long long)b * a.C + c) * 4 + 1],
+                   r3 = a.rows[((long long)b * a.C + c) * 4 + 2];
+      dg += r2;
+      db += r1;
+      if (a.norm) {
+        const double rstd = a.stats[2 * b + 1], m1 = a.stats[2 * a.B + 2 * b], m2 = a.stats[2 * a.B + 2 * b + 1];
+        dsb += rstd * ((double)a.gamma[c] * r1 - (double)a.P * m1 - r3 * m2);  // sum_p of gv over the row
+      } else {
+        dsb += r1;
+      }
+    }
+    if (a.ggamma) a.ggamma[c] = (float)dg;
+    if (a.gbeta) a.gbeta[c] = (float)db;
+    if (a.gsbias) a.gsbias[c] = (float)dsb;
+  }
+}
+
+// backward pass 2: gv = rstd (gamma gt - m1 - xh m2)   (norm == 0: gv = gt)
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnArgs a) {
+  const long long n4 = (long long)a.B * a.C * a.P / 4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4, row = e / a.P;
+    const int c = (int)(row % a.C), b = (int)(row / a.C);
+    const f32x4 g4 = *(const f32x4*)&a.gt[e];
+    if (!a.norm) {
+      *(f32x4*)&a.gv[e] = g4;
+      continue;
+    }
+    const float mean = a.stats[2 * b], rstd = a.stats[2 * b + 1];
+    const float m1 = a.stats[2 * a.B + 2 * b], m2 = a.stats[2 * a.B + 2 * b + 1];
+    const f32x4 xh = (*(const f32x4*)&a.v[e] + (a.sbias ? a.sbias[c] : 0.f) - mean) * rstd;
+    *(f32x4*)&a.gv[e] = (g4 * a.gamma[c] - m1 - xh * m2) * rstd;
+  }
+}
+
+static int gn_check(int B, int C, int P) {
+  if (B < 1 || C < 1 || P < 4 || (P & 3)) {
+    ppsci_set_error("fno block tail: invalid shape (P must be a positive multiple of 4)");
+    return PPSCI_E_INVALID;
+  }
+  return PPSCI_OK;
+}
+
+// rows: [B*C*4] floats of scratch; stats: [4*B] floats (mean, rstd per sample; the backward appends two more per sample)
+extern "C" int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                                  const float* gamma, const float* beta, const float* skip, float* rows, float* stats,
+                                  float* t, float* y, void* stream) {
+  if (gn_check(B, C, P) != PPSCI_OK || !v || !t || !rows || !stats || (norm && (!gamma || !beta))) {
+    ppsci_set_error("fno_tail_fwd: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  GnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.v = v, a.sbias = sbias, a.gamma = gamma, a.beta = beta, a.skip = skip, a.rows = rows, a.stats = stats, a.t = t, a.y = y;
+  a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu, a.eps = eps;
+  if (norm) {
+    PPSCI_LAUNCH(gn_rowstats_kernel, GnArgs, B * C, 256, 0, stream, a);
+    PPSCI_LAUNCH(gn_finalize_kernel, GnArgs, (B + 63) / 64, 64, 0, stream, a);
+  }
+  const long long n4 = (long long)B * C * P / 4;
+  long long grid = (n4 + 255) / 256;
+  if (grid > 8 * PPSCI_NUM_CU) grid = 8 * PPSCI_NUM_CU;
+  PPSCI_LAUNCH(gn_apply_kernel, GnArgs, (int)grid, 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("fno_tail_fwd: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+// ggamma / gbeta / gsbias: [C] each (null to skip); gt: dL/dt (= gradient of the skip branch); gv: dL/dv
+extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias,
+                                  const float* gamma, const float* t, const float* gout, float* rows, float* stats,
+                                  float* gt, float* gv, float* ggamma, float* gbeta, float* gsbias, void* stream) {
+  if (gn_check(B, C, P) != PPSCI_OK || !v || !gout || !rows || !stats || !gt || !gv || (gelu && !t) || (norm && !gamma)) {
+    ppsci_set_error("fno_tail_bwd: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  GnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.v = v, a.sbias = sbias, a.gamma = gamma, a.t = (float*)t, a.gout = gout, a.rows = rows, a.stats = stats;
+  a.gt = gt, a.gv = gv, a.ggamma = ggamma, a.gbeta = gbeta, a.gsbias = gsbias;
+  a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu;
+  PPSCI_LAUNCH(gn_bwd_rows_kernel, GnArgs, B * C, 256, 0, stream, a);
+  PPSCI_LAUNCH(gn_bwd_finalize_kernel, GnArgs, 1, 256, 0, stream, a);
+  const long long n4 = (long long)B * C * P / 4;
+  long long grid = (n4 + 255) / 256;
+  if (grid > 8 * PPSCI_NUM_CU) grid = 8 * PPSCI_NUM_CU;
+  PPSCI_LAUNCH(gn_bwd_apply_kernel, GnArgs, (int)grid, 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("fno_tail_bwd: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

@@ -34,6 +34,7 @@ struct SpecArgs {
   int conj_t;       // 0: out = x . w            (forward)
                     // 1: out = x . conj(w)^T    (gradient w.r.t. the input spectrum)
   int c0, ntile_b, nblk_n, cin, cout;
+  float scale;      // applied to the result (1/(H*W) when the FFTs around the contraction are unscaled hipFFT calls)
 };
 
 __device__ __forceinline__ int spec_row(const ppsci_spectral_desc& d, int c0, int m) {
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(64) spectral_contract_kernel(SpecArgs a) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int b = tb * 16 + 4 * g + rr;
-      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix + part] = acc[rr];
+      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix + part] = acc[rr] * a.scale;
     }
   }
 }
@@ -104,6 +105,8 @@ struct SpecWArgs {
   float* gwi;
   int c0;
   long long total;
+  float wscale;  // see ppsci_spectral_conv2d_bwd_real
+  int w_full;    // > 0: g is rfftn(dL/dy): weight gradients get wscale * c(my), c = 1 on the DC / Nyquist columns, else 2
 };
 
 __global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
@@ -125,6 +128,11 @@ __global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
     sr += xr * gr + xi * gi;
     si += xr * gi - xi * gr;
   }
+  if (a.w_full > 0) {
+    const float cm = a.wscale * ((my == 0 || 2 * my == a.w_full) ? 1.f : 2.f);
+    sr *= cm;
+    si *= cm;
+  }
   a.gwr[t] = sr;
   a.gwi[t] = si;
 }
@@ -145,7 +153,7 @@ static int spec_check(const ppsci_spectral_desc* d, int* c0) {
 }
 
 static int launch_contract(const ppsci_spectral_desc* d, const float* x, const float* wr, const float* wi, float* out,
-                           int conj_t, void* stream) {
+                           int conj_t, void* stream, float scale = 1.f) {
   SpecArgs a;
   memset(&a, 0, sizeof(a));
   int rc = spec_check(d, &a.c0);
@@ -156,6 +164,7 @@ static int launch_contract(const ppsci_spectral_desc* d, const float* x, const f
   a.wi = wi;
   a.out = out;
   a.conj_t = conj_t;
+  a.scale = scale;
   a.cin = conj_t ? d->c_out : d->c_in;
   a.cout = conj_t ? d->c_in : d->c_out;
   a.ntile_b = (d->batch + 15) / 16;
@@ -179,15 +188,83 @@ extern "C" int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const flo
   return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream);
 }
 
+static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                        const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
+                        void* stream, float xscale = 1.f);
+
+// out_ft = scale * (x_ft . w) on the kept modes, after clearing the WHOLE output spectrum (`zero_fill` != 0): for callers
+// whose inverse transform destroys its input (hipFFT C2R, ppsci_fft2d_c2r) or that hand over uninitialised memory.
+extern "C" int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                                const float* w_im, float* out_ft, float scale, int zero_fill,
+                                                void* stream) {
+  if (!d || !x_ft || !w_re || !w_im || !out_ft) {
+    ppsci_set_error("spectral_conv2d_fwd_scaled: null pointer");
+    return PPSCI_E_INVALID;
+  }
+#ifndef PPSCI_EMU
+  if (zero_fill &&
+      hipMemsetAsync(out_ft, 0, (size_t)d->batch * d->c_out * d->h * d->wf * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    ppsci_set_error("spectral_conv2d_fwd_scaled: hipMemsetAsync failed");
+    return PPSCI_E_LAUNCH;
+  }
+#else
+  if (zero_fill) memset(out_ft, 0, (size_t)d->batch * d->c_out * d->h * d->wf * 2 * sizeof(float));
+#endif
+  return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream, scale);
+}
+
+// ppsci_spectral_conv2d_bwd_real with the input-spectrum gradient scaled by `xscale` and its buffer cleared first
+extern "C" int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                                     const float* w_im, const float* ghat_ft, float* gx_ft, float* gw_re,
+                                                     float* gw_im, float wscale, int w_full, float xscale, int zero_fill,
+                                                     void* stream) {
+  if (!d || w_full < 1 || !gx_ft) {
+    ppsci_set_error("spectral_conv2d_bwd_real_scaled: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+#ifndef PPSCI_EMU
+  if (zero_fill &&
+      hipMemsetAsync(gx_ft, 0, (size_t)d->batch * d->c_in * d->h * d->wf * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    ppsci_set_error("spectral_conv2d_bwd_real_scaled: hipMemsetAsync failed");
+    return PPSCI_E_LAUNCH;
+  }
+#else
+  if (zero_fill) memset(gx_ft, 0, (size_t)d->batch * d->c_in * d->h * d->wf * 2 * sizeof(float));
+#endif
+  return spectral_bwd(d, x_ft, w_re, w_im, ghat_ft, gx_ft, gw_re, gw_im, wscale, w_full, stream, xscale);
+}
+
 extern "C" int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
                                          const float* w_im, const float* gout_ft, float* gx_ft, float* gw_re,
                                          float* gw_im, void* stream) {
+  return spectral_bwd(d, x_ft, w_re, w_im, gout_ft, gx_ft, gw_re, gw_im, 1.f, 0, stream);
+}
+
+// Backward of  y = irfftn(contract(rfftn(x)))  WITHOUT an autograd graph around the FFTs: `ghat_ft` = rfftn(dL/dy)
+// (same norm as the forward transforms).  The adjoint of the real-to-complex / complex-to-real pair folds into
+//   dL/dx = irfftn(gx_ft),  gx_ft = ghat . conj(w)^T                       (the Hermitian weights c cancel)
+//   dL/dw[i,o,m] = wscale * c(m) * sum_b conj(x_ft[b,i,m]) ghat[b,o,m]     (c = 1 on the DC / Nyquist column, else 2;
+//                  wscale = inverse-transform scale / forward-transform scale: H*W for norm "forward", 1/(H*W) for
+//                  "backward", 1 for "ortho")
+extern "C" int ppsci_spectral_conv2d_bwd_real(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
+                                              const float* w_im, const float* ghat_ft, float* gx_ft, float* gw_re,
+                                              float* gw_im, float wscale, int w_full, void* stream) {
+  if (w_full < 1) {
+    ppsci_set_error("spectral_conv2d_bwd_real: w_full (the real grid width) must be positive");
+    return PPSCI_E_INVALID;
+  }
+  return spectral_bwd(d, x_ft, w_re, w_im, ghat_ft, gx_ft, gw_re, gw_im, wscale, w_full, stream);
+}
+
+static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
+                        const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
+                        void* stream, float xscale) {
   if (!x_ft || !w_re || !w_im || !gout_ft) {
     ppsci_set_error("spectral_conv2d_bwd: null pointer");
     return PPSCI_E_INVALID;
   }
   if (gx_ft) {
-    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream);
+    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale);
     if (rc != PPSCI_OK) return rc;
   }
   if (gw_re && gw_im) {
@@ -201,6 +278,8 @@ extern "C" int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const flo
     a.gwr = gw_re;
     a.gwi = gw_im;
     a.total = (long long)d->c_in * d->c_out * d->modes_x * d->modes_y;
+    a.wscale = wscale;
+    a.w_full = w_full;
     PPSCI_LAUNCH(spectral_wgrad_kernel, SpecWArgs, (int)((a.total + 255) / 256), 256, 0, stream, a);
     int e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) {

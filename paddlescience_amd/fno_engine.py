@@ -1,0 +1,206 @@
+"""Native forward + backward of ppsci.arch.FNONet / TFNO2dNet: every non-FFT operation of a training step is one of
+this framework's HIP kernels (csrc/fno.hip, csrc/spectral_conv.hip) and the backward pass is written out by hand -- no
+autograd graph, no rocBLAS / MIOpen kernels.  What the reference runs per step (tfnonet.py:179-193):
+
+    x = lifting(x)                                   fno_block.MLP: conv1x1 -> GELU -> conv1x1        (fno_block.py:263-320)
+    for l: x = act( norm(SpectralConv_l(x)) + skip_l(x) )   forward_with_postactivation          (fno_block.py:1191-1220)
+    y = projection(x)                                fno_block.MLP
+
+    SpectralConv (fno_block.py:707-796): rfftn -> per-mode complex channel contraction on the kept modes -> irfftn, + bias
+
+The FFTs are raw hipFFT executions on the launch stream (ppsci_fft2d_r2c / ppsci_fft2d_c2r, csrc/fft.hip: unscaled, no
+clones, no normalisation kernels; they are linear, so their adjoints are FFTs again, see `ppsci_spectral_conv2d_bwd_real`);
+everything else is ppsci_pw_conv / ppsci_pw_conv_wgrad / ppsci_fno_tail_* / ppsci_spectral_conv2d_* / ppsci_reduce_rows.
+The 1/(H*W) of the rfftn / irfftn pair -- the same for every `fft_norm` -- is folded into the spectral contraction.  Gradients are written straight into the views of `model.flat_grad`.
+
+Supported configuration (`supports`): the one the reference's TFNO examples use -- 2-D, dense spectral weights, GELU,
+post-activation blocks, linear or identity skip, GroupNorm(1 group) or no norm, two-layer (or one-layer) lifting and a
+two-layer projection, no stabilizer.  Anything else trains through torch autograd around the spectral kernel
+(paddlescience_amd/operator_engine.py), as before."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import hotpath as hp
+from .hotpath import _p, _stream_ptr
+
+
+def supports(model) -> Optional[str]:
+    """None when the native path can run `model`, else the reason it cannot."""
+    from .arch import fno
+
+    if not isinstance(model, fno.FNONet):
+        return "not an FNONet"
+    fb = model.fno_blocks
+    if fb.non_linearity is not torch.nn.functional.gelu or model.projection.non_linearity is not torch.nn.functional.gelu:
+        return "non-GELU activation"
+    if fb.stabilizer is not None:
+        return "stabilizer"
+    if fb.norm is not None and not all(isinstance(n, torch.nn.GroupNorm) and n.num_groups == 1 for n in fb.norm):
+        return "norm other than GroupNorm(1 group)"
+    if model.lifting.n_layers not in (1, 2) or model.projection.n_layers != 2:
+        return "lifting / projection depth"
+    if model._input_transform is not None or model._output_transform is not None:
+        return "input / output transform"
+    return None
+
+
+def _pw_conv(B, cin, cout, P, x, W, out, bias=None, zmul=None, act=None, transpose=False, accumulate=False):
+    L.check(L.lib().ppsci_pw_conv(B, cin, cout, P, _p(x), _p(W), 1 if transpose else 0, _p(bias), _p(zmul),
+                                  1 if accumulate else 0, _p(out), _p(act), _stream_ptr(out)))
+
+
+class FnoNative:
+    def __init__(self, model):
+        why = supports(model)
+        if why is not None:
+            raise NotImplementedError(f"native FNO path: {why}")
+        self.m = model
+        self.shape = None
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self, B: int, H: int, W: int) -> None:
+        m = self.m
+        dev = m.flat_params.device
+        f = dict(dtype=torch.float32, device=dev)
+        P, Ch, nl = H * W, m.hidden_channels, m.n_layers
+        if P % 16 != 0:
+            raise NotImplementedError(f"native FNO path: H*W = {P} must be a multiple of 16")
+        self.shape = (B, H, W)
+        self.P = P
+        lift, proj = m.lifting.fcs, m.projection.fcs
+        self.c_lift = lift[0].out_channels if len(lift) == 2 else 0
+        self.c_proj = proj[0].out_channels
+        if self.c_lift:
+            self.z1, self.a1 = torch.empty((B, self.c_lift, P), **f), torch.empty((B, self.c_lift, P), **f)
+        self.x = [torch.empty((B, Ch, P), **f) for _ in range(nl + 1)]          # block inputs, x[nl] = blocks' output
+        self.s = torch.empty((B, Ch, P), **f)                                    # skip branch of the current block
+        self.t = [torch.empty((B, Ch, P), **f) for _ in range(nl)]              # pre-activations
+        Wf = W // 2 + 1
+        self.v = [torch.empty((B, Ch, P), **f) for _ in range(nl)]               # spectral outputs (irfftn results)
+        self.xft = [torch.empty((B, Ch, H, Wf, 2), **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
+        self.out_ft = torch.empty((B, Ch, H, Wf, 2), **f)  # cleared + kept modes written every time (C2R destroys it)
+        self.gx_ft = torch.empty((B, Ch, H, Wf, 2), **f)
+        self.ghat = torch.empty((B, Ch, H, Wf, 2), **f)
+        self.gsp = torch.empty((B, Ch, P), **f)
+        self.rows = torch.empty(B * Ch * 4, **f)
+        self.stats = [torch.empty(4 * B, **f) for _ in range(nl)]
+        self.z2, self.a2 = torch.empty((B, self.c_proj, P), **f), torch.empty((B, self.c_proj, P), **f)
+        self.y = torch.empty((B, m.out_channels, P), **f)
+        # backward scratch
+        cmax = max(Ch, self.c_lift, self.c_proj)
+        self.ga = torch.empty((B, cmax, P), **f)
+        self.gb = torch.empty((B, cmax, P), **f)
+        self.gt = torch.empty((B, Ch, P), **f)
+        self.gv = torch.empty((B, Ch, P), **f)
+        self.chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))
+        wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels))
+        self.part_w = torch.empty(self.chunks * wmax, **f)
+        self.part_b = torch.empty(self.chunks * cmax, **f)
+        mx, my = m.fno_blocks.convs[0].n_modes
+        self.desc = L.SpectralDesc()
+        d = self.desc
+        d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, Ch, Ch, H, Wf, mx, my
+        self.inv_n = 1.0 / float(H * W)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, C_in, H, W] on the device -> y [B, C_out, H, W] (a buffer owned by the engine)."""
+        m = self.m
+        B, _, H, W = x.shape
+        if self.shape != (B, H, W):
+            self._alloc(B, H, W)
+        P, Ch, nl = self.P, m.hidden_channels, m.n_layers
+        self.x_in = x.contiguous().view(B, m.in_channels, P)
+        lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
+        if self.c_lift:
+            _pw_conv(B, m.in_channels, self.c_lift, P, self.x_in, lift[0].weight, self.z1, bias=lift[0].bias, act=self.a1)
+            _pw_conv(B, self.c_lift, Ch, P, self.a1, lift[1].weight, self.x[0], bias=lift[1].bias)
+        else:
+            _pw_conv(B, m.in_channels, Ch, P, self.x_in, lift[0].weight, self.x[0], bias=lift[0].bias)
+        st = _stream_ptr(self.y)
+        for l in range(nl):
+            xl = self.x[l]
+            conv = fb.convs[l]
+            skip = fb.fno_skips[l]
+            if isinstance(skip, torch.nn.Conv2d):
+                _pw_conv(B, Ch, Ch, P, xl, skip.weight, self.s)
+                sk = self.s
+            else:
+                sk = xl
+            xft, v = self.xft[l], self.v[l]
+            L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
+            L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
+                                                             _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
+            L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.out_ft), _p(v), st))
+            nrm = fb.norm[l] if fb.norm is not None else None
+            last = l == nl - 1
+            L.check(L.lib().ppsci_fno_tail_fwd(
+                B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
+                _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
+                _p(sk), _p(self.rows), _p(self.stats[l]), _p(self.t[l]), None if last else _p(self.x[l + 1]), st))
+        xo = self.t[nl - 1]  # no activation behind the last block
+        _pw_conv(B, Ch, self.c_proj, P, xo, proj[0].weight, self.z2, bias=proj[0].bias, act=self.a2)
+        _pw_conv(B, self.c_proj, m.out_channels, P, self.a2, proj[1].weight, self.y, bias=proj[1].bias)
+        return self.y.view(B, m.out_channels, H, W)
+
+    # ------------------------------------------------------------------ backward
+    def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param) -> None:
+        L.check(L.lib().ppsci_pw_conv_wgrad(B, ci, co, P, _p(x), _p(gy), _p(self.part_w),
+                                            _p(self.part_b) if b_param is not None else None, _stream_ptr(gy)))
+        hp.reduce_rows(self.part_w, self.chunks, co * ci, w_param.grad.view(-1), False)
+        if b_param is not None:
+            hp.reduce_rows(self.part_b, self.chunks, co, b_param.grad.view(-1), False)
+
+    def backward(self, gy: torch.Tensor) -> None:
+        """gy = dL/dy [B, C_out, H, W]; writes dL/d(parameter) into every parameter's `.grad` (views of flat_grad)."""
+        m = self.m
+        B, H, W = self.shape
+        P, Ch, nl = self.P, m.hidden_channels, m.n_layers
+        lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
+        gy = gy.contiguous().view(B, m.out_channels, P)
+        st = _stream_ptr(self.y)
+        # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
+        self._wgrad(B, self.c_proj, m.out_channels, P, self.a2, gy, proj[1].weight, proj[1].bias)
+        gz2 = self.ga.view(-1)[:B * self.c_proj * P].view(B, self.c_proj, P)
+        _pw_conv(B, m.out_channels, self.c_proj, P, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
+        self._wgrad(B, Ch, self.c_proj, P, self.t[nl - 1], gz2, proj[0].weight, proj[0].bias)
+        gx = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)  # dL/d(block output), ping-pongs with `gnext`
+        gnext = self.ga.view(-1)[:B * Ch * P].view(B, Ch, P)
+        _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
+        for l in range(nl - 1, -1, -1):
+            conv, skip = fb.convs[l], fb.fno_skips[l]
+            nrm = fb.norm[l] if fb.norm is not None else None
+            last = l == nl - 1
+            L.check(L.lib().ppsci_fno_tail_bwd(
+                B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
+                _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(self.rows), _p(self.stats[l]),
+                _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
+                _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
+            # skip branch: s = Wskip x_l  (identity: the gradient passes straight through)
+            if isinstance(skip, torch.nn.Conv2d):
+                self._wgrad(B, Ch, Ch, P, self.x[l], self.gt, skip.weight, None)
+                _pw_conv(B, Ch, Ch, P, self.gt, skip.weight, gnext, transpose=True)
+            else:
+                hp.reduce_rows(self.gt.view(1, -1), 1, B * Ch * P, gnext.view(-1), False)
+            # spectral branch: dL/dx_l += irfftn( rfftn(gv) . conj(w)^T ), weight gradients from x_ft and rfftn(gv)
+            L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
+            L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
+                C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat), _p(self.gx_ft),
+                _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, 1, st))
+            L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
+            hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
+            gx, gnext = gnext, gx
+        # lifting
+        if self.c_lift:
+            self._wgrad(B, self.c_lift, Ch, P, self.a1, gx, lift[1].weight, lift[1].bias)
+            gz1 = self.gb if gx.data_ptr() != self.gb.data_ptr() else self.ga
+            gz1 = gz1.view(-1)[:B * self.c_lift * P].view(B, self.c_lift, P)
+            _pw_conv(B, Ch, self.c_lift, P, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
+            self._wgrad(B, m.in_channels, self.c_lift, P, self.x_in, gz1, lift[0].weight, lift[0].bias)
+        else:
+            self._wgrad(B, m.in_channels, Ch, P, self.x_in, gx, lift[0].weight, lift[0].bias)

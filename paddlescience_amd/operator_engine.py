@@ -71,6 +71,23 @@ class OperatorConstraint:
             total = v if total is None else total + v
         return total
 
+    def forward_backward_native(self, native) -> None:
+        """Network forward + backward on the hand-written kernels (fno_engine.FnoNative); only the user's loss
+        expression -- arbitrary Python on the network OUTPUT -- is differentiated by torch, which yields dL/dy."""
+        m = self.model
+        xs = [self.inp[k] for k in m.input_keys]
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+        y = native.forward(x).detach().requires_grad_(True)
+        data = {**self.inp, m.output_keys[0]: y}
+        vals = {k: f(data) for k, f in self.output_expr.items()}
+        losses = self.loss_fn(vals, self.lab, self.w)
+        self._last = {k: v.detach() for k, v in losses.items()}
+        total = None
+        for v in losses.values():
+            total = v if total is None else total + v
+        (gy,) = torch.autograd.grad(total, y)
+        native.backward(gy)
+
     def losses(self) -> Dict[str, float]:
         return {k: float(v) for k, v in self._last.items()}
 
@@ -85,8 +102,23 @@ class OperatorEngine:
         from .engine import StepGraph
 
         self._step_graph = StepGraph(self.grad.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0")
+        # FNO / TFNO in the supported configuration: forward and backward on this framework's own kernels, no autograd
+        # graph (fno_engine.py); PPSCI_FNO_NATIVE=0 keeps the torch-autograd path around the spectral kernel
+        self.native = None
+        if os.environ.get("PPSCI_FNO_NATIVE", "1") != "0":
+            from . import fno_engine
+
+            why = fno_engine.supports(model)
+            if why is None:
+                self.native = fno_engine.FnoNative(model)
+            else:
+                from .utils import logger
+
+                logger.message(f"FNO: native forward/backward not used ({why}); training through torch autograd")
 
     def _forward_backward_eager(self, constraints: List[OperatorConstraint]):
+        if self.native is not None and len(constraints) == 1:
+            return constraints[0].forward_backward_native(self.native)
         self.grad.zero_()
         for c in constraints:
             c.forward_loss().backward()

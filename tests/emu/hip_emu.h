@@ -27,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__
+#define __shared__ static  // blocks run one after the other: one instance is the block's LDS variable
 
 struct emu_dim3 {
   unsigned x = 1, y = 1, z = 1;

@@ -44,7 +44,7 @@ def test_python_binding_table_matches_header():
 def test_struct_sizes_match_header_constants():
     from paddlescience_amd import _lib as L
 
-    assert ctypes.sizeof(L.MlpDesc) == 4 * 8 + 4 * L.MAX_IN + 4 * L.MAX_IN + 4 * L.MAX_DIRS * L.MAX_IN + 8
+    assert ctypes.sizeof(L.MlpDesc) == 4 * 8 + 4 * L.MAX_IN + 4 * L.MAX_IN + 4 * L.MAX_DIRS * L.MAX_IN + 8 + 8  # + n3, n4
     assert ctypes.sizeof(L.Instr) == 16 and ctypes.sizeof(L.Residual) == 24
     assert ctypes.sizeof(L.EpilogueDesc) == 20 + 16 * L.MAX_PROG + 24 * L.MAX_RES
 

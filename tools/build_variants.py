@@ -42,7 +42,7 @@ def build_variant(name, extra):
         objs = list(ex.map(one, G.SOURCES))
     os.makedirs(os.path.join(ROOT, "variants_out"), exist_ok=True)
     lib = os.path.join(ROOT, "variants_out", name + ".so")  # travels with gpurun (build/ does not)
-    subprocess.check_call([G.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([G.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lhipfft"])
     return lib
 
 

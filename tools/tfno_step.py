@@ -1,0 +1,28 @@
+"""One TFNO-2D training configuration (BASELINE config 4 shape) stepped through the OperatorEngine: used under
+rocprofv3 to list the kernels of a step (tools: rocprofv3 --kernel-trace --stats -- python tools/tfno_step.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ppsci  # noqa: E402
+from paddlescience_amd.operator_engine import OperatorConstraint, OperatorEngine  # noqa: E402
+
+B, H, W = 16, 64, 64
+torch.manual_seed(0)
+model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
+                             lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm")
+x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, H, W)).astype(np.float32)).cuda()
+opt = ppsci.optimizer.Adam(1e-3)(model)
+cst = OperatorConstraint("Sup", model, {"y": lambda d: d["y"]}, ppsci.loss.FunctionalLoss(
+    lambda o, l, w=None: {"y": ((o["y"] - l["y"]) ** 2).mean()}), x.device, ["y"], B)
+cst.bind({"x": x}, {"y": y})
+eng = OperatorEngine(model)
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
+    eng.forward_backward([cst])
+    opt.step(model.flat_grad)
+torch.cuda.synchronize()
+print("native:", eng.native is not None, "loss", cst.losses())
