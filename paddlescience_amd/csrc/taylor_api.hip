@@ -97,8 +97,9 @@ extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_
   const long long slots = bwd_wpart_slots(a, grid);
   const long long chunks = slots < PPSCI_WRED_CHUNKS ? slots : PPSCI_WRED_CHUNKS;
   // hidden-weight blocks per tile (+ the spare slot) or per workgroup | chunk sums | per-workgroup small-parameter
-  // rows | their sum
-  const long long fl = (slots + chunks) * bwd_per_tile_floats(a) + ((long long)grid + 1) * ppsci_small_params(a.d, a.q);
+  // rows | their chunk sums
+  const long long fl = (slots + chunks) * bwd_per_tile_floats(a) +
+                       ((long long)grid + PPSCI_WRED_CHUNKS) * ppsci_small_params(a.d, a.q);
   return fl * 4 + 16;
 }
 
@@ -138,14 +139,13 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   float* wpart = (float*)workspace;
   float* tmp = wpart + slots * bwd_per_tile_floats(a);
   float* small_rows = tmp + chunks * bwd_per_tile_floats(a);
-  float* small_sum = small_rows + (long long)grid * psmall;
+  float* small_tmp = small_rows + (long long)grid * psmall;  // [PPSCI_WRED_CHUNKS][psmall]
   a.partials = small_rows;
   a.wpart = (f32x4*)workspace;
   int rc = run_bwd_act(a, stream, 1, &grid);
   if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
-  // W0 / biases / W_last: fixed-order sum over the workgroups' compact rows (a few hundred KB, not rows x P)
-  rc = ppsci_reduce_rows(small_rows, grid, psmall, small_sum, 0, stream);
-  if (rc != PPSCI_OK) return rc;
-  // hidden-to-hidden matrices: fixed-order tree sum over the tiles' (or the workgroups') blocks
-  return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_sum, grad_partials, stream);
+  // fixed-order two-stage sum over the tiles' (or the workgroups') hidden-weight blocks and over the workgroups' compact
+  // rows of W0 / biases / W_last, written in the canonical parameter layout
+  return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_rows, grid, small_tmp, grad_partials,
+                            stream);
 }

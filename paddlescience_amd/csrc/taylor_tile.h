@@ -361,7 +361,7 @@ __host__ __device__ inline int ppsci_small_params(const ppsci_mlp_desc& d, const
 // layout; the entries that are not hidden-to-hidden weights are taken from `small_sum` (compact order above).
 #define PPSCI_WRED_CHUNKS 64
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
-                       const float* small_sum, float* row, void* stream);
+                       const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream);
 
 // per-activation entry points (one translation unit each, so they compile in parallel).
 // launch == 0: only plan (fills a.resident / a.iters and *grid_out); launch == 1: plan + launch.

@@ -7,15 +7,31 @@ struct WRedArgs {
   const float* wpart;  // [ntiles][per_tile]
   float* tmp;          // [nchunks][per_tile]
   float* row;          // [P]
-  const float* small;  // [ppsci_small_params]: summed W0 | biases | W_last | b_last gradients
+  const float* small;  // [nsmall_rows][psmall]: per-workgroup rows of the W0 | biases | W_last | b_last gradients
+  float* tmp_small;    // [nchunks][psmall]: their chunk sums
+  int nsmall_rows, psmall, nbs;  // nbs = workgroups per chunk for the small part
   int m, d0;
   ppsci_derived q;
   int L, H, ntiles, nchunks, nb4;  // nb4 = workgroups per chunk (each covers 256 float4)
   long long per_tile;              // (L-1)*HP*HP floats
 };
 
-// stage 1: tmp[chunk][j] = sum_{tile in chunk} wpart[tile][j]
+// stage 1: tmp[chunk][j] = sum_{tile in chunk} wpart[tile][j]; the workgroups behind those do the same for the
+// per-workgroup rows of the small tensors (one launch instead of a separate row reduction)
 __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(WRedArgs a) {
+  if ((int)blockIdx.x >= a.nchunks * a.nb4) {
+    const int bid = (int)blockIdx.x - a.nchunks * a.nb4;
+    const int chunk = bid / a.nbs;
+    const int j = (bid - chunk * a.nbs) * 256 + threadIdx.x;
+    if (j >= a.psmall) return;
+    const int r0 = (int)((long long)a.nsmall_rows * chunk / a.nchunks);
+    const int r1 = (int)((long long)a.nsmall_rows * (chunk + 1) / a.nchunks);
+    float v = 0.f;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) v += a.small[(long long)r * a.psmall + j];
+    a.tmp_small[(long long)chunk * a.psmall + j] = v;
+    return;
+  }
   const int chunk = blockIdx.x / a.nb4;
   const long long j4 = (long long)(blockIdx.x - chunk * a.nb4) * 256 + threadIdx.x;
   if (j4 * 4 >= a.per_tile) return;
@@ -62,15 +78,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
       while (l + 1 < L && idx >= a.q.offW[l + 1]) ++l;  // the bias that follows W_l
       ci = a.d0 * H + l * H + (idx - a.q.offB[l]);
     }
-    v = a.small[ci];
+#pragma unroll 8
+    for (int c = 0; c < a.nchunks; ++c) v += a.tmp_small[(long long)c * a.psmall + ci];
   }
   a.row[idx] = v;
 }
 
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
-                       const float* small_sum, float* row, void* stream) {
+                       const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream) {
   WRedArgs a;
-  a.small = small_sum;
+  a.small = small_rows;
+  a.tmp_small = tmp_small;
+  a.nsmall_rows = nsmall_rows;
+  a.psmall = ppsci_small_params(d, q);
+  a.nbs = (a.psmall + 255) / 256;
   a.m = d.d_out;
   a.d0 = q.d0;
   a.wpart = wpart;
@@ -81,17 +102,16 @@ int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntil
   a.H = d.width;
   a.ntiles = ntiles;
   a.nchunks = ntiles < PPSCI_WRED_CHUNKS ? ntiles : PPSCI_WRED_CHUNKS;
+  if (a.nchunks < 1) a.nchunks = 1;
   a.per_tile = (long long)(d.n_hidden - 1) * q.HP * q.HP;
-  if (a.per_tile > 0) {
-    a.nb4 = (int)((a.per_tile / 4 + 255) / 256);
-    PPSCI_LAUNCH(wgrad_reduce1_kernel, WRedArgs, a.nchunks * a.nb4, 256, 0, stream, a);
+  a.nb4 = a.per_tile > 0 ? (int)((a.per_tile / 4 + 255) / 256) : 0;
+  {
+    PPSCI_LAUNCH(wgrad_reduce1_kernel, WRedArgs, a.nchunks * (a.nb4 + a.nbs), 256, 0, stream, a);
     int e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) {
       ppsci_set_error("wgrad_reduce1: launch failed (hip error %d)", e);
       return PPSCI_E_LAUNCH;
     }
-  } else {
-    a.nb4 = 0;
   }
   PPSCI_LAUNCH(wgrad_reduce2_kernel, WRedArgs, (q.P + 255) / 256, 256, 0, stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();

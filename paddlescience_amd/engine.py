@@ -139,10 +139,16 @@ class FusedConstraint:
         st = getattr(self, "eq_store", None)
         return (None, None) if st is None else (st.values, self.eq_partials if train else None)
 
-    def backward(self, params: torch.Tensor) -> None:
+    def backward(self, params: torch.Tensor, out: Optional[torch.Tensor] = None) -> bool:
+        """Reverse sweeps of every member network.  `out` (the flat gradient): a single-network constraint whose reverse
+        sweep finishes with ONE gradient row writes it there directly -- no copy pass -- and True is returned."""
+        direct = out is not None and len(self.nets) == 1 and self.nets[0]["grad_rows"] == 1
         for nt in self.nets:
-            hp.taylor_bwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["Ubar"],
-                          nt["stash"], nt["workspace"], nt["grad_partials"], self.n)
+            n = nt["layout"].n_params
+            dst = out[nt["off"]:nt["off"] + n].view(1, n) if direct else nt["grad_partials"]
+            hp.taylor_bwd(nt["desc"], params[nt["off"]:nt["off"] + n], nt["inputs"], nt["Ubar"],
+                          nt["stash"], nt["workspace"], dst, self.n)
+        return direct
 
     def reduce_grads(self, grad: torch.Tensor, accumulate: bool) -> None:
         """grad[member's slice] (+)= this constraint's gradient of that member (fixed order)."""
@@ -263,8 +269,9 @@ class Engine:
         else:
             for i, c in enumerate(constraints):
                 c.forward(self.params, True)
-                c.backward(self.params)
-                c.reduce_grads(self.grad, several or i > 0)
+                # the first constraint's gradient row goes straight into the flat gradient (no copy kernel)
+                if not c.backward(self.params, self.grad if (i == 0 and not several) else None):
+                    c.reduce_grads(self.grad, several or i > 0)
         # d loss / d (learnable equation parameter): per-block sums of every constraint that reads one, in order
         first = True
         for c in constraints:

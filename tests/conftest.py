@@ -29,3 +29,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip_gpu)
+
+
+@pytest.fixture(autouse=True)
+def _poison_free_device_memory(request):
+    """GPU tests: fill the caching allocator's free blocks with NaN before every test, so that any kernel that reads a
+    buffer it was supposed to have written first (torch.empty hands out recycled memory) fails loudly instead of passing
+    on leftover zeros of a fresh process."""
+    if "gpu" in request.keywords and _has_gpu():
+        import torch
+
+        blocks = [torch.full((64 << 20,), float("nan"), device="cuda") for _ in range(4)]  # 4 x 256 MB
+        del blocks
+    yield

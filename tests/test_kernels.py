@@ -604,7 +604,7 @@ def test_bwd_workgroup_accumulation_matches_streaming_and_oracle(hidden, dout, n
 
 
 @pytest.mark.parametrize("hidden,dout,n2,N", [([64, 64, 64, 64], 1, 1, 20_000), ([20, 20, 20], 1, 2, 10_000),
-                                              ([128] * 5, 3, 2, 4_000)])
+                                              ([128] * 5, 3, 2, 4_000), ([256] * 4, 1, 1, 24), ([256] * 4, 1, 1, 5_000)])
 def test_bwd_is_bitwise_reproducible(hidden, dout, n2, N, dev):
     """No float atomics across waves: two launches on the same inputs give bit-identical gradients (on the GPU this
     is also the race detector for the slot-barrier scheme)."""
@@ -615,6 +615,10 @@ def test_bwd_is_bitwise_reproducible(hidden, dout, n2, N, dev):
     rng = np.random.default_rng(5)
     X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
     Ubar = (rng.standard_normal((dout, 1 + 2 + n2, N)) / N).astype(np.float32).astype(np.float64)
-    runs = [_run_bwd(net, X, dirs, n2, Ubar) for _ in range(4)]
+    runs = [_run_bwd(net, X, dirs, n2, Ubar) for _ in range(6)]
     for r in runs[1:]:
         assert np.array_equal(r, runs[0])
+    net32 = net.astype(np.float32).astype(np.float64)
+    if N <= 5_000:  # and it is the right gradient (the oracle finishes in seconds at this size)
+        _, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+        assert _rel(runs[0], T.flat_grads(*T.taylor_backward(net32, cache, Ubar))) < 2e-5
