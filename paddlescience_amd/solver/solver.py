@@ -228,9 +228,23 @@ class Solver:
                                           "rank); use drop_last")
             if len(cst.data_loader) == 1:
                 bsz = cst.data_loader.batch_sampler.num_samples
-        cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
-                                bsz * self.world_size, self.device, train=True,
-                                extra_parameters=self._extra_parameters())
+        try:
+            cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
+                                    bsz * self.world_size, self.device, train=True,
+                                    extra_parameters=self._extra_parameters())
+        except (NotImplementedError, TypeError) as e:
+            # the expressions cannot be lowered to the fused kernels (row slices, tensor methods, control flow, a derivative
+            # set beyond the instantiated stream sets ...): this constraint runs the reference's own execution model --
+            # op-by-op tensors + autograd (eager.py); the others stay fused
+            from ..eager import EagerConstraint
+
+            if self._extra_parameters() or getattr(self.loss_aggregator, "per_loss_grad", False) or \
+                    getattr(self.optimizer, "is_lbfgs", False) or os.environ.get("PPSCI_EAGER_FALLBACK", "1") == "0":
+                raise
+            cc = EagerConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
+                                 bsz * self.world_size, self.device, reason=f"{type(e).__name__}: {e}")
+            logger.warning(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e}); "
+                           "it trains through the eager fallback (torch autograd, slow)")
         self._static[name] = _is_full_static_batch(cst)
         if self._static[name]:
             inp, lab, w = next(cst.data_iter)
@@ -260,7 +274,8 @@ class Solver:
                         else:
                             cc.bind(inp, lab, w)
                 reader_cost = time.perf_counter() - reader_tic
-                eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts]
+                eager_csts = [c for c in csts if getattr(c, "is_eager", False)]
+                eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts if c not in eager_csts]
                 gscale = (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0
                 if getattr(self.optimizer, "is_lbfgs", False):
                     # train_LBFGS_epoch_func (solver/train.py:216-315): the optimizer re-evaluates loss + gradient
@@ -280,7 +295,13 @@ class Solver:
                     self.optimizer.step(closure)
                 else:
                     self._materialize()
-                    self.engine.forward_backward(eng_csts)
+                    if eng_csts:
+                        self.engine.forward_backward(eng_csts)
+                    else:
+                        self.engine.grad.zero_()
+                    for ec in eager_csts:  # eager fallback constraints add their gradient before the all-reduce
+                        mean = getattr(ec.loss, "reduction", "mean") == "mean"
+                        ec.forward_backward(self.engine.grad, (1.0 / self.world_size) if mean else 1.0)
                     self.engine.allreduce()
                     self._allreduce_eq_params()
                     if getattr(self.loss_aggregator, "per_loss_grad", False):
@@ -411,8 +432,12 @@ class Solver:
                 vals = cc.losses()  # keys are whatever the loss returns (FunctionalLoss), not the label keys
                 keys = list(vals.keys())
             else:
-                vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
-                keys = cc.label_keys
+                if getattr(cc, "is_eager", False):
+                    vals = cc.losses()
+                    keys = list(vals.keys())
+                else:
+                    vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
+                    keys = cc.label_keys
                 if getattr(self.loss_aggregator, "per_loss_grad", False) and hasattr(cc, "_base_scales"):
                     # the kernels applied the aggregator's weights through the residual scales: report raw terms
                     order = self._loss_key_order()

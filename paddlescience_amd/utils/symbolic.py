@@ -12,7 +12,9 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
+import numpy as np
 import sympy as sp
+import torch
 
 from ..autodiff import hessian, jacobian
 from ..equation.pde.base import DETACH_FUNC_NAME
@@ -91,24 +93,26 @@ class ComposedNode:
                 val = val * data[_cvt_to_key(a)]
             return val
         if node.func == sp.Pow:
-            return apply("pow", _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
+            return _apply_any("pow", _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
         if node.func in (sp.Max, sp.Min):
             op = "max" if node.func == sp.Max else "min"
-            val = apply(op, _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
+            val = _apply_any(op, _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
             for a in node.args[2:]:
-                val = apply(op, val, _as_sym(data[_cvt_to_key(a)]))
+                val = _apply_any(op, val, _as_sym(data[_cvt_to_key(a)]))
             return val
         if node.func == sp.atan2:
-            return apply("atan2", _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
+            return _apply_any("atan2", _as_sym(data[_cvt_to_key(node.args[0])]), _as_sym(data[_cvt_to_key(node.args[1])]))
         if node.func == sp.Heaviside:
-            return apply("heaviside", _as_sym(data[_cvt_to_key(node.args[0])]))
+            return _apply_any("heaviside", _as_sym(data[_cvt_to_key(node.args[0])]))
         if isinstance(node, sp.Function) and str(node.func) == DETACH_FUNC_NAME:  # DetachNode :165-181
             return _as_sym(data[_cvt_to_key(node.args[0])]).detach()
         if isinstance(node, sp.Function) and node.func in _SYMPY_UNARY:
-            return apply(_SYMPY_UNARY[node.func], _as_sym(data[_cvt_to_key(node.args[0])]))
+            return _apply_any(_SYMPY_UNARY[node.func], _as_sym(data[_cvt_to_key(node.args[0])]))
         if node.is_Number or node.is_NumberSymbol:  # ConstantNode :433-468
             if not (node.is_Float or node.is_Integer or node.is_Boolean or node.is_Rational):
                 raise TypeError(f"expr({node}) should be Float/Integer/Boolean/Rational, but got {type(node)}")
+            if any(isinstance(v, torch.Tensor) for v in data.values()):  # eager: an fp32 scalar (ConstantNode)
+                return float(np.float32(float(node)))
             return Sym.const(float(node))
         raise NotImplementedError(f"The node {node} is not supported in lambdify.")
 
@@ -129,6 +133,8 @@ class ComposedNode:
                 continue
             if isinstance(node, sp.Symbol):  # ParameterNode symbolic.py:471-485: one scalar, broadcast over the points
                 hit = [p for p in self.parameters if p.name == node.name]
+                if any(isinstance(v, torch.Tensor) for v in data_dict.values()):
+                    raise NotImplementedError("learnable equation parameters on the eager fallback path")
                 data_dict[key] = Sym.param(hit[0].name, hit[0].slot)
                 continue
             data_dict[key] = self._eval(node, data_dict)
@@ -137,10 +143,29 @@ class ComposedNode:
     forward = __call__
 
 
-def _as_sym(v) -> Sym:
-    if isinstance(v, Sym):
+def _as_sym(v):
+    if isinstance(v, (Sym, torch.Tensor)):
         return v
     return Sym.const(float(v))
+
+
+_TORCH_FUNCS = {"pow": torch.pow, "max": torch.maximum, "min": torch.minimum, "atan2": torch.atan2,
+                "heaviside": lambda x: torch.heaviside(x, torch.zeros_like(x)), "sin": torch.sin, "cos": torch.cos,
+                "tanh": torch.tanh, "exp": torch.exp, "log": torch.log, "sqrt": torch.sqrt, "abs": torch.abs, "sinh": torch.sinh,
+                "cosh": torch.cosh, "tan": torch.tan, "sign": torch.sign, "asin": torch.asin, "acos": torch.acos,
+                "atan": torch.atan, "asinh": torch.asinh, "acosh": torch.acosh, "atanh": torch.atanh, "erf": torch.erf,
+                "lgamma": torch.lgamma, "ceil": torch.ceil, "floor": torch.floor, "neg": torch.neg}
+
+
+def _apply_any(op: str, *args):
+    """graph.apply on traced values; the same operator on real tensors (eager fallback): constants arrive as fp32
+    scalars like the reference's ConstantNode."""
+    if any(isinstance(a, torch.Tensor) for a in args):
+        ref = next(a for a in args if isinstance(a, torch.Tensor))
+        ts = [a if isinstance(a, torch.Tensor) else torch.full_like(ref, float(a.value if isinstance(a, Sym) else a))
+              for a in args]
+        return _TORCH_FUNCS[op](*ts)
+    return apply(op, *args)
 
 
 def lambdify(

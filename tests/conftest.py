@@ -39,6 +39,9 @@ def _poison_free_device_memory(request):
     if "gpu" in request.keywords and _has_gpu():
         import torch
 
+        # large pool (>= 1 MB blocks) and small pool (< 1 MB): both are recycled by torch.empty
         blocks = [torch.full((64 << 20,), float("nan"), device="cuda") for _ in range(4)]  # 4 x 256 MB
+        blocks += [torch.full((n,), float("nan"), device="cuda") for n in (1 << 18, 1 << 16, 1 << 14, 1 << 12, 1 << 10, 256)
+                   for _ in range(64)]
         del blocks
     yield

@@ -675,3 +675,54 @@ def test_periodic_constraint_batches_and_training_step(tmp_path):
     for k in ("u", "u_x"):
         assert got[k] == pytest.approx(losses[k], rel=5e-4), k
     assert rel(model.flat_params.cpu().numpy()[:p.size], p) < 1e-5
+
+
+def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
+    """examples/euler_beam/euler_beam.py: the PDE u_xxxx + 1 = 0 runs on the fused kernels (fourth-order streams); its
+    boundary terms pick ROWS of the batch (`d["u"][0:1]`, `jacobian(...)[1:2]`, ...), which no per-point program can
+    express: that constraint falls back to the eager path (op-by-op tensors + autograd, the reference's execution model).
+    Loss terms and the summed parameter gradient against the oracle's reverse-over-reverse restatement."""
+    from ppsci.autodiff import hessian, jacobian
+
+    model = ppsci.arch.MLP(("x",), ("u",), 3, 20, "tanh")
+    net = T.make_net(1, [20, 20, 20], 1, bias_scale=0.1)
+    set_model_weights(model, net)
+    rng = np.random.default_rng(5)
+    Xi = rng.uniform(0, 1, (32, 1)).astype(np.float32)
+    Xb = np.asarray([[0.0], [0.0], [1.0], [1.0]], np.float32)
+    eq = ppsci.equation.Biharmonic(1, -1.0, 1.0)
+    pde = _sup_constraint({"x": Xi}, {"biharmonic": np.zeros((32, 1), np.float32)}, eq.equations, ppsci.loss.MSELoss("mean"), name="EQ")
+    bc_exprs = {"u0": lambda d: d["u"][0:1], "u__x": lambda d: jacobian(d["u"], d["x"])[1:2],
+                "u__x__x": lambda d: hessian(d["u"], d["x"])[2:3],
+                "u__x__x__x": lambda d: jacobian(hessian(d["u"], d["x"]), d["x"])[3:4]}
+    bc = _sup_constraint({"x": Xb}, {k: np.zeros((4, 1), np.float32) for k in bc_exprs}, bc_exprs, ppsci.loss.MSELoss("sum"),
+                         name="BC")
+    solver = _solver(tmp_path, model, {"EQ": pde, "BC": bc})
+    assert getattr(solver._compiled["BC"], "is_eager", False) and not getattr(solver._compiled["EQ"], "is_eager", False)
+    p0 = model.flat_params.clone()
+    solver.train()  # one Adam step through both paths
+    assert torch.isfinite(model.flat_params).all() and not torch.equal(model.flat_params, p0)
+    model.flat_params.copy_(p0)
+    solver.engine.forward_backward([solver._compiled["EQ"].fused])
+    solver._compiled["BC"].forward_backward(solver.engine.grad)
+    g = solver.engine.grad.cpu().numpy().astype(np.float64)
+
+    omodel = R.MLP(("x",), ("u",), net.astype(np.float32).astype(np.float64))
+
+    def ograd(y, x):
+        return torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+
+    def d1(d): return ograd(d["u"], d["x"])  # noqa: E704
+    def d2(d): return ograd(d1(d), d["x"])  # noqa: E704
+    def d3(d): return ograd(d2(d), d["x"])  # noqa: E704
+    oc = [dict(name="EQ", input={"x": Xi.astype(np.float64)}, exprs={k: R.lambdify(e, omodel) for k, e in eq.equations.items()},
+               label={"biharmonic": np.zeros((32, 1))}, reduction="mean"),
+          dict(name="BC", input={"x": Xb.astype(np.float64)},
+               exprs={"u0": lambda d: d["u"][0:1], "u__x": lambda d: d1(d)[1:2], "u__x__x": lambda d: d2(d)[2:3],
+                      "u__x__x__x": lambda d: d3(d)[3:4]},
+               label={k: np.zeros((4, 1)) for k in bc_exprs}, reduction="sum")]
+    total, losses, gref, _ = R.loss_and_grads(omodel, oc)
+    mine = {**solver._compiled["EQ"].fused.losses(), **solver._compiled["BC"].losses()}
+    for k in losses:
+        assert mine[k] == pytest.approx(losses[k], rel=2e-4, abs=1e-9), k
+    assert rel(g, gref) < 2e-4
