@@ -258,6 +258,14 @@ int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const 
                              float* b_out, void* stream);
 int ppsci_linear_pullback(int kind, int fin, int fout, const float* v, const float* g, const float* gW,
                           const float* gb, float* gv, float* gg, float* gb_out, void* stream);
+/* Per-layer widths (MLP(hidden_size=(h1, h2, ...)), mlp.py:199-201): the Taylor kernels run the padded width max(h_l); a
+ * layer's trainable [fin_src, fout_src] matrix (+ bias) is the top-left block of its zero-filled [fin_dst, fout_dst] slice of
+ * the kernel parameter buffer (ppsci_linear_pad, before the forward sweep), and only that block of the kernel-layout gradient
+ * is copied back (ppsci_linear_unpad): the padding never trains. */
+int ppsci_linear_pad(int fin_src, int fout_src, int fin_dst, int fout_dst, const float* v, const float* b, float* W,
+                     float* b_out, void* stream);
+int ppsci_linear_unpad(int fin_src, int fout_src, int fin_dst, int fout_dst, const float* gW, const float* gb, float* gv,
+                       float* gb_out, void* stream);
 
 /* ---- FNO spectral convolution (BASELINE config 4) --------------------------------------------------
  * Replaces the per-mode complex channel contraction of FactorizedSpectralConv.forward

@@ -18,6 +18,7 @@ ACT = {"tanh": 0, "silu": 1, "sin": 2, "sigmoid": 3, "cos": 4, "gelu": 5, "swish
 PARAM_ACTS = ("swish", "stan")  # a trainable per-feature parameter vector per hidden layer (behind the last bias)
 SIREN_W0 = 30.0  # activation.py:98
 LINEAR_PLAIN, LINEAR_WEIGHT_NORM, LINEAR_RWF, LINEAR_FOURIER, LINEAR_BROADCAST = range(5)
+LINEAR_PADDED = 100  # host-side record kind: ppsci_linear_pad / ppsci_linear_unpad (per-layer widths)
 EMBED_NONE, EMBED_PERIOD, EMBED_STREAMS = 0, 1, 2
 
 (OP_LD_IN, OP_LD_U, OP_LD_AUX, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_POW, OP_SIN, OP_COS,
@@ -136,6 +137,10 @@ _SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_linear_materialize": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    "ppsci_linear_pad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "ppsci_linear_unpad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "ppsci_linear_pullback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -109,8 +109,16 @@ class MLP(Arch):
         if output_dim is not None and int(output_dim) != len(self.output_keys):
             raise NotImplementedError(f"output_dim={output_dim} with {len(self.output_keys)} output key(s): multi-column "
                                       "outputs are not supported on the HIP path (give one key per column)")
-        if len(set(hidden)) != 1:
-            raise NotImplementedError("the fused HIP kernels need one width for all hidden layers")
+        # per-layer widths (mlp.py:199-201): the kernels run the padded width max(hidden); the trainable tensors keep the
+        # reference's shapes and are embedded into zero-filled kernel-layout matrices before every sweep (reparam.hip)
+        self._widths = list(hidden)
+        padded = len(set(hidden)) != 1
+        if padded:
+            if weight_norm or random_weight or fourier:
+                raise NotImplementedError("per-layer widths together with weight_norm / random_weight / fourier")
+            if activation.lower() in L.PARAM_ACTS:
+                raise NotImplementedError("per-layer widths together with a learnable activation")
+            hidden = [max(hidden)] * len(hidden)
         self.activation = act_mod.get_activation(activation)
         self.skip_connection = bool(skip_connection)
         self.periods = periods
@@ -137,7 +145,7 @@ class MLP(Arch):
         self._param_act = self.activation in L.PARAM_ACTS  # swish (scalar beta per layer) / stan (beta[H] per layer)
         if self._param_act and fourier_half:
             raise NotImplementedError("fourier embedding together with a learnable activation")
-        self.reparam = bool(fourier_half) or self._linear_kind != L.LINEAR_PLAIN or self._param_act
+        self.reparam = bool(fourier_half) or self._linear_kind != L.LINEAR_PLAIN or self._param_act or padded
         self.layout = hp.NetLayout(len(self.input_keys), len(hidden) + (1 if fourier_half else 0), hidden[0],
                                    len(self.output_keys), self.activation, self.skip_connection, embed, omega,
                                    fourier_half)
@@ -149,12 +157,13 @@ class MLP(Arch):
             shapes.append(("fourier_emb.kernel", (fin, fourier_half)))
             fin = 2 * fourier_half
         for l in range(len(hidden)):
+            wl = self._widths[l]  # == hidden[0] unless the widths differ per layer
             if self._linear_kind == L.LINEAR_PLAIN:
-                shapes += [(f"linears.{l}.weight", (fin, hidden[0])), (f"linears.{l}.bias", (hidden[0],))]
+                shapes += [(f"linears.{l}.weight", (fin, wl)), (f"linears.{l}.bias", (wl,))]
             else:  # WeightNormLinear / RandomWeightFactorization: weight_v, weight_g, bias (mlp.py:35-41, :69-75)
-                shapes += [(f"linears.{l}.weight_v", (fin, hidden[0])), (f"linears.{l}.weight_g", (hidden[0],)),
-                           (f"linears.{l}.bias", (hidden[0],))]
-            fin = hidden[0]
+                shapes += [(f"linears.{l}.weight_v", (fin, wl)), (f"linears.{l}.weight_g", (wl,)),
+                           (f"linears.{l}.bias", (wl,))]
+            fin = wl
         if self._param_act:  # self.acts is registered between self.linears and self.last_fc (mlp.py:262-263, :274)
             shapes += [(f"acts.{l}.beta", () if self.activation == "swish" else (hidden[0],)) for l in range(len(hidden))]
         if self._linear_kind == L.LINEAR_RWF:  # mlp.py:266-272: with random_weight the last linear is factorised too
@@ -192,7 +201,11 @@ class MLP(Arch):
                 kl = 1
             for l in range(len(hidden)):
                 w, b = kviews[2 * (kl + l)], kviews[2 * (kl + l) + 1]
-                if self._linear_kind == L.LINEAR_PLAIN:
+                if padded:  # (kind, source dims, ...): the trainable block is smaller than the kernel-layout slice
+                    fs = self.layout.d0 if l == 0 else self._widths[l - 1]
+                    self._records.append((L.LINEAR_PADDED, (fs, self._widths[l]), w[2], f"linears.{l}.weight", None,
+                                          f"linears.{l}.bias", w, b))
+                elif self._linear_kind == L.LINEAR_PLAIN:
                     self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], f"linears.{l}.weight", None,
                                           f"linears.{l}.bias", w, b))
                 else:
@@ -203,6 +216,9 @@ class MLP(Arch):
             if self._linear_kind == L.LINEAR_RWF:
                 self._records.append((L.LINEAR_RWF, w[2][0], w[2][1], "last_fc.weight_v", "last_fc.weight_g",
                                       "last_fc.bias", w, b))
+            elif padded:
+                self._records.append((L.LINEAR_PADDED, (self._widths[-1], w[2][1]), w[2], "last_fc.weight", None, "last_fc.bias",
+                                      w, b))
             else:
                 self._records.append((L.LINEAR_PLAIN, w[2][0], w[2][1], "last_fc.weight", None, "last_fc.bias", w, b))
             if self._param_act:  # ... and then one [H] parameter vector per hidden layer
@@ -266,6 +282,9 @@ class MLP(Arch):
         """Fill `kernel_params` from the trainable tensors; call before every forward sweep."""
         t = self._byname
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
+            if kind == L.LINEAR_PADDED:
+                hp.linear_pad(fin, fout, t[v].reshape(-1), t[b], self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn])
+                continue
             hp.linear_materialize(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, t[b] if b else None,
                                   self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn] if bn else None)
         return self.kernel_params
@@ -276,6 +295,9 @@ class MLP(Arch):
             return grad_kernel
         t, gt = self._byname, self._gviews
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
+            if kind == L.LINEAR_PADDED:
+                hp.linear_unpad(fin, fout, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn], gt[v].reshape(-1), gt[b])
+                continue
             hp.linear_pullback(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, grad_kernel[wo:wo + wn],
                                grad_kernel[bo:bo + bn] if bn else None, gt[v].reshape(-1), gt[g] if g else None,
                                gt[b] if b else None)

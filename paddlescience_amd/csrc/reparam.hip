@@ -146,3 +146,52 @@ extern "C" int ppsci_linear_pullback(int kind, int fin, int fout, const float* v
   }
   return PPSCI_OK;
 }
+
+// ---- per-layer widths (mlp.py:199-201: hidden_size as a tuple): the Taylor kernels run ONE padded width H = max(widths);
+// a layer's [fin_s, fout_s] matrix is the top-left block of its [fin_d, fout_d] kernel-layout matrix, everything else is zero.
+// Padded features evaluate act(0) but feed only zero weights; their gradient entries are never pulled back, so they stay zero.
+struct PadArgs {
+  int fin_s, fout_s, fin_d, fout_d, back;
+  const float* src;   // forward: trainable W [fin_s, fout_s];  back: kernel-layout gradient [fin_d, fout_d]
+  const float* srcb;  // bias [fout_s] / [fout_d] or null
+  float* dst;
+  float* dstb;
+};
+
+__global__ void __launch_bounds__(256) linear_pad_kernel(PadArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (!a.back) {
+    if (j >= a.fout_d) return;
+    for (int i = 0; i < a.fin_d; ++i) a.dst[i * a.fout_d + j] = (i < a.fin_s && j < a.fout_s) ? a.src[i * a.fout_s + j] : 0.f;
+    if (a.dstb) a.dstb[j] = (a.srcb && j < a.fout_s) ? a.srcb[j] : 0.f;
+  } else {
+    if (j >= a.fout_s) return;
+    for (int i = 0; i < a.fin_s; ++i) a.dst[i * a.fout_s + j] = a.src[i * a.fout_d + j];
+    if (a.dstb && a.srcb) a.dstb[j] = a.srcb[j];
+  }
+}
+
+static int launch_pad(PadArgs& a, void* stream) {
+  if (a.fin_s < 1 || a.fout_s < 1 || a.fin_d < a.fin_s || a.fout_d < a.fout_s || !a.src || !a.dst) {
+    ppsci_set_error("linear_pad: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  PPSCI_LAUNCH(linear_pad_kernel, PadArgs, ((a.back ? a.fout_s : a.fout_d) + 255) / 256, 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("linear_pad: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_linear_pad(int fin_src, int fout_src, int fin_dst, int fout_dst, const float* v, const float* b, float* W,
+                                float* b_out, void* stream) {
+  PadArgs a{fin_src, fout_src, fin_dst, fout_dst, 0, v, b, W, b_out};
+  return launch_pad(a, stream);
+}
+
+extern "C" int ppsci_linear_unpad(int fin_src, int fout_src, int fin_dst, int fout_dst, const float* gW, const float* gb,
+                                  float* gv, float* gb_out, void* stream) {
+  PadArgs a{fin_src, fout_src, fin_dst, fout_dst, 1, gW, gb, gv, gb_out};
+  return launch_pad(a, stream);
+}

@@ -204,6 +204,22 @@ def linear_materialize(kind: int, fin: int, fout: int, v: torch.Tensor, g: Optio
     L.check(L.lib().ppsci_linear_materialize(kind, fin, fout, _p(v), _p(g), _p(b), _p(W), _p(b_out), _stream_ptr(W)))
 
 
+def linear_pad(src_dims, dst_dims, v: torch.Tensor, b: torch.Tensor, W: torch.Tensor, b_out: torch.Tensor) -> None:
+    """ppsci_linear_pad: trainable [fin_s, fout_s] block (+ bias) -> zero-filled kernel-layout [fin_d, fout_d] slice."""
+    _require_device(W)
+    _chk_f32(v, b, W, b_out)
+    L.check(L.lib().ppsci_linear_pad(src_dims[0], src_dims[1], dst_dims[0], dst_dims[1], _p(v), _p(b), _p(W), _p(b_out),
+                                     _stream_ptr(W)))
+
+
+def linear_unpad(src_dims, dst_dims, gW: torch.Tensor, gb: torch.Tensor, gv: torch.Tensor, gb_out: torch.Tensor) -> None:
+    """ppsci_linear_unpad: the trainable block of the kernel-layout gradient."""
+    _require_device(gW)
+    _chk_f32(gW, gb, gv, gb_out)
+    L.check(L.lib().ppsci_linear_unpad(src_dims[0], src_dims[1], dst_dims[0], dst_dims[1], _p(gW), _p(gb), _p(gv),
+                                       _p(gb_out), _stream_ptr(gW)))
+
+
 def linear_pullback(kind: int, fin: int, fout: int, v: Optional[torch.Tensor], g: Optional[torch.Tensor],
                     gW: torch.Tensor, gb: Optional[torch.Tensor], gv: torch.Tensor, gg: Optional[torch.Tensor],
                     gb_out: Optional[torch.Tensor]) -> None:

@@ -726,3 +726,45 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
     for k in losses:
         assert mine[k] == pytest.approx(losses[k], rel=2e-4, abs=1e-9), k
     assert rel(g, gref) < 2e-4
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid"])
+def test_per_layer_widths(tmp_path, act):
+    """MLP(hidden_size=(24, 16, 32)) (mlp.py:199-201): the kernels run the padded width 32, the trainable tensors keep the
+    reference's shapes; loss, gradient (in the reference's parameter layout) and two Adam steps against the oracle.
+    sigmoid: act(0) != 0 on the padded features -- they must still contribute nothing."""
+    hidden = [24, 16, 32]
+    model = ppsci.arch.MLP(("x", "y"), ("u",), None, tuple(hidden), act)
+    assert [tuple(p.shape) for p in model.parameters()] == [(2, 24), (24,), (24, 16), (16,), (16, 32), (32,), (32, 1), (1,)]
+    net = T.make_net(2, hidden, 1, activation=act, bias_scale=0.1)
+    set_model_weights(model, net)
+    N = 37
+    X = np.random.default_rng(8).uniform(0, 1, (N, 2)).astype(np.float32)
+    lab = np.random.default_rng(9).standard_normal((N, 1)).astype(np.float32) * 0.1
+    eq = ppsci.equation.Laplace(2)
+    cst = _sup_constraint({"x": X[:, :1], "y": X[:, 1:]}, {"laplace": lab}, eq.equations, ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    solver._materialize()
+    solver.engine.forward_backward([solver._compiled["EQ"].fused])
+    g = solver._train_grad().cpu().numpy().astype(np.float64)
+    omodel = R.MLP(("x", "y"), ("u",), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={"x": X[:, :1].astype(np.float64), "y": X[:, 1:].astype(np.float64)},
+              exprs={k: R.lambdify(e, omodel) for k, e in R.laplace_exprs(2).items()}, label={"laplace": lab.astype(np.float64)},
+              reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    assert g.shape == gref.shape
+    assert solver._compiled["EQ"].fused.losses()["laplace"] == pytest.approx(total, rel=5e-5)
+    assert rel(g, gref) < 1e-4
+    solver.epochs = 2
+    solver.train()
+    p = np.concatenate([q.detach().numpy().ravel() for q in omodel.parameters()])
+    adam = R.Adam(p.size, 1e-3)
+    for _ in range(2):
+        off = 0
+        with torch.no_grad():
+            for q in omodel.parameters():
+                q.copy_(torch.from_numpy(p[off:off + q.numel()].reshape(q.shape)))
+                off += q.numel()
+        _, _, gg, _ = R.loss_and_grads(omodel, [oc])
+        p = adam.step(p, gg)
+    assert rel(model.flat_params.cpu().numpy(), p) < 2e-5
