@@ -349,6 +349,14 @@ int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params, int64_t n_
 /* grad_partials: [n_points, P], fully overwritten (sum the rows with ppsci_reduce_rows). */
 int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params, int64_t n_points, const float* x,
                      const float* Fbar, const float* stash, float* grad_partials, void* stream);
+/* The same for up to 3 networks of one shape (the SPINN axes: spinn.py:124-137 loops over them) in ONE launch:
+ * arrays of `nbatch` pointers / point counts; workgroup = (network, point). */
+int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n_points,
+                           const float* const* x, float* const* F, float* const* stash /* NULL for inference */,
+                           void* stream);
+int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n_points,
+                           const float* const* x, const float* const* Fbar, const float* const* stash,
+                           float* const* grad_partials, void* stream);
 
 /* Tensor-product grid: q(i,j,k) = sum_r fx[i,r] fy[j,r] fz[k,r] (SPINN.forward_tensor spinn.py:140-167) for
  * q in {u, u_xx, u_yy, u_zz}; res = cu*u + cxx*u_xx + cyy*u_yy + czz*u_zz (Helmholtz helmholtz.py:78-93:

@@ -123,6 +123,11 @@ _SYMBOLS = {
                                    C.c_void_p]),
     "ppsci_modmlp_bwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "ppsci_modmlp_fwd_batch": (C.c_int, [C.POINTER(ModMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "ppsci_modmlp_bwd_batch": (C.c_int, [C.POINTER(ModMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.c_void_p]),
     "ppsci_spinn_grid_partial_rows": (C.c_int64, [C.POINTER(SpinnGridDesc)]),
     "ppsci_spinn_grid_fwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

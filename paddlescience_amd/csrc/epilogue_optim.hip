@@ -255,6 +255,23 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
   }
 }
 
+// Few columns, many rows (loss partials: one row per wave): one workgroup per column, thread t sums rows t, t+256, ...
+// in order, then a fixed-shape LDS tree (deterministic).
+__global__ void __launch_bounds__(256) reduce_rows_narrow_kernel(ReduceArgs a) {
+  PPSCI_DYN_SMEM(red);  // [256]
+  const long long j = blockIdx.x;
+  float s = 0.f;
+#pragma unroll 8
+  for (long long r = threadIdx.x; r < a.rows; r += 256) s += a.partials[r * a.cols + j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.out[j] = a.accumulate ? a.out[j] + red[0] : red[0];
+}
+
 struct AdamArgs {
   float* p;
   const float* g;
@@ -523,8 +540,12 @@ extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t co
     return PPSCI_E_INVALID;
   }
   ReduceArgs a{partials, out, rows, cols, accumulate};
-  const int grid = (int)((cols + RED_COLS - 1) / RED_COLS);
-  PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, RED_GROUPS * RED_COLS * sizeof(float), stream, a);
+  if (cols <= 8 && rows >= 512) {
+    PPSCI_LAUNCH(reduce_rows_narrow_kernel, ReduceArgs, (int)cols, 256, 256 * sizeof(float), stream, a);
+  } else {
+    const int grid = (int)((cols + RED_COLS - 1) / RED_COLS);
+    PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, RED_GROUPS * RED_COLS * sizeof(float), stream, a);
+  }
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("reduce_rows: launch failed (hip error %d)", err);

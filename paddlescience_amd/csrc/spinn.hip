@@ -77,9 +77,8 @@ static inline void mod_offsets(const ppsci_modmlp_desc& d, ModOff& o) {
   o.P = off;
 }
 
-struct ModArgs {
-  ppsci_modmlp_desc d;
-  ModOff o;
+#define SP_MAXBATCH 3
+struct ModBranch {     // one network (one SPINN axis) and its points
   const float* params;
   const float* x;      // [N]
   float* F;            // fwd out: [3][N][R]
@@ -88,6 +87,18 @@ struct ModArgs {
   float* partials;     // bwd out: [N][P]
   int N;
 };
+struct ModArgs {       // up to SP_MAXBATCH networks of the same shape in one launch: workgroup = (branch, point)
+  ppsci_modmlp_desc d;
+  ModOff o;
+  ModBranch br[SP_MAXBATCH];
+  int nbatch;
+};
+
+__device__ __forceinline__ int mod_locate(const ModArgs& a, int& pt) {
+  int bi = 0;
+  while (bi + 1 < a.nbatch && pt >= a.br[bi].N) { pt -= a.br[bi].N; ++bi; }
+  return bi;
+}
 
 // streams of the gated layer output o = v + a*(u - v) from the activation streams a and the embeddings
 __device__ __forceinline__ void sp_gate(const float a[3], const float U[3], const float V[3], float o[3]) {
@@ -105,13 +116,38 @@ __device__ __forceinline__ void sp_act_streams(int act, const float z[3], float 
   a[2] = d2 * z[1] * z[1] + d1 * z[2];
 }
 
+// [rows][cols] row-major global matrix -> LDS with row stride cols + 1 (thread = row reads are then conflict-free).
+// 16 coalesced loads are issued before the first LDS write (a one-wave workgroup has nothing else to hide the
+// latency behind); (row, col) of the running element are tracked incrementally -- no integer division.
+__device__ __forceinline__ void sp_stage_rows(float* ws, const float* src, int rows, int cols, int f, int nthr) {
+  const int total = rows * cols;
+  int k = 0, j = f;
+  while (j >= cols) { j -= cols; ++k; }
+  for (int base = 0; base < total; base += 16 * nthr) {
+    float tmp[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * nthr + f;
+      tmp[u] = idx < total ? src[idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * nthr + f;
+      if (idx < total) ws[k * (cols + 1) + j] = tmp[u];
+      j += nthr;
+      while (j >= cols) { j -= cols; ++k; }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(SP_MAXH) modmlp_fwd_kernel(ModArgs a) {
   PPSCI_DYN_SMEM(sh);  // [3][H]
   const int f = threadIdx.x, H = a.d.width, L = a.d.n_hidden, R = a.d.d_out, act = a.d.activation;
-  const int pt = blockIdx.x;
-  const float x = a.x[pt];
-  const float* P = a.params;
-  float* st = a.stash ? a.stash + (long long)pt * (L + 2) * 3 * H : nullptr;
+  int pt = blockIdx.x;
+  const ModBranch& B = a.br[mod_locate(a, pt)];
+  const float x = B.x[pt];
+  const float* P = B.params;
+  float* st = B.stash ? B.stash + (long long)pt * (L + 2) * 3 * H : nullptr;
   float U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, o[3] = {0, 0, 0};
   if (f < H) {
     float z[3], d1, d2, d3;
@@ -136,6 +172,7 @@ __global__ void __launch_bounds__(SP_MAXH) modmlp_fwd_kernel(ModArgs a) {
       if (f < H) {
         const float* W = P + a.o.w[l];
         float s0 = P[a.o.b[l] + f], s1 = 0.f, s2 = 0.f;
+#pragma unroll 16
         for (int k = 0; k < H; ++k) {
           const float w = W[k * H + f];
           s0 += w * sh[k]; s1 += w * sh[H + k]; s2 += w * sh[2 * H + k];
@@ -156,26 +193,31 @@ __global__ void __launch_bounds__(SP_MAXH) modmlp_fwd_kernel(ModArgs a) {
   for (int r = f; r < R; r += blockDim.x) {
     const float* W = P + a.o.wl;
     float s0 = P[a.o.bl + r], s1 = 0.f, s2 = 0.f;
+#pragma unroll 16
     for (int k = 0; k < H; ++k) {
       const float w = W[k * R + r];
       s0 += w * sh[k]; s1 += w * sh[H + k]; s2 += w * sh[2 * H + k];
     }
-    a.F[((long long)0 * a.N + pt) * R + r] = s0;
-    a.F[((long long)1 * a.N + pt) * R + r] = s1;
-    a.F[((long long)2 * a.N + pt) * R + r] = s2;
+    B.F[((long long)0 * B.N + pt) * R + r] = s0;
+    B.F[((long long)1 * B.N + pt) * R + r] = s1;
+    B.F[((long long)2 * B.N + pt) * R + r] = s2;
   }
 }
 
-__global__ void __launch_bounds__(SP_MAXH) modmlp_bwd_kernel(ModArgs a) {
-  PPSCI_DYN_SMEM(sh);  // [3][H] exchange + [3][R] Fbar
+// 256 threads per point: the first H own a feature each, all of them move the weight tiles and write the per-point
+// weight gradients.
+#define MOD_BWD_BLOCK 256
+__global__ void __launch_bounds__(MOD_BWD_BLOCK) modmlp_bwd_kernel(ModArgs a) {
+  PPSCI_DYN_SMEM(sh);  // [3][H] exchange + [3][R] Fbar + [H][max(H, R) + 1] weight rows
   const int f = threadIdx.x, H = a.d.width, L = a.d.n_hidden, R = a.d.d_out, act = a.d.activation;
-  const int pt = blockIdx.x;
-  const float x = a.x[pt];
-  const float* P = a.params;
-  const float* st = a.stash + (long long)pt * (L + 2) * 3 * H;
-  float* G = a.partials + (long long)pt * a.o.P;
+  int pt = blockIdx.x;
+  const ModBranch& B = a.br[mod_locate(a, pt)];
+  const float x = B.x[pt];
+  const float* P = B.params;
+  const float* st = B.stash + (long long)pt * (L + 2) * 3 * H;
+  float* G = B.partials + (long long)pt * a.o.P;
   float* fb = sh + 3 * H;
-  for (int i = f; i < 3 * R; i += blockDim.x) fb[i] = a.Fbar[((long long)(i / R) * a.N + pt) * R + (i % R)];
+  for (int i = f; i < 3 * R; i += blockDim.x) fb[i] = B.Fbar[((long long)(i / R) * B.N + pt) * R + (i % R)];
   // embeddings (recomputed)
   float U[3] = {0, 0, 0}, V[3] = {0, 0, 0}, zu[3] = {0, 0, 0}, zv[3] = {0, 0, 0};
   float du1 = 0, du2 = 0, du3 = 0, dv1 = 0, dv2 = 0, dv3 = 0;
@@ -193,15 +235,32 @@ __global__ void __launch_bounds__(SP_MAXH) modmlp_bwd_kernel(ModArgs a) {
     sp_act_streams(act, zl, al, d1, d2, d3);
     sp_gate(al, U, V, ol);
   }
-  __syncthreads();
   // last_fc: obar_s[k] = sum_r WL[k][r] Fbar_s[r];  gWL[k][r] = sum_s o_s[k] Fbar_s[r];  gbL[r] = Fbar_0[r]
+  // Weight rows are read by "thread = row": staged through LDS (coalesced global read, row stride + 1 -> conflict-
+  // free row reads) instead of 64 different cache lines per load.
+  float* shz = fb + 3 * R;  // [3][H] zbar of the layer
+  float* ws = shz + 3 * H;  // [H][max(H, R) + 1]
+  const int hstep = (int)blockDim.x / H, hr = f / H, hc = f - hr * H;  // blockDim >= H
+  if (f < H) { sh[f] = ol[0]; sh[H + f] = ol[1]; sh[2 * H + f] = ol[2]; }
+  // (thread -> (row, column) of a [H][R] tile with ONE integer division: a wave has nothing to hide them behind)
+  const int rstep = (int)blockDim.x / R;  // rows per trip; 0: a row is wider than the workgroup
+  const int fr = rstep > 0 ? f / R : 0, fc = rstep > 0 ? f - fr * R : f;
+  const int rinc = rstep > 0 ? rstep : 1, cinc = rstep > 0 ? R : (int)blockDim.x;
+  const bool live = rstep == 0 || fr < rstep;
+  sp_stage_rows(ws, P + a.o.wl, H, R, f, (int)blockDim.x);
+  __syncthreads();
   float ob[3] = {0, 0, 0};
+  if (live) {
+#pragma unroll 4
+    for (int k = fr; k < H; k += rinc)
+      for (int r = fc; r < R; r += cinc)
+        G[a.o.wl + k * R + r] = sh[k] * fb[r] + sh[H + k] * fb[R + r] + sh[2 * H + k] * fb[2 * R + r];
+  }
   if (f < H) {
-    const float* W = P + a.o.wl + f * R;
+    const float* W = ws + f * (R + 1);
     for (int r = 0; r < R; ++r) {
       const float w = W[r];
       ob[0] += w * fb[r]; ob[1] += w * fb[R + r]; ob[2] += w * fb[2 * R + r];
-      G[a.o.wl + f * R + r] = ol[0] * fb[r] + ol[1] * fb[R + r] + ol[2] * fb[2 * R + r];
     }
   }
   for (int r = f; r < R; r += blockDim.x) G[a.o.bl + r] = fb[r];
@@ -238,21 +297,24 @@ __global__ void __launch_bounds__(SP_MAXH) modmlp_bwd_kernel(ModArgs a) {
       sp_gate(ap, U, V, op);
     }
     __syncthreads();
-    if (f < H) { sh[f] = op[0]; sh[H + f] = op[1]; sh[2 * H + f] = op[2]; }
-    __syncthreads();
-    if (f < H) {  // gW_l[k][f] = sum_s o_prev_s[k] zbar_s[f]
-      float* gw = G + a.o.w[l];
-      for (int k = 0; k < H; ++k) gw[k * H + f] = sh[k] * zb[0] + sh[H + k] * zb[1] + sh[2 * H + k] * zb[2];
+    if (f < H) {
+      sh[f] = op[0]; sh[H + f] = op[1]; sh[2 * H + f] = op[2];
+      shz[f] = zb[0]; shz[H + f] = zb[1]; shz[2 * H + f] = zb[2];
     }
+    sp_stage_rows(ws, P + a.o.w[l], H, H, f, (int)blockDim.x);
     __syncthreads();
-    if (f < H) { sh[f] = zb[0]; sh[H + f] = zb[1]; sh[2 * H + f] = zb[2]; }
-    __syncthreads();
+    if (hr < hstep) {  // gW_l[k][j] = sum_s o_prev_s[k] zbar_s[j]   (all threads: thread = (row phase, column j))
+      float* gw = G + a.o.w[l];
+      const float z0 = shz[hc], z1 = shz[H + hc], z2 = shz[2 * H + hc];
+#pragma unroll 4
+      for (int k = hr; k < H; k += hstep) gw[k * H + hc] = sh[k] * z0 + sh[H + k] * z1 + sh[2 * H + k] * z2;
+    }
     if (f < H) {  // obar_prev_s[k=f] = sum_j W_l[f][j] zbar_s[j]
-      const float* W = P + a.o.w[l] + f * H;
+      const float* W = ws + f * (H + 1);
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
       for (int j = 0; j < H; ++j) {
         const float w = W[j];
-        s0 += w * sh[j]; s1 += w * sh[H + j]; s2 += w * sh[2 * H + j];
+        s0 += w * shz[j]; s1 += w * shz[H + j]; s2 += w * shz[2 * H + j];
       }
       ob[0] = s0; ob[1] = s1; ob[2] = s2;
       zl[0] = zp[0]; zl[1] = zp[1]; zl[2] = zp[2];
@@ -285,7 +347,24 @@ struct GridArgs {
   float* Fpart;          // bwd scratch: [n_a][groups][2][R]
   int axis;
   int iters;
+  int ngrp;  // fbar_sum: partial groups per index
+  // axis < 0: all three axes in one launch -- workgroups [0, wg3[0]) axis 0, the next wg3[1] axis 1, ...
+  float* Fbar3[3];
+  long long poff3[3];  // offset of the axis' partial rows in Fpart
+  int ngrp3[3];
+  int wg3[3];
 };
+
+__device__ __forceinline__ int grid_locate(const GridArgs& a, int& bx, int& ngrp, float*& Fbar, float*& Fpart) {
+  int ax = a.axis;
+  ngrp = a.ngrp; Fbar = a.Fbar; Fpart = a.Fpart;
+  if (ax < 0) {
+    ax = 0;
+    while (ax < 2 && bx >= a.wg3[ax]) { bx -= a.wg3[ax]; ++ax; }
+    ngrp = a.ngrp3[ax]; Fbar = a.Fbar3[ax]; Fpart = a.Fpart + a.poff3[ax];
+  }
+  return ax;
+}
 
 #define GRID_BLOCK 256
 #define GRID_JT 8  // j rows per forward workgroup
@@ -417,23 +496,250 @@ __global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_bwd_kernel(GridArgs a) 
   }
 }
 
-__global__ void __launch_bounds__(GRID_BLOCK) spinn_fbar_sum_kernel(GridArgs a) {
-  const int R = a.d.rank, ax = a.axis, na = a.d.n[ax];
-  const int b = ax == 0 ? 1 : 0;
-  const int ngrp = (a.d.n[b] + GRID_JG - 1) / GRID_JG;
-  const long long t = (long long)blockIdx.x * GRID_BLOCK + threadIdx.x;
-  if (t >= (long long)na * R) return;
-  const int i = (int)(t / R), r = (int)(t % R);
-  float s0 = 0.f, s2 = 0.f;
-  for (int g = 0; g < ngrp; ++g) {
-    const float* p = a.Fpart + ((long long)i * ngrp + g) * 2 * R;
-    s0 += p[r];
-    s2 += p[R + r];
+// ---- MFMA forms of the two grid contractions (rank <= 64, rank % 4 == 0); the scalar kernels above stay for the rest.
+//
+// v_mfma_f32_16x16x4_f32: lane (g = l>>4, c = l&15) supplies A[row c][k g], B[k g][col c] and holds D[row 4g+rr][col c].
+// The order in which the contraction index is fed to the k-steps is free, and both kernels use it to make every
+// operand load a 16-byte one: k-step (q, e) of a 16-wide slab q takes index 16q + 4g + e from lane group g, i.e. each
+// lane loads ONE float4 per slab and operand (4 lane groups = 64 contiguous bytes of one row).
+//
+// Forward as a GEMM per i:  res[(j), k] = sum_{r'} A[j][r'] B[r'][k],  r' over the 2R columns (p_r | q_r):
+// one wave = (i, 16 rows j, every GRID_CS-th 16-column tile of k); the wave computes its A operand (16 x 2R) once
+// into registers; B[r'][k] = fz[k,r] / fz''[k,r] from the (L1/L2-resident) factor table.  Consecutive lanes c =
+// consecutive k: label read and adjoint write in 64 B runs.  The kernel is latency-bound (8 MB of labels, a few
+// hundred MFMAs per wave): the label loads are issued with the B-operand loads, ahead of the MFMA chain, and the
+// column split puts 4 waves on every SIMD.
+#define GRID_CS 4
+template <int NQ>
+__global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_fwd_mfma_kernel(GridArgs a) {
+  const int R = a.d.rank, nx = a.d.n[0], ny = a.d.n[1], nz = a.d.n[2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int njb = (ny + 15) / 16;
+  const int wid = blockIdx.x * (GRID_BLOCK / 64) + wave;  // ((i, j block), column phase)
+  if (wid >= nx * njb * GRID_CS) return;
+  const int cs = wid % GRID_CS, ij = wid / GRID_CS;
+  const int i = ij / njb, j0 = (ij % njb) * 16;
+  const long long sy = (long long)ny * R, sz = (long long)nz * R;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 Ap[NQ], Aq[NQ];
+  {
+    const int j = j0 + c;
+    f32x4 x0[NQ], x2[NQ], y0[NQ], y2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int r4 = 16 * q + 4 * g;
+      const bool ok = j < ny && r4 < R;
+      x0[q] = ok ? *(const f32x4*)&a.F[0][(long long)i * R + r4] : zero4;
+      x2[q] = ok ? *(const f32x4*)&a.F[0][2 * (long long)nx * R + (long long)i * R + r4] : zero4;
+      y0[q] = ok ? *(const f32x4*)&a.F[1][(long long)j * R + r4] : zero4;
+      y2[q] = ok ? *(const f32x4*)&a.F[1][2 * sy + (long long)j * R + r4] : zero4;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      Ap[q] = (a.d.cu * x0[q] + a.d.cxx * x2[q]) * y0[q] + a.d.cyy * x0[q] * y2[q];
+      Aq[q] = a.d.czz * x0[q] * y0[q];
+    }
   }
+  float lsum = 0.f;
+  for (int k0 = 16 * cs; k0 < nz; k0 += 16 * GRID_CS) {
+    const int k = k0 + c;
+    f32x4 B0[NQ], B2[NQ];
+    float lab[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = j0 + 4 * g + rr;
+      lab[rr] = (a.label && j < ny && k < nz) ? a.label[((long long)i * ny + j) * nz + k] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int r4 = 16 * q + 4 * g;
+      const bool ok = k < nz && r4 < R;
+      B0[q] = ok ? *(const f32x4*)&a.F[2][(long long)k * R + r4] : zero4;
+      B2[q] = ok ? *(const f32x4*)&a.F[2][2 * sz + (long long)k * R + r4] : zero4;
+    }
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[q][e], B0[q][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Aq[q][e], B2[q][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = j0 + 4 * g + rr;
+      if (j < ny && k < nz) {
+        const long long pidx = ((long long)i * ny + j) * nz + k;
+        const float res = acc[rr];
+        if (a.resid) a.resid[pidx] = res;
+        const float diff = res - lab[rr];
+        lsum += a.d.scale * diff * diff;
+        if (a.gadj) a.gadj[pidx] = 2.f * a.d.scale * diff;
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 1, 64);
+  lsum += __shfl_xor(lsum, 2, 64);
+  lsum += __shfl_xor(lsum, 4, 64);
+  lsum += __shfl_xor(lsum, 8, 64);
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (lane == 0) a.loss_partials[wid] = lsum;
+}
+
+// Reverse for axis `ax`, other axes (b, c), K = the c axis:  one wave = (16 consecutive indices i on `ax`, a chunk of
+// GRID_JC indices jb on b); one workgroup = 4 such chunks of the same i block.  Per jb a GEMM
+//     T[i, n] = sum_kc g(i,jb,kc) * [fc | fc''][kc, n]     (M = 16 i, N = 2R)
+// then -- elementwise in the D layout, no cross-lane traffic --
+//     value  += fb[jb,r]*(cu*t0 + coef_c*t2) + fb''[jb,r]*coef_b*t0,     second += fb[jb,r]*t0
+// accumulated over the chunk in registers.  fc / fc'' are staged once per workgroup in LDS with a row stride = 4
+// mod 32 floats (B operand reads of the (q, e) k-order conflict-free).  The adjoint rows are read as float4 along kc
+// where kc is the contiguous axis (ax = 0, 1; nz % 4 == 0) and as 64 B runs along i otherwise (ax = 2); the loads of a
+// whole 128-wide slab are issued together, ahead of the MFMA chain.  The 4 waves' sums are added through LDS in
+// wave order; the workgroup partials -> `Fpart`, summed by spinn_fbar_sum_kernel.
+#define GRID_JC 1
+#define GRID_QSLAB 8  // 16-wide slabs of kc per trip
+template <int NT>
+__global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_bwd_mfma_kernel(GridArgs a) {
+  PPSCI_DYN_SMEM(sm);
+  int bx = blockIdx.x, ngrp;  // ngrp: workgroup partials per index
+  float *Fbar_, *Fpart;
+  const int R = a.d.rank, ax = grid_locate(a, bx, ngrp, Fbar_, Fpart);
+  (void)Fbar_;
+  const int b = ax == 0 ? 1 : 0, c = ax == 2 ? 1 : 2;
+  const int na = a.d.n[ax], nb = a.d.n[b], nc = a.d.n[c];
+  const int RP = a.iters;   // padded LDS row stride
+  const int ncp = (nc + 15) & ~15;
+  const float coef[3] = {a.d.cxx, a.d.cyy, a.d.czz};
+  long long stride[3];
+  stride[2] = 1; stride[1] = a.d.n[2]; stride[0] = (long long)a.d.n[1] * a.d.n[2];
+  const long long sb = (long long)nb * R, sc = (long long)nc * R;
+  const bool vec = stride[c] == 1 && (a.d.n[2] & 3) == 0;
+  float* f0 = sm;             // [ncp][RP]
+  float* f2 = f0 + ncp * RP;  // [ncp][RP]
+  float* ex = f2 + ncp * RP;  // [4 waves][2][NT][4][64] exchange
+  for (int t = threadIdx.x; t < ncp * RP; t += GRID_BLOCK) {
+    const int kc = t / RP, r = t % RP;
+    const bool ok = kc < nc && r < R;
+    f0[t] = ok ? a.F[c][(long long)kc * R + r] : 0.f;
+    f2[t] = ok ? a.F[c][2 * sc + (long long)kc * R + r] : 0.f;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, cl = lane & 15;
+  const int i0 = (bx / ngrp) * 16, grp = bx % ngrp;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v0[NT], v2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    v0[nt] = zero4;
+    v2[nt] = zero4;
+  }
+  const int irow = i0 + cl;
+  for (int jj = 0; jj < GRID_JC; ++jj) {
+    const int jb = (grp * (GRID_BLOCK / 64) + wave) * GRID_JC + jj;
+    if (jb >= nb) break;
+    f32x4 t0[NT], t2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      t0[nt] = zero4;
+      t2[nt] = zero4;
+    }
+    const float* gp = a.gadj + (long long)irow * stride[ax] + (long long)jb * stride[b];
+    for (int k0 = 0; k0 < ncp; k0 += 16 * GRID_QSLAB) {
+      f32x4 av[GRID_QSLAB];
+#pragma unroll
+      for (int q = 0; q < GRID_QSLAB; ++q) {
+        const int kc = k0 + 16 * q + 4 * g;
+        if (vec) {
+          av[q] = (irow < na && kc < nc) ? *(const f32x4*)&gp[kc] : zero4;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[q][e] = (irow < na && kc + e < nc) ? gp[(long long)(kc + e) * stride[c]] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < GRID_QSLAB; ++q) {
+        if (k0 + 16 * q < ncp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kr = k0 + 16 * q + 4 * g + e;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              t0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], f0[kr * RP + 16 * nt + cl], t0[nt], 0, 0, 0);
+              t2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][e], f2[kr * RP + 16 * nt + cl], t2[nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = 16 * nt + cl;
+      const float y0 = r < R ? a.F[b][(long long)jb * R + r] : 0.f;
+      const float y2 = r < R ? a.F[b][2 * sb + (long long)jb * R + r] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        v0[nt][rr] += y0 * (a.d.cu * t0[nt][rr] + coef[c] * t2[nt][rr]) + y2 * coef[b] * t0[nt][rr];
+        v2[nt][rr] += y0 * t0[nt][rr];
+      }
+    }
+  }
+  // the 4 waves' sums, added in wave order
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      ex[((wave * 2 + 0) * NT * 4 + nt * 4 + rr) * 64 + lane] = v0[nt][rr];
+      ex[((wave * 2 + 1) * NT * 4 + nt * 4 + rr) * 64 + lane] = v2[nt][rr];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * NT * 4 * 64; e += GRID_BLOCK) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < GRID_BLOCK / 64; ++w) sum += ex[w * 2 * NT * 4 * 64 + e];
+    const int l = e & 63, q = e >> 6, rr = q & 3, nt = (q >> 2) % NT, which = q / (4 * NT);
+    const int i = i0 + 4 * (l >> 4) + rr, r = 16 * nt + (l & 15);
+    if (i < na && r < R) {
+      float* out = Fpart + ((long long)i * ngrp + grp) * 2 * R;
+      if (which == 0) out[r] = sum;
+      else out[R + r] = coef[ax] * sum;
+    }
+  }
+}
+
+// One workgroup per index i: thread = (column of the [2][R] partial row, one of FSUM_PARTS interleaved group
+// subsets); the subsets' sums are combined through LDS in a fixed order (the loads of one thread are independent:
+// one round of memory latency instead of one per group).
+#define FSUM_PARTS 8
+__global__ void __launch_bounds__(GRID_BLOCK) spinn_fbar_sum_kernel(GridArgs a) {
+  PPSCI_DYN_SMEM(red);  // [FSUM_PARTS][2R]
+  int bx = blockIdx.x, ngrp;
+  float *Fbar, *Fpart;
+  const int R = a.d.rank, ax = grid_locate(a, bx, ngrp, Fbar, Fpart), na = a.d.n[ax];
+  const int i = bx, C2 = 2 * R;
+  for (int e = threadIdx.x; e < C2 * FSUM_PARTS; e += GRID_BLOCK) {
+    const int part = e / C2, col = e % C2;
+    const float* p = Fpart + (long long)i * ngrp * C2 + col;
+    float s = 0.f;
+#pragma unroll 4
+    for (int g = part; g < ngrp; g += FSUM_PARTS) s += p[(long long)g * C2];
+    red[e] = s;
+  }
+  __syncthreads();
   const long long sa = (long long)na * R;
-  a.Fbar[t] = s0;
-  a.Fbar[sa + t] = 0.f;  // first-derivative stream is not used by these residuals
-  a.Fbar[2 * sa + t] = s2;
+  for (int col = threadIdx.x; col < C2; col += GRID_BLOCK) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < FSUM_PARTS; ++q) s += red[q * C2 + col];
+    const long long t = (long long)i * R + (col % R);
+    if (col < R) {
+      Fbar[t] = s;
+      Fbar[sa + t] = 0.f;  // first-derivative stream is not used by these residuals
+    } else {
+      Fbar[2 * sa + t] = s;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -460,9 +766,9 @@ extern "C" int64_t ppsci_modmlp_stash_floats(const ppsci_modmlp_desc* d, int64_t
 
 static int block_for(int H) { return ((H + 63) / 64) * 64; }
 
-extern "C" int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params, int64_t n, const float* x, float* F,
-                                float* stash, void* stream) {
-  if (mod_check(d) != PPSCI_OK || !params || !x || !F || n < 1) {
+extern "C" int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
+                                      const float* const* x, float* const* F, float* const* stash, void* stream) {
+  if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || !F) {
     ppsci_set_error("modmlp_fwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -470,16 +776,33 @@ extern "C" int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params,
   memset(&a, 0, sizeof(a));
   a.d = *d;
   mod_offsets(*d, a.o);
-  a.params = params; a.x = x; a.F = F; a.stash = stash; a.N = (int)n;
-  PPSCI_LAUNCH(modmlp_fwd_kernel, ModArgs, (int)n, block_for(d->width), 3 * d->width * sizeof(float), stream, a);
+  a.nbatch = nbatch;
+  long long total = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    if (!params[b] || !x[b] || !F[b] || n[b] < 1) {
+      ppsci_set_error("modmlp_fwd: invalid argument (branch %d)", b);
+      return PPSCI_E_INVALID;
+    }
+    a.br[b].params = params[b]; a.br[b].x = x[b]; a.br[b].F = F[b]; a.br[b].stash = stash ? stash[b] : nullptr;
+    a.br[b].N = (int)n[b];
+    total += n[b];
+  }
+  PPSCI_LAUNCH(modmlp_fwd_kernel, ModArgs, (int)total, block_for(d->width), 3 * d->width * sizeof(float), stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) { ppsci_set_error("modmlp_fwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   return PPSCI_OK;
 }
 
-extern "C" int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params, int64_t n, const float* x,
-                                const float* Fbar, const float* stash, float* grad_partials, void* stream) {
-  if (mod_check(d) != PPSCI_OK || !params || !x || !Fbar || !stash || !grad_partials || n < 1) {
+extern "C" int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params, int64_t n, const float* x, float* F,
+                                float* stash, void* stream) {
+  return ppsci_modmlp_fwd_batch(d, 1, &params, &n, &x, &F, stash ? &stash : nullptr, stream);
+}
+
+extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
+                                      const float* const* x, const float* const* Fbar, const float* const* stash,
+                                      float* const* grad_partials, void* stream) {
+  if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || !Fbar || !stash ||
+      !grad_partials) {
     ppsci_set_error("modmlp_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -487,16 +810,42 @@ extern "C" int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params,
   memset(&a, 0, sizeof(a));
   a.d = *d;
   mod_offsets(*d, a.o);
-  a.params = params; a.x = x; a.Fbar = Fbar; a.stash = (float*)stash; a.partials = grad_partials; a.N = (int)n;
-  PPSCI_LAUNCH(modmlp_bwd_kernel, ModArgs, (int)n, block_for(d->width),
-               (3 * d->width + 3 * d->d_out) * sizeof(float), stream, a);
+  a.nbatch = nbatch;
+  long long total = 0;
+  for (int b = 0; b < nbatch; ++b) {
+    if (!params[b] || !x[b] || !Fbar[b] || !stash[b] || !grad_partials[b] || n[b] < 1) {
+      ppsci_set_error("modmlp_bwd: invalid argument (branch %d)", b);
+      return PPSCI_E_INVALID;
+    }
+    a.br[b].params = params[b]; a.br[b].x = x[b]; a.br[b].Fbar = Fbar[b]; a.br[b].stash = (float*)stash[b];
+    a.br[b].partials = grad_partials[b]; a.br[b].N = (int)n[b];
+    total += n[b];
+  }
+  const int wcols = (d->width > d->d_out ? d->width : d->d_out) + 1;
+  PPSCI_LAUNCH(modmlp_bwd_kernel, ModArgs, (int)total, MOD_BWD_BLOCK,
+               (6 * d->width + 3 * d->d_out + (size_t)d->width * wcols) * sizeof(float), stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) { ppsci_set_error("modmlp_bwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   return PPSCI_OK;
 }
 
-static int grid_fwd_blocks(const ppsci_spinn_grid_desc* d) {
+extern "C" int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params, int64_t n, const float* x,
+                                const float* Fbar, const float* stash, float* grad_partials, void* stream) {
+  return ppsci_modmlp_bwd_batch(d, 1, &params, &n, &x, &Fbar, &stash, &grad_partials, stream);
+}
+
+#define GRID_MFMA_MAX_RANK 64
+static bool grid_mfma(const ppsci_spinn_grid_desc* d) { return d->rank <= GRID_MFMA_MAX_RANK && d->rank % 4 == 0; }
+
+static int grid_fwd_blocks(const ppsci_spinn_grid_desc* d) {  // = loss partial rows
+  if (grid_mfma(d)) return d->n[0] * ((d->n[1] + 15) / 16) * GRID_CS;
   return d->n[0] * ((d->n[1] + GRID_JT - 1) / GRID_JT);
+}
+
+static int grid_bwd_groups(const ppsci_spinn_grid_desc* d, int ax) {
+  const int b = ax == 0 ? 1 : 0;
+  const int per_wg = GRID_JC * (GRID_BLOCK / 64);
+  return grid_mfma(d) ? (d->n[b] + per_wg - 1) / per_wg : (d->n[b] + GRID_JG - 1) / GRID_JG;
 }
 
 static int grid_fwd_kc(const ppsci_spinn_grid_desc* d) {
@@ -523,6 +872,15 @@ extern "C" int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float*
   a.d = *d;
   a.F[0] = Fx; a.F[1] = Fy; a.F[2] = Fz;
   a.label = label; a.resid = resid; a.gadj = gadj; a.loss_partials = loss_partials;
+  if (grid_mfma(d)) {
+    const int waves = grid_fwd_blocks(d), wg = (waves + GRID_BLOCK / 64 - 1) / (GRID_BLOCK / 64);
+    if (d->rank <= 16) PPSCI_LAUNCH(spinn_grid_fwd_mfma_kernel<1>, GridArgs, wg, GRID_BLOCK, 0, stream, a);
+    else if (d->rank <= 32) PPSCI_LAUNCH(spinn_grid_fwd_mfma_kernel<2>, GridArgs, wg, GRID_BLOCK, 0, stream, a);
+    else PPSCI_LAUNCH(spinn_grid_fwd_mfma_kernel<4>, GridArgs, wg, GRID_BLOCK, 0, stream, a);
+    int e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) { ppsci_set_error("spinn_grid_fwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
+    return PPSCI_OK;
+  }
   const int grid = grid_fwd_blocks(d);
   a.iters = grid_fwd_kc(d);
   const size_t lds = (size_t)(2 * d->rank * a.iters + GRID_JT * 2 * d->rank + GRID_BLOCK) * sizeof(float);
@@ -539,11 +897,7 @@ extern "C" int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float*
 extern "C" int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_desc* d) {
   if (!d || d->rank < 1) return 0;
   long long m = 0;
-  for (int ax = 0; ax < 3; ++ax) {
-    const int b = ax == 0 ? 1 : 0;
-    const long long v = (long long)d->n[ax] * ((d->n[b] + GRID_JG - 1) / GRID_JG) * 2 * d->rank;
-    if (v > m) m = v;
-  }
+  for (int ax = 0; ax < 3; ++ax) m += (long long)d->n[ax] * grid_bwd_groups(d, ax) * 2 * d->rank;  // one region per axis
   return m;
 }
 
@@ -555,6 +909,59 @@ extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float*
     return PPSCI_E_INVALID;
   }
   float* outs[3] = {Fbar_x, Fbar_y, Fbar_z};
+  if (grid_mfma(d)) {  // the three axes in one launch each for the contraction and for the partial sums
+    GridArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d = *d;
+    a.F[0] = Fx; a.F[1] = Fy; a.F[2] = Fz;
+    a.gadj = (float*)gadj;
+    a.Fpart = scratch;
+    a.axis = -1;
+    const int rp = ((d->rank + 15) / 16) * 16, RP = (rp % 32 == 0) ? rp + 4 : rp + 20;  // row stride = 4 mod 32
+    a.iters = RP;
+    const int nt = d->rank <= 16 ? 1 : d->rank <= 32 ? 2 : 4;
+    int wg = 0, nsum = 0, ncmax = 0;
+    long long off = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+      const int c = ax == 2 ? 1 : 2;
+      a.Fbar3[ax] = outs[ax];
+      a.ngrp3[ax] = grid_bwd_groups(d, ax);
+      a.wg3[ax] = ((d->n[ax] + 15) / 16) * a.ngrp3[ax];
+      a.poff3[ax] = off;
+      off += (long long)d->n[ax] * a.ngrp3[ax] * 2 * d->rank;
+      wg += a.wg3[ax];
+      nsum += d->n[ax];
+      if (d->n[c] > ncmax) ncmax = d->n[c];
+    }
+    const int ncp = (ncmax + 15) & ~15;
+    const size_t lds = ((size_t)2 * ncp * RP + (size_t)(GRID_BLOCK / 64) * 2 * nt * 4 * 64) * sizeof(float);
+    if (lds > (size_t)PPSCI_LDS_LIMIT_BYTES) {
+      ppsci_set_error("spinn_grid_bwd: axis of %d points x rank %d does not fit LDS", ncmax, d->rank);
+      return PPSCI_E_UNSUPPORTED;
+    }
+    int se;
+    if (d->rank <= 16) {
+      se = PPSCI_SET_MAX_LDS(spinn_grid_bwd_mfma_kernel<1>, lds);
+      if (se == 0) PPSCI_LAUNCH(spinn_grid_bwd_mfma_kernel<1>, GridArgs, wg, GRID_BLOCK, lds, stream, a);
+    } else if (d->rank <= 32) {
+      se = PPSCI_SET_MAX_LDS(spinn_grid_bwd_mfma_kernel<2>, lds);
+      if (se == 0) PPSCI_LAUNCH(spinn_grid_bwd_mfma_kernel<2>, GridArgs, wg, GRID_BLOCK, lds, stream, a);
+    } else {
+      se = PPSCI_SET_MAX_LDS(spinn_grid_bwd_mfma_kernel<4>, lds);
+      if (se == 0) PPSCI_LAUNCH(spinn_grid_bwd_mfma_kernel<4>, GridArgs, wg, GRID_BLOCK, lds, stream, a);
+    }
+    if (se != 0) {
+      ppsci_set_error("spinn_grid_bwd: cannot raise dynamic LDS to %zu B", lds);
+      return PPSCI_E_LAUNCH;
+    }
+    int e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) { ppsci_set_error("spinn_grid_bwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
+    a.wg3[0] = d->n[0]; a.wg3[1] = d->n[1]; a.wg3[2] = d->n[2];
+    PPSCI_LAUNCH(spinn_fbar_sum_kernel, GridArgs, nsum, GRID_BLOCK, (size_t)FSUM_PARTS * 2 * d->rank * sizeof(float), stream, a);
+    e = PPSCI_LAST_LAUNCH_ERROR();
+    if (e != 0) { ppsci_set_error("spinn_fbar_sum: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
+    return PPSCI_OK;
+  }
   for (int ax = 0; ax < 3; ++ax) {
     GridArgs a;
     memset(&a, 0, sizeof(a));
@@ -564,21 +971,25 @@ extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float*
     a.Fbar = outs[ax];
     a.Fpart = scratch;
     a.axis = ax;
-    const int b = ax == 0 ? 1 : 0, c = ax == 2 ? 1 : 2;
-    const int ngrp = (d->n[b] + GRID_JG - 1) / GRID_JG;
-    const size_t lds = ((size_t)2 * d->n[c] * d->rank + (size_t)GRID_JG * d->n[c] + 2 * GRID_BLOCK) * sizeof(float);
-    if (lds > (size_t)PPSCI_LDS_LIMIT_BYTES) {
-      ppsci_set_error("spinn_grid_bwd: axis of %d points x rank %d does not fit LDS", d->n[c], d->rank);
-      return PPSCI_E_UNSUPPORTED;
+    const int c = ax == 2 ? 1 : 2;
+    const int ngrp = grid_bwd_groups(d, ax);
+    a.ngrp = ngrp;
+    int e;
+    {
+      const size_t lds = ((size_t)2 * d->n[c] * d->rank + (size_t)GRID_JG * d->n[c] + 2 * GRID_BLOCK) * sizeof(float);
+      if (lds > (size_t)PPSCI_LDS_LIMIT_BYTES) {
+        ppsci_set_error("spinn_grid_bwd: axis of %d points x rank %d does not fit LDS", d->n[c], d->rank);
+        return PPSCI_E_UNSUPPORTED;
+      }
+      if (PPSCI_SET_MAX_LDS(spinn_grid_bwd_kernel, lds) != 0) {
+        ppsci_set_error("spinn_grid_bwd: cannot raise dynamic LDS to %zu B", lds);
+        return PPSCI_E_LAUNCH;
+      }
+      PPSCI_LAUNCH(spinn_grid_bwd_kernel, GridArgs, d->n[ax] * ngrp, GRID_BLOCK, lds, stream, a);
     }
-    if (PPSCI_SET_MAX_LDS(spinn_grid_bwd_kernel, lds) != 0) {
-      ppsci_set_error("spinn_grid_bwd: cannot raise dynamic LDS to %zu B", lds);
-      return PPSCI_E_LAUNCH;
-    }
-    PPSCI_LAUNCH(spinn_grid_bwd_kernel, GridArgs, d->n[ax] * ngrp, GRID_BLOCK, lds, stream, a);
-    int e = PPSCI_LAST_LAUNCH_ERROR();
+    e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) { ppsci_set_error("spinn_grid_bwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
-    PPSCI_LAUNCH(spinn_fbar_sum_kernel, GridArgs, (d->n[ax] * d->rank + GRID_BLOCK - 1) / GRID_BLOCK, GRID_BLOCK, 0, stream, a);
+    PPSCI_LAUNCH(spinn_fbar_sum_kernel, GridArgs, d->n[ax], GRID_BLOCK, (size_t)FSUM_PARTS * 2 * d->rank * sizeof(float), stream, a);
     e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) { ppsci_set_error("spinn_fbar_sum: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   }

@@ -105,9 +105,10 @@ class SpinnConstraint:
 
     def forward(self, train: bool):
         m, lib = self.model, L.lib()
-        for b in range(3):
-            L.check(lib.ppsci_modmlp_fwd(C.byref(m.spec.desc), _p(m.branch(b)), self.x[b].numel(), _p(self.x[b]),
-                                         _p(self.F[b]), _p(self.stash[b]) if train else None, _stream_ptr(self.x[b])))
+        vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
+        L.check(lib.ppsci_modmlp_fwd_batch(C.byref(m.spec.desc), 3, vp([m.branch(b) for b in range(3)]),
+                                           (C.c_int64 * 3)(*[t.numel() for t in self.x]), vp(self.x), vp(self.F),
+                                           vp(self.stash) if train else None, _stream_ptr(self.x[0])))
         L.check(lib.ppsci_spinn_grid_fwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.label), None,
                                          _p(self.gadj) if train else None, _p(self.lpart), _stream_ptr(self.label)))
         hp.reduce_rows(self.lpart, self.lrows, 1, self.loss_term, False)
@@ -117,9 +118,10 @@ class SpinnConstraint:
         L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
                                          _p(self.bscratch), _p(self.Fbar[0]), _p(self.Fbar[1]), _p(self.Fbar[2]),
                                          _stream_ptr(self.gadj)))
-        for b in range(3):
-            L.check(lib.ppsci_modmlp_bwd(C.byref(m.spec.desc), _p(m.branch(b)), self.x[b].numel(), _p(self.x[b]),
-                                         _p(self.Fbar[b]), _p(self.stash[b]), _p(self.gpart[b]), _stream_ptr(self.x[b])))
+        vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
+        L.check(lib.ppsci_modmlp_bwd_batch(C.byref(m.spec.desc), 3, vp([m.branch(b) for b in range(3)]),
+                                           (C.c_int64 * 3)(*[t.numel() for t in self.x]), vp(self.x), vp(self.Fbar),
+                                           vp(self.stash), vp(self.gpart), _stream_ptr(self.x[0])))
 
     def loss(self) -> float:
         return float(self.loss_term.cpu()[0])

@@ -27,9 +27,9 @@ def _params_of(model, b):
                 wl=vals["last_fc.weight"], bl=vals["last_fc.bias"])
 
 
-def _build(tmp_path, shape=(7, 5, 6), act="tanh"):
+def _build(tmp_path, shape=(7, 5, 6), act="tanh", r=4):
     np.random.seed(111)
-    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), r=4, num_layers=3, hidden_size=16, activation=act)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), r=r, num_layers=3, hidden_size=16, activation=act)
     with torch.no_grad():  # non-zero biases so that every path is exercised
         model.flat_params.add_(torch.from_numpy(np.random.default_rng(5).uniform(-0.1, 0.1, model.flat_params.numel()).astype(np.float32)).to(model.flat_params.device))
     eq = ppsci.equation.Helmholtz(3, 1.0)
@@ -55,9 +55,12 @@ def _build(tmp_path, shape=(7, 5, 6), act="tanh"):
     return solver, model, xs, uc, face
 
 
-@pytest.mark.parametrize("act", ["tanh", "sin"])
-def test_spinn_helmholtz_losses_and_grads(tmp_path, act):
-    solver, model, xs, uc, face = _build(tmp_path, act=act)
+@pytest.mark.parametrize("act,shape,r", [("tanh", (7, 5, 6), 4), ("sin", (7, 5, 6), 4), ("tanh", (18, 35, 21), 20),
+                                         ("tanh", (17, 9, 20), 40), ("tanh", (5, 6, 7), 70)])
+def test_spinn_helmholtz_losses_and_grads(tmp_path, act, shape, r):
+    """ranks 4 / 20 / 40 take the MFMA grid kernels with 4 / 8 / 16 k-steps (ragged row, column and rank tails); rank 70
+    the scalar ones."""
+    solver, model, xs, uc, face = _build(tmp_path, shape=shape, act=act, r=r)
     nets = [R.ModifiedMLP1(_params_of(model, b), act) for b in range(3)]
     tx = [torch.tensor(x.astype(np.float64), requires_grad=True) for x in xs]
     u, res = R.spinn_helmholtz(nets, tx, 1.0)
@@ -79,7 +82,7 @@ def test_spinn_helmholtz_losses_and_grads(tmp_path, act):
     assert rel(solver.engine.grad.cpu().numpy(), gref) < 1e-4
     # eager forward == predict on the grid
     pred = solver.predict({"x": xs[0], "y": xs[1], "z": xs[2]}, batch_size=None, return_numpy=True)["u"]
-    assert pred.shape == (7, 5, 6, 1)
+    assert pred.shape == tuple(shape) + (1,)
     assert rel(pred[..., 0], u.detach().numpy()) < 5e-6
 
 

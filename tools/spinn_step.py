@@ -1,0 +1,14 @@
+"""cfg5 (SPINN Helmholtz3D, 128^3 grid) step in isolation, for rocprofv3:  python tools/spinn_step.py [steps]"""
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    with tempfile.TemporaryDirectory() as tmp:
+        r = bench.secondary_spinn(tmp, steps, 10)
+    print(json.dumps({k: r[k] for k in ("value", "ms_per_step", "parity", "roofline")}))
