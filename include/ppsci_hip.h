@@ -358,6 +358,47 @@ int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
                            const float* const* x, const float* const* Fbar, const float* const* stash,
                            float* const* grad_partials, void* stream);
 
+/* ---- ppsci.arch.PirateNet (mlp.py:530-820), layer by layer on Taylor streams (csrc/pirate.hip) ---------------------
+ * Every tensor is a stream block [S][C][NP]: S = 1 + n1 + n2 streams (value, first derivatives along n1 directions,
+ * second derivatives along the first n2 of them), C features, NP = N rounded up to a multiple of 16 (zero padding) --
+ * the [B, C, P] layout of ppsci_pw_conv, which runs every dense layer on all streams at once (B = S, no bias: the
+ * bias belongs to the value stream and is added by ppsci_pirate_act_*). */
+typedef struct ppsci_pirate_embed_desc {
+  int32_t d_raw;                 /* raw inputs */
+  int32_t d0;                    /* embedded features: d_raw + number of PPSCI_EMBED_PERIOD inputs */
+  int32_t half;                  /* FourierEmbedding.kernel is [d0, half]; x0 has 2*half features (cos | sin) */
+  int32_t n1, n2;
+  int32_t embed[PPSCI_MAX_IN];   /* PPSCI_EMBED_NONE / PPSCI_EMBED_PERIOD */
+  float omega[PPSCI_MAX_IN];     /* 2 pi / period */
+  float dirs[PPSCI_MAX_DIRS][PPSCI_MAX_IN];
+  int64_t N, NP;
+} ppsci_pirate_embed_desc;
+/* x0 = [cos(B e) ; sin(B e)] with its streams (PeriodEmbedding mlp.py:95-114 + FourierEmbedding :117-136). */
+int ppsci_pirate_embed_fwd(const ppsci_pirate_embed_desc* d, const float* const* inputs_host, const float* B, float* X,
+                           void* stream);
+/* d loss / d B as partial rows [ppsci_pirate_embed_chunks(N)][d0*half] (sum with ppsci_reduce_rows). */
+int64_t ppsci_pirate_embed_chunks(int64_t N);
+int ppsci_pirate_embed_bwd(const ppsci_pirate_embed_desc* d, const float* const* inputs_host, const float* B,
+                           const float* Xbar, float* partials, void* stream);
+/* a = act(z + bias) on streams, then by mode:
+ *   ACT   out = a                                   (embed_u / embed_v, mlp.py:706-745)
+ *   GATE  out = a * U + (1 - a) * V                  (PirateNetBlock.forward mlp.py:615-618)
+ *   RES   out = alpha * a + (1 - alpha) * x          (mlp.py:619-620; alpha: device scalar)
+ * backward: zbar = d loss / d z; GATE adds into Ubar / Vbar; RES writes xbar = (1 - alpha) obar; the bias gradient
+ * as partial rows [ppsci_pirate_act_chunks(NP)][H], the alpha gradient as [H * chunks] partial values. */
+enum { PPSCI_PIRATE_ACT = 0, PPSCI_PIRATE_GATE = 1, PPSCI_PIRATE_RES = 2 };
+int64_t ppsci_pirate_act_chunks(int64_t NP);
+int ppsci_pirate_act_fwd(int mode, int act, int H, int64_t N, int64_t NP, int n1, int n2, const float* z,
+                         const float* bias, const float* U, const float* V, const float* x, const float* alpha,
+                         float* out, void* stream);
+int ppsci_pirate_act_bwd(int mode, int act, int H, int64_t N, int64_t NP, int n1, int n2, const float* z,
+                         const float* bias, const float* U, const float* V, const float* x, const float* alpha,
+                         const float* obar, float* zbar, float* Ubar, float* Vbar, float* xbar, float* partials_b,
+                         float* partials_alpha, void* stream);
+/* last_fc output Y [S][m][NP] (+ bias on the value stream) -> the U rows [m*S][N] of ppsci_epilogue, and back. */
+int ppsci_pirate_out_fwd(int S, int m, int64_t N, int64_t NP, const float* Y, const float* bias, float* U, void* stream);
+int ppsci_pirate_out_bwd(int S, int m, int64_t N, int64_t NP, const float* Ubar, float* Ybar, void* stream);
+
 /* Tensor-product grid: q(i,j,k) = sum_r fx[i,r] fy[j,r] fz[k,r] (SPINN.forward_tensor spinn.py:140-167) for
  * q in {u, u_xx, u_yy, u_zz}; res = cu*u + cxx*u_xx + cyy*u_yy + czz*u_zz (Helmholtz helmholtz.py:78-93:
  * cu = k^2, cxx = cyy = czz = 1; a boundary constraint on u: cu = 1, others 0);

@@ -50,6 +50,15 @@ class SpinnGridDesc(C.Structure):
                 ("czz", C.c_float), ("scale", C.c_float)]
 
 
+class PirateEmbedDesc(C.Structure):
+    _fields_ = [("d_raw", C.c_int32), ("d0", C.c_int32), ("half", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("embed", C.c_int32 * MAX_IN), ("omega", C.c_float * MAX_IN), ("dirs", (C.c_float * MAX_IN) * MAX_DIRS),
+                ("N", C.c_int64), ("NP", C.c_int64)]
+
+
+PIRATE_ACT, PIRATE_GATE, PIRATE_RES = 0, 1, 2
+
+
 class Instr(C.Structure):
     _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_float)]
 
@@ -128,6 +137,15 @@ _SYMBOLS = {
     "ppsci_modmlp_bwd_batch": (C.c_int, [C.POINTER(ModMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.c_void_p]),
+    "ppsci_pirate_embed_fwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pirate_embed_chunks": (C.c_int64, [C.c_int64]),
+    "ppsci_pirate_embed_bwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "ppsci_pirate_act_chunks": (C.c_int64, [C.c_int64]),
+    "ppsci_pirate_act_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 8),
+    "ppsci_pirate_act_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 14),
+    "ppsci_pirate_out_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pirate_out_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_spinn_grid_partial_rows": (C.c_int64, [C.POINTER(SpinnGridDesc)]),
     "ppsci_spinn_grid_fwd": (C.c_int, [C.POINTER(SpinnGridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -47,6 +47,8 @@ struct PwArgs {
   int B, Cin, Cout, P, ldw, transpose, accumulate;
   int kq;              // ceil(Cin / 16)
   int nob;             // ceil(Cout / 16)
+  int co0, CoutT;      // this launch computes output channels [co0, co0 + Cout) of CoutT (weights that do not fit LDS
+                       // at once are processed in slabs of output channels)
 };
 
 #define PW_WAVES 4
@@ -65,7 +67,8 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int k = 16 * q + 4 * r + (l >> 4);
       float w = 0.f;
-      if (o < a.Cout && k < a.Cin) w = a.transpose ? a.W[(long long)k * a.ldw + o] : a.W[(long long)o * a.ldw + k];
+      if (o < a.Cout && k < a.Cin)
+        w = a.transpose ? a.W[(long long)k * a.ldw + a.co0 + o] : a.W[(long long)(a.co0 + o) * a.ldw + k];
       v[r] = w;
     }
     *(f32x4*)&smem[(long long)idx * 4] = v;
@@ -110,9 +113,9 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
         for (int rr = 0; rr < 4; ++rr) {
           const int o = 16 * (ob0 + j) + 4 * g + rr;
           if (o >= a.Cout || !pok) continue;
-          const long long off = ((long long)b * a.Cout + o) * a.P + p0;
+          const long long off = ((long long)b * a.CoutT + a.co0 + o) * a.P + p0;
           f32x4 v = (f32x4){acc[j][0][rr], acc[j][1][rr], acc[j][2][rr], acc[j][3][rr]};
-          if (a.bias) v += a.bias[o];
+          if (a.bias) v += a.bias[a.co0 + o];
           if (a.zmul) {
             const f32x4 z = *(const f32x4*)&a.zmul[off];
 #pragma unroll
@@ -143,23 +146,33 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
   a.x = x, a.W = W, a.bias = bias, a.zmul = zmul, a.out = out, a.act = act;
   a.B = B, a.Cin = Cin, a.Cout = Cout, a.P = P, a.transpose = transpose, a.accumulate = accumulate;
   a.ldw = transpose ? Cout : Cin;  // W is [Co, Ci] = [rows, ldw]; transposed use: rows = Cin(of this call), ld = Cout
-  a.kq = (Cin + 15) / 16, a.nob = (Cout + 15) / 16;
-  const long long lds = (long long)a.nob * a.kq * 64 * 16;
-  if (lds > PPSCI_LDS_LIMIT_BYTES) {
-    ppsci_set_error("pw_conv: %d x %d weights do not fit LDS", Cout, Cin);
+  a.kq = (Cin + 15) / 16;
+  a.CoutT = Cout;
+  // output-channel slabs: the A fragments of one slab (16-row blocks x kq x 1 KiB) must fit LDS
+  const int nob_all = (Cout + 15) / 16;
+  int nob_max = (int)(PPSCI_LDS_LIMIT_BYTES / ((long long)a.kq * 64 * 16));
+  if (nob_max < 1) {
+    ppsci_set_error("pw_conv: a 16 x %d weight block does not fit LDS", Cin);
     return PPSCI_E_UNSUPPORTED;
   }
-  if (PPSCI_SET_MAX_LDS(pw_conv_kernel, (int)lds) != 0) {
-    ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
-    return PPSCI_E_LAUNCH;
-  }
+  if (nob_max > nob_all) nob_max = nob_all;
   const long long nchunk = (long long)B * ((P + 63) / 64);
   long long grid = (nchunk + PW_WAVES - 1) / PW_WAVES;
   if (grid > 4 * PPSCI_NUM_CU) grid = 4 * PPSCI_NUM_CU;
-  PPSCI_LAUNCH(pw_conv_kernel, PwArgs, (int)grid, 64 * PW_WAVES, (int)lds, stream, a);
-  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
-    ppsci_set_error("pw_conv: launch failed");
-    return PPSCI_E_LAUNCH;
+  for (int ob0 = 0; ob0 < nob_all; ob0 += nob_max) {
+    a.co0 = 16 * ob0;
+    a.Cout = Cout - a.co0 < 16 * nob_max ? Cout - a.co0 : 16 * nob_max;
+    a.nob = (a.Cout + 15) / 16;
+    const long long lds = (long long)a.nob * a.kq * 64 * 16;
+    if (PPSCI_SET_MAX_LDS(pw_conv_kernel, (int)lds) != 0) {
+      ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
+      return PPSCI_E_LAUNCH;
+    }
+    PPSCI_LAUNCH(pw_conv_kernel, PwArgs, (int)grid, 64 * PW_WAVES, (int)lds, stream, a);
+    if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+      ppsci_set_error("pw_conv: launch failed");
+      return PPSCI_E_LAUNCH;
+    }
   }
   return PPSCI_OK;
 }

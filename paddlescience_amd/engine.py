@@ -47,6 +47,19 @@ class FusedConstraint:
         self.nets = []
         row = 0
         for lay, off, spec, idx, pre in nets:
+            if getattr(lay, "is_pirate", False):
+                # PirateNet runs layer by layer (arch/piratenet.py): its executor stands in for taylor_fwd / taylor_bwd and
+                # delivers ONE gradient row in the trainable layout
+                if pre is not None:
+                    raise NotImplementedError("PirateNet with a registered input transform")
+                nr = lay.d_out * streams.S
+                net_inputs = [self.inputs[j] for j in idx]
+                self.nets.append(dict(layout=lay, off=off, desc=None, inputs=net_inputs, pre=None,
+                                      exec=lay.make_exec(spec, self.n, net_inputs),
+                                      U=self.U[row:row + nr], Ubar=self.Ubar[row:row + nr], stash=None, grad_rows=1,
+                                      grad_partials=torch.empty((1, lay.n_params), **f32), workspace=None))
+                row += nr
+                continue
             desc = lay.desc(spec)
             rows = hp.bwd_partial_rows(desc, self.n)
             if rows <= 0:
@@ -106,6 +119,9 @@ class FusedConstraint:
             if nt["pre"] is not None:
                 for ed, rows in nt["pre"]:
                     hp.epilogue(ed, self.n, self.inputs, None, self.aux, rows, None, self._pre_partials)
+            if "exec" in nt:
+                nt["exec"].forward(params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["U"], train)
+                continue
             hp.taylor_fwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["U"],
                           nt["stash"] if train else None, self.n)
         if getattr(self, "causal", None):
@@ -146,6 +162,9 @@ class FusedConstraint:
         for nt in self.nets:
             n = nt["layout"].n_params
             dst = out[nt["off"]:nt["off"] + n].view(1, n) if direct else nt["grad_partials"]
+            if "exec" in nt:
+                nt["exec"].backward(params[nt["off"]:nt["off"] + n], nt["Ubar"], dst)
+                continue
             hp.taylor_bwd(nt["desc"], params[nt["off"]:nt["off"] + n], nt["inputs"], nt["Ubar"],
                           nt["stash"], nt["workspace"], dst, self.n)
         return direct

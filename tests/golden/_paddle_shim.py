@@ -96,6 +96,21 @@ class LayerList(Layer):
         self._list.append(l)
 
 
+class Sequential(Layer):
+    """nn.Sequential(*layers): sublayers named "0", "1", ... applied in order."""
+
+    def __init__(self, *layers):
+        super().__init__()
+        self._seq = list(layers)
+        for i, l in enumerate(self._seq):
+            self._subs[str(i)] = l
+
+    def forward(self, x):
+        for l in self._seq:
+            x = l(x)
+        return x
+
+
 class ParameterList(Layer):
     def __init__(self, params=()):
         super().__init__()
@@ -196,6 +211,7 @@ def install():
     paddle.no_grad = torch.no_grad
     paddle.ParamAttr = type("ParamAttr", (), {"__init__": lambda self, trainable=True, **k: setattr(self, "trainable", trainable)})
     nn.Layer, nn.LayerList, nn.ParameterList, nn.Linear = Layer, LayerList, ParameterList, Linear
+    nn.Sequential = Sequential
     nn.Tanh, nn.Sigmoid, nn.Identity = _act(torch.tanh), _act(torch.sigmoid), _act(lambda x: x)
     nn.ReLU, nn.ELU, nn.SELU, nn.GELU = _act(torch.relu), _act(torch.nn.functional.elu), _act(torch.selu), _act(torch.nn.functional.gelu)
     nn.LeakyReLU = _act(torch.nn.functional.leaky_relu)
