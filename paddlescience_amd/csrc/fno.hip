@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <math.h>
+#include <stdint.h>
 #include <string.h>
 
 extern "C" void ppsci_set_error(const char* fmt, ...);
@@ -47,6 +48,7 @@ struct PwArgs {
   int B, Cin, Cout, P, ldw, transpose, accumulate;
   int kq;              // ceil(Cin / 16)
   int nob;             // ceil(Cout / 16)
+  int vec;             // 16-byte staging path (dimensions and pointers aligned)
   int co0, CoutT;      // this launch computes output channels [co0, co0 + Cout) of CoutT (weights that do not fit LDS
                        // at once are processed in slabs of output channels)
 };
@@ -58,41 +60,95 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  // stage W as A-operand fragments: comp r of lane (g,c) for (ob, q): Weff[o = 16ob + c][k = 16q + 4r + g]
-  for (int idx = tid; idx < a.nob * a.kq * 64; idx += blockDim.x) {
-    const int l = idx & 63, q = (idx >> 6) % a.kq, ob = (idx >> 6) / a.kq;
-    const int o = 16 * ob + (l & 15);
-    f32x4 v;
+  // stage W as A-operand fragments: comp r of lane (g,c) for (ob, q): Weff[o = 16ob + c][k = 16q + 4r + g].
+  // Fast paths (no integer division, 16-byte coalesced global loads, 16 loads in flight per thread): a thread reads
+  // four consecutive elements along the matrix' contiguous axis and scatters them to the four lanes / components
+  // they belong to.
+  if (a.vec) {
+    const int hi = tid >> 4, lo = tid & 15;  // 16 rows x 16 float4 columns per pass
+    if (!a.transpose) {
+      // W[o][k], contiguous along k: float4 = k 16q + 4r .. + 3 (g = 0..3) of row o -> lanes (g, c), component r
+      const int k4n = a.Cin >> 2;
+      for (int ob = 0; ob < a.nob; ++ob) {
+        const int o = 16 * ob + hi;
+        const float* row = a.W + (long long)(a.co0 + o) * a.ldw;
+        for (int k4 = lo; k4 < 4 * a.kq; k4 += 16) {
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (o < a.Cout && k4 < k4n) v = *(const f32x4*)&row[4 * k4];
+          const int q = k4 >> 2, r = k4 & 3;
+          float* dst = smem + ((long long)(ob * a.kq + q) * 64 + hi) * 4 + r;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 16 * q + 4 * r + (l >> 4);
-      float w = 0.f;
-      if (o < a.Cout && k < a.Cin)
-        w = a.transpose ? a.W[(long long)k * a.ldw + a.co0 + o] : a.W[(long long)(a.co0 + o) * a.ldw + k];
-      v[r] = w;
+          for (int gg = 0; gg < 4; ++gg) dst[gg * 64] = v[gg];  // lane (gg, c = hi)
+        }
+      }
+    } else {
+      // W[k][o], contiguous along o: float4 = o 16ob + 4c4 .. + 3 of row k -> lanes (g, c = 4c4 + e), same (q, r)
+      const int o4n = a.Cout >> 2;  // Cout (slab) is a multiple of 4 on this path
+      for (int q = 0; q < a.kq; ++q) {
+        const int k = 16 * q + hi, r = hi >> 2, g2 = hi & 3;
+        const float* row = a.W + (long long)k * a.ldw + a.co0;
+        for (int o4 = lo; o4 < 4 * a.nob; o4 += 16) {
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (k < a.Cin && o4 < o4n) v = *(const f32x4*)&row[4 * o4];
+          const int ob = o4 >> 2, c0 = (o4 & 3) * 4;
+          float* dst = smem + ((long long)(ob * a.kq + q) * 64 + g2 * 16 + c0) * 4 + r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e * 4] = v[e];  // lane (g2, c0 + e)
+        }
+      }
     }
-    *(f32x4*)&smem[(long long)idx * 4] = v;
+  } else {
+    for (int idx = tid; idx < a.nob * a.kq * 64; idx += blockDim.x) {
+      const int l = idx & 63, q = (idx >> 6) % a.kq, ob = (idx >> 6) / a.kq;
+      const int o = 16 * ob + (l & 15);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * q + 4 * r + (l >> 4);
+        float w = 0.f;
+        if (o < a.Cout && k < a.Cin)
+          w = a.transpose ? a.W[(long long)k * a.ldw + a.co0 + o] : a.W[(long long)(a.co0 + o) * a.ldw + k];
+        v[r] = w;
+      }
+      *(f32x4*)&smem[(long long)idx * 4] = v;
+    }
   }
   __syncthreads();
   const long long chunks_per_b = (a.P + 63) / 64;
   const long long nchunk = (long long)a.B * chunks_per_b;
-  for (long long ch = (long long)blockIdx.x * PW_WAVES + wave; ch < nchunk; ch += (long long)gridDim.x * PW_WAVES) {
+  // work item = (64-pixel chunk, group of PW_OC output blocks): the waves of a workgroup take neighbouring groups of
+  // the same chunk (its B operands then come from L1), and wide layers on few pixels still fill the chip
+  const int ngrp = (a.nob + PW_OC - 1) / PW_OC;
+  const long long nitem = nchunk * ngrp;
+  for (long long item = (long long)blockIdx.x * PW_WAVES + wave; item < nitem; item += (long long)gridDim.x * PW_WAVES) {
+    const long long ch = item / ngrp;
+    const int ob0 = (int)(item - ch * ngrp) * PW_OC;
     const int b = (int)(ch / chunks_per_b);
     const int p0 = (int)(ch - (long long)b * chunks_per_b) * 64 + 4 * c;  // this lane's 4 pixels
     const bool pok = p0 + 3 < a.P;  // P is a multiple of 4 (checked on the host): all four or none
     const float* xb = a.x + (long long)b * a.Cin * a.P;
-    for (int ob0 = 0; ob0 < a.nob; ob0 += PW_OC) {
+    {
       f32x4 acc[PW_OC][4];
 #pragma unroll
       for (int j = 0; j < PW_OC; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < a.kq; ++q) {
-        f32x4 xv[4];  // k-step r: channel 16q + 4r + g, pixels p0..p0+3
+      f32x4 xn[4];  // k-step r: channel 16q + 4r + g, pixels p0..p0+3; loaded one q ahead of its MFMA chains
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * q + 4 * r + g;
-          xv[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * r + g;
+        xn[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      for (int q = 0; q < a.kq; ++q) {
+        f32x4 xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = xn[r];
+        if (q + 1 < a.kq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = 16 * (q + 1) + 4 * r + g;
+            xn[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
         }
 #pragma unroll
         for (int j = 0; j < PW_OC; ++j) {
@@ -156,14 +212,27 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
     return PPSCI_E_UNSUPPORTED;
   }
   if (nob_max > nob_all) nob_max = nob_all;
+  {  // balanced slabs, each a whole number of PW_OC groups where possible (256 rows: 128 + 128, not 160 + 96)
+    const int nslab = (nob_all + nob_max - 1) / nob_max;
+    int per = (nob_all + nslab - 1) / nslab;
+    per = (per + PW_OC - 1) / PW_OC * PW_OC;
+    if (per < nob_max) nob_max = per;
+  }
   const long long nchunk = (long long)B * ((P + 63) / 64);
-  long long grid = (nchunk + PW_WAVES - 1) / PW_WAVES;
-  if (grid > 4 * PPSCI_NUM_CU) grid = 4 * PPSCI_NUM_CU;
   for (int ob0 = 0; ob0 < nob_all; ob0 += nob_max) {
     a.co0 = 16 * ob0;
     a.Cout = Cout - a.co0 < 16 * nob_max ? Cout - a.co0 : 16 * nob_max;
     a.nob = (a.Cout + 15) / 16;
+    a.vec = ((reinterpret_cast<uintptr_t>(W) & 15) == 0 && (a.ldw & 3) == 0 &&
+             (transpose ? (a.Cout & 3) == 0 && (a.co0 & 3) == 0 : (Cin & 3) == 0)) ? 1 : 0;
     const long long lds = (long long)a.nob * a.kq * 64 * 16;
+    // every workgroup stages the slab's weights once: no more workgroups than can be resident, each loops over items
+    const long long nitem = nchunk * ((a.nob + PW_OC - 1) / PW_OC);
+    long long resident = (PPSCI_LDS_LIMIT_BYTES / (lds > 0 ? lds : 1));
+    if (resident < 1) resident = 1;
+    if (resident > 4) resident = 4;
+    long long grid = (nitem + PW_WAVES - 1) / PW_WAVES;
+    if (grid > resident * PPSCI_NUM_CU) grid = resident * PPSCI_NUM_CU;
     if (PPSCI_SET_MAX_LDS(pw_conv_kernel, (int)lds) != 0) {
       ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
       return PPSCI_E_LAUNCH;
@@ -186,42 +255,76 @@ struct PwWArgs {
   int B, Ci, Co, P, nib, nob, cpix, chunks_per_b;
 };
 
-// one wave per (pixel chunk, out block, in block); cpix pixels of one sample per chunk (a multiple of 16)
+// one wave per (pixel chunk, PAIR of out blocks, PAIR of in blocks) = a 32 x 32 tile of gW; cpix pixels of one sample
+// per chunk (a multiple of 16).  Four accumulators per wave: every operand float4 feeds two MFMA chains, which
+// halves the L2 traffic per flop of the one-tile-per-wave form.
 __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int nib2 = (a.nib + 1) / 2, nob2 = (a.nob + 1) / 2;
   int id = blockIdx.x;
-  const int ib = id % a.nib;
-  id /= a.nib;
-  const int ob = id % a.nob;
-  const int ch = id / a.nob;
+  const int ib = 2 * (id % nib2);
+  id /= nib2;
+  const int ob = 2 * (id % nob2);
+  const int ch = id / nob2;
   const int b = ch / a.chunks_per_b;
   const int p0 = (ch - b * a.chunks_per_b) * a.cpix;
-  const int o = 16 * ob + c, i = 16 * ib + c;
-  const float* gr = a.gy + ((long long)b * a.Co + (o < a.Co ? o : 0)) * a.P;
-  const float* xr = a.x + ((long long)b * a.Ci + (i < a.Ci ? i : 0)) * a.P;
-  const float mo = o < a.Co ? 1.f : 0.f, mi = i < a.Ci ? 1.f : 0.f;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  const float* gr[2];
+  const float* xr[2];
+  float mo[2], mi[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int o = 16 * (ob + u) + c, i = 16 * (ib + u) + c;
+    gr[u] = a.gy + ((long long)b * a.Co + (o < a.Co ? o : 0)) * a.P;
+    xr[u] = a.x + ((long long)b * a.Ci + (i < a.Ci ? i : 0)) * a.P;
+    mo[u] = o < a.Co ? 1.f : 0.f;
+    mi[u] = i < a.Ci ? 1.f : 0.f;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
   const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
   for (int p = p0; p < pend; p += 16) {
     // k-step r <-> pixel p + 4g + r for both operands
-    const f32x4 gv = *(const f32x4*)&gr[p + 4 * g] * mo;
-    const f32x4 xv = *(const f32x4*)&xr[p + 4 * g] * mi;
+    f32x4 gv[2], xv[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[r], xv[r], acc, 0, 0, 0);
-    bsum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+    for (int u = 0; u < 2; ++u) {
+      gv[u] = *(const f32x4*)&gr[u][p + 4 * g] * mo[u];
+      xv[u] = *(const f32x4*)&xr[u][p + 4 * g] * mi[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[u][r], xv[v][r], acc[u][v], 0, 0, 0);
+      bsum[u] += (gv[u][0] + gv[u][1]) + (gv[u][2] + gv[u][3]);
+    }
   }
   float* prow = a.part + (long long)ch * ((long long)a.Co * a.Ci);
   // D[row = 4g + rr][col = c] = gW[o = 16ob + 4g + rr][i = 16ib + c]
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int oo = 16 * ob + 4 * g + rr;
-    if (oo < a.Co && i < a.Ci) prow[(long long)oo * a.Ci + i] = acc[rr];
-  }
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = 16 * (ib + v) + c;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int oo = 16 * (ob + u) + 4 * g + rr;
+        if (oo < a.Co && i < a.Ci) prow[(long long)oo * a.Ci + i] = acc[u][v][rr];
+      }
+    }
   if (ib == 0 && a.part_b) {
-    bsum += __shfl_xor(bsum, 16, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (g == 0 && o < a.Co) a.part_b[(long long)ch * a.Co + o] = bsum;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float bs = bsum[u];
+      bs += __shfl_xor(bs, 16, 64);
+      bs += __shfl_xor(bs, 32, 64);
+      const int o = 16 * (ob + u) + c;
+      if (g == 0 && o < a.Co) a.part_b[(long long)ch * a.Co + o] = bs;
+    }
   }
 }
 
@@ -244,7 +347,7 @@ extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x,
   a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
   a.cpix = P >= 1024 ? 1024 : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
-  const long long grid = (long long)B * a.chunks_per_b * a.nob * a.nib;
+  const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
   PPSCI_LAUNCH(pw_wgrad_kernel, PwWArgs, (int)grid, 64, 0, stream, a);
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("pw_conv_wgrad: launch failed");

@@ -9,8 +9,6 @@
 //
 // materialize: trainable tensors -> the layer's slice of the kernel parameter buffer (before the forward sweep);
 // pullback   : gradient of that slice -> gradients of the trainable tensors (after the reverse sweep).
-// One thread per output column; a column's rows are read with stride `fout`, so neighbouring threads coalesce.
-// Sizes are at most 256 x 256 per layer: launch-latency sized, not a hot spot.
 #include "ppsci_common.h"
 
 #ifndef PPSCI_EMU
@@ -34,76 +32,114 @@ struct ReparamArgs {
   float* gb_out;
 };
 
+// One workgroup = RP_COLS output columns x RP_RG row groups (256 threads): thread (tc, rg) owns rows rg, rg + RP_RG, ...
+// of column j (neighbouring threads = neighbouring columns: 64 B runs); column sums (weight-norm's ||v||, the g
+// gradients) are the row groups' partial sums added through LDS in group order (fixed order, no atomics).
+#define RP_COLS 16
+#define RP_RG 16
+
+__device__ __forceinline__ float rp_colsum(float v, float* red, int tc, int rg) {
+  __syncthreads();
+  red[rg * RP_COLS + tc] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < RP_RG; ++k) s += red[k * RP_COLS + tc];
+  return s;
+}
+
 __global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.fout) return;
-  if (a.kind == PPSCI_LINEAR_FOURIER) {
-    const int half = a.fout / 2, jj = j < half ? j : j - half;
-    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = a.v[i * half + jj];
-    if (a.b_out) a.b_out[j] = 0.f;
+  __shared__ float red[RP_COLS * RP_RG];
+  const int tc = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
+  const int j = blockIdx.x * RP_COLS + tc;
+  const bool live = j < a.fout;
+  if (a.kind == PPSCI_LINEAR_BROADCAST) {
+    if (live && rg == 0) a.W[j] = a.v[0];
     return;
   }
-  if (a.kind == PPSCI_LINEAR_BROADCAST) {
-    a.W[j] = a.v[0];
+  if (a.kind == PPSCI_LINEAR_FOURIER) {
+    const int half = a.fout / 2, jj = j < half ? j : j - half;
+    if (live) {
+      for (int i = rg; i < a.fin; i += RP_RG) a.W[i * a.fout + j] = a.v[i * half + jj];
+      if (a.b_out && rg == 0) a.b_out[j] = 0.f;
+    }
     return;
   }
   if (a.kind == PPSCI_LINEAR_PLAIN) {
-    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = a.v[i * a.fout + j];
+    if (live)
+      for (int i = rg; i < a.fin; i += RP_RG) a.W[i * a.fout + j] = a.v[i * a.fout + j];
   } else if (a.kind == PPSCI_LINEAR_RWF) {
-    const float gj = a.g[j];
-    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j];
+    if (live) {
+      const float gj = a.g[j];
+      for (int i = rg; i < a.fin; i += RP_RG) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j];
+    }
   } else {  // weight norm: weight_g * weight_v / norm, in that order (mlp.py:53)
     float ss = 0.f;
-    for (int i = 0; i < a.fin; ++i) {
-      const float x = a.v[i * a.fout + j];
-      ss += x * x;
+    if (live)
+      for (int i = rg; i < a.fin; i += RP_RG) {
+        const float x = a.v[i * a.fout + j];
+        ss += x * x;
+      }
+    ss = rp_colsum(ss, red, tc, rg);
+    if (live) {
+      const float nrm = sqrtf(ss), gj = a.g[j];
+      for (int i = rg; i < a.fin; i += RP_RG) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j] / nrm;
     }
-    const float nrm = sqrtf(ss), gj = a.g[j];
-    for (int i = 0; i < a.fin; ++i) a.W[i * a.fout + j] = gj * a.v[i * a.fout + j] / nrm;
   }
-  if (a.b_out && a.b) a.b_out[j] = a.b[j];
+  if (live && rg == 0 && a.b_out && a.b) a.b_out[j] = a.b[j];
 }
 
 __global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[RP_COLS * RP_RG];
+  const int tc = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
+  const int j = blockIdx.x * RP_COLS + tc;
   if (a.kind == PPSCI_LINEAR_FOURIER) {
     const int half = a.fout / 2;
     if (j >= half) return;
-    for (int i = 0; i < a.fin; ++i) a.gv[i * half + j] = a.gW[i * a.fout + j] + a.gW[i * a.fout + j + half];
+    for (int i = rg; i < a.fin; i += RP_RG) a.gv[i * half + j] = a.gW[i * a.fout + j] + a.gW[i * a.fout + j + half];
     return;
   }
   if (a.kind == PPSCI_LINEAR_BROADCAST) {  // one thread: a fixed-order sum of at most 256 values
-    if (j != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float sum = 0.f;
     for (int k = 0; k < a.fout; ++k) sum += a.gW[k];
     a.gv[0] = sum;
     return;
   }
-  if (j >= a.fout) return;
+  const bool live = j < a.fout;
   if (a.kind == PPSCI_LINEAR_PLAIN) {
-    for (int i = 0; i < a.fin; ++i) a.gv[i * a.fout + j] = a.gW[i * a.fout + j];
+    if (live)
+      for (int i = rg; i < a.fin; i += RP_RG) a.gv[i * a.fout + j] = a.gW[i * a.fout + j];
   } else if (a.kind == PPSCI_LINEAR_RWF) {
-    const float gj = a.g[j];
     float dot = 0.f;
-    for (int i = 0; i < a.fin; ++i) {
-      const float gw = a.gW[i * a.fout + j];
-      dot += gw * a.v[i * a.fout + j];
-      a.gv[i * a.fout + j] = gw * gj;
+    if (live) {
+      const float gj = a.g[j];
+      for (int i = rg; i < a.fin; i += RP_RG) {
+        const float gw = a.gW[i * a.fout + j];
+        dot += gw * a.v[i * a.fout + j];
+        a.gv[i * a.fout + j] = gw * gj;
+      }
     }
-    a.gg[j] = dot;
+    dot = rp_colsum(dot, red, tc, rg);
+    if (live && rg == 0) a.gg[j] = dot;
   } else {
     float ss = 0.f, dot = 0.f;
-    for (int i = 0; i < a.fin; ++i) {
-      const float x = a.v[i * a.fout + j];
-      ss += x * x;
-      dot += a.gW[i * a.fout + j] * x;
+    if (live)
+      for (int i = rg; i < a.fin; i += RP_RG) {
+        const float x = a.v[i * a.fout + j];
+        ss += x * x;
+        dot += a.gW[i * a.fout + j] * x;
+      }
+    ss = rp_colsum(ss, red, tc, rg);
+    dot = rp_colsum(dot, red, tc, rg);
+    if (live) {
+      const float nrm = sqrtf(ss), gj = a.g[j];
+      const float sc = gj / nrm, c = dot / ss;
+      for (int i = rg; i < a.fin; i += RP_RG) a.gv[i * a.fout + j] = sc * (a.gW[i * a.fout + j] - c * a.v[i * a.fout + j]);
+      if (rg == 0) a.gg[j] = dot / nrm;
     }
-    const float nrm = sqrtf(ss), gj = a.g[j];
-    const float s = gj / nrm, c = dot / ss;
-    for (int i = 0; i < a.fin; ++i) a.gv[i * a.fout + j] = s * (a.gW[i * a.fout + j] - c * a.v[i * a.fout + j]);
-    a.gg[j] = dot / nrm;
   }
-  if (a.gb_out && a.gb) a.gb_out[j] = a.gb[j];
+  if (live && rg == 0 && a.gb_out && a.gb) a.gb_out[j] = a.gb[j];
 }
 
 static bool reparam_kind_ok(int kind) { return kind >= PPSCI_LINEAR_PLAIN && kind <= PPSCI_LINEAR_BROADCAST; }
@@ -118,7 +154,7 @@ extern "C" int ppsci_linear_materialize(int kind, int fin, int fout, const float
   }
   ReparamArgs a{};
   a.kind = kind, a.fin = fin, a.fout = fout, a.v = v, a.g = g, a.b = b, a.W = W, a.b_out = b_out;
-  PPSCI_LAUNCH(linear_materialize_kernel, ReparamArgs, (fout + 255) / 256, 256, 0, stream, a);
+  PPSCI_LAUNCH(linear_materialize_kernel, ReparamArgs, (fout + RP_COLS - 1) / RP_COLS, 256, 0, stream, a);
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("linear_materialize: launch failed (hip error %d)", err);
@@ -138,7 +174,7 @@ extern "C" int ppsci_linear_pullback(int kind, int fin, int fout, const float* v
   ReparamArgs a{};
   a.kind = kind, a.fin = fin, a.fout = fout, a.v = v, a.g = g, a.gW = gW, a.gb = gb, a.gv = gv, a.gg = gg,
   a.gb_out = gb_out;
-  PPSCI_LAUNCH(linear_pullback_kernel, ReparamArgs, (fout + 255) / 256, 256, 0, stream, a);
+  PPSCI_LAUNCH(linear_pullback_kernel, ReparamArgs, (fout + RP_COLS - 1) / RP_COLS, 256, 0, stream, a);
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("linear_pullback: launch failed (hip error %d)", err);
