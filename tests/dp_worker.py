@@ -11,13 +11,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_solver(outdir, world_batch, reduction, steps):
+def build_solver(outdir, world_batch, reduction, steps, pirate=False):
     import ppsci
     from oracle import taylor_np as T
     from tests.common import set_model_weights
 
-    model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
-    set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
+    if pirate:  # layer-by-layer PirateNet path: period + Fourier embedding, RWF, gates, alpha
+        ppsci.utils.misc.set_random_seed(5)
+        model = ppsci.arch.PirateNet(("t", "x"), ("u",), 2, 16, "tanh", periods={"x": (2.0, False)},
+                                     fourier={"dim": 16, "scale": 1.0}, random_weight={"mean": 1.0, "std": 0.1})
+        with torch.no_grad():
+            for n_, v_ in model.named_parameters():
+                if n_.endswith("alpha"):
+                    v_.fill_(0.4)
+    else:
+        model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
+        set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
     N = world_batch
     X = np.random.default_rng(3).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
     lab = np.random.default_rng(4).standard_normal((N, 1)).astype(np.float32) * 0.1
@@ -118,7 +127,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo")
-    solver, model = build_solver(outdir, 64, reduction, 2)
+    pirate = reduction == "pirate"
+    solver, model = build_solver(outdir, 64, "mean" if pirate else reduction, 2, pirate=pirate)
     solver.train()
     pred = solver.predict({"t": np.linspace(0, 1, 11, dtype=np.float32).reshape(-1, 1),
                            "x": np.linspace(-1, 1, 11, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)

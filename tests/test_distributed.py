@@ -35,6 +35,16 @@ def test_two_ranks_reproduce_single_rank(tmp_path, reduction):
     assert np.isfinite(two["loss"])
 
 
+def test_two_ranks_reproduce_single_rank_piratenet(tmp_path):
+    """PirateNet (layer-by-layer kernels, RWF, trainable Fourier kernel and alpha): the flat trainable-layout gradient is
+    all-reduced like an MLP's."""
+    d = str(tmp_path)
+    one = _run(d, 1, "pirate")
+    two = _run(d, 2, "pirate")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
+
+
 def test_two_ranks_reproduce_single_rank_fno(tmp_path):
     """Operator path (TFNO2dNet): per-rank mean loss over its half of the batch, gradients averaged over ranks
     == the single-rank run on the whole batch."""
