@@ -231,26 +231,29 @@ struct ReduceArgs {
   float* out;
   long long rows, cols;
   int accumulate;
+  int groups;  // row groups per workgroup (8 or 32)
 };
 
-// 256 threads = 32 columns x 8 row groups; each thread sums rows r = rg, rg+8, ... of its column in a
-// fixed order, the 8 group sums are combined in a fixed order through LDS (deterministic).
+// 256 threads = `cols_wg` columns x `groups` row groups (32 x 8, or 8 x 32 for tall narrow inputs: many partial rows of a
+// small weight matrix); each thread sums rows r = rg, rg + groups, ... of its column in a fixed order, the group sums are
+// combined in a fixed order through LDS (deterministic).
 #define RED_COLS 32
 #define RED_GROUPS 8
 __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
-  PPSCI_DYN_SMEM(red);  // [RED_GROUPS][RED_COLS]
-  const int tc = threadIdx.x % RED_COLS, rg = threadIdx.x / RED_COLS;
-  const long long j = (long long)blockIdx.x * RED_COLS + tc;
+  PPSCI_DYN_SMEM(red);  // [groups][cols_wg] = 256 floats
+  const int groups = a.groups, cw = 256 / groups;
+  const int tc = threadIdx.x % cw, rg = threadIdx.x / cw;
+  const long long j = (long long)blockIdx.x * cw + tc;
   float s = 0.f;
   if (j < a.cols) {
 #pragma unroll 8
-    for (long long r = rg; r < a.rows; r += RED_GROUPS) s += a.partials[r * a.cols + j];
+    for (long long r = rg; r < a.rows; r += groups) s += a.partials[r * a.cols + j];
   }
-  red[rg * RED_COLS + tc] = s;
+  red[rg * cw + tc] = s;
   __syncthreads();
   if (rg == 0 && j < a.cols) {
     float t = red[tc];
-    for (int k = 1; k < RED_GROUPS; ++k) t += red[k * RED_COLS + tc];
+    for (int k = 1; k < groups; ++k) t += red[k * cw + tc];
     a.out[j] = a.accumulate ? a.out[j] + t : t;
   }
 }
@@ -539,12 +542,16 @@ extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t co
     ppsci_set_error("reduce_rows: invalid argument");
     return PPSCI_E_INVALID;
   }
-  ReduceArgs a{partials, out, rows, cols, accumulate};
+  ReduceArgs a{partials, out, rows, cols, accumulate, RED_GROUPS};
   if (cols <= 8 && rows >= 512) {
     PPSCI_LAUNCH(reduce_rows_narrow_kernel, ReduceArgs, (int)cols, 256, 256 * sizeof(float), stream, a);
   } else {
-    const int grid = (int)((cols + RED_COLS - 1) / RED_COLS);
-    PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, RED_GROUPS * RED_COLS * sizeof(float), stream, a);
+    // tall inputs: more row parallelism and more workgroups; narrower column runs only while the matrix is small
+    if (rows >= 128 && cols <= 2048) a.groups = 32;
+    else if (rows >= 128 && cols <= 32768) a.groups = 16;
+    const int cw = 256 / a.groups;
+    const int grid = (int)((cols + cw - 1) / cw);
+    PPSCI_LAUNCH(reduce_rows_kernel, ReduceArgs, grid, 256, 256 * sizeof(float), stream, a);
   }
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {

@@ -328,8 +328,11 @@ __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
   }
 }
 
+// pixels per chunk: 256 -- a 32x32 layer on a 16 x 64 x 64 batch is then 256 waves of 16 MFMA rounds instead of 64 waves
+// of 64 (the kernel is latency-bound per wave); the partial rows are summed by ppsci_reduce_rows' tall variant
+#define PW_WGRAD_CPIX 256
 extern "C" int64_t ppsci_pw_conv_wgrad_chunks(int B, int P) {
-  const int cpix = P >= 1024 ? 1024 : P;
+  const int cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   return (int64_t)B * ((P + cpix - 1) / cpix);
 }
 
@@ -345,7 +348,7 @@ extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x,
   a.x = x, a.gy = gy, a.part = partials, a.part_b = partials_b;
   a.B = B, a.Ci = Ci, a.Co = Co, a.P = P;
   a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
-  a.cpix = P >= 1024 ? 1024 : P;
+  a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
   const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
   PPSCI_LAUNCH(pw_wgrad_kernel, PwWArgs, (int)grid, 64, 0, stream, a);
