@@ -25,11 +25,7 @@
 // feeds dot products with O(1) terms, and the derivative factors 1 - s^2, -2 s s' see it damped by s.
 // Saturates correctly: exp -> inf gives 1, exp -> 0 gives -1.
 __device__ __forceinline__ float ppsci_tanh(float x) {
-#ifdef PPSCI_EMU
-  return 1.f - 2.f / (expf(2.f * x) + 1.f);
-#else
   return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);
-#endif
 }
 
 // Internal template id: a tanh net whose hidden layer 0 is the Fourier embedding (ppsci_mlp_desc.fourier_half).
@@ -308,13 +304,9 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
 // partially filled last round is spread over many CUs instead of filling a few of them.
 __device__ __forceinline__ int ppsci_tile_index(int it, int waves) {
   const int t = (it * waves + (int)(threadIdx.x >> 6)) * (int)gridDim.x + (int)blockIdx.x;
-#ifdef PPSCI_EMU
-  return t;
-#else
   // wave-uniform by construction; telling the compiler moves the tile's address arithmetic to the scalar
   // unit and turns every `tile < ntiles` guard into a scalar branch instead of an exec-mask region
   return __builtin_amdgcn_readfirstlane(t);
-#endif
 }
 
 // ---- kernel argument blocks ------------------------------------------------------------------

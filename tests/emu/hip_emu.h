@@ -201,6 +201,11 @@ static emu::GdimProxy gridDim;
 inline void __syncthreads() { emu::barrier_wait(emu::st().block_bar); }
 inline void ppsci_wave_sync() { emu::barrier_wait(emu::my_wave().bar); }
 
+// device intrinsics the product sources use unconditionally (the emulator executes one lane at a time):
+inline float __expf(float x) { return expf(x); }                    // v_exp_f32 path
+inline float __builtin_amdgcn_rcpf(float x) { return 1.f / x; }     // v_rcp_f32
+inline int __builtin_amdgcn_readfirstlane(int x) { return x; }      // the value is wave-uniform by construction
+
 inline float __shfl_xor(float v, int mask, int width = 64) {
   const float* buf = emu::wave_publish(v);
   unsigned l = emu::my_lane();
