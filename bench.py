@@ -462,6 +462,62 @@ def secondary_spinn(tmp, steps, warmup, nc=128):
             "parity": parity}
 
 
+def extra_piratenet(tmp, steps, warmup, n=8192):
+    """Not a BASELINE config: ppsci.arch.PirateNet at the configuration of examples/allen_cahn/conf/allen_cahn_piratenet.yaml
+    (3 blocks x 256, periodic x, Fourier 256 scale 2, RWF), Allen-Cahn residual on 8192 points -- the layer-by-layer HIP path
+    (csrc/pirate.hip + the MFMA 1x1-conv GEMMs), with parity of that path against the reference-run fixture."""
+    import ppsci
+    from tests.golden.make_piratenet_golden import CASES, equations
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "piratenet.npz"))
+    name = "allen_cahn_rwf"
+    c = CASES[name]
+    small = ppsci.arch.PirateNet(c["inputs"], c["outputs"], c["blocks"], c["hidden"], c["act"], periods=c["periods"],
+                                 fourier=c["fourier"], random_weight=c["rwf"])
+    small.set_state_dict({k.split("/", 2)[2]: gold[k] for k in gold.files if k.startswith(f"{name}/param/")})
+    X = gold[f"{name}/X"].astype(np.float32)
+    inp = {k: X[:, j:j + 1] for j, k in enumerate(c["inputs"])}
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": inp,
+                       "label": {"allen_cahn": gold[f"{name}/label/allen_cahn"][:, None].astype(np.float32)}}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss(c["reduction"]), equations(c), name="EQ")
+    solver = ppsci.solver.Solver(small, {"EQ": cst}, os.path.join(tmp, "pirate_parity"), ppsci.optimizer.Adam(1e-3)(small),
+                                 epochs=1, iters_per_epoch=1)
+    solver.engine.forward_backward([solver._compiled["EQ"].fused])
+    g = solver.engine.grad.cpu().numpy()
+    gref = np.concatenate([gold[f"{name}/grad/{n_}"].ravel() for n_, _ in small.named_parameters()])
+    res = solver.predict(inp, equations(c), batch_size=None, return_numpy=True)
+    parity = {"reference": "tests/golden/piratenet.npz (the reference's own PirateNet, fp64, torch-backed paddle shim), case "
+                           "allen_cahn_rwf: 2 blocks x 32, 40 points",
+              "residual_rel_l2": rel(res["allen_cahn"][:, 0], gold[f"{name}/res/allen_cahn"]), "grad_rel_l2": rel(g, gref)}
+
+    np.random.seed(1)
+    model = ppsci.arch.PirateNet(("t", "x"), ("u",), 3, 256, "tanh", periods={"x": [2.0, False]},
+                                 fourier={"dim": 256, "scale": 2.0}, random_weight={"mean": 1.0, "std": 0.1})
+    eq = ppsci.equation.AllenCahn(eps=0.01)
+    tx = np.random.default_rng(0).uniform([0, -1], [1, 1], (n, 2)).astype(np.float32)
+    big = {"t": tx[:, 0:1], "x": tx[:, 1:2]}
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": big, "label": {"allen_cahn": np.zeros((n, 1), np.float32)}}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), eq.equations, name="PDE")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PDE": cst}, os.path.join(tmp, "pirate"), opt, epochs=1, iters_per_epoch=1)
+    fused = solver._compiled["PDE"].fused
+
+    def step():
+        solver.engine.forward_backward([fused])
+        opt.step(solver.engine.grad)
+
+    t = time_wall(step, steps, warmup)
+    S, H, nb = fused.streams.S, 256, 3
+    flops = 3 * 2 * (2 + 3 * nb) * H * H * S * n  # the H x H layers: forward + data gradient + weight gradient
+    ach = flops / t / 1e12
+    return {"config": "extra (not a BASELINE config): PirateNet 3 blocks x 256 tanh, periodic x, Fourier 256, RWF "
+                      f"(allen_cahn_piratenet.yaml), Allen-Cahn residual (u_t, u_xx: S = {S} streams), {n} points, MSE-mean, Adam",
+            "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
+            "roofline": {"bound": "mfma", "kernel": "pw_conv_kernel / pw_wgrad_kernel (dense layers on all Taylor streams) over "
+                                                    "the whole step", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS}, "parity": parity}
+
+
 # ------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -587,7 +643,8 @@ def main():
             k, w = max(10, args.steps // 2), max(3, args.warmup // 2)
             sec = []
             for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),
-                       lambda: secondary_ns(tmp, k, w), lambda: secondary_tfno(k, w), lambda: secondary_spinn(tmp, k, w)):
+                       lambda: secondary_ns(tmp, k, w), lambda: secondary_tfno(k, w), lambda: secondary_spinn(tmp, k, w),
+                       lambda: extra_piratenet(tmp, k, w)):
                 try:
                     sec.append(fn())
                 except Exception as e:  # noqa: BLE001 -- a secondary entry must not cost the primary line
