@@ -499,6 +499,23 @@ def extra_piratenet(tmp, steps, warmup, n=8192):
     cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": big, "label": {"allen_cahn": np.zeros((n, 1), np.float32)}}}
     cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), eq.equations, name="PDE")
     opt = ppsci.optimizer.Adam(1e-3)(model)
+    # the TIMED model (3 x 256: two output-channel slabs per GEMM) on the first 256 points against the fp64 oracle
+    # (oracle/ref_torch.PirateNet, pinned by the fixture above)
+    from oracle import ref_torch as R
+
+    state = {nm: v.detach().cpu().numpy().astype(np.float64) for nm, v in model.named_parameters()}
+    om = R.PirateNet(("t", "x"), ("u",), state, "tanh", {"x": (2.0, False)})
+    sub = {k: v[:256] for k, v in big.items()}
+    ocst = dict(name="EQ", input={k: v.astype(np.float64) for k, v in sub.items()},
+                exprs={"allen_cahn": R.allen_cahn_fn(0.01)}, label={"allen_cahn": np.zeros((256, 1))}, reduction="mean")
+    _, _, go, oo = R.loss_and_grads(om, [ocst])
+    cfg_s = {"dataset": {"name": "IterableNamedArrayDataset", "input": sub, "label": {"allen_cahn": np.zeros((256, 1), np.float32)}}}
+    cst_s = ppsci.constraint.SupervisedConstraint(cfg_s, ppsci.loss.MSELoss("mean"), eq.equations, name="PDE")
+    sol_s = ppsci.solver.Solver(model, {"PDE": cst_s}, os.path.join(tmp, "pirate_s"), opt, epochs=1, iters_per_epoch=1)
+    sol_s.engine.forward_backward([sol_s._compiled["PDE"].fused])
+    rs = sol_s.predict(sub, eq.equations, batch_size=None, return_numpy=True)
+    parity["timed_model_vs_oracle"] = {"points": 256, "residual_rel_l2": rel(rs["allen_cahn"][:, 0], oo[0]["allen_cahn"].detach().numpy()[:, 0]),
+                                       "grad_rel_l2": rel(sol_s.engine.grad.cpu().numpy(), go)}
     solver = ppsci.solver.Solver(model, {"PDE": cst}, os.path.join(tmp, "pirate"), opt, epochs=1, iters_per_epoch=1)
     fused = solver._compiled["PDE"].fused
 

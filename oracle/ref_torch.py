@@ -10,6 +10,7 @@ What it follows in /root/reference (file:line):
   * ppsci/arch/base.py:78-148        concat_to_tensor / split_to_dict
   * ppsci/arch/mlp.py:95-114         PeriodEmbedding
   * ppsci/arch/mlp.py:281-315        MLP.forward_tensor / MLP.forward (incl. the skip quirk)
+  * ppsci/arch/mlp.py:530-820        PirateNetBlock / PirateNet
   * ppsci/arch/activation.py:77-88   Silu = x * sigmoid(x)
   * ppsci/autodiff/ad.py:30-341      _Jacobian / Jacobians / _Hessian / Hessians / clear
   * ppsci/utils/symbolic.py:111-137  _cvt_to_key
@@ -157,6 +158,58 @@ class MLP:
         t = self.forward_tensor(t)
         outs = torch.split(t, 1, dim=-1)  # base.py:145-148
         return {k: v for k, v in zip(self.output_keys, outs)}
+
+
+class PirateNet:
+    """Restatement of ppsci.arch.PirateNet (mlp.py:530-820) on explicit named tensors (the reference's parameter names):
+    PeriodEmbedding :95-114 -> FourierEmbedding :117-136 -> U, V = act(embed_{u,v}(x0)) :793-796 ->
+    PirateNetBlock.forward :614-621 x num_blocks -> last_fc.  `state`: {name: array}; layers are RandomWeightFactorization
+    (:57-92, W = weight_g * weight_v) when the names carry weight_v / weight_g, nn.Linear otherwise.  Pinned by
+    tests/golden/piratenet.npz (tests/test_golden_piratenet.py)."""
+
+    def __init__(self, input_keys, output_keys, state: Dict[str, np.ndarray], activation="tanh", periods=None,
+                 dtype=torch.float64):
+        self.input_keys, self.output_keys = tuple(input_keys), tuple(output_keys)
+        self.activation, self.dtype = activation, dtype
+        self.periods = {k: float(np.float32(2 * np.pi / float(p))) for k, (p, _) in (periods or {}).items()}
+        self.names = list(state)
+        self.t = {n: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for n, v in state.items()}
+        self.num_blocks = 1 + max(int(n.split(".")[1]) for n in state if n.startswith("blocks."))
+        self.skip_connection = False
+
+    def parameters(self) -> List[torch.Tensor]:
+        return [self.t[n] for n in self.names]
+
+    _act = MLP._act
+
+    def _linear(self, name, y):
+        t = self.t
+        if name + ".weight_v" in t:
+            return y @ (t[name + ".weight_g"] * t[name + ".weight_v"]) + t[name + ".bias"]
+        return y @ t[name + ".weight"] + t[name + ".bias"]
+
+    def __call__(self, x: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if self.periods:
+            y = dict(x)
+            for k, w in self.periods.items():
+                y[k] = torch.cat([torch.cos(w * x[k]), torch.sin(w * x[k])], dim=-1)
+            x = y
+        e = torch.cat([x[k] for k in self.input_keys], dim=-1)
+        kern = self.t["fourier_emb.kernel"]
+        h = torch.cat([torch.cos(e @ kern), torch.sin(e @ kern)], dim=-1)
+        u = self._act(self._linear("embed_u.0", h))
+        v = self._act(self._linear("embed_v.0", h))
+        for i in range(self.num_blocks):
+            pre = f"blocks.{i}."
+            f = self._act(self._linear(pre + "linear1", h))
+            z1 = f * u + (1 - f) * v
+            g = self._act(self._linear(pre + "linear2", z1))
+            z2 = g * u + (1 - g) * v
+            hh = self._act(self._linear(pre + "linear3", z2))
+            al = self.t[pre + "alpha"]
+            h = al * hh + (1 - al) * h
+        out = self._linear("last_fc", h)
+        return {k: o for k, o in zip(self.output_keys, torch.split(out, 1, dim=-1))}
 
 
 class ModelList:

@@ -82,7 +82,11 @@ def test_native_path_matches_autograd_path_and_is_reproducible(dev):
     assert torch.equal(runs[0], runs[1])
 
 
-def test_pw_conv_and_tail_kernels_known_answers(dev):
+@pytest.mark.parametrize("shape", [(2, 5, 37, 48), (3, 256, 256, 80), (2, 200, 176, 64), (1, 64, 1, 32), (2, 36, 260, 16)])
+def test_pw_conv_and_tail_kernels_known_answers(dev, shape):
+    """(B, Ci, Co, P): small ragged channels (scalar weight staging), 256 x 256 (two output-channel slabs, 16-byte staging,
+    2 x 2 weight-gradient tiles), channel counts that are not multiples of 16 on the vector path, one output channel, and more
+    output channels than one slab with a ragged tail."""
     import ctypes as C
 
     from paddlescience_amd import _lib as L
@@ -90,7 +94,7 @@ def test_pw_conv_and_tail_kernels_known_answers(dev):
 
     d = device.get_device()
     rng = np.random.default_rng(1)
-    B, Ci, Co, P = 2, 5, 37, 48
+    B, Ci, Co, P = shape
     x = torch.as_tensor(rng.standard_normal((B, Ci, P)).astype(np.float32)).to(d)
     W = torch.as_tensor(rng.standard_normal((Co, Ci)).astype(np.float32)).to(d)
     b = torch.as_tensor(rng.standard_normal(Co).astype(np.float32)).to(d)
