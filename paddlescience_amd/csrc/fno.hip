@@ -53,9 +53,12 @@ struct PwArgs {
                        // at once are processed in slabs of output channels)
 };
 
-#define PW_WAVES 4
-#define PW_OC 4  // output-channel blocks (of 16) per accumulation pass
+#define PW_OC_MAX 4  // output-channel blocks (of 16) per work item: 4 with 4 waves per workgroup, or -- when the weight
+                     // slab leaves room for ONE workgroup per CU -- 2 with 8 waves, so that every SIMD holds two waves and
+                     // one wave's MFMA chains cover the other's operand waits
+#define PW_STAGE 16  // weight float4s in flight per thread while staging
 
+template <int PW_OC, int PW_WAVES>
 __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,40 +67,54 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   // Fast paths (no integer division, 16-byte coalesced global loads, 16 loads in flight per thread): a thread reads
   // four consecutive elements along the matrix' contiguous axis and scatters them to the four lanes / components
   // they belong to.
-  if (a.vec) {
-    const int hi = tid >> 4, lo = tid & 15;  // 16 rows x 16 float4 columns per pass
-    if (!a.transpose) {
-      // W[o][k], contiguous along k: float4 = k 16q + 4r .. + 3 (g = 0..3) of row o -> lanes (g, c), component r
-      const int k4n = a.Cin >> 2;
-      for (int ob = 0; ob < a.nob; ++ob) {
-        const int o = 16 * ob + hi;
-        const float* row = a.W + (long long)(a.co0 + o) * a.ldw;
-        for (int k4 = lo; k4 < 4 * a.kq; k4 += 16) {
-          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (o < a.Cout && k4 < k4n) v = *(const f32x4*)&row[4 * k4];
-          const int q = k4 >> 2, r = k4 & 3;
-          float* dst = smem + ((long long)(ob * a.kq + q) * 64 + hi) * 4 + r;
+  if (a.vec && tid < 256) {
+    const int hi = tid >> 4, lo = tid & 15;  // 16 rows x 16 float4 columns per pass (the first 256 threads)
+    // A thread's float4s are enumerated (outer, inner): outer = output block (plain) / k-slab q (transposed), inner =
+    // its float4 column lo, lo + 16, ...; PW_STAGE of them are loaded before the first LDS write.
+    const int nouter = a.transpose ? a.kq : a.nob;
+    const int ninner = a.transpose ? (4 * a.nob + 15 - lo) / 16 : (4 * a.kq + 15 - lo) / 16;  // columns lo + 16 j < 4 * n
+    const int k4n = a.Cin >> 2, o4n = a.Cout >> 2;  // Cout (slab) is a multiple of 4 on the transposed path
+    int eo = 0, ej = 0;  // running (outer, inner) of the next float4 to load
+    const int total = nouter * ninner;
+    for (int e0 = 0; e0 < total; e0 += PW_STAGE) {
+      f32x4 buf[PW_STAGE];
+      int lo_o = eo, lo_j = ej;
 #pragma unroll
-          for (int gg = 0; gg < 4; ++gg) dst[gg * 64] = v[gg];  // lane (gg, c = hi)
+      for (int u = 0; u < PW_STAGE; ++u) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (e0 + u < total) {
+          const int c4 = lo + 16 * lo_j;
+          if (!a.transpose) {  // W[o][k], contiguous along k: float4 = k 16q + 4r .. + 3 (g = 0..3) of row o
+            const int o = 16 * lo_o + hi;
+            if (o < a.Cout && c4 < k4n) v = *(const f32x4*)&a.W[(long long)(a.co0 + o) * a.ldw + 4 * c4];
+          } else {  // W[k][o], contiguous along o: float4 = o 16ob + 4c4' .. + 3 of row k
+            const int k = 16 * lo_o + hi;
+            if (k < a.Cin && c4 < o4n) v = *(const f32x4*)&a.W[(long long)k * a.ldw + a.co0 + 4 * c4];
+          }
+          if (++lo_j == ninner) { lo_j = 0; ++lo_o; }
         }
+        buf[u] = v;
       }
-    } else {
-      // W[k][o], contiguous along o: float4 = o 16ob + 4c4 .. + 3 of row k -> lanes (g, c = 4c4 + e), same (q, r)
-      const int o4n = a.Cout >> 2;  // Cout (slab) is a multiple of 4 on this path
-      for (int q = 0; q < a.kq; ++q) {
-        const int k = 16 * q + hi, r = hi >> 2, g2 = hi & 3;
-        const float* row = a.W + (long long)k * a.ldw + a.co0;
-        for (int o4 = lo; o4 < 4 * a.nob; o4 += 16) {
-          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (k < a.Cin && o4 < o4n) v = *(const f32x4*)&row[4 * o4];
-          const int ob = o4 >> 2, c0 = (o4 & 3) * 4;
-          float* dst = smem + ((long long)(ob * a.kq + q) * 64 + g2 * 16 + c0) * 4 + r;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst[e * 4] = v[e];  // lane (g2, c0 + e)
+      for (int u = 0; u < PW_STAGE; ++u) {
+        if (e0 + u < total) {
+          const int c4 = lo + 16 * ej;
+          if (!a.transpose) {  // -> lanes (g, c = hi), component r
+            const int q = c4 >> 2, r = c4 & 3;
+            float* dst = smem + ((long long)(eo * a.kq + q) * 64 + hi) * 4 + r;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) dst[gg * 64] = buf[u][gg];
+          } else {  // -> lanes (g2, c0 + e), same (q, r)
+            const int r = hi >> 2, g2 = hi & 3, ob = c4 >> 2, c0 = (c4 & 3) * 4;
+            float* dst = smem + ((long long)(ob * a.kq + eo) * 64 + g2 * 16 + c0) * 4 + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * 4] = buf[u][e];
+          }
+          if (++ej == ninner) { ej = 0; ++eo; }
         }
       }
     }
-  } else {
+  } else if (!a.vec) {
     for (int idx = tid; idx < a.nob * a.kq * 64; idx += blockDim.x) {
       const int l = idx & 63, q = (idx >> 6) % a.kq, ob = (idx >> 6) / a.kq;
       const int o = 16 * ob + (l & 15);
@@ -212,10 +229,10 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
     return PPSCI_E_UNSUPPORTED;
   }
   if (nob_max > nob_all) nob_max = nob_all;
-  {  // balanced slabs, each a whole number of PW_OC groups where possible (256 rows: 128 + 128, not 160 + 96)
+  {  // balanced slabs, each a whole number of groups where possible (256 rows: 128 + 128, not 160 + 96)
     const int nslab = (nob_all + nob_max - 1) / nob_max;
     int per = (nob_all + nslab - 1) / nslab;
-    per = (per + PW_OC - 1) / PW_OC * PW_OC;
+    per = (per + PW_OC_MAX - 1) / PW_OC_MAX * PW_OC_MAX;
     if (per < nob_max) nob_max = per;
   }
   const long long nchunk = (long long)B * ((P + 63) / 64);
@@ -227,18 +244,28 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
              (transpose ? (a.Cout & 3) == 0 && (a.co0 & 3) == 0 : (Cin & 3) == 0)) ? 1 : 0;
     const long long lds = (long long)a.nob * a.kq * 64 * 16;
     // every workgroup stages the slab's weights once: no more workgroups than can be resident, each loops over items
-    const long long nitem = nchunk * ((a.nob + PW_OC - 1) / PW_OC);
     long long resident = (PPSCI_LDS_LIMIT_BYTES / (lds > 0 ? lds : 1));
     if (resident < 1) resident = 1;
     if (resident > 4) resident = 4;
-    long long grid = (nitem + PW_WAVES - 1) / PW_WAVES;
+    const bool wide = resident == 1;  // one workgroup per CU: 8 waves of 2-block items
+    const int oc = wide ? 2 : 4, waves = wide ? 8 : 4;
+    const long long nitem = nchunk * ((a.nob + oc - 1) / oc);
+    long long grid = (nitem + waves - 1) / waves;
     if (grid > resident * PPSCI_NUM_CU) grid = resident * PPSCI_NUM_CU;
-    if (PPSCI_SET_MAX_LDS(pw_conv_kernel, (int)lds) != 0) {
+    int se, le;
+    if (wide) {
+      se = PPSCI_SET_MAX_LDS((pw_conv_kernel<2, 8>), (int)lds);
+      if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<2, 8>), PwArgs, (int)grid, 64 * 8, (int)lds, stream, a);
+    } else {
+      se = PPSCI_SET_MAX_LDS((pw_conv_kernel<4, 4>), (int)lds);
+      if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<4, 4>), PwArgs, (int)grid, 64 * 4, (int)lds, stream, a);
+    }
+    if (se != 0) {
       ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
       return PPSCI_E_LAUNCH;
     }
-    PPSCI_LAUNCH(pw_conv_kernel, PwArgs, (int)grid, 64 * PW_WAVES, (int)lds, stream, a);
-    if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    le = PPSCI_LAST_LAUNCH_ERROR();
+    if (le != 0) {
       ppsci_set_error("pw_conv: launch failed");
       return PPSCI_E_LAUNCH;
     }
