@@ -36,7 +36,7 @@ def build() -> str:
             subprocess.check_call([CLANG] + flags + ["-c", s, "-o", obj])
         return obj
 
-    with ThreadPoolExecutor(8) as ex:
+    with ThreadPoolExecutor(min(len(SOURCES), os.cpu_count() or 8)) as ex:
         objs = list(ex.map(one, SOURCES))
     if not _newer(lib, objs):
         subprocess.check_call([CLANG, "-shared", "-o", lib] + objs)
