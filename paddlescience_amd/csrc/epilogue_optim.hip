@@ -258,6 +258,24 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
   }
 }
 
+// One row: a plain copy / accumulate of `cols` floats (gradient hand-over between stages), every thread busy, float4
+// where the pointers allow it.
+__global__ void __launch_bounds__(256) reduce_rows_one_kernel(ReduceArgs a) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (a.groups) {  // float4 path
+    const long long n4 = a.cols >> 2;
+    if (t < n4) {
+      f32x4 v = ((const f32x4*)a.partials)[t];
+      if (a.accumulate) v += ((const f32x4*)a.out)[t];
+      ((f32x4*)a.out)[t] = v;
+    } else if (t == n4) {
+      for (long long j = 4 * n4; j < a.cols; ++j) a.out[j] = a.accumulate ? a.out[j] + a.partials[j] : a.partials[j];
+    }
+  } else if (t < a.cols) {
+    a.out[t] = a.accumulate ? a.out[t] + a.partials[t] : a.partials[t];
+  }
+}
+
 // Few columns, many rows (loss partials: one row per wave): one workgroup per column, thread t sums rows t, t+256, ...
 // in order, then a fixed-shape LDS tree (deterministic).
 __global__ void __launch_bounds__(256) reduce_rows_narrow_kernel(ReduceArgs a) {
@@ -543,7 +561,11 @@ extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t co
     return PPSCI_E_INVALID;
   }
   ReduceArgs a{partials, out, rows, cols, accumulate, RED_GROUPS};
-  if (cols <= 8 && rows >= 512) {
+  if (rows == 1) {
+    a.groups = (((uintptr_t)partials | (uintptr_t)out) & 15) == 0 ? 1 : 0;  // here: 1 = float4 path
+    const long long nthr = a.groups ? (cols >> 2) + 1 : cols;
+    PPSCI_LAUNCH(reduce_rows_one_kernel, ReduceArgs, (int)((nthr + 255) / 256), 256, 0, stream, a);
+  } else if (cols <= 8 && rows >= 512) {
     PPSCI_LAUNCH(reduce_rows_narrow_kernel, ReduceArgs, (int)cols, 256, 256 * sizeof(float), stream, a);
   } else {
     // tall inputs: more row parallelism and more workgroups; narrower column runs only while the matrix is small
