@@ -62,9 +62,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
       // block (ib, ob), lane 16g + c, component r  <->  (in = 16ib + 4g + r, out = 16ob + c)
       const long long j = (long long)(l - 1) * HP * HP +
                           ((long long)((in >> 4) * NB + (out >> 4)) * 64 + 16 * ((in & 15) >> 2) + (out & 15)) * 4 + (in & 3);
-      // independent loads, in-order adds: unrolled so that 8 loads are in flight per thread
-#pragma unroll 8
-      for (int c = 0; c < a.nchunks; ++c) v += a.tmp[(long long)c * a.per_tile + j];
+      // four interleaved chains (chunk c goes to chain c & 3), combined in a fixed order: 16 loads in flight per thread
+      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int c = 0; c < a.nchunks; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // clamped index + select: the loads stay unconditional (no branch between them)
+          const int cu = c + u < a.nchunks ? c + u : a.nchunks - 1;
+          const float t = a.tmp[(long long)cu * a.per_tile + j];
+          v4[u] += c + u < a.nchunks ? t : 0.f;
+        }
+      }
+      v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     }
   }
   if (!hidden) {  // W0, a bias, W_last or b_last: compact index into the summed small block
@@ -78,8 +87,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
       while (l + 1 < L && idx >= a.q.offW[l + 1]) ++l;  // the bias that follows W_l
       ci = a.d0 * H + l * H + (idx - a.q.offB[l]);
     }
-#pragma unroll 8
-    for (int c = 0; c < a.nchunks; ++c) v += a.tmp_small[(long long)c * a.psmall + ci];
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = 0; c < a.nchunks; c += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cu = c + u < a.nchunks ? c + u : a.nchunks - 1;
+        const float t = a.tmp_small[(long long)cu * a.psmall + ci];
+        v4[u] += c + u < a.nchunks ? t : 0.f;
+      }
+    }
+    v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
   }
   a.row[idx] = v;
 }

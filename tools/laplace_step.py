@@ -1,0 +1,14 @@
+"""cfg1 (Laplace2D 3x20, 10 k interior + boundary points) step in isolation, for rocprofv3:  python tools/laplace_step.py [steps]"""
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    with tempfile.TemporaryDirectory() as tmp:
+        r = bench.secondary_laplace(tmp, steps, 10, False)
+    print(json.dumps({k: r[k] for k in ("value", "ms_per_step")}))

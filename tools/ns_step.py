@@ -1,0 +1,14 @@
+"""cfg3 shard (NavierStokes 5x128, 125 k points) step in isolation, for rocprofv3:  python tools/ns_step.py [steps]"""
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    with tempfile.TemporaryDirectory() as tmp:
+        r = bench.secondary_ns(tmp, steps, 5)
+    print(json.dumps({k: r[k] for k in ("value", "ms_per_step")}))
