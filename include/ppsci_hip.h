@@ -356,7 +356,9 @@ int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
                            void* stream);
 int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n_points,
                            const float* const* x, const float* const* Fbar, const float* const* stash,
-                           float* const* grad_partials, void* stream);
+                           float* const* grad_partials, int64_t partial_stride /* floats between a network's partial rows;
+                           0 = P.  3P with the three pointers P apart interleaves the networks' rows [n][3][P], so that ONE
+                           ppsci_reduce_rows(n, 3P) sums all three */, void* stream);
 
 /* ---- ppsci.arch.PirateNet (mlp.py:530-820), layer by layer on Taylor streams (csrc/pirate.hip) ---------------------
  * Every tensor is a stream block [S][C][NP]: S = 1 + n1 + n2 streams (value, first derivatives along n1 directions,

@@ -136,7 +136,7 @@ _SYMBOLS = {
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "ppsci_modmlp_bwd_batch": (C.c_int, [C.POINTER(ModMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                         C.POINTER(C.c_void_p), C.c_void_p]),
+                                         C.POINTER(C.c_void_p), C.c_int64, C.c_void_p]),
     "ppsci_pirate_embed_fwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_pirate_embed_chunks": (C.c_int64, [C.c_int64]),
     "ppsci_pirate_embed_bwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,

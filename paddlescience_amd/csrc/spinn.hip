@@ -84,7 +84,8 @@ struct ModBranch {     // one network (one SPINN axis) and its points
   float* F;            // fwd out: [3][N][R]
   const float* Fbar;   // bwd in : [3][N][R]
   float* stash;        // [N][(L+2)][3][H]: zu, zv, z_0 .. z_{L-1}
-  float* partials;     // bwd out: [N][P]
+  float* partials;     // bwd out: [N][P], row stride `pstride` floats
+  long long pstride;
   int N;
 };
 struct ModArgs {       // up to SP_MAXBATCH networks of the same shape in one launch: workgroup = (branch, point)
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(MOD_BWD_BLOCK) modmlp_bwd_kernel(ModArgs a) {
   const float x = B.x[pt];
   const float* P = B.params;
   const float* st = B.stash + (long long)pt * (L + 2) * 3 * H;
-  float* G = B.partials + (long long)pt * a.o.P;
+  float* G = B.partials + (long long)pt * B.pstride;
   float* fb = sh + 3 * H;
   for (int i = f; i < 3 * R; i += blockDim.x) fb[i] = B.Fbar[((long long)(i / R) * B.N + pt) * R + (i % R)];
   // embeddings (recomputed)
@@ -800,7 +801,7 @@ extern "C" int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params,
 
 extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
                                       const float* const* x, const float* const* Fbar, const float* const* stash,
-                                      float* const* grad_partials, void* stream) {
+                                      float* const* grad_partials, int64_t partial_stride, void* stream) {
   if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || !Fbar || !stash ||
       !grad_partials) {
     ppsci_set_error("modmlp_bwd: invalid argument");
@@ -819,6 +820,7 @@ extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
     }
     a.br[b].params = params[b]; a.br[b].x = x[b]; a.br[b].Fbar = Fbar[b]; a.br[b].stash = (float*)stash[b];
     a.br[b].partials = grad_partials[b]; a.br[b].N = (int)n[b];
+    a.br[b].pstride = partial_stride > 0 ? partial_stride : a.o.P;
     total += n[b];
   }
   const int wcols = (d->width > d->d_out ? d->width : d->d_out) + 1;
@@ -831,7 +833,7 @@ extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
 
 extern "C" int ppsci_modmlp_bwd(const ppsci_modmlp_desc* d, const float* params, int64_t n, const float* x,
                                 const float* Fbar, const float* stash, float* grad_partials, void* stream) {
-  return ppsci_modmlp_bwd_batch(d, 1, &params, &n, &x, &Fbar, &stash, &grad_partials, stream);
+  return ppsci_modmlp_bwd_batch(d, 1, &params, &n, &x, &Fbar, &stash, &grad_partials, 0, stream);
 }
 
 #define GRID_MFMA_MAX_RANK 64

@@ -44,7 +44,14 @@ class SpinnConstraint:
         self.F = [torch.zeros((3, n, R), **f32) for n in shape]
         self.Fbar = [torch.zeros((3, n, R), **f32) for n in shape]
         self.stash = [torch.zeros(int(L.lib().ppsci_modmlp_stash_floats(C.byref(m.spec.desc), n)), **f32) for n in shape]
-        self.gpart = [torch.zeros((n, P), **f32) for n in shape]
+        # per-point gradient rows of the three branch nets: with equal point counts they interleave as [n][3][P], so that one
+        # reduce_rows(n, 3P) call sums all three into the flat gradient (branch b's parameters are grad[bP:(b+1)P])
+        self.gjoint = len(set(shape)) == 1
+        if self.gjoint:
+            self.gpart_all = torch.zeros((shape[0], 3 * P), **f32)
+            self.gpart = [self.gpart_all.view(-1)[b * P:] for b in range(3)]  # row 0 of branch b; rows are 3P apart
+        else:
+            self.gpart = [torch.zeros((n, P), **f32) for n in shape]
         total = nx * ny * nz
         self.label = torch.zeros(total, **f32)
         self.gadj = torch.zeros(total, **f32)
@@ -121,7 +128,8 @@ class SpinnConstraint:
         vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
         L.check(lib.ppsci_modmlp_bwd_batch(C.byref(m.spec.desc), 3, vp([m.branch(b) for b in range(3)]),
                                            (C.c_int64 * 3)(*[t.numel() for t in self.x]), vp(self.x), vp(self.Fbar),
-                                           vp(self.stash), vp(self.gpart), _stream_ptr(self.x[0])))
+                                           vp(self.stash), vp(self.gpart), 3 * m.branch_params if self.gjoint else 0,
+                                           _stream_ptr(self.x[0])))
 
     def loss(self) -> float:
         return float(self.loss_term.cpu()[0])
@@ -147,6 +155,9 @@ class SpinnEngine:
                 c.forward(True)
                 c.backward()
         for i, c in enumerate(constraints):
+            if c.gjoint:
+                hp.reduce_rows(c.gpart_all, c.gpart_all.shape[0], 3 * P, self.grad[:3 * P], i > 0)
+                continue
             for b in range(3):
                 hp.reduce_rows(c.gpart[b], c.gpart[b].shape[0], P, self.grad[b * P:(b + 1) * P], i > 0)
 

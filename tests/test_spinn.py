@@ -56,10 +56,10 @@ def _build(tmp_path, shape=(7, 5, 6), act="tanh", r=4):
 
 
 @pytest.mark.parametrize("act,shape,r", [("tanh", (7, 5, 6), 4), ("sin", (7, 5, 6), 4), ("tanh", (18, 35, 21), 20),
-                                         ("tanh", (17, 9, 20), 40), ("tanh", (5, 6, 7), 70)])
+                                         ("tanh", (17, 9, 20), 40), ("tanh", (5, 6, 7), 70), ("tanh", (9, 9, 9), 8)])
 def test_spinn_helmholtz_losses_and_grads(tmp_path, act, shape, r):
     """ranks 4 / 20 / 40 take the MFMA grid kernels with 4 / 8 / 16 k-steps (ragged row, column and rank tails); rank 70
-    the scalar ones."""
+    the scalar ones; equal point counts on the three axes take the joint gradient-row layout (one reduce for all branches)."""
     solver, model, xs, uc, face = _build(tmp_path, shape=shape, act=act, r=r)
     nets = [R.ModifiedMLP1(_params_of(model, b), act) for b in range(3)]
     tx = [torch.tensor(x.astype(np.float64), requires_grad=True) for x in xs]
