@@ -244,6 +244,33 @@ def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
         cur.wait_stream(st)
 
 
+_NATIVE_COMM = None  # None: not decided yet; False: torch.distributed; True: ppsci_comm_* is initialised
+
+
+def native_comm_ready() -> bool:
+    """PPSCI_NATIVE_ALLREDUCE=1 on a multi-rank GPU job: create (once) the RCCL communicator of the C ABI -- rank 0's
+    128-byte id travels over the existing torch.distributed group -- and use ppsci_allreduce_sum for the gradient
+    all-reduce.  Default (unset / 0): torch.distributed.all_reduce, which is the same RCCL underneath."""
+    global _NATIVE_COMM
+    if _NATIVE_COMM is None:
+        dist = torch.distributed
+        if os.environ.get("PPSCI_NATIVE_ALLREDUCE", "0") != "1" or not dist.is_initialized() or dist.get_world_size() < 2 \
+                or not torch.cuda.is_available() or L.is_emulated():
+            _NATIVE_COMM = False
+        else:
+            import ctypes as C
+
+            lib = L.lib()
+            buf = C.create_string_buffer(128)
+            if dist.get_rank() == 0:
+                L.check(lib.ppsci_comm_unique_id(buf))
+            box = [buf.raw if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            L.check(lib.ppsci_comm_init(dist.get_rank(), dist.get_world_size(), C.c_char_p(box[0])))
+            _NATIVE_COMM = True
+    return _NATIVE_COMM
+
+
 class Engine:
     def __init__(self, layout: hp.NetLayout, params: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8,
                  dp_reduce: str = "sum"):
@@ -318,7 +345,10 @@ class Engine:
 
     def allreduce(self) -> None:
         if self.world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            if native_comm_ready():  # PPSCI_NATIVE_ALLREDUCE=1: the C ABI's RCCL communicator (csrc/comm.hip)
+                L.check(L.lib().ppsci_allreduce_sum(hp._p(self.grad), self.grad.numel(), hp._stream_ptr(self.grad)))
+            else:
+                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
 
     def optimizer_step(self, lr: float) -> None:
         self.t += 1

@@ -10,7 +10,7 @@ EXTRA = os.environ.get("PPSCI_EMU_EXTRA_FLAGS", "").split()  # experiment builds
 OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "_".join(f.lstrip("-D") for f in EXTRA) if EXTRA else ""))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
-           "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "fft.hip", "spinn.hip", "pirate.hip", "epilogue_optim.hip"]
+           "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "fft.hip", "spinn.hip", "pirate.hip", "comm.hip", "epilogue_optim.hip"]
 HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc", "taylor_fwd_wide.inc", "taylor_bwd_wide.inc"]
 
 
