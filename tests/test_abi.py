@@ -63,3 +63,35 @@ def test_no_cpu_fallback():
     emu = build_emu.build()
     lib = _lib._bind(emu)
     assert lib.ppsci_is_device_build() == 0  # the product loader (`_lib.lib()`) rejects such a build
+
+
+def test_invalid_arguments_are_reported_not_executed(libpath):
+    """Error behaviour of the entry points added in round 2 (no device work: every call is rejected by its argument check):
+    a non-zero status and a message behind ppsci_last_error(), as for the round-1 entry points."""
+    from paddlescience_amd import _lib as L
+
+    lib = L._bind(libpath)
+
+    def bad(rc, needle):
+        assert rc != 0
+        msg = lib.ppsci_last_error().decode()
+        assert needle in msg, msg
+
+    d = L.PirateEmbedDesc()
+    bad(lib.ppsci_pirate_embed_fwd(ctypes.byref(d), None, None, None, None), "pirate_embed")  # d_raw = 0
+    d.d_raw, d.d0, d.half, d.n1, d.n2, d.N, d.NP = 2, 2, 8, 2, 1, 100, 100  # NP not a multiple of 16
+    bad(lib.ppsci_pirate_embed_fwd(ctypes.byref(d), None, None, None, None), "pirate_embed")
+    bad(lib.ppsci_pirate_act_fwd(7, L.ACT["tanh"], 16, 32, 32, 1, 1, None, None, None, None, None, None, None, None), "pirate_act")
+    bad(lib.ppsci_pirate_act_fwd(L.PIRATE_ACT, L.ACT["relu"], 16, 32, 32, 1, 1, None, None, None, None, None, None, None, None),
+        "no PirateNet kernel")
+    bad(lib.ppsci_pirate_act_fwd(L.PIRATE_GATE, L.ACT["tanh"], 16, 32, 32, 2, 3, None, None, None, None, None, None, None, None),
+        "pirate_act")  # n2 > n1
+    bad(lib.ppsci_pirate_out_fwd(0, 1, 8, 16, None, None, None, None), "pirate_out_fwd")
+    bad(lib.ppsci_pirate_out_bwd(4, 1, 8, 4, None, None, None), "pirate_out_bwd")  # NP < N
+    md = L.ModMlpDesc()
+    bad(lib.ppsci_modmlp_fwd_batch(ctypes.byref(md), 3, None, None, None, None, None, None), "modmlp")
+    bad(lib.ppsci_linear_pad(4, 4, 2, 8, None, None, None, None, None), "linear_pad")  # destination smaller than the source
+    bad(lib.ppsci_pw_conv(1, 8, 8, 6, None, None, 0, None, None, 0, None, None, None), "pw_conv")  # P not a multiple of 4
+    bad(lib.ppsci_allreduce_sum(None, 4, None), "comm_init has not been called")
+    bad(lib.ppsci_comm_init(2, 2, None), "comm_init")
+    assert lib.ppsci_comm_world_size() == 0
