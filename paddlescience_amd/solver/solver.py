@@ -328,13 +328,20 @@ class Solver:
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
                     self.lr_scheduler.step()
                 self.global_step += 1
-                if self.benchmark_flag and torch.cuda.is_available():
+                # The reference converts every loss term to a Python float in every iteration (expression.py:122), i.e. its
+                # batch_cost always contains the device time.  Here the loss terms are fetched only when they are logged; that
+                # fetch is the iteration's device->host sync, so it has to sit INSIDE the timed window: the logging iteration
+                # then absorbs the queued device work of its window and the window's mean batch_cost / ips are true device
+                # figures (a fetch after the clock stop reported launch time only: ips 8e8 for a 3 ms step).
+                log_now = iter_id == 1 or iter_id % self.log_freq == 0
+                if log_now:
+                    self._update_train_loss()
+                elif self.benchmark_flag and torch.cuda.is_available():
                     torch.cuda.synchronize()
                 batch_cost = time.perf_counter() - batch_tic
                 self.train_time_info["reader_cost"].update(reader_cost)
                 self.train_time_info["batch_cost"].update(batch_cost)
-                if iter_id == 1 or iter_id % self.log_freq == 0:
-                    self._update_train_loss()
+                if log_now:
                     self._log_train_info(total_batch_size, epoch_id, iter_id)
                 batch_tic = time.perf_counter()
             if self.lr_scheduler is not None and getattr(self.lr_scheduler, "by_epoch", False):
