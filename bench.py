@@ -537,6 +537,35 @@ def extra_piratenet(tmp, steps, warmup, n=8192):
                          "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS}, "parity": parity}
 
 
+def extra_cylinder2d(tmp, steps, warmup):
+    """Not a BASELINE config: the case behind the reference's published TIPC throughput (cylinder2d_unsteady_Re100, fp32, one
+    unnamed NVIDIA GPU: ips = 1 264 165.641 points/s, /root/reference/test_tipc/README.MD:17) at the sizes of its yaml, built by
+    examples/cylinder2d_unsteady.py (same-size synthetic point sets: the CSV files are not shipped).  `ips` of the reference =
+    points of all constraints per iteration / batch_cost (train.py:106, printer.py:66) = `value` here."""
+    from examples.cylinder2d_unsteady import DEFAULTS, build
+
+    cfg = dict(DEFAULTS, output_dir=os.path.join(tmp, "cyl"), epochs=1)
+    solver = build(cfg)
+    csts = [c.fused for c in solver._compiled.values()]
+    n = sum(c.n for c in csts)
+
+    def step():
+        solver.engine.forward_backward(csts)
+        solver.optimizer.step(solver.engine.grad)
+
+    t = time_wall(step, max(steps, 20), max(warmup, 5))
+    S = csts[0].streams.S
+    p_mat = 3 * 64 + 4 * 64 * 64 + 64 * 3  # padded width 64
+    pub = 1264165.641
+    return {"config": "extra (not a BASELINE config): cylinder2d_unsteady_Re100 at the reference yaml's sizes -- MLP (t,x,y)->(u,v,p) "
+                      f"5x50 tanh, unsteady NavierStokes, {n} points per iteration in 4 constraints (S = {S} streams for the PDE), "
+                      "MSE-mean, Adam",
+            "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "points_per_iteration": n,
+            "published_reference": {"value": pub, "unit": "points/s (TIPC ips, fp32, N1C1, unnamed NVIDIA GPU)",
+                                    "source": "test_tipc/README.MD:17", "ratio": n / t / pub},
+            "matrix_tflops_step": 6.0 * p_mat * S * csts[0].n / t / 1e12}
+
+
 # ------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -663,7 +692,7 @@ def main():
             sec = []
             for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),
                        lambda: secondary_ns(tmp, k, w), lambda: secondary_tfno(k, w), lambda: secondary_spinn(tmp, k, w),
-                       lambda: extra_piratenet(tmp, k, w)):
+                       lambda: extra_piratenet(tmp, k, w), lambda: extra_cylinder2d(tmp, k, w)):
                 try:
                     sec.append(fn())
                 except Exception as e:  # noqa: BLE001 -- a secondary entry must not cost the primary line

@@ -50,12 +50,14 @@ def stamped(xy, stamps, labels=None):
     return inp, ({k: rep(v) for k, v in labels.items()} if labels else None)
 
 
-if __name__ == "__main__":
-    cfg = parse(dict(seed=42, output_dir="./output_cylinder2d_unsteady", epochs=200, log_freq=20, viscosity=0.02, density=1.0,
-                     time_start=1.0, time_end=50.0, num_timestamps=50, train_num_timestamps=30, npoint_pde=9420,
-                     npoint_inlet_cylinder=161, npoint_outlet=81, num_layers=5, hidden_size=50, learning_rate=1e-3))
+DEFAULTS = dict(seed=42, output_dir="./output_cylinder2d_unsteady", epochs=200, log_freq=20, viscosity=0.02, density=1.0,
+                time_start=1.0, time_end=50.0, num_timestamps=50, train_num_timestamps=30, npoint_pde=9420,
+                npoint_inlet_cylinder=161, npoint_outlet=81, num_layers=5, hidden_size=50, learning_rate=1e-3)
+
+
+def build(cfg):
+    """model, constraints and Solver of the case (also used by bench.py's `extra` entry)."""
     ppsci.utils.misc.set_random_seed(cfg["seed"])
-    logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
     rng = np.random.default_rng(cfg["seed"])
     model = ppsci.arch.MLP(("t", "x", "y"), ("u", "v", "p"), cfg["num_layers"], cfg["hidden_size"], "tanh")
     equation = {"NavierStokes": ppsci.equation.NavierStokes(cfg["viscosity"], cfg["density"], 2, True)}
@@ -89,4 +91,10 @@ if __name__ == "__main__":
                                  equation=equation, geom=geom)
     logger.info(f"points per iteration: EQ {cfg['npoint_pde'] * ntime} + BC {len(inlet_cyl) * ntime} + {len(outlet) * ntime} + IC {len(dom)}"
                 f" (reference TIPC ips for this case: 1 264 165.6)")
-    solver.train()
+    return solver
+
+
+if __name__ == "__main__":
+    cfg = parse(dict(DEFAULTS))
+    logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
+    build(cfg).train()
