@@ -18,11 +18,13 @@ from examples._args import parse  # noqa: E402
 from ppsci.autodiff import hessian, jacobian  # noqa: E402
 from ppsci.utils import logger  # noqa: E402
 
-if __name__ == "__main__":
-    cfg = parse(dict(seed=42, output_dir="./output_euler_beam", epochs=10000, iters_per_epoch=1, q=-1.0, D=1.0, num_layers=3,
-                     hidden_size=20, learning_rate=1e-3, batch_pde=100, batch_bc=4, eval_total=100, log_freq=500))
+DEFAULTS = dict(seed=42, output_dir="./output_euler_beam", epochs=10000, iters_per_epoch=1, q=-1.0, D=1.0, num_layers=3,
+                hidden_size=20, learning_rate=1e-3, batch_pde=100, batch_bc=4, eval_total=100, log_freq=500)
+
+
+def build(cfg):
+    """model, constraints, validator and Solver of the case (also used by bench.py's `extra` entry)."""
     ppsci.utils.misc.set_random_seed(cfg["seed"])
-    logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
     geom = {"interval": ppsci.geometry.Interval(0, 1)}
     model = ppsci.arch.MLP(("x",), ("u",), cfg["num_layers"], cfg["hidden_size"])
     equation = {"biharmonic": ppsci.equation.Biharmonic(dim=1, q=cfg["q"], D=cfg["D"])}
@@ -48,5 +50,12 @@ if __name__ == "__main__":
     solver = ppsci.solver.Solver(model, {pde.name: pde, bc.name: bc}, cfg["output_dir"], opt, epochs=cfg["epochs"],
                                  iters_per_epoch=cfg["iters_per_epoch"], log_freq=cfg["log_freq"], equation=equation, geom=geom,
                                  validator={val.name: val})
+    return solver
+
+
+if __name__ == "__main__":
+    cfg = parse(dict(DEFAULTS))
+    logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
+    solver = build(cfg)
     solver.train()
     solver.eval()
