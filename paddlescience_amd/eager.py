@@ -138,6 +138,7 @@ class EagerConstraint:
         self.batch_size, self.n_global = batch_size, n_global
         self.inp = self.lab = self.w = None
         self._last: Dict[str, float] = {}
+        self._graph = None  # None: not captured yet; False: capture failed; (key, CUDAGraph)
         self._fns: Dict[str, Callable] = {}
 
     def _t(self, a):
@@ -148,9 +149,18 @@ class EagerConstraint:
         return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
 
     def bind(self, input, label, weight=None):
-        self.inp = {k: self._t(v) for k, v in input.items()}
-        self.lab = {k: self._t(v) for k, v in (label or {}).items()}
-        self.w = {k: self._t(v) for k, v in (weight or {}).items()}
+        """New batch: written IN PLACE into the tensors of the previous one when names and shapes agree, so that a captured
+        graph of the step (below) keeps reading the right memory."""
+        def put(old, new):
+            new = {k: self._t(v) for k, v in (new or {}).items()}
+            if old is not None and old.keys() == new.keys() and all(old[k].shape == new[k].shape for k in new):
+                for k, v in new.items():
+                    old[k].copy_(v)
+                return old
+            self._graph = None  # shapes changed: the captured step is stale
+            return new
+
+        self.inp, self.lab, self.w = put(self.inp, input), put(self.lab, label), put(self.w, weight)
 
     def _values(self, flat: torch.Tensor, need_grad: bool):
         from .utils.symbolic import lambdify
@@ -176,9 +186,7 @@ class EagerConstraint:
             vals["area"] = self.inp["area"]
         return vals
 
-    def forward_backward(self, grad: torch.Tensor, dp_scale: float = 1.0) -> None:
-        """loss terms -> `self._last`; d(sum of terms)/d(trainable parameters) is ADDED into `grad` (flat, trainable layout).
-        `dp_scale`: batch_size / n_global for "mean" losses so that the SUM all-reduce over ranks yields the global mean."""
+    def _step(self, grad: torch.Tensor, dp_scale: float) -> None:
         flat = self.model.flat_params.detach().requires_grad_(True)
         vals = self._values(flat, True)
         losses = self.loss(vals, self.lab, self.w if self.w else None)
@@ -190,7 +198,44 @@ class EagerConstraint:
         (g,) = torch.autograd.grad(total, flat, allow_unused=True)
         if g is not None:
             grad.add_(g)
-        self._last = {k: float(v.detach()) for k, v in losses.items()}
+        self._loss_t = {k: v.detach() for k, v in losses.items()}  # fetched by losses(), i.e. only when they are logged
+
+    def forward_backward(self, grad: torch.Tensor, dp_scale: float = 1.0) -> None:
+        """loss terms -> `losses()`; d(sum of terms)/d(trainable parameters) is ADDED into `grad` (flat, trainable layout).
+        `dp_scale`: batch_size / n_global for "mean" losses so that the SUM all-reduce over ranks yields the global mean.
+
+        The op-by-op path is a few hundred tiny torch kernels (4 boundary points with fourth derivatives: 4 ms of launches); with
+        static shapes the whole sequence -- forward, higher-order autograd, the gradient add -- is captured once into a HIP graph
+        and replayed (PPSCI_EAGER_GRAPH=0 or a failed capture: launched op by op)."""
+        import os
+
+        key = (grad.data_ptr(), float(dp_scale))
+        if not grad.is_cuda or os.environ.get("PPSCI_EAGER_GRAPH", "1") == "0" or self._graph is False:
+            return self._step(grad, dp_scale)
+        if self._graph is not None and self._graph[0] == key:
+            self._graph[1].replay()
+            return
+        self._calls = getattr(self, "_calls", 0) + 1
+        self._step(grad, dp_scale)  # the first calls run op by op (allocator warm-up, lazy initialisation inside torch)
+        if self._calls < 3:
+            return
+        try:
+            torch.cuda.synchronize()
+            saved, eager_losses = grad.clone(), self._loss_t
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="relaxed"):
+                self._step(grad, dp_scale)
+            grad.copy_(saved)  # (a capture does not execute; this only guards against a partial one)
+            for k, v in self._loss_t.items():  # the graph's loss tensors: this iteration's values come from the eager run above
+                v.copy_(eager_losses[k])
+            self._graph = (key, g)
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation, never a requirement
+            from .utils import logger
+
+            logger.warning(f"constraint {self.name}: HIP-graph capture of the eager step failed ({type(e).__name__}: {e}); it "
+                           "stays op by op")
+            self._graph = False
+            torch.cuda.synchronize()
 
     def values(self) -> Dict[str, torch.Tensor]:
         with torch.enable_grad():
@@ -198,4 +243,5 @@ class EagerConstraint:
         return {k: v.detach() for k, v in vals.items() if isinstance(v, torch.Tensor)}
 
     def losses(self) -> Dict[str, float]:
+        self._last = {k: float(v) for k, v in getattr(self, "_loss_t", {}).items()}
         return dict(self._last)
