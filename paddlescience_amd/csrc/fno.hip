@@ -282,49 +282,53 @@ struct PwWArgs {
   int B, Ci, Co, P, nib, nob, cpix, chunks_per_b;
 };
 
-// one wave per (pixel chunk, PAIR of out blocks, PAIR of in blocks) = a 32 x 32 tile of gW; cpix pixels of one sample
-// per chunk (a multiple of 16).  Four accumulators per wave: every operand float4 feeds two MFMA chains, which
-// halves the L2 traffic per flop of the one-tile-per-wave form.
+// one wave per (pixel chunk, TB x TB group of 16 x 16 blocks) = a 16TB x 16TB tile of gW; cpix pixels of one sample per chunk
+// (a multiple of 16).  TB*TB accumulators per wave: every operand float4 feeds TB MFMA chains -- the kernel is bound by
+// the L2 traffic of its operands (each wave streams 2 * 16TB rows x cpix pixels), which per flop falls as 1 / TB.
+// TB = 2 for small layers (a 32 x 32 FNO layer is ONE tile), TB = 4 from 128 x 128 on.
+template <int TB>
 __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int nib2 = (a.nib + 1) / 2, nob2 = (a.nob + 1) / 2;
+  const int nibt = (a.nib + TB - 1) / TB, nobt = (a.nob + TB - 1) / TB;
   int id = blockIdx.x;
-  const int ib = 2 * (id % nib2);
-  id /= nib2;
-  const int ob = 2 * (id % nob2);
-  const int ch = id / nob2;
+  const int ib = TB * (id % nibt);
+  id /= nibt;
+  const int ob = TB * (id % nobt);
+  const int ch = id / nobt;
   const int b = ch / a.chunks_per_b;
   const int p0 = (ch - b * a.chunks_per_b) * a.cpix;
-  const float* gr[2];
-  const float* xr[2];
-  float mo[2], mi[2];
+  const float* gr[TB];
+  const float* xr[TB];
+  float mo[TB], mi[TB];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < TB; ++u) {
     const int o = 16 * (ob + u) + c, i = 16 * (ib + u) + c;
     gr[u] = a.gy + ((long long)b * a.Co + (o < a.Co ? o : 0)) * a.P;
     xr[u] = a.x + ((long long)b * a.Ci + (i < a.Ci ? i : 0)) * a.P;
     mo[u] = o < a.Co ? 1.f : 0.f;
     mi[u] = i < a.Ci ? 1.f : 0.f;
   }
-  f32x4 acc[2][2];
+  f32x4 acc[TB][TB];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < TB; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
+    for (int v = 0; v < TB; ++v) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[TB];
+#pragma unroll
+  for (int u = 0; u < TB; ++u) bsum[u] = 0.f;
   const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
   for (int p = p0; p < pend; p += 16) {
     // k-step r <-> pixel p + 4g + r for both operands
-    f32x4 gv[2], xv[2];
+    f32x4 gv[TB], xv[TB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TB; ++u) {
       gv[u] = *(const f32x4*)&gr[u][p + 4 * g] * mo[u];
       xv[u] = *(const f32x4*)&xr[u][p + 4 * g] * mi[u];
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TB; ++u) {
 #pragma unroll
-      for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < TB; ++v)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[u][r], xv[v][r], acc[u][v], 0, 0, 0);
       bsum[u] += (gv[u][0] + gv[u][1]) + (gv[u][2] + gv[u][3]);
@@ -333,9 +337,9 @@ __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
   float* prow = a.part + (long long)ch * ((long long)a.Co * a.Ci);
   // D[row = 4g + rr][col = c] = gW[o = 16ob + 4g + rr][i = 16ib + c]
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < TB; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < TB; ++v) {
       const int i = 16 * (ib + v) + c;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
     }
   if (ib == 0 && a.part_b) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TB; ++u) {
       float bs = bsum[u];
       bs += __shfl_xor(bs, 16, 64);
       bs += __shfl_xor(bs, 32, 64);
@@ -377,8 +381,13 @@ extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x,
   a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
   a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
-  const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
-  PPSCI_LAUNCH(pw_wgrad_kernel, PwWArgs, (int)grid, 64, 0, stream, a);
+  if (Ci >= 128 && Co >= 128) {
+    const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 3) / 4) * ((a.nib + 3) / 4);
+    PPSCI_LAUNCH(pw_wgrad_kernel<4>, PwWArgs, (int)grid, 64, 0, stream, a);
+  } else {
+    const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
+    PPSCI_LAUNCH(pw_wgrad_kernel<2>, PwWArgs, (int)grid, 64, 0, stream, a);
+  }
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("pw_conv_wgrad: launch failed");
     return PPSCI_E_LAUNCH;
