@@ -16,9 +16,11 @@ class ModelList(Arch):
     def __init__(self, model_list: Tuple[Arch, ...]):
         super().__init__()
         model_list = tuple(model_list)
+        from .piratenet import PirateNet
+
         for m in model_list:
-            if not isinstance(m, MLP):
-                raise NotImplementedError("ModelList members must be ppsci.arch.MLP on the fused HIP path")
+            if not isinstance(m, (MLP, PirateNet)):
+                raise NotImplementedError("ModelList members must be ppsci.arch.MLP / PirateNet on the fused HIP path")
         keys: List[str] = []
         for m in model_list:  # the reference keeps a set; a stable order is needed for the kernels' input arrays
             keys += [k for k in m.input_keys if k not in keys]

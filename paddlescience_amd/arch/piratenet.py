@@ -150,6 +150,12 @@ class PirateNet(Arch):
             off += n
         self._byname = dict(zip(self._names, self._views))
 
+    def rehome(self, flat: torch.Tensor, flat_grad=None, kernel=None) -> None:
+        """ModelList: move the trainable parameters into `flat` (a slice of the list's buffer), keeping their values."""
+        assert flat.numel() == self.flat_params.numel()
+        flat.copy_(self.flat_params)
+        self._bind_views(flat)
+
     def linear_names(self) -> List[str]:
         out = ["embed_u.0", "embed_v.0"]
         for i in range(self.num_blocks):

@@ -138,3 +138,34 @@ def test_loading_a_file_with_foreign_keys_raises_instead_of_keeping_random_weigh
     other = ppsci.arch.ModelList((_model(), ppsci.arch.MLP(("x", "y"), ("v",), 3, 16, "tanh")))
     with pytest.raises(ValueError, match="no key of the file"):
         save_load.load_pretrain(other, path)
+
+
+def test_piratenet_checkpoint_round_trip(tmp_path, dev):
+    """PirateNet's state dict carries the reference's names (blocks.i.alpha, blocks.i.linear{1,2,3}.weight_v / weight_g / bias,
+    embed_u.0.*, fourier_emb.kernel, last_fc.*) and survives save_checkpoint / load_checkpoint with the optimizer state."""
+    def make(seed):
+        ppsci.utils.misc.set_random_seed(seed)
+        return ppsci.arch.PirateNet(("t", "x"), ("u",), 2, 16, "tanh", periods={"x": (2.0, False)},
+                                    fourier={"dim": 16, "scale": 1.0}, random_weight={"mean": 1.0, "std": 0.1})
+
+    model = make(1)
+    with torch.no_grad():
+        model.flat_params.add_(0.01)
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    opt.m.uniform_(-1, 1), opt.v.uniform_(0, 1)
+    opt.t = 5
+    save_load.save_checkpoint(model, opt, {"metric": 0.5, "epoch": 2}, None, str(tmp_path), "epoch_2")
+    path = os.path.join(str(tmp_path), "checkpoints", "epoch_2")
+    with open(path + ".pdparams", "rb") as f:
+        raw = pickle.load(f)
+    for n in ("fourier_emb.kernel", "embed_u.0.weight_v", "embed_v.0.weight_g", "blocks.0.alpha", "blocks.1.linear3.bias",
+              "last_fc.weight_v"):
+        assert n in raw, n
+    assert raw["blocks.0.alpha"].shape == (1,) and raw["fourier_emb.kernel"].shape == (3, 8)
+    other = make(2)
+    opt2 = ppsci.optimizer.Adam(1e-3)(other)
+    assert not torch.equal(other.flat_params, model.flat_params)
+    best = save_load.load_checkpoint(path, other, opt2)
+    assert best["epoch"] == 2
+    assert torch.equal(other.flat_params, model.flat_params)
+    assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v) and opt2.t == 5

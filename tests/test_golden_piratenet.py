@@ -128,6 +128,49 @@ def test_piratenet_full_width_matches_oracle(dev, tmp_path, hidden, blocks, n):
     assert rel(res["allen_cahn"][:, 0], outs[0]["allen_cahn"].detach().numpy()[:, 0]) < 3e-5
 
 
+def test_model_list_of_an_mlp_and_a_piratenet(dev, tmp_path):
+    """ppsci.arch.ModelList((MLP, PirateNet)): the members' outputs are coupled in one residual; both gradients against the fp64
+    oracle (torch autograd over oracle MLP + oracle PirateNet)."""
+    import sympy as sp
+
+    from oracle import ref_torch as R
+    from oracle import taylor_np as T
+    from tests.common import set_model_weights
+
+    c, pir = _model("two_out_gelu")  # (x, y) -> (u, v)
+    net = T.make_net(2, [16, 16], 1, seed=9, bias_scale=0.05)
+    mlp = ppsci.arch.MLP(("x", "y"), ("p",), 2, 16, "tanh")
+    set_model_weights(mlp, net)
+    model = ppsci.arch.ModelList((mlp, pir))
+    assert model.output_keys == ("p", "u", "v")
+    x, y = sp.symbols("x y")
+    u, v, p = (sp.Function(k)(x, y) for k in ("u", "v", "p"))
+    eqs = {"mx": u * u.diff(x) + v * u.diff(y) - 0.1 * (u.diff(x, 2) + u.diff(y, 2)) + p.diff(x), "div": u.diff(x) + v.diff(y) + p}
+    N = 37
+    X = np.random.default_rng(4).uniform(-1, 1, (N, 2)).astype(np.float32)
+    inp = {"x": X[:, :1], "y": X[:, 1:]}
+    lab = {k: np.zeros((N, 1), np.float32) for k in eqs}
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": inp, "label": lab}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), eqs, name="EQ")
+    solver = ppsci.solver.Solver(model, {"EQ": cst}, str(tmp_path), ppsci.optimizer.Adam(1e-3)(model), epochs=1, iters_per_epoch=1)
+    solver.engine.forward_backward([solver._compiled["EQ"].fused])
+    g = solver.engine.grad.cpu().numpy()
+    state = {k.split("/", 2)[2]: GOLD[k] for k in GOLD.files if k.startswith("two_out_gelu/param/")}
+    om = R.ModelList((R.MLP(("x", "y"), ("p",), net.astype(np.float32).astype(np.float64)),
+                      R.PirateNet(c["inputs"], c["outputs"], state, c["act"], c["periods"])))
+    oc = dict(name="EQ", input={k: v.astype(np.float64) for k, v in inp.items()}, exprs={k: R.lambdify(e, om) for k, e in eqs.items()},
+              label={k: np.zeros((N, 1)) for k in eqs}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(om, [oc])
+    got = solver._compiled["EQ"].fused.losses()
+    for k in eqs:
+        assert got[k] == pytest.approx(losses[k], rel=1e-4)
+    n_mlp = mlp.flat_params.numel()
+    assert rel(g[mlp._param_offset:mlp._param_offset + n_mlp], gref[:n_mlp]) < 1e-4
+    n_p = pir.flat_params.numel()
+    assert rel(g[pir._param_offset:pir._param_offset + n_p], gref[n_mlp:]) < 3e-4
+    solver.train()
+
+
 def test_piratenet_trains(dev, tmp_path):
     c, model = _model("three_blocks_silu")
     rng = np.random.default_rng(0)
