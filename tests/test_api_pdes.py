@@ -768,3 +768,35 @@ def test_per_layer_widths(tmp_path, act):
         _, _, gg, _ = R.loss_and_grads(omodel, [oc])
         p = adam.step(p, gg)
     assert rel(model.flat_params.cpu().numpy(), p) < 2e-5
+
+
+@pytest.mark.parametrize("hidden,layers", [(20, 3), (50, 5), (100, 2)])
+def test_unsteady_two_dimensional_stream_set(tmp_path, hidden, layers):
+    """(t, x, y) inputs with first derivatives in all three and second derivatives in x and y only -- unsteady NavierStokes
+    (cylinder2d_unsteady_Re100) and heat / Allen-Cahn in 2-D: the (3, 2) stream set (6 streams instead of the padded (3, 3)'s 7)
+    on the single-wave kernels (width 20 / 50) and on the feature-split ones (width 100), against the fp64 oracle."""
+    from paddlescience_amd import graph
+
+    assert (3, 2, 0, 0) in graph._INSTANTIATED
+    net = T.make_net(3, [hidden] * layers, 3, seed=21, bias_scale=0.05)
+    model = ppsci.arch.MLP(("t", "x", "y"), ("u", "v", "p"), layers, hidden, "tanh")
+    set_model_weights(model, net)
+    eq = ppsci.equation.NavierStokes(0.02, 1.0, 2, True)
+    N = 45
+    X = np.random.default_rng(8).uniform([1, -1, -1], [2, 1, 1], (N, 3)).astype(np.float32)
+    inp = {"t": X[:, :1], "x": X[:, 1:2], "y": X[:, 2:]}
+    lab = {k: np.zeros((N, 1), np.float32) for k in eq.equations}
+    cst = _sup_constraint(inp, lab, eq.equations, ppsci.loss.MSELoss("mean"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    fused = solver._compiled["EQ"].fused
+    assert (len(fused.streams.dirs), fused.streams.n2) == (3, 2)
+    solver.engine.forward_backward([fused])
+    om = R.MLP(("t", "x", "y"), ("u", "v", "p"), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={k: v.astype(np.float64) for k, v in inp.items()},
+              exprs={k: R.lambdify(e, om) for k, e in R.navier_stokes_exprs(0.02, 1.0, 2, True).items()},
+              label={k: np.zeros((N, 1)) for k in eq.equations}, reduction="mean")
+    total, losses, gref, _ = R.loss_and_grads(om, [oc])
+    got = fused.losses()
+    for k in eq.equations:
+        assert got[k] == pytest.approx(losses[k], rel=5e-5), k
+    assert rel(solver.engine.grad.cpu().numpy(), gref) < 1e-4
