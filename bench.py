@@ -544,7 +544,7 @@ def extra_cylinder2d(tmp, steps, warmup):
     points of all constraints per iteration / batch_cost (train.py:106, printer.py:66) = `value` here."""
     from examples.cylinder2d_unsteady import DEFAULTS, build
 
-    cfg = dict(DEFAULTS, output_dir=os.path.join(tmp, "cyl"), epochs=1)
+    cfg = dict(DEFAULTS, output_dir=os.path.join(tmp, "cyl"), data_dir=os.path.join(tmp, "cyl_data"), epochs=1)
     solver = build(cfg)
     csts = [c.fused for c in solver._compiled.values()]
     n = sum(c.n for c in csts)

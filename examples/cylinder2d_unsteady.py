@@ -5,8 +5,9 @@ points and 81 outlet points x 30 time stamps, 9 420 initial-condition points, we
 case behind the reference's published TIPC throughput (`ips` 1 264 165.6 points/s, fp32, one unnamed NVIDIA GPU,
 test_tipc/README.MD:17): `ips` in the [Train] log lines below is the same quantity (train.py:106, printer.py:66).
 
-The reference reads the point sets and OpenFOAM labels from ./datasets/*.csv (download_dataset.py; no network here): when
-`data_dir` does not hold them, point sets of the same sizes are generated (uniform points of the channel [-8, 25] x [-8, 8] minus
+The reference reads the point sets and OpenFOAM labels from ./datasets/*.csv (download_dataset.py; no network here) through
+`reader.load_csv_file` / `IterableCSVDataset`, and so does this script: when `data_dir` does not hold the tables, CSV files of the same
+sizes and column names are written first (uniform points of the channel [-8, 25] x [-8, 8] minus
 the cylinder of radius 0.5, inlet / cylinder / outlet boundary points) with the inflow state as labels -- the arithmetic per
 iteration is the reference's, the flow it converges to is not validated.
 
@@ -42,15 +43,31 @@ def synthetic_points(cfg, rng):
     return dom, inlet_cyl, uv, outlet
 
 
-def stamped(xy, stamps, labels=None):
-    """IterableCSVDataset with `timestamps` (csv_dataset.py): every point at every time stamp, time-major."""
-    t = np.repeat(np.asarray(stamps, np.float32), len(xy)).reshape(-1, 1)
-    rep = lambda a: np.tile(a, (len(stamps), 1))  # noqa: E731
-    inp = {"t": t, "x": rep(xy[:, 0:1]), "y": rep(xy[:, 1:2])}
-    return inp, ({k: rep(v) for k, v in labels.items()} if labels else None)
+def ensure_data(cfg, rng):
+    """The four CSV tables of the reference's dataset (domain_train / domain_inlet_cylinder / domain_outlet / initial/ic0.1) in
+    its column naming (`Points:0`, `Points:1`, `U:0`, `U:1`, `p`); written with synthetic content when missing."""
+    d = cfg["data_dir"]
+    paths = {k: os.path.join(d, f) for k, f in (("dom", "domain_train.csv"), ("in", "domain_inlet_cylinder.csv"),
+                                                 ("out", "domain_outlet.csv"), ("ic", os.path.join("initial", "ic0.1.csv")))}
+    if all(os.path.exists(f) for f in paths.values()):
+        return paths
+    logger.warning(f"{d}: CSV tables not found, writing synthetic stand-ins of the reference's sizes")
+    os.makedirs(os.path.join(d, "initial"), exist_ok=True)
+    dom, inlet_cyl, uv, outlet = synthetic_points(cfg, rng)
+
+    def write(path, cols):
+        keys = list(cols)
+        np.savetxt(path, np.stack([cols[k] for k in keys], 1), delimiter=",", header=",".join(keys), comments="", fmt="%.8g")
+
+    write(paths["dom"], {"Points:0": dom[:, 0], "Points:1": dom[:, 1]})
+    write(paths["in"], {"Points:0": inlet_cyl[:, 0], "Points:1": inlet_cyl[:, 1], "U:0": uv[:, 0], "U:1": uv[:, 1]})
+    write(paths["out"], {"Points:0": outlet[:, 0], "Points:1": outlet[:, 1], "p": np.zeros(len(outlet))})
+    write(paths["ic"], {"Points:0": dom[:, 0], "Points:1": dom[:, 1], "U:0": np.ones(len(dom)), "U:1": np.zeros(len(dom)),
+                        "p": np.zeros(len(dom))})
+    return paths
 
 
-DEFAULTS = dict(seed=42, output_dir="./output_cylinder2d_unsteady", epochs=200, log_freq=20, viscosity=0.02, density=1.0,
+DEFAULTS = dict(seed=42, output_dir="./output_cylinder2d_unsteady", data_dir="./datasets/cylinder2d_unsteady", epochs=200, log_freq=20, viscosity=0.02, density=1.0,
                 time_start=1.0, time_end=50.0, num_timestamps=50, train_num_timestamps=30, npoint_pde=9420,
                 npoint_inlet_cylinder=161, npoint_outlet=81, num_layers=5, hidden_size=50, learning_rate=1e-3)
 
@@ -64,33 +81,33 @@ def build(cfg):
     stamps = np.linspace(cfg["time_start"], cfg["time_end"], cfg["num_timestamps"], endpoint=True).astype("float32")
     train_stamps = np.sort(np.random.choice(stamps, cfg["train_num_timestamps"]))
     t0 = np.array([cfg["time_start"]], dtype="float32")
-    dom, inlet_cyl, uv, outlet = synthetic_points(cfg, rng)
+    paths = ensure_data(cfg, rng)
+    alias = {"x": "Points:0", "y": "Points:1", "u": "U:0", "v": "U:1"}
     geom = {"time_rect": ppsci.geometry.TimeXGeometry(
         ppsci.geometry.TimeDomain(cfg["time_start"], cfg["time_end"], timestamps=np.concatenate((t0, train_stamps), axis=0)),
-        ppsci.geometry.PointCloud({"x": dom[:, 0:1], "y": dom[:, 1:2]}, ("x", "y")))}
+        ppsci.geometry.PointCloud(ppsci.utils.reader.load_csv_file(paths["dom"], ("x", "y"), alias), ("x", "y")))}
     ntime = len(train_stamps)
     pde = ppsci.constraint.InteriorConstraint(
         equation["NavierStokes"].equations, {"continuity": 0, "momentum_x": 0, "momentum_y": 0}, geom["time_rect"],
         {"dataset": "IterableNamedArrayDataset", "batch_size": cfg["npoint_pde"] * ntime, "iters_per_epoch": 1},
         ppsci.loss.MSELoss("mean"), name="EQ")
 
-    def sup(name, xy, stamps_, labels, weight):
-        inp, lab = stamped(xy, stamps_, labels)
-        w = {k: np.full_like(v, weight) for k, v in lab.items()}
-        return ppsci.constraint.SupervisedConstraint(
-            {"dataset": {"name": "IterableNamedArrayDataset", "input": inp, "label": lab, "weight": w}},
-            ppsci.loss.MSELoss("mean"), name=name)
+    def sup(name, path, labels, stamps_, weight):  # cylinder2d_unsteady_Re100.py:98-155
+        ds = {"name": "IterableCSVDataset", "file_path": path, "input_keys": ("x", "y"), "label_keys": labels,
+              "alias_dict": alias, "timestamps": stamps_}
+        if weight:
+            ds["weight_dict"] = {k: weight for k in labels}
+        return ppsci.constraint.SupervisedConstraint({"dataset": ds}, ppsci.loss.MSELoss("mean"), name=name)
 
-    bc_in = sup("BC_inlet_cylinder", inlet_cyl, train_stamps, {"u": uv[:, 0:1], "v": uv[:, 1:2]}, 10.0)
-    bc_out = sup("BC_outlet", outlet, train_stamps, {"p": np.zeros((len(outlet), 1), np.float32)}, 1.0)
-    ic = sup("IC", dom, t0, {"u": np.ones((len(dom), 1), np.float32), "v": np.zeros((len(dom), 1), np.float32),
-                             "p": np.zeros((len(dom), 1), np.float32)}, 10.0)
+    bc_in = sup("BC_inlet_cylinder", paths["in"], ("u", "v"), train_stamps, 10)
+    bc_out = sup("BC_outlet", paths["out"], ("p",), train_stamps, None)
+    ic = sup("IC", paths["ic"], ("u", "v", "p"), t0, 10)
     constraint = {c.name: c for c in (pde, bc_in, bc_out, ic)}
     optimizer = ppsci.optimizer.Adam(cfg["learning_rate"])(model)
     solver = ppsci.solver.Solver(model, constraint, cfg["output_dir"], optimizer, None, cfg["epochs"], 1, log_freq=cfg["log_freq"],
                                  equation=equation, geom=geom)
-    logger.info(f"points per iteration: EQ {cfg['npoint_pde'] * ntime} + BC {len(inlet_cyl) * ntime} + {len(outlet) * ntime} + IC {len(dom)}"
-                f" (reference TIPC ips for this case: 1 264 165.6)")
+    logger.info("points per iteration: " + " + ".join(f"{n} {getattr(c.data_loader, 'dataset', c.data_loader).num_samples}" for n, c in constraint.items())
+                + " (reference TIPC ips for this case: 1 264 165.6)")
     return solver
 
 

@@ -17,6 +17,8 @@ sys.modules["ppsci.optimizer.lr_scheduler"] = _impl.optimizer.lr_scheduler
 sys.modules["ppsci.utils.misc"] = _impl.utils.misc
 sys.modules["ppsci.utils.logger"] = _impl.utils.logger
 sys.modules["ppsci.utils.expression"] = _impl.utils.expression
+sys.modules["ppsci.utils.reader"] = _impl.utils.reader
+sys.modules["ppsci.utils.save_load"] = _impl.utils.save_load
 sys.modules["ppsci.utils.save_load"] = _impl.utils.save_load
 sys.modules["ppsci.utils.symbolic"] = _impl.utils.symbolic
 lambdify = _impl.lambdify
