@@ -379,7 +379,8 @@ int ppsci_comm_destroy(void);
 typedef struct ppsci_pirate_embed_desc {
   int32_t d_raw;                 /* raw inputs */
   int32_t d0;                    /* embedded features: d_raw + number of PPSCI_EMBED_PERIOD inputs */
-  int32_t half;                  /* FourierEmbedding.kernel is [d0, half]; x0 has 2*half features (cos | sin) */
+  int32_t half;                  /* FourierEmbedding.kernel is [d0, half]; x0 has 2*half features (cos | sin);
+                                  * 0: no Fourier embedding, x0 = the d0 embedded features (forward only) */
   int32_t n1, n2;
   int32_t embed[PPSCI_MAX_IN];   /* PPSCI_EMBED_NONE / PPSCI_EMBED_PERIOD */
   float omega[PPSCI_MAX_IN];     /* 2 pi / period */

@@ -11,6 +11,7 @@ What it follows in /root/reference (file:line):
   * ppsci/arch/mlp.py:95-114         PeriodEmbedding
   * ppsci/arch/mlp.py:281-315        MLP.forward_tensor / MLP.forward (incl. the skip quirk)
   * ppsci/arch/mlp.py:530-820        PirateNetBlock / PirateNet
+  * ppsci/arch/mlp.py:318-528        ModifiedMLP
   * ppsci/arch/activation.py:77-88   Silu = x * sigmoid(x)
   * ppsci/autodiff/ad.py:30-341      _Jacobian / Jacobians / _Hessian / Hessians / clear
   * ppsci/utils/symbolic.py:111-137  _cvt_to_key
@@ -208,6 +209,39 @@ class PirateNet:
             hh = self._act(self._linear(pre + "linear3", z2))
             al = self.t[pre + "alpha"]
             h = al * hh + (1 - al) * h
+        out = self._linear("last_fc", h)
+        return {k: o for k, o in zip(self.output_keys, torch.split(out, 1, dim=-1))}
+
+
+class ModifiedMLPN(PirateNet):
+    """Restatement of ppsci.arch.ModifiedMLP (mlp.py:318-528) on explicit named tensors, any number of inputs:
+    x0 = [period-embedded inputs] or its FourierEmbedding; U, V = act(embed_{u,v}(x0)); y <- act(linears.i(y)); y <- y*U + (1-y)*V;
+    last_fc (forward_tensor :495-511).  Pinned by tests/golden/modified_mlp.npz (tests/test_golden_modified_mlp.py)."""
+
+    def __init__(self, input_keys, output_keys, state, activation="tanh", periods=None, dtype=torch.float64):
+        self.input_keys, self.output_keys = tuple(input_keys), tuple(output_keys)
+        self.activation, self.dtype = activation, dtype
+        self.periods = {k: float(np.float32(2 * np.pi / float(p))) for k, (p, _) in (periods or {}).items()}
+        self.names = list(state)
+        self.t = {n: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for n, v in state.items()}
+        self.num_layers = 1 + max(int(n.split(".")[1]) for n in state if n.startswith("linears."))
+        self.skip_connection = False
+
+    def __call__(self, x):
+        if self.periods:
+            y = dict(x)
+            for k, w in self.periods.items():
+                y[k] = torch.cat([torch.cos(w * x[k]), torch.sin(w * x[k])], dim=-1)
+            x = y
+        h = torch.cat([x[k] for k in self.input_keys], dim=-1)
+        if "fourier_emb.kernel" in self.t:
+            kern = self.t["fourier_emb.kernel"]
+            h = torch.cat([torch.cos(h @ kern), torch.sin(h @ kern)], dim=-1)
+        u = self._act(self._linear("embed_u.0", h))
+        v = self._act(self._linear("embed_v.0", h))
+        for i in range(self.num_layers):
+            h = self._act(self._linear(f"linears.{i}", h))
+            h = h * u + (1 - h) * v
         out = self._linear("last_fc", h)
         return {k: o for k, o in zip(self.output_keys, torch.split(out, 1, dim=-1))}
 

@@ -275,8 +275,10 @@ class PirateExec:
         d.N, d.NP = self.n, self.NP
         self._in_ptrs = (C.c_void_p * d.d_raw)(*[t.data_ptr() for t in self.inputs])
         blk = lambda c=self.H: torch.zeros((self.S, c, self.NP), **f32)  # noqa: E731
-        self.X0, self.ZU, self.ZV, self.U, self.V = blk(), blk(), blk(), blk(), blk()
+        self.c0 = int(getattr(model, "c0", self.H))  # channels of x0 (PirateNet: = hidden; ModifiedMLP: d0 or fourier dim)
+        self.X0, self.ZU, self.ZV, self.U, self.V = blk(self.c0), blk(), blk(), blk(), blk()
         self.blocks = [dict(Z1=blk(), O1=blk(), Z2=blk(), O2=blk(), Z3=blk(), X=blk()) for _ in range(self.nb)]
+        self.layers = [dict(Z=blk(), O=blk()) for _ in range(int(getattr(model, "num_gated_layers", 0)))]  # ModifiedMLP
         self.Y = blk(self.m)
         self._train_ready = False
         # effective weights of the factorised layers (v * g): [fin, fout] row-major, what the GEMMs read
@@ -363,9 +365,11 @@ class PirateExec:
         self.echunks = int(lib.ppsci_pirate_embed_chunks(self.n))
         self.pb = torch.zeros((self.achunks, self.H), **f32)
         self.palpha = torch.zeros(self.H * self.achunks, **f32)
-        self.pw = torch.zeros((self.wchunks, self.H * self.H), **f32)
-        self.pB = torch.zeros((self.echunks, self.model.d0 * self.model.half), **f32)
-        self.gw_eff = torch.zeros(self.H * self.H, **f32) if self.model._rwf else None
+        wmax = max(self.H, self.c0) * self.H
+        self.pw = torch.zeros((self.wchunks, wmax), **f32)
+        self.pB = torch.zeros((self.echunks, max(1, self.model.d0 * self.model.half)), **f32)
+        self.gw_eff = torch.zeros(wmax, **f32) if self.model._rwf else None
+        self.XB0 = blk(self.c0) if self.c0 != self.H else None  # adjoint of x0 when its width differs from the hidden one
         self._train_ready = True
 
     def _wgrad(self, x, zbar, fin, fout, name, params, grad):

@@ -102,6 +102,26 @@ __global__ void __launch_bounds__(PR_BLOCK) pirate_embed_fwd_kernel(PrEmbArgs a)
   const long long p = (long long)(blockIdx.x % nch) * PR_BLOCK + threadIdx.x;
   if (p >= a.d.NP) return;
   const int half = a.d.half, n1 = a.d.n1, n2 = a.d.n2, C = 2 * half;
+  if (half == 0) {  // no Fourier embedding (ModifiedMLP without `fourier`): x0 = the d0 embedded features themselves
+    const long long NP0 = a.d.NP, plane0 = (long long)a.d.d0 * NP0;
+    float* o = a.X + (long long)m * NP0 + p;
+    if (p >= a.d.N) {
+      for (int s = 0; s < 1 + n1 + n2; ++s) o[s * plane0] = 0.f;
+      return;
+    }
+    float e0[2 * PPSCI_MAX_IN], e1[2 * PPSCI_MAX_IN][PPSCI_MAX_DIRS], e2[2 * PPSCI_MAX_IN][PPSCI_MAX_DIRS];
+    pr_features(a, p, e0, e1, e2);
+    float v0 = 0.f, v1[PPSCI_MAX_DIRS] = {0, 0, 0, 0}, v2[PPSCI_MAX_DIRS] = {0, 0, 0, 0};
+    for (int k = 0; k < a.d.d0; ++k)  // select feature m without dynamic register indexing
+      if (k == m) {
+        v0 = e0[k];
+        for (int q = 0; q < n1; ++q) { v1[q] = e1[k][q]; v2[q] = e2[k][q]; }
+      }
+    o[0] = v0;
+    for (int q = 0; q < n1; ++q) o[(1 + q) * plane0] = v1[q];
+    for (int q = 0; q < n2; ++q) o[(1 + n1 + q) * plane0] = v2[q];
+    return;
+  }
   const long long NP = a.d.NP, plane = (long long)C * NP;
   float* oc = a.X + (long long)m * NP + p;            // cos feature m
   float* os = a.X + (long long)(half + m) * NP + p;   // sin feature half + m
@@ -367,7 +387,7 @@ __global__ void __launch_bounds__(PR_BLOCK) pirate_out_bwd_kernel(PrOutArgs a) {
 
 // ------------------------------------------------------------------------------------------ C ABI
 static int emb_check(const ppsci_pirate_embed_desc* d) {
-  if (!d || d->d_raw < 1 || d->d_raw > PPSCI_MAX_IN || d->d0 < d->d_raw || d->d0 > 2 * PPSCI_MAX_IN || d->half < 1 ||
+  if (!d || d->d_raw < 1 || d->d_raw > PPSCI_MAX_IN || d->d0 < d->d_raw || d->d0 > 2 * PPSCI_MAX_IN || d->half < 0 ||
       d->n1 < 0 || d->n1 > PPSCI_MAX_DIRS || d->n2 < 0 || d->n2 > d->n1 || d->N < 1 || d->NP < d->N || (d->NP & 15)) {
     ppsci_set_error("pirate_embed: invalid descriptor");
     return PPSCI_E_INVALID;
@@ -381,13 +401,13 @@ extern "C" int64_t ppsci_pirate_act_chunks(int64_t NP) { return (NP + PR_BLOCK -
 extern "C" int ppsci_pirate_embed_fwd(const ppsci_pirate_embed_desc* d, const float* const* inputs_host, const float* B,
                                       float* X, void* stream) {
   if (emb_check(d) != PPSCI_OK) return PPSCI_E_INVALID;
-  if (!inputs_host || !B || !X) { ppsci_set_error("pirate_embed_fwd: null argument"); return PPSCI_E_INVALID; }
+  if (!inputs_host || (!B && d->half > 0) || !X) { ppsci_set_error("pirate_embed_fwd: null argument"); return PPSCI_E_INVALID; }
   PrEmbArgs a;
   memset(&a, 0, sizeof(a));
   a.d = *d;
   for (int j = 0; j < d->d_raw; ++j) a.x[j] = inputs_host[j];
   a.B = B; a.X = X;
-  const long long grid = (long long)d->half * ((d->NP + PR_BLOCK - 1) / PR_BLOCK);
+  const long long grid = (long long)(d->half > 0 ? d->half : d->d0) * ((d->NP + PR_BLOCK - 1) / PR_BLOCK);
   PPSCI_LAUNCH(pirate_embed_fwd_kernel, PrEmbArgs, (int)grid, PR_BLOCK, 0, stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) { ppsci_set_error("pirate_embed_fwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
@@ -397,7 +417,7 @@ extern "C" int ppsci_pirate_embed_fwd(const ppsci_pirate_embed_desc* d, const fl
 extern "C" int ppsci_pirate_embed_bwd(const ppsci_pirate_embed_desc* d, const float* const* inputs_host, const float* B,
                                       const float* Xbar, float* partials, void* stream) {
   if (emb_check(d) != PPSCI_OK) return PPSCI_E_INVALID;
-  if (!inputs_host || !B || !Xbar || !partials) { ppsci_set_error("pirate_embed_bwd: null argument"); return PPSCI_E_INVALID; }
+  if (!inputs_host || !B || !Xbar || !partials || d->half < 1) { ppsci_set_error("pirate_embed_bwd: null argument"); return PPSCI_E_INVALID; }
   PrEmbArgs a;
   memset(&a, 0, sizeof(a));
   a.d = *d;
