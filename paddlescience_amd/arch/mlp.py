@@ -70,6 +70,24 @@ class PeriodEmbedding:
 
 
 class MLP(Arch):
+    def __new__(cls, input_keys=None, output_keys=None, num_layers=None, hidden_size=None, *args, **kwargs):
+        """Configurations outside the fused kernels' envelope (width > 256, a Fourier embedding whose dim differs from
+        hidden_size, per-layer widths with factored layers) are served by the layer-by-layer class (arch/layerwise_mlp.py):
+        same constructor, same parameter names."""
+        if cls is MLP:
+            from .layerwise_mlp import LayerwiseMLP, wants_layerwise
+
+            names = ("activation", "skip_connection", "weight_norm", "input_dim", "output_dim", "periods", "fourier", "random_weight")
+            kw = dict(zip(names, args))
+            kw.update(kwargs)
+            try:
+                layerwise = wants_layerwise(num_layers, hidden_size, **kw)
+            except TypeError:
+                layerwise = False
+            if layerwise:
+                return LayerwiseMLP(input_keys, output_keys, num_layers, hidden_size, **kw)
+        return super().__new__(cls)
+
     def __init__(
         self,
         input_keys: Tuple[str, ...],
