@@ -49,8 +49,9 @@ struct PwArgs {
   int kq;              // ceil(Cin / 16)
   int nob;             // ceil(Cout / 16)
   int vec;             // 16-byte staging path (dimensions and pointers aligned)
-  int co0, CoutT;      // this launch computes output channels [co0, co0 + Cout) of CoutT (weights that do not fit LDS
+  int co0, CoutT;      // this workgroup computes output channels [co0, co0 + Cout) of CoutT (weights that do not fit LDS
                        // at once are processed in slabs of output channels)
+  int nslab, slab_rows;  // > 1 slabs in ONE launch: workgroup b works on slab b % nslab (co0 = slab * slab_rows)
 };
 
 #define PW_OC_MAX 4  // output-channel blocks (of 16) per work item: 4 with 4 waves per workgroup, or -- when the weight
@@ -61,6 +62,12 @@ struct PwArgs {
 template <int PW_OC, int PW_WAVES>
 __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
+  // several output-channel slabs in one launch: neighbouring workgroups take different slabs, so that the weight stage
+  // of one workgroup on a CU overlaps the MFMA phase of another (64 KB slabs: two or more workgroups per CU)
+  const int slab = (int)blockIdx.x % a.nslab, wg = (int)blockIdx.x / a.nslab, nwg = (int)gridDim.x / a.nslab;
+  a.co0 = slab * a.slab_rows;
+  a.Cout = a.CoutT - a.co0 < a.slab_rows ? a.CoutT - a.co0 : a.slab_rows;
+  a.nob = (a.Cout + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   // stage W as A-operand fragments: comp r of lane (g,c) for (ob, q): Weff[o = 16ob + c][k = 16q + 4r + g].
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   // the same chunk (its B operands then come from L1), and wide layers on few pixels still fill the chip
   const int ngrp = (a.nob + PW_OC - 1) / PW_OC;
   const long long nitem = nchunk * ngrp;
-  for (long long item = (long long)blockIdx.x * PW_WAVES + wave; item < nitem; item += (long long)gridDim.x * PW_WAVES) {
+  for (long long item = (long long)wg * PW_WAVES + wave; item < nitem; item += (long long)nwg * PW_WAVES) {
     const long long ch = item / ngrp;
     const int ob0 = (int)(item - ch * ngrp) * PW_OC;
     const int b = (int)(ch / chunks_per_b);
@@ -221,54 +228,60 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
   a.ldw = transpose ? Cout : Cin;  // W is [Co, Ci] = [rows, ldw]; transposed use: rows = Cin(of this call), ld = Cout
   a.kq = (Cin + 15) / 16;
   a.CoutT = Cout;
-  // output-channel slabs: the A fragments of one slab (16-row blocks x kq x 1 KiB) must fit LDS
+  // output-channel slabs: the A fragments of one slab (16-row blocks x kq x 1 KiB) must fit LDS.  Everything in one
+  // workgroup's LDS when it is small (<= 64 KiB: FNO layers); otherwise slabs of about 64 KiB -- all of them in ONE
+  // launch, two or more workgroups per CU with 8 waves each: the weight stage of one overlaps the MFMAs of the other.
   const int nob_all = (Cout + 15) / 16;
-  int nob_max = (int)(PPSCI_LDS_LIMIT_BYTES / ((long long)a.kq * 64 * 16));
-  if (nob_max < 1) {
+  const long long blk = (long long)a.kq * 64 * 16;  // bytes of one 16-row block
+  if (blk > PPSCI_LDS_LIMIT_BYTES) {
     ppsci_set_error("pw_conv: a 16 x %d weight block does not fit LDS", Cin);
     return PPSCI_E_UNSUPPORTED;
   }
-  if (nob_max > nob_all) nob_max = nob_all;
-  {  // balanced slabs, each a whole number of groups where possible (256 rows: 128 + 128, not 160 + 96)
-    const int nslab = (nob_all + nob_max - 1) / nob_max;
-    int per = (nob_all + nslab - 1) / nslab;
-    per = (per + PW_OC_MAX - 1) / PW_OC_MAX * PW_OC_MAX;
-    if (per < nob_max) nob_max = per;
+  int nob_slab = nob_all;
+  if ((long long)nob_all * blk > 64 * 1024) {
+    nob_slab = (int)(64 * 1024 / blk);
+    nob_slab = nob_slab / 4 * 4;  // whole 4-block groups
+    if (nob_slab < 4) nob_slab = (int)(PPSCI_LDS_LIMIT_BYTES / blk) >= 4 ? 4 : (int)(PPSCI_LDS_LIMIT_BYTES / blk);
+    const int nslab0 = (nob_all + nob_slab - 1) / nob_slab;
+    int per = (nob_all + nslab0 - 1) / nslab0;  // balanced
+    per = (per + 3) / 4 * 4;
+    if (per < nob_slab) nob_slab = per;
   }
+  const int nslab = (nob_all + nob_slab - 1) / nob_slab;
+  a.nslab = nslab;
+  a.slab_rows = 16 * nob_slab;
+  const long long lds = (long long)nob_slab * blk;
+  // the 16-byte staging path needs every slab's first column / row aligned
+  a.vec = ((reinterpret_cast<uintptr_t>(W) & 15) == 0 && (a.ldw & 3) == 0 &&
+           (transpose ? (Cout & 3) == 0 : (Cin & 3) == 0)) ? 1 : 0;
+  long long resident = PPSCI_LDS_LIMIT_BYTES / (lds > 0 ? lds : 1);
+  if (resident < 1) resident = 1;
+  if (resident > 4) resident = 4;
+  // one workgroup per CU (a slab above 80 KiB): 8 waves of 2-block items so that every SIMD still holds two waves; otherwise
+  // 4 waves of 4-block items (a 64-row slab = one item per chunk: the B operand is streamed once per slab)
+  const bool wide = resident == 1;
+  const int oc = wide ? 2 : 4, waves = wide ? 8 : 4;
   const long long nchunk = (long long)B * ((P + 63) / 64);
-  for (int ob0 = 0; ob0 < nob_all; ob0 += nob_max) {
-    a.co0 = 16 * ob0;
-    a.Cout = Cout - a.co0 < 16 * nob_max ? Cout - a.co0 : 16 * nob_max;
-    a.nob = (a.Cout + 15) / 16;
-    a.vec = ((reinterpret_cast<uintptr_t>(W) & 15) == 0 && (a.ldw & 3) == 0 &&
-             (transpose ? (a.Cout & 3) == 0 && (a.co0 & 3) == 0 : (Cin & 3) == 0)) ? 1 : 0;
-    const long long lds = (long long)a.nob * a.kq * 64 * 16;
-    // every workgroup stages the slab's weights once: no more workgroups than can be resident, each loops over items
-    long long resident = (PPSCI_LDS_LIMIT_BYTES / (lds > 0 ? lds : 1));
-    if (resident < 1) resident = 1;
-    if (resident > 4) resident = 4;
-    const bool wide = resident == 1;  // one workgroup per CU: 8 waves of 2-block items
-    const int oc = wide ? 2 : 4, waves = wide ? 8 : 4;
-    const long long nitem = nchunk * ((a.nob + oc - 1) / oc);
-    long long grid = (nitem + waves - 1) / waves;
-    if (grid > resident * PPSCI_NUM_CU) grid = resident * PPSCI_NUM_CU;
-    int se, le;
-    if (wide) {
-      se = PPSCI_SET_MAX_LDS((pw_conv_kernel<2, 8>), (int)lds);
-      if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<2, 8>), PwArgs, (int)grid, 64 * 8, (int)lds, stream, a);
-    } else {
-      se = PPSCI_SET_MAX_LDS((pw_conv_kernel<4, 4>), (int)lds);
-      if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<4, 4>), PwArgs, (int)grid, 64 * 4, (int)lds, stream, a);
-    }
-    if (se != 0) {
-      ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
-      return PPSCI_E_LAUNCH;
-    }
-    le = PPSCI_LAST_LAUNCH_ERROR();
-    if (le != 0) {
-      ppsci_set_error("pw_conv: launch failed");
-      return PPSCI_E_LAUNCH;
-    }
+  const long long nitem = nchunk * ((nob_slab + oc - 1) / oc);  // per slab
+  long long wg_slab = (nitem + waves - 1) / waves;
+  const long long cap = resident * PPSCI_NUM_CU / nslab > 0 ? resident * PPSCI_NUM_CU / nslab : 1;
+  if (wg_slab > cap) wg_slab = cap;
+  const long long grid = wg_slab * nslab;
+  int se;
+  if (wide) {
+    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<2, 8>), (int)lds);
+    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<2, 8>), PwArgs, (int)grid, 64 * 8, (int)lds, stream, a);
+  } else {
+    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<4, 4>), (int)lds);
+    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<4, 4>), PwArgs, (int)grid, 64 * 4, (int)lds, stream, a);
+  }
+  if (se != 0) {
+    ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("pw_conv: launch failed");
+    return PPSCI_E_LAUNCH;
   }
   return PPSCI_OK;
 }
