@@ -2,8 +2,8 @@
 clamped at x = 0 (u = u_x = 0), free at x = 1 (u_xx = u_xxx = 0); exact solution -x^4/24 + x^3/6 - x^2/4.
 
 The PDE constraint (Biharmonic(dim=1), 100 Hammersley points) runs on the fused kernels with fourth-order derivative streams;
-the boundary constraint of the reference picks ROWS of its four-point batch (`d["u"][0:1]`, `jacobian(...)[1:2]`, ...), which is
-not a per-point program: it takes the eager fallback (paddlescience_amd/eager.py), as the log says.
+the boundary constraint of the reference picks ROWS of its four-point batch (`d["u"][0:1]`, `jacobian(...)[1:2]`, ...): one-row
+slices as whole outputs are lowered too (a per-point weight mask, paddlescience_amd/compile.py), so both constraints are fused.
 
     python examples/euler_beam.py epochs=2000
 """

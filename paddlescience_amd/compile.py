@@ -61,6 +61,28 @@ class CompiledConstraint:
                  extra_parameters: Sequence = ()):
         self.name, self.model, self.loss = name, model, loss
         outputs = trace_exprs(model, input_keys, exprs, extra_parameters)
+        # Row slices `expr[a:a+1]` as whole outputs (examples/euler_beam/euler_beam.py:49-54).  The reference's loss then
+        # broadcasts the [1, 1] value against the [n, 1] label / weight columns (mse.py:82-105):
+        #     sum_p w_p (v_a - l_p)^2  =  W (v_a - lbar)^2 + const,   W = sum w_p,  lbar = sum w_p l_p / W,
+        # i.e. a per-point loss on row a alone with label lbar and weight W -- which IS a per-point program: at bind time the
+        # label column becomes lbar, the weight column a one-hot W at row a, and const is added to the reported term.
+        self._row_slices: Dict[str, int] = {}
+        for k, v in list(outputs.items()):
+            if isinstance(v, Sym) and v.kind == "rows":
+                a, b = v.comp
+                b = batch_size if b is None else b
+                if (a, b) == (0, batch_size):
+                    outputs[k] = v.args[0]
+                    continue
+                simple = (b - a == 1 and 0 <= a < batch_size and k in label_keys and loss is not None
+                          and getattr(loss, "term_kind", 0) == 0 and not getattr(loss, "causal", None)
+                          and not getattr(loss, "periodic", False) and n_global == batch_size)
+                if not simple:
+                    raise NotImplementedError(f"row slice [{a}:{b}] of output {k!r}: only one-row slices under MSELoss on a "
+                                              "single rank are lowered to the fused kernels")
+                self._row_slices[k] = a
+                outputs[k] = v.args[0]
+        weight_keys = list(weight_keys) + [k for k in self._row_slices if k not in weight_keys]
         for k in label_keys:
             if k not in outputs:
                 # a label on a raw network output (expression.py: output_dict holds the model outputs too)
@@ -76,6 +98,7 @@ class CompiledConstraint:
                                kind=getattr(loss, "term_kind", 0) if loss is not None else 0,
                                causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None,
                                periodic=bool(getattr(loss, "periodic", False))))
+        self._loss_rows = losses
         self.low = graph.lower(outputs, losses, extra_outputs)
         if getattr(loss, "periodic", False):
             if batch_size % 2:
@@ -129,6 +152,8 @@ class CompiledConstraint:
     def bind(self, input: Dict[str, object], label: Optional[Dict[str, object]], weight: Optional[Dict[str, object]]):
         """Upload one batch (named [n,1] arrays) into the constraint's device buffers."""
         names = list(self.low.input_names) + list(self.low.aux_names)
+        if self._row_slices:
+            label, weight = self._bind_row_slices(input, dict(label or {}), dict(weight or {}))
         srcs: List[object] = []
         for i, name in enumerate(names):
             if i < len(self.low.input_names):
@@ -137,6 +162,9 @@ class CompiledConstraint:
                 srcs.append(label[name[len(LABEL_PREFIX):]])
             elif name.startswith(WEIGHT_PREFIX):
                 w = weight[name[len(WEIGHT_PREFIX):]]
+                if name[len(WEIGHT_PREFIX):] in self._row_slices:
+                    srcs.append(w)  # already the effective column
+                    continue
                 srcs.append(self.loss.batch_weight(w) if hasattr(self.loss, "batch_weight") else w)
             elif name.startswith(CAUSAL_PREFIX):
                 srcs.append(None)  # written on the device every step (engine.FusedConstraint.forward)
@@ -163,6 +191,33 @@ class CompiledConstraint:
         ev = torch.cuda.Event()
         ev.record()
         self._stage_done[k] = ev
+
+    def _bind_row_slices(self, input, label, weight):
+        """Label / weight columns of the row-sliced outputs (see __init__) and the constant part of their loss terms."""
+        def host(a):
+            a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            return a.astype(np.float64).reshape(-1)
+
+        n = self.batch_size
+        area = host(input["area"]) if ("area" in input and "area" in self.low.input_names + self.low.aux_names) else np.ones(n)
+        offsets = {}
+        for k, a in self._row_slices.items():
+            lab = np.broadcast_to(host(label[k]), (n,)) if k in label else np.zeros(n)
+            w = weight.get(k)
+            w = np.ones(n) if w is None else np.broadcast_to(host(self.loss.batch_weight(w) if hasattr(self.loss, "batch_weight")
+                                                                  else w), (n,))
+            we = w * area
+            W = float(we.sum())
+            lbar = float((we * lab).sum() / W) if W != 0.0 else 0.0
+            const = float((we * lab * lab).sum() - W * lbar * lbar)
+            col = np.zeros(n, np.float32)
+            col[a] = W / area[a] if area[a] != 0.0 else 0.0
+            label[k] = np.full((n, 1), lbar, np.float32)
+            weight[k] = col.reshape(n, 1)
+            scale = next(float(r["scale"]) for r in self._loss_rows if r["key"] == k)
+            offsets[k] = scale * const
+        self.fused.loss_offsets = offsets
+        return label, weight
 
     def values(self) -> Dict[str, torch.Tensor]:
         """Per-point values of every loss key / extra output ([n,1] tensors), after a forward."""

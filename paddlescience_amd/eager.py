@@ -1,8 +1,9 @@
 """Eager fallback: the reference's own execution model -- model forward, `jacobian` / `hessian` and the operator tree run op
 by op on real device tensors with a dynamic autograd graph (/root/reference/ppsci/utils/expression.py:89-126,
 ppsci/autodiff/ad.py:56-77, ppsci/solver/train.py:158) -- for constraints whose expressions the tracer cannot lower to the
-fused kernels: row slices such as `d["u"][0:1]` (examples/euler_beam/euler_beam.py:49-54), data-dependent Python control
-flow, derivative sets beyond the instantiated stream sets, expressions that call tensor methods the proxy does not have.
+fused kernels: data-dependent Python control flow, row windows wider than one row (one-row slices such as `d["u"][0:1]` of
+examples/euler_beam/euler_beam.py:49-54 ARE lowered, compile.py), derivative sets beyond the instantiated stream sets,
+expressions that call tensor methods the proxy does not have.
 
 This path is torch library kernels + torch.autograd on the GPU -- correct, general and slow; the Solver takes it per
 constraint, only after the fused lowering of that constraint raised, and says so in the log.  The other constraints of the

@@ -177,7 +177,8 @@ class FusedConstraint:
 
     def losses(self) -> Dict[str, float]:
         vals = self.loss_terms.detach().cpu().tolist()  # one device->host sync, only when logging
-        return {k: vals[i] for i, k in enumerate(self.loss_keys)}
+        off = getattr(self, "loss_offsets", None) or {}  # constant parts of row-sliced terms (compile.CompiledConstraint)
+        return {k: vals[i] + off.get(k, 0.0) for i, k in enumerate(self.loss_keys)}
 
 
 class StepGraph:

@@ -118,6 +118,17 @@ class Sym:
         raise TypeError("a traced expression has no truth value: data-dependent Python control flow cannot be "
                         "lowered to the fused HIP path")
 
+    def __float__(self):
+        raise TypeError("a traced expression has no value at trace time: float(...) of it cannot be lowered to the fused HIP path")
+
+    def __getitem__(self, key):
+        """`expr[a:b]`: ROWS a..b of the batch (examples/euler_beam/euler_beam.py:49-54 picks the boundary point each condition
+        belongs to).  Legal only as the whole of an output expression; compile.CompiledConstraint turns a one-row slice into a
+        per-point weight mask (see there).  Anything else with it raises and the constraint takes the eager path."""
+        if isinstance(key, slice) and key.step in (None, 1) and all(isinstance(v, (int, type(None))) for v in (key.start, key.stop)):
+            return Sym("rows", comp=(key.start or 0, key.stop), args=(self,))
+        raise TypeError("a traced expression can only be indexed by a contiguous row slice x[a:b]")
+
     def sin(self): return apply("sin", self)
     def cos(self): return apply("cos", self)
     def tanh(self): return apply("tanh", self)
@@ -145,6 +156,8 @@ def is_const(s: Sym, v: Optional[float] = None) -> bool:
 def apply(op: str, *args: Sym) -> Sym:
     """Builds an op node.  Only exact algebraic identities with 0/1 are folded (they do not change the
     fp32 result), so the reference's operation order is preserved."""
+    if any(a.kind == "rows" for a in args):
+        raise TypeError("arithmetic on a row slice of the batch is not a per-point program")
     if op in _BINARY_OPS:
         a, b = args
         if op == "add":

@@ -692,7 +692,10 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
     Xb = np.asarray([[0.0], [0.0], [1.0], [1.0]], np.float32)
     eq = ppsci.equation.Biharmonic(1, -1.0, 1.0)
     pde = _sup_constraint({"x": Xi}, {"biharmonic": np.zeros((32, 1), np.float32)}, eq.equations, ppsci.loss.MSELoss("mean"), name="EQ")
-    bc_exprs = {"u0": lambda d: d["u"][0:1], "u__x": lambda d: jacobian(d["u"], d["x"])[1:2],
+    # (one-row slices alone are lowered since round 2 -- see the next test; the data-dependent branch in u0 is what no tracer
+    # can follow)
+    bc_exprs = {"u0": lambda d: d["u"][0:1] if float(d["x"][0]) == 0.0 else d["u"][3:4],
+                "u__x": lambda d: jacobian(d["u"], d["x"])[1:2],
                 "u__x__x": lambda d: hessian(d["u"], d["x"])[2:3],
                 "u__x__x__x": lambda d: jacobian(hessian(d["u"], d["x"]), d["x"])[3:4]}
     bc = _sup_constraint({"x": Xb}, {k: np.zeros((4, 1), np.float32) for k in bc_exprs}, bc_exprs, ppsci.loss.MSELoss("sum"),
@@ -800,3 +803,47 @@ def test_unsteady_two_dimensional_stream_set(tmp_path, hidden, layers):
     for k in eq.equations:
         assert got[k] == pytest.approx(losses[k], rel=5e-5), k
     assert rel(solver.engine.grad.cpu().numpy(), gref) < 1e-4
+
+
+@pytest.mark.parametrize("reduction", ["sum", "mean"])
+def test_one_row_slices_are_lowered_to_the_fused_kernels(tmp_path, reduction):
+    """`d["u"][0:1]`, `jacobian(...)[1:2]`, ... as whole output expressions (examples/euler_beam/euler_beam.py:49-54): the
+    reference's loss broadcasts the [1, 1] value against the [n, 1] label and weight columns; that equals a per-point loss on the
+    one row with the weighted mean label and the summed weight plus a constant, which is what the fused path runs.  Non-zero,
+    non-constant labels and weights; loss terms and gradient against the oracle's literal restatement."""
+    from ppsci.autodiff import hessian, jacobian
+
+    model = ppsci.arch.MLP(("x",), ("u",), 3, 20, "tanh")
+    net = T.make_net(1, [20, 20, 20], 1, bias_scale=0.1, seed=3)
+    set_model_weights(model, net)
+    rng = np.random.default_rng(9)
+    Xb = np.asarray([[0.0], [0.3], [0.7], [1.0]], np.float32)
+    bc_exprs = {"u0": lambda d: d["u"][0:1], "u__x": lambda d: jacobian(d["u"], d["x"])[1:2],
+                "u__x__x": lambda d: hessian(d["u"], d["x"])[2:3],
+                "u__x__x__x": lambda d: jacobian(hessian(d["u"], d["x"]), d["x"])[3:4], "all": lambda d: d["u"][0:4]}
+    lab = {k: rng.standard_normal((4, 1)).astype(np.float32) * 0.3 for k in bc_exprs}
+    wts = {"u0": rng.uniform(0.5, 2.0, (4, 1)).astype(np.float32), "u__x__x": rng.uniform(0.5, 2.0, (4, 1)).astype(np.float32)}
+    bc = _sup_constraint({"x": Xb}, lab, bc_exprs, ppsci.loss.MSELoss(reduction), weights=wts, name="BC")
+    solver = _solver(tmp_path, model, {"BC": bc})
+    cc = solver._compiled["BC"]
+    assert not getattr(cc, "is_eager", False) and cc._row_slices == {"u0": 0, "u__x": 1, "u__x__x": 2, "u__x__x__x": 3}
+    solver.engine.forward_backward([cc.fused])
+    g = solver.engine.grad.cpu().numpy().astype(np.float64)
+    omodel = R.MLP(("x",), ("u",), net.astype(np.float32).astype(np.float64))
+
+    def ograd(y, x):
+        return torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)[0]
+
+    def d1(d): return ograd(d["u"], d["x"])  # noqa: E704
+    def d2(d): return ograd(d1(d), d["x"])  # noqa: E704
+    def d3(d): return ograd(d2(d), d["x"])  # noqa: E704
+    oc = [dict(name="BC", input={"x": Xb.astype(np.float64)},
+               exprs={"u0": lambda d: d["u"][0:1], "u__x": lambda d: d1(d)[1:2], "u__x__x": lambda d: d2(d)[2:3],
+                      "u__x__x__x": lambda d: d3(d)[3:4], "all": lambda d: d["u"][0:4]},
+               label={k: v.astype(np.float64) for k, v in lab.items()}, weight={k: v.astype(np.float64) for k, v in wts.items()},
+               reduction=reduction)]
+    total, losses, gref, _ = R.loss_and_grads(omodel, oc)
+    mine = cc.fused.losses()
+    for k in losses:
+        assert mine[k] == pytest.approx(losses[k], rel=2e-4, abs=1e-8), k
+    assert rel(g, gref) < 2e-4
