@@ -36,11 +36,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HIDDEN, WIDTH, N_PER_GPU = 4, 64, 100_000
+# TEST MODE (tests/test_bench_launch.py only): the launch / rank plumbing of this file on the CPU SIMT emulator with the
+# gloo backend and tiny sizes; the JSON line says so in `data`.  Never set on a GPU box.
+EMU = os.environ.get("PPSCI_BENCH_EMU") == "1"
+if EMU:
+    N_PER_GPU = 128
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (f32 in) peak == fp32 vector peak
 PEAK_HBM_TBPS = 8.0       # MI355X_MICROARCH.md: HBM3E
 EPS = 0.01
 N_FIX = 2048              # points of the reference-run fixtures (tests/golden/bench_nets.npz)
-NS_TOTAL = 1_000_000      # BASELINE configs[2]
+NS_TOTAL = 64 if EMU else 1_000_000  # BASELINE configs[2]
 CPU_THREADS = 8  # measured on the GPU box (tools/cpu_threads.py): 8 threads is the fastest setting for this
                  # graph of small ops; 32+ threads are slower, 256 threads 100x slower
 
@@ -67,8 +72,13 @@ def gold():
     return np.load(os.path.join(ROOT, "tests", "golden", "bench_nets.npz"))
 
 
+def _sync():
+    if not EMU:
+        torch.cuda.synchronize()
+
+
 def time_wall(fn, steps, warmup, barrier=None):
-    sync = barrier or torch.cuda.synchronize
+    sync = barrier or _sync
     for _ in range(warmup):
         fn()
     sync()
@@ -81,6 +91,8 @@ def time_wall(fn, steps, warmup, barrier=None):
 
 def time_events(fn, reps=20):
     """Average duration of `fn`'s launches with HIP events on the launch stream (torch's current stream)."""
+    if EMU:
+        return time_wall(fn, 1, 0)
     fn()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
@@ -89,12 +101,6 @@ def time_events(fn, reps=20):
         ev[i + 1].record()
     torch.cuda.synchronize()
     return float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(reps)])) * 1e-3
-
-
-def main_kernel_only(on):
-    from paddlescience_amd import _lib
-
-    _lib.lib().ppsci_set_bwd_main_only(1 if on else 0)
 
 
 # ------------------------------------------------------------------------------------------ cfg 2 (primary)
@@ -248,9 +254,7 @@ def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
         opt.step(solver.engine.grad)
 
     t = time_wall(step, steps, warmup)
-    main_kernel_only(True)
-    t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))
-    main_kernel_only(False)
+    t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))  # incl. the two small reduction kernels
     t_fwd = time_events(lambda: cc.fused.forward(solver.engine.params, True))
     ach = 4.0 * p_mat * S * n / t_bwd / 1e12
     return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
@@ -315,7 +319,7 @@ def strong_ns(tmp, world, rank, steps, warmup, barrier):
         opt.step(eng.grad)
 
     t = time_wall(step, steps, warmup, barrier)
-    tt = torch.tensor([t], device="cuda", dtype=torch.float64)
+    tt = torch.tensor([t], device="cpu" if EMU else "cuda", dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     t = float(tt[0])
@@ -324,6 +328,7 @@ def strong_ns(tmp, world, rank, steps, warmup, barrier):
             "value": NS_TOTAL / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps, "n_gpus": world,
             "scaling": "strong", "points_total": NS_TOTAL, "points_per_rank": n_local,
             "allreduce_bytes": int(eng.grad.numel()) * 4, "comm_world_size": eng.world,
+            "comm_backend": torch.distributed.get_backend() if world > 1 else None,
             "matrix_tflops_per_gpu": 6.0 * NS_PMAT * 5 * n_local / t / 1e12}
 
 
@@ -596,7 +601,11 @@ def extra_euler_beam(tmp, epochs=2000):
 def main():
     # stdout carries exactly ONE line, the JSON record: everything else this process prints (the ppsci logger of the API-level
     # entries writes to sys.stdout, as the reference's does) goes to stderr
-    json_out, sys.stdout = sys.stdout, sys.stderr
+    # (also at the file-descriptor level: RCCL / gloo / the HIP runtime print from C)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -606,26 +615,51 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the 1 M-point NavierStokes strong-scaling entry")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) through
+        # torch.distributed.run on the loopback interface; rank 0's stdout (the one JSON line) is passed through
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        json_out.flush()
+        sys.exit(subprocess.call(cmd, stdout=json_out.fileno()))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
-        assert torch.distributed.get_world_size() == world == args.gpus, "one RCCL rank per GPU"
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks (one rank per GPU)"
+    if EMU:
+        dev = torch.device("cpu")
+        if world > 1:
+            torch.distributed.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            torch.distributed.init_process_group("nccl", device_id=dev)
+    comm_world = torch.distributed.get_world_size() if world > 1 else 1
+    assert comm_world == world == args.gpus, "one RCCL rank per GPU"
 
+    if EMU:
+        from tests.emu import build_emu
+
+        build_emu.inject()
     from paddlescience_amd import hotpath as hp
     from paddlescience_amd.engine import Engine
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     flat = bench_weights(2, [WIDTH] * HIDDEN, 1)
     X = np.random.default_rng(42 + rank).uniform([0, -1], [1, 1], (N_PER_GPU, 2)).astype(np.float32)
-    parity = parity_allen_cahn(dev, flat, X) if rank == 0 else None
+    parity = parity_allen_cahn(dev, flat, X) if rank == 0 and not EMU else None
     # MSE-mean over the GLOBAL batch: the all-reduce is then a pure SUM
     lay, cst = allen_cahn_constraint(dev, X, N_PER_GPU * world)
     params = torch.tensor(flat, device=dev)
@@ -648,9 +682,9 @@ def main():
 
     # per-kernel timing of the dominant kernel (reverse sweep) with HIP events on the launch stream
     t_fwd = time_events(lambda: hp.taylor_fwd(cst.desc, params, cst.inputs, cst.U, cst.stash))
-    main_kernel_only(True)  # the dominant kernel alone (not the small reduction kernels behind it)
+    # ppsci_taylor_bwd = the reverse kernel + the two small fixed-order reduction kernels behind it (~10 us): the
+    # roofline fraction below charges them to the dominant kernel (rocprofv3's per-kernel average is in profiles/)
     t_bwd = time_events(lambda: cst.backward(params))
-    main_kernel_only(False)
     # SURVEY.md 8(d) "R": residual evaluation only (forward streams + epilogue, no stash, no adjoints)
     t_res = time_events(lambda: cst.forward(params, False))
     p_mat = 2 * WIDTH + (HIDDEN - 1) * WIDTH * WIDTH + WIDTH  # matrix weights (P = 12 480)
@@ -681,7 +715,8 @@ def main():
     tmp = tempfile.mkdtemp(prefix="ppsci_bench_")
     if not args.no_strong:
         try:
-            strong = strong_ns(tmp, world, rank, max(5, args.steps // 5), max(2, args.warmup // 3), barrier)
+            strong = strong_ns(tmp, world, rank, 1 if EMU else max(5, args.steps // 5), 0 if EMU else max(2, args.warmup // 3),
+                               barrier)
         except Exception as e:  # noqa: BLE001
             if world > 1:  # the other ranks are inside collectives: fail the job rather than hang it
                 raise
@@ -700,7 +735,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not EMU else "synthetic -- EMULATOR TEST MODE (CPU, gloo, tiny sizes): not a measurement",
             "config": {"workload": "Allen-Cahn 1D+t, MLP 2->64x4->1 tanh, 100k collocation pts per GPU, "
                                    "residual+MSE-mean+grad+Adam (BASELINE.json configs[1])",
                        "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss,
@@ -713,10 +748,10 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not EMU:
             out["cpu_baseline"] = cpu_baseline("allen_cahn", flat, X)
             out["speedup_vs_cpu_best_thread"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not EMU:
             k, w = max(10, args.steps // 2), max(3, args.warmup // 2)
             sec = []
             for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),

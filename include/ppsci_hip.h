@@ -148,10 +148,6 @@ const char* ppsci_last_error(void);
 /* Tuning/testing knob: cap the number of workgroups of the tile kernels (0 = automatic, the default).
  * Results do not depend on it beyond fp32 summation order. */
 void ppsci_set_max_grid(int max_blocks);
-/* Measurement knob (bench.py): when non-zero, ppsci_taylor_bwd launches ONLY its main kernel and skips the
- * two small tree-reduction kernels, so that HIP events around the call time that one kernel.  The
- * hidden-layer weight-gradient row is then left unwritten.  Default 0. */
-void ppsci_set_bwd_main_only(int on);
 /* Testing knob: nets whose padded width / 16 is at least this use the feature-split ("wide") kernels, in which
  * the waves of a workgroup share one 16-point tile.  Default 8 (width > 64); 16 keeps width <= 128 on the
  * single-wave kernels; width > 128 always uses the wide kernels. */

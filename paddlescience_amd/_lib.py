@@ -84,7 +84,6 @@ _SYMBOLS = {
     "ppsci_last_error": (C.c_char_p, []),
     "ppsci_is_device_build": (C.c_int, []),
     "ppsci_set_max_grid": (None, [C.c_int]),
-    "ppsci_set_bwd_main_only": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),
     "ppsci_set_bwd_accum": (None, [C.c_int]),
     "ppsci_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),

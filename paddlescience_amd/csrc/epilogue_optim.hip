@@ -379,9 +379,6 @@ extern "C" const char* ppsci_last_error(void) { return g_err; }
 static int g_max_grid = 0;
 extern "C" void ppsci_set_max_grid(int max_blocks) { g_max_grid = max_blocks > 0 ? max_blocks : 0; }
 extern "C" int ppsci_get_max_grid(void) { return g_max_grid; }
-static int g_bwd_main_only = 0;
-extern "C" void ppsci_set_bwd_main_only(int on) { g_bwd_main_only = on ? 1 : 0; }
-extern "C" int ppsci_get_bwd_main_only(void) { return g_bwd_main_only; }
 static int g_wide_min_nb = 8;
 extern "C" void ppsci_set_wide_min_nb(int nb) { g_wide_min_nb = nb; }
 extern "C" int ppsci_get_wide_min_nb(void) { return g_wide_min_nb; }

@@ -48,7 +48,6 @@ __device__ __forceinline__ void ppsci_block_sync_lds() {
 #endif
 
 extern "C" int ppsci_get_max_grid(void);
-extern "C" int ppsci_get_bwd_main_only(void);
 extern "C" int ppsci_get_wide_min_nb(void);
 extern "C" int ppsci_get_bwd_accum(void);
 

@@ -143,7 +143,7 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   a.partials = small_rows;
   a.wpart = (f32x4*)workspace;
   int rc = run_bwd_act(a, stream, 1, &grid);
-  if (rc != PPSCI_OK || ppsci_get_bwd_main_only()) return rc;
+  if (rc != PPSCI_OK) return rc;
   // fixed-order two-stage sum over the tiles' (or the workgroups') hidden-weight blocks and over the workgroups' compact
   // rows of W0 / biases / W_last, written in the canonical parameter layout
   return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_rows, grid, small_tmp, grad_partials,

@@ -46,11 +46,7 @@ __device__ __forceinline__ void ppsci_fourier_eval(float z, bool is_cos, float& 
 template <int ACT>
 __device__ __forceinline__ void ppsci_act_eval(float z, float& s, float& d1, float& d2, float& d3) {
   if (ACT == PPSCI_ACT_TANH) {
-#ifdef PPSCI_OCML_TANH
-    s = tanhf(z);
-#else
     s = ppsci_tanh(z);
-#endif
     d1 = 1.f - s * s;
     d2 = -2.f * s * d1;
     d3 = d1 * (6.f * s * s - 2.f);
@@ -237,9 +233,6 @@ __device__ __forceinline__ float ppsci_zscale(const ppsci_mlp_desc& d, int layer
 // Sum over the 16 lanes of a DPP row (= over the 16 points of the tile, lanes sharing g).
 // The total is valid in the LAST lane of the row (c == 15); VALU-rate (4 DPP adds), no LDS.
 __device__ __forceinline__ float ppsci_row_sum16_last(float v) {
-#ifdef PPSCI_ABL_NOROWSUM
-  return v;
-#endif
 #define PPSCI_DPP_ADD(ctrl)                                                                            \
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
   PPSCI_DPP_ADD(0x111);  // row_shr:1
@@ -260,11 +253,6 @@ __device__ __forceinline__ float ppsci_group_sum4(float v) {
 // T layout -> N layout of NS 16x16 blocks at once through the wave-private scratch (NS slots).
 template <int NS>
 __device__ __forceinline__ void ppsci_t2n(const f32x4 (&v)[NS], f32x4 (&o)[NS], float* scr, int g, int c) {
-#ifdef PPSCI_ABL_NOT2N
-#pragma unroll
-  for (int s = 0; s < NS; ++s) o[s] = v[s];
-  return;
-#endif
 #pragma unroll
   for (int s = 0; s < NS; ++s) *(f32x4*)&scr[s * PPSCI_SCR_FLOATS + c * PPSCI_SCR_LD + 4 * g] = v[s];  // scr[point][feature]
   ppsci_wave_sync();

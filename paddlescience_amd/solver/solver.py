@@ -238,8 +238,15 @@ class Solver:
             # op-by-op tensors + autograd (eager.py); the others stay fused
             from ..eager import EagerConstraint
 
+            # OPT-IN (PPSCI_EAGER_FALLBACK=1): by default a constraint that cannot run on this framework's kernels
+            # raises with the reason instead of silently training on torch library kernels
+            if os.environ.get("PPSCI_EAGER_FALLBACK", "0") != "1":
+                raise NotImplementedError(
+                    f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e}).  Set "
+                    "PPSCI_EAGER_FALLBACK=1 to run this constraint op by op through torch autograd (slow, library "
+                    "kernels)") from e
             if self._extra_parameters() or getattr(self.loss_aggregator, "per_loss_grad", False) or \
-                    getattr(self.optimizer, "is_lbfgs", False) or os.environ.get("PPSCI_EAGER_FALLBACK", "1") == "0":
+                    getattr(self.optimizer, "is_lbfgs", False):
                 raise
             cc = EagerConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
                                  bsz * self.world_size, self.device, reason=f"{type(e).__name__}: {e}")

@@ -677,7 +677,7 @@ def test_periodic_constraint_batches_and_training_step(tmp_path):
     assert rel(model.flat_params.cpu().numpy()[:p.size], p) < 1e-5
 
 
-def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
+def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path, monkeypatch):
     """examples/euler_beam/euler_beam.py: the PDE u_xxxx + 1 = 0 runs on the fused kernels (fourth-order streams); its
     boundary terms pick ROWS of the batch (`d["u"][0:1]`, `jacobian(...)[1:2]`, ...), which no per-point program can
     express: that constraint falls back to the eager path (op-by-op tensors + autograd, the reference's execution model).
@@ -700,6 +700,11 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
                 "u__x__x__x": lambda d: jacobian(hessian(d["u"], d["x"]), d["x"])[3:4]}
     bc = _sup_constraint({"x": Xb}, {k: np.zeros((4, 1), np.float32) for k in bc_exprs}, bc_exprs, ppsci.loss.MSELoss("sum"),
                          name="BC")
+    # the reroute is OPT-IN: by default the constraint is refused with the reason
+    monkeypatch.delenv("PPSCI_EAGER_FALLBACK", raising=False)
+    with pytest.raises(NotImplementedError, match="PPSCI_EAGER_FALLBACK=1"):
+        _solver(tmp_path, model, {"EQ": pde, "BC": bc})
+    monkeypatch.setenv("PPSCI_EAGER_FALLBACK", "1")
     solver = _solver(tmp_path, model, {"EQ": pde, "BC": bc})
     assert getattr(solver._compiled["BC"], "is_eager", False) and not getattr(solver._compiled["EQ"], "is_eager", False)
     p0 = model.flat_params.clone()

@@ -1,0 +1,40 @@
+"""bench.py's launch contract on the CPU SIMT emulator (gloo, tiny sizes; PPSCI_BENCH_EMU=1 is a test-only mode):
+`python bench.py --gpus 2` WITHOUT a launcher must start two ranks itself and print one JSON line that says so."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, args):
+    env = dict(os.environ, PPSCI_BENCH_EMU="1", OMP_NUM_THREADS="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    from tests.emu import build_emu
+
+    build_emu.build()  # once, before two ranks race for the build directory
+    r = _run({}, ["--gpus", "2", "--steps", "1", "--warmup", "1"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "dp2" and r["steps"] == 1
+    assert "EMULATOR TEST MODE" in r["data"]
+    s = r["strong_scaling"]
+    assert s["n_gpus"] == 2 and s["comm_world_size"] == 2 and s["comm_backend"] == "gloo"
+    assert s["points_per_rank"] * 2 == s["points_total"] and s["scaling"] == "strong"
+    assert r["value"] > 0 and s["value"] > 0
+
+
+def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
+    env = dict(os.environ, PPSCI_BENCH_EMU="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
