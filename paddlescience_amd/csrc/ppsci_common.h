@@ -21,7 +21,27 @@
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PPSCI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+// two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32; low half = a
+__device__ __forceinline__ unsigned ppsci_cvt_pk_bf16(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
+}
+// v_mfma_f32_16x16x32_bf16: lane (g = l>>4, c = l&15) supplies A[i = c][k = 8g + j] and B[k = 8g + j][n = c], j = 0..7
+// (here as two 4-bf16 halves: j = 0..3 from *_lo, 4..7 from *_hi); C/D as the fp32 16x16 MFMAs (row 4g + r, col c)
+__device__ __forceinline__ f32x4 ppsci_xdl32(u32x2 a_lo, u32x2 a_hi, u32x2 b_lo, u32x2 b_hi, f32x4 c) {
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  const u32x4 a = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]}, b = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x16_bf16: A[i = c][k = 4g + j], B[k = 4g + j][n = c], j = 0..3
+__device__ __forceinline__ f32x4 ppsci_xdl16(u32x2 a, u32x2 b, f32x4 c) {
+  typedef short s16x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_, a), __builtin_bit_cast(s16x4_, b), c, 0, 0, 0);
+}
 #define PPSCI_LAUNCH(KERNEL, ARGT, grid, block, lds, stream, args)                                   \
   hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), (lds), (hipStream_t)(stream), (args))
 #define PPSCI_SET_MAX_LDS(KERNEL, bytes)                                                             \

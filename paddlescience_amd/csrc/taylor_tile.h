@@ -263,6 +263,94 @@ __device__ __forceinline__ void ppsci_t2n(const f32x4 (&v)[NS], f32x4 (&o)[NS], 
   ppsci_wave_sync();
 }
 
+// ---- fp32 GEMMs on the bf16 (XDL) matrix pipe -----------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (157 TFLOP/s) and, on gfx950, shares its issue slots with the
+// pointwise VALU work; the bf16 MFMAs run 16x faster and overlap with VALU.  Every fp32 operand is
+// therefore split into three bf16 terms  x = h + m + l  (8 + 8 + 8 significand bits, round-to-nearest at each level,
+// so the sum is exact up to the last fp32 bit) and a product is evaluated as the six cross terms that matter,
+//      a b ~= a_h b_l + a_l b_h + a_m b_m + a_h b_m + a_m b_h + a_h b_h           (dropped: 2^-24 relative and below)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Measured on MI355X
+// (tools/microbench/xdl_split.hip): rms error 1.8e-8 of sum|a||b| at K = 64 against 2.8e-8 for the fp32 MFMA's fmaf
+// chain -- at least as accurate as the instruction it replaces -- at 6/16 of its matrix-pipe time.
+// Layouts: the K = 32 operand of lane (g, c) is 8 bf16 = the 4 + 4 values that two T-layout (or N-layout) float4
+// registers of that lane hold, so a "half operand" (4 bf16, one u32x2) is the split of ONE float4 register and any
+// two blocks / streams can be paired; the A halves come from LDS with one ds_read_b64 each.
+#ifndef PPSCI_XDL
+#define PPSCI_XDL 1  // 0: the fp32-input MFMA everywhere (build option for A/B measurements)
+#endif
+struct ppsci_split4 {
+  u32x2 p[3];  // planes h, m, l: 4 packed bf16 each
+};
+__device__ __forceinline__ float ppsci_bf16lo_f32(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float ppsci_bf16hi_f32(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ ppsci_split4 ppsci_split(f32x4 x) {
+  ppsci_split4 o;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = x[2 * i], b = x[2 * i + 1];
+    const unsigned h = ppsci_cvt_pk_bf16(a, b);
+    a -= ppsci_bf16lo_f32(h);
+    b -= ppsci_bf16hi_f32(h);
+    const unsigned m = ppsci_cvt_pk_bf16(a, b);
+    a -= ppsci_bf16lo_f32(m);
+    b -= ppsci_bf16hi_f32(m);
+    o.p[0][i] = h;
+    o.p[1][i] = m;
+    o.p[2][i] = ppsci_cvt_pk_bf16(a, b);
+  }
+  return o;
+}
+// the six products, small terms first: (plane of A, plane of B)
+#define PPSCI_XDL_NPROD 6
+__device__ static constexpr int ppsci_xdl_pa[6] = {0, 2, 1, 0, 1, 0};
+__device__ static constexpr int ppsci_xdl_pb[6] = {2, 0, 1, 1, 0, 0};
+// acc += A B over one K = 32 step (two paired halves per operand), all six products, one accumulator
+__device__ __forceinline__ f32x4 ppsci_xdl6(const ppsci_split4& a0, const ppsci_split4& a1, const ppsci_split4& b0,
+                                            const ppsci_split4& b1, f32x4 acc) {
+#pragma unroll
+  for (int q = 0; q < PPSCI_XDL_NPROD; ++q)
+    acc = ppsci_xdl32(a0.p[ppsci_xdl_pa[q]], a1.p[ppsci_xdl_pa[q]], b0.p[ppsci_xdl_pb[q]], b1.p[ppsci_xdl_pb[q]], acc);
+  return acc;
+}
+// K = 16 step (one half per operand): the odd stream of a stream-paired contraction
+__device__ __forceinline__ f32x4 ppsci_xdl6_k16(const ppsci_split4& a0, const ppsci_split4& b0, f32x4 acc) {
+#pragma unroll
+  for (int q = 0; q < PPSCI_XDL_NPROD; ++q) acc = ppsci_xdl16(a0.p[ppsci_xdl_pa[q]], b0.p[ppsci_xdl_pb[q]], acc);
+  return acc;
+}
+
+// XDL weight fragments in LDS: per (row block rb, k block kb) three planes of 64 lanes x 4 bf16 (u32x2):
+//   frag[((rb*NB + kb)*3 + plane)*64 + lane]
+// forward  (z = W^T h):    rb = output block, lane (g, c) holds W[in = 16kb + 4g + r][out = 16rb + c], r = 0..3
+// backward (hbar = W zbar): rb = input block,  lane (g, c) holds W[in = 16rb + c][out = 16kb + 4g + r]
+#define PPSCI_XFRAG_FLOATS(HP) ((HP) * (HP) * 3 / 2)  // size of one layer's fragments in floats (6 bytes per weight)
+template <bool BWD>
+__device__ __forceinline__ void ppsci_stage_frag_xdl(float* dst_, const float* W, int H, int NB, int tid, int nthr) {
+  u32x2* dst = (u32x2*)dst_;
+  for (int idx = tid; idx < NB * NB * 64; idx += nthr) {
+    const int lane = idx & 63, pair = idx >> 6, rb = pair / NB, kb = pair - rb * NB;
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int in = BWD ? 16 * rb + c : 16 * kb + 4 * g + r, out = BWD ? 16 * kb + 4 * g + r : 16 * rb + c;
+      v[r] = (in < H && out < H) ? W[in * H + out] : 0.f;
+    }
+    const ppsci_split4 sp = ppsci_split(v);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[(pair * 3 + q) * 64 + lane] = sp.p[q];
+  }
+}
+// the three planes of fragment (rb, kb) for this lane
+__device__ __forceinline__ ppsci_split4 ppsci_load_frag_xdl(const float* frag, int NB, int rb, int kb, int lane) {
+  const u32x2* f = (const u32x2*)frag + ((rb * NB + kb) * 3) * 64 + lane;
+  ppsci_split4 o;
+  o.p[0] = f[0];
+  o.p[1] = f[64];
+  o.p[2] = f[128];
+  return o;
+}
+
 // ---- LDS staging of weights --------------------------------------------------------------
 // Forward A-fragments of hidden layer l (W is [H,H] row-major [in,out] in HBM):
 //   fragF[((ob*NB + kb)*64 + lane)*4 + r] = W[in = 16kb + 4g + r][out = 16ob + c]
@@ -286,6 +374,17 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
     int ib = in >> 4, c = in & 15, kb = out >> 4, g = (out & 15) >> 2, r = out & 3;
     dst[((ib * NB + kb) * 64 + 16 * g + c) * 4 + r] = v;
   }
+}
+
+// one layer's hidden-weight fragments in LDS (floats) and their staging, for the MFMA flavour this build uses
+#define PPSCI_FRAG_FLOATS(HP) (PPSCI_XDL ? PPSCI_XFRAG_FLOATS(HP) : (HP) * (HP))
+__device__ __forceinline__ void ppsci_stage_fwd_frag(float* dst, const float* W, int H, int NB, int tid, int nthr) {
+  if (PPSCI_XDL) ppsci_stage_frag_xdl<false>(dst, W, H, NB, tid, nthr);
+  else ppsci_stage_fragF(dst, W, H, NB, tid, nthr);
+}
+__device__ __forceinline__ void ppsci_stage_bwd_frag(float* dst, const float* W, int H, int NB, int tid, int nthr) {
+  if (PPSCI_XDL) ppsci_stage_frag_xdl<true>(dst, W, H, NB, tid, nthr);
+  else ppsci_stage_fragB(dst, W, H, NB, tid, nthr);
 }
 
 // Tile owned by (iteration, block, wave): consecutive tiles go to different workgroups first, so a

@@ -20,6 +20,8 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define __global__
 #define __device__
@@ -46,6 +48,7 @@ struct Wave {
   Barrier bar;
   float xa[2][kWave];
   float xb[2][kWave];
+  unsigned xw[2][kWave][8];  // wide operands (bf16 MFMAs): 4 dwords of A, 4 of B per lane
   unsigned op = 0;  // collective counter (same in every lane of the wave)
 };
 
@@ -235,6 +238,52 @@ inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int
     d[r] = acc;
   }
   return d;
+}
+
+// ---- bf16 (XDL) MFMAs: operands are packed bf16 pairs; products are exact in fp32, accumulated in k order ----------
+inline unsigned ppsci_cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: round to nearest even, low half = a
+  auto rne = [](float x) -> unsigned {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  return (rne(a) & 0xffffu) | (rne(b) << 16);
+}
+inline float emu_bf16_at(const unsigned* w, int j) {  // j-th bf16 of a packed array
+  const unsigned v = (j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16);
+  float f;
+  std::memcpy(&f, &v, 4);
+  return f;
+}
+inline f32x4 emu_xdl(const unsigned* a, const unsigned* b, int ndw, f32x4 c) {  // ndw dwords per operand and lane
+  emu::Wave& w = emu::my_wave();
+  emu::Fiber& f = emu::st().fibers[emu::st().cur];
+  const unsigned buf = f.wave_op & 1u;
+  f.wave_op++;
+  const unsigned l = emu::my_lane();
+  for (int i = 0; i < ndw; ++i) w.xw[buf][l][i] = a[i], w.xw[buf][l][4 + i] = b[i];
+  emu::barrier_wait(w.bar);
+  const unsigned g = l >> 4, col = l & 15;
+  const int per = 2 * ndw;  // bf16 per lane: k = per * group + j
+  f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const unsigned row = 4 * g + r;
+    float acc = c[r];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int j = 0; j < per; ++j)
+        acc = std::fmaf(emu_bf16_at(w.xw[buf][16 * kg + row], j), emu_bf16_at(&w.xw[buf][16 * kg + col][4], j), acc);
+    d[r] = acc;
+  }
+  return d;
+}
+inline f32x4 ppsci_xdl32(u32x2 a_lo, u32x2 a_hi, u32x2 b_lo, u32x2 b_hi, f32x4 c) {
+  const unsigned a[4] = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]}, b[4] = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+  return emu_xdl(a, b, 4, c);
+}
+inline f32x4 ppsci_xdl16(u32x2 a, u32x2 b, f32x4 c) {
+  const unsigned aa[2] = {a[0], a[1]}, bb[2] = {b[0], b[1]};
+  return emu_xdl(aa, bb, 2, c);
 }
 
 // DPP row_shr:n (ctrl 0x110+n) with bound_ctrl: lane i of each 16-lane row reads lane i-n, 0 if outside.
