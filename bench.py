@@ -297,7 +297,7 @@ def secondary_ns(tmp, steps, warmup):
     solver, opt, cc, _ = ns_setup(tmp, X, "ns")
     e = pinn_entry("cfg3 shard: LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 125 000 points (rank 0 of 8 of the "
                    "1 M-point cloud), continuity + momentum_x + momentum_y, weights 1e-4, MSE-sum, Adam",
-                   solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wide_kernel<8, 4, 2, 2, 0>")
+                   solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wx_kernel<8, 1, 5, 2, 2, 0>")
     e["parity"] = api_parity("ns2d_5x128", ("x", "y"), ("u", "v", "p"), [128] * 5,
                              lambda: ppsci.equation.NavierStokes(0.01, 1.0, 2, False), "sum", 1e-4, tmp)
     return e
@@ -645,6 +645,10 @@ def main():
     comm_world = torch.distributed.get_world_size() if world > 1 else 1
     assert comm_world == world == args.gpus, "one RCCL rank per GPU"
 
+    # the CPU-side checkers (oracle parity legs, cpu_baseline) run small-op graphs: 8 threads is the fastest setting on
+    # the GPU box (tools/cpu_threads.py), and a 256-thread pool left spinning behind them slows the host side of the
+    # timed GPU steps that follow (TFNO: 0.98 -> 3.6 ms per step when the pool was left at its default size)
+    torch.set_num_threads(CPU_THREADS)
     if EMU:
         from tests.emu import build_emu
 

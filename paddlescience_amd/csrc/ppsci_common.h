@@ -18,12 +18,16 @@
 #define PPSCI_OCCUPANCY(KERNEL, block, lds, out) (*(out) = 2, 0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define ppsci_block_sync_lds() __syncthreads()
+#define PPSCI_OPAQUE(v) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PPSCI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+// Makes the VGPR value `v` opaque to the optimiser at this point: what is derived from it afterwards can neither be
+// hoisted out of the enclosing loops nor strength-reduced into per-operand address registers (taylor_bwd_wx.inc).
+#define PPSCI_OPAQUE(v) asm volatile("" : "+v"(v))
 // two fp32 -> packed bf16 (round to nearest even): one v_cvt_pk_bf16_f32; low half = a
 __device__ __forceinline__ unsigned ppsci_cvt_pk_bf16(float a, float b) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -36,6 +40,19 @@ __device__ __forceinline__ f32x4 ppsci_xdl32(u32x2 a_lo, u32x2 a_hi, u32x2 b_lo,
   typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
   const u32x4 a = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]}, b = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+// the same with the A operand already paired (one 16-byte fragment)
+__device__ __forceinline__ f32x4 ppsci_xdl32a(u32x4 a, u32x2 b_lo, u32x2 b_hi, f32x4 c) {
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  const u32x4 b = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: 64 bits per lane with a 16-bit-element transpose inside each 16-lane group: element j of lane i
+// (i = lane & 15) is element (i & 3) of the 8 bytes that lane 4j + (i >> 2) of the same group addresses (checked on
+// MI355X, tools/microbench/tr_test.hip).  `p` must be 8-byte aligned LDS.
+__device__ __forceinline__ u32x2 ppsci_lds_read_tr16(const void* p) {
+  typedef short s16x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)p));
 }
 // v_mfma_f32_16x16x16_bf16: A[i = c][k = 4g + j], B[k = 4g + j][n = c], j = 0..3
 __device__ __forceinline__ f32x4 ppsci_xdl16(u32x2 a, u32x2 b, f32x4 c) {

@@ -4,6 +4,96 @@
 
 #include <string.h>
 
+// ---- pre-split hidden-weight fragments for the feature-split XDL kernels (taylor_fwd_wx.inc / taylor_bwd_wx.inc) ----
+// One thread per (layer, row block, k-pair, lane): the two 4-value halves of the K = 32 A operand, split into three bf16
+// planes.  forward (bwd = 0): rb = output block, lane (g, c) holds W[in = 16kb + 4g + r][out = 16rb + c];
+// backward (bwd = 1): rb = input block, lane (g, c) holds W[in = 16rb + c][out = 16kb + 4g + r]  (taylor_tile.h).
+__global__ void __launch_bounds__(256) ppsci_presplit_kernel(const float* params, ppsci_derived q, int H, int L, int bwd,
+                                                             u32x4* out) {
+  const int NB = q.NB, NKP = NB / 2;
+  const int per_layer = NB * NKP * 64;
+  const int total = (L - 1) * per_layer;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int l = 1 + idx / per_layer, rem = idx % per_layer;
+    const int lane = rem & 63, pair = rem >> 6, rb = pair / NKP, kp = pair - rb * NKP;
+    const int g = lane >> 4, c = lane & 15;
+    const float* W = params + q.offW[l];
+    ppsci_split4 sp[2];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int kb = 2 * kp + hlf;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int in = bwd ? 16 * rb + c : 16 * kb + 4 * g + r, o = bwd ? 16 * kb + 4 * g + r : 16 * rb + c;
+        v[r] = (in < H && o < H) ? W[in * H + o] : 0.f;
+      }
+      sp[hlf] = ppsci_split(v);
+    }
+    u32x4* dst = out + (long long)(l - 1) * (NB * NKP * 3 * 64) + (long long)(pair * 3) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * 64] = (u32x4){sp[0].p[p][0], sp[0].p[p][1], sp[1].p[p][0], sp[1].p[p][1]};
+  }
+}
+
+// Fragment cache: one device buffer per (parameter buffer, direction), allocated on first use (an eager call: the
+// engine captures HIP graphs only from the second step on) and re-filled by every launch that needs it -- the
+// parameters change every step.  Never freed: a handful of entries of <= a few MiB.
+struct FragEntry {
+  const void* key;
+  int bwd;
+  size_t bytes;
+  void* dev;
+};
+static FragEntry g_frag[64];
+static int g_nfrag = 0;
+static void* frag_cache_get(const void* key, int bwd, size_t bytes) {
+  for (int i = 0; i < g_nfrag; ++i)
+    if (g_frag[i].key == key && g_frag[i].bwd == bwd && g_frag[i].bytes >= bytes) return g_frag[i].dev;
+  if (g_nfrag == 64) g_nfrag = 0;  // recycle the table (the old buffers stay allocated: their launches may be in flight)
+  void* dev = nullptr;
+#ifdef PPSCI_EMU
+  dev = malloc(bytes);
+#else
+  if (hipMalloc(&dev, bytes) != hipSuccess) dev = nullptr;
+#endif
+  if (!dev) return nullptr;
+  g_frag[g_nfrag++] = FragEntry{key, bwd, bytes, dev};
+  return dev;
+}
+
+const void* ppsci_presplit(const float* params, const ppsci_mlp_desc& d, const ppsci_derived& q, int bwd, void* stream) {
+  const int L = d.n_hidden;
+  const long long n4 = (long long)(L - 1) * q.NB * (q.NB / 2) * 3 * 64;
+  void* dev = frag_cache_get(params, bwd, (size_t)n4 * 16);
+  if (!dev) {
+    ppsci_set_error("presplit: cannot allocate %lld B of fragment cache", n4 * 16);
+    return nullptr;
+  }
+  const int total = (L - 1) * q.NB * (q.NB / 2) * 64;
+  int grid = (total + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  struct PArgs {
+    const float* params;
+    ppsci_derived q;
+    int H, L, bwd;
+    u32x4* out;
+  };
+#ifdef PPSCI_EMU
+  PArgs pa{params, q, d.width, L, bwd, (u32x4*)dev};
+  emu::launch(emu_dim3{(unsigned)grid}, emu_dim3{256u}, 0,
+              [](void* p) { PArgs& a = *(PArgs*)p; ppsci_presplit_kernel(a.params, a.q, a.H, a.L, a.bwd, a.out); }, &pa);
+#else
+  hipLaunchKernelGGL(ppsci_presplit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, q, d.width, L, bwd,
+                     (u32x4*)dev);
+  if (hipGetLastError() != hipSuccess) {
+    ppsci_set_error("presplit: launch failed");
+    return nullptr;
+  }
+#endif
+  return dev;
+}
+
 static int fill_fwd(FwdArgs& a, const ppsci_mlp_desc* d, int64_t n_points) {
   memset(&a, 0, sizeof(a));
   if (!d || ppsci_derive(d, &a.q) != PPSCI_OK) return PPSCI_E_INVALID;

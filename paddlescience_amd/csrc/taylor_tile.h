@@ -376,6 +376,23 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
   }
 }
 
+// ---- feature-split XDL kernels (taylor_fwd_wx.inc, taylor_bwd_wx.inc) ----
+// LDS chunk index of (feature group fg = 4 features, point pt) inside one 16x16 bf16 plane (64 chunks of 8 bytes):
+// feature-group-major, i.e. lane (g, c) owns chunk ~lane, so the 16 lanes of a group always touch one contiguous
+// 128-byte run -- conflict-free for every DS form the compiler picks (ds_read_b64, ds_read2st64_b64, ds_write2st64_b64
+// are served per 16-lane group over 32 banks; a point-major layout measured 47 % conflict cycles there).  The points
+// of groups 2 and 3 are XOR-ed with 8 so that ds_read_b64_tr_b16, whose 32-lane halves gather chunks (fg = 0..3,
+// pt = 8 consecutive points), hits 64 distinct banks as well.
+__device__ __forceinline__ int ppsci_xchunk(int fg, int pt) { return fg * 16 + (pt ^ ((fg >> 1) << 3)); }
+
+// u32x4 units per hidden-to-hidden layer of the pre-split global fragments:
+//   gfrag[((rb * (NB/2) + kp) * 3 + plane) * 64 + lane] = the K = 32 A operand of row block rb, k-blocks (2kp | 2kp+1)
+#define PPSCI_GFRAG_PER_LAYER(NB) ((NB) * ((NB) / 2) * 3 * 64)
+
+// defined in taylor_api.hip: splits the hidden-to-hidden matrices of `params` into the fragment cache entry of
+// (params, bwd) on `stream` and returns the device pointer (nullptr + ppsci_set_error on failure)
+const void* ppsci_presplit(const float* params, const ppsci_mlp_desc& d, const ppsci_derived& q, int bwd, void* stream);
+
 // one layer's hidden-weight fragments in LDS (floats) and their staging, for the MFMA flavour this build uses
 #define PPSCI_FRAG_FLOATS(HP) (PPSCI_XDL ? PPSCI_XFRAG_FLOATS(HP) : (HP) * (HP))
 __device__ __forceinline__ void ppsci_stage_fwd_frag(float* dst, const float* W, int H, int NB, int tid, int nthr) {
@@ -409,6 +426,7 @@ struct FwdArgs {
   int iters;     // tile iterations per wave (uniform over the grid)
   int resident;  // 1: all hidden-layer fragments stay in LDS; 0: re-staged per layer (lock-step)
   int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
+  const void* xfrag;  // feature-split XDL kernels: pre-split hidden-weight fragments (ppsci_presplit)
 };
 
 struct BwdArgs {
@@ -426,6 +444,7 @@ struct BwdArgs {
   int resident;
   int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
   int accum;     // 1: hidden-weight gradient blocks accumulated per WORKGROUP (wpart has one slot per workgroup)
+  const void* xfrag;  // feature-split XDL kernels: pre-split hidden-weight fragments (ppsci_presplit)
 };
 
 // Parameters that are NOT hidden-to-hidden matrices, in the compact order the reverse kernels flush their LDS

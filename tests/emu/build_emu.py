@@ -11,7 +11,7 @@ OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "_".join(f.lstrip("-D") 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
            "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "fft.hip", "spinn.hip", "pirate.hip", "comm.hip", "epilogue_optim.hip"]
-HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc", "taylor_fwd_wide.inc", "taylor_bwd_wide.inc"]
+HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc", "taylor_fwd_wide.inc", "taylor_bwd_wide.inc", "taylor_fwd_wx.inc", "taylor_bwd_wx.inc"]
 
 
 def _newer(dst, srcs):

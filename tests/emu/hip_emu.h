@@ -48,6 +48,7 @@ struct Wave {
   Barrier bar;
   float xa[2][kWave];
   float xb[2][kWave];
+  const void* xp[2][kWave];  // addresses (LDS transpose reads)
   unsigned xw[2][kWave][8];  // wide operands (bf16 MFMAs): 4 dwords of A, 4 of B per lane
   unsigned op = 0;  // collective counter (same in every lane of the wave)
 };
@@ -280,6 +281,25 @@ inline f32x4 emu_xdl(const unsigned* a, const unsigned* b, int ndw, f32x4 c) {  
 inline f32x4 ppsci_xdl32(u32x2 a_lo, u32x2 a_hi, u32x2 b_lo, u32x2 b_hi, f32x4 c) {
   const unsigned a[4] = {a_lo[0], a_lo[1], a_hi[0], a_hi[1]}, b[4] = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
   return emu_xdl(a, b, 4, c);
+}
+inline f32x4 ppsci_xdl32a(u32x4 a, u32x2 b_lo, u32x2 b_hi, f32x4 c) {
+  const unsigned aa[4] = {a[0], a[1], a[2], a[3]}, b[4] = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
+  return emu_xdl(aa, b, 4, c);
+}
+// ds_read_b64_tr_b16: element j of lane i (of a 16-lane group) = 16-bit element (i & 3) at the address of lane 4j + (i >> 2)
+inline u32x2 ppsci_lds_read_tr16(const void* p) {
+  emu::Wave& w = emu::my_wave();
+  emu::Fiber& f = emu::st().fibers[emu::st().cur];
+  const unsigned buf = f.wave_op & 1u;
+  f.wave_op++;
+  const unsigned l = emu::my_lane();
+  w.xp[buf][l] = p;
+  emu::barrier_wait(w.bar);
+  const unsigned grp = l & ~15u, i = l & 15u;
+  unsigned short e[4];
+  for (unsigned j = 0; j < 4; ++j) e[j] = ((const unsigned short*)w.xp[buf][grp + 4 * j + (i >> 2)])[i & 3];
+  emu::barrier_wait(w.bar);  // nobody may overwrite the source before every lane has gathered
+  return (u32x2){(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16)};
 }
 inline f32x4 ppsci_xdl16(u32x2 a, u32x2 b, f32x4 c) {
   const unsigned aa[2] = {a[0], a[1]}, bb[2] = {b[0], b[1]};

@@ -9,7 +9,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "taylor" not in k:
+        if "taylor" not in k and "presplit" not in k and "wgrad" not in k:
             continue
         acc[k.split("(")[0][-60:]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in sorted(acc.items()):
