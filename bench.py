@@ -39,6 +39,9 @@ HIDDEN, WIDTH, N_PER_GPU = 4, 64, 100_000
 # TEST MODE (tests/test_bench_launch.py only): the launch / rank plumbing of this file on the CPU SIMT emulator with the
 # gloo backend and tiny sizes; the JSON line says so in `data`.  Never set on a GPU box.
 EMU = os.environ.get("PPSCI_BENCH_EMU") == "1"
+# profiling runs (tools/*_step.py under rocprofv3): launch nothing but the training steps, so that launches / steps in the
+# counter files are launches per step
+PURE = os.environ.get("PPSCI_BENCH_PURE_STEPS") == "1"
 if EMU:
     N_PER_GPU = 128
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (f32 in) peak == fp32 vector peak
@@ -87,6 +90,61 @@ def time_wall(fn, steps, warmup, barrier=None):
         fn()
     sync()
     return (time.perf_counter() - t0) / steps
+
+
+def profile_info(stem, kernel_substr=None, ms_per_step=None, once_per_step=False):
+    """What the committed rocprofv3 summaries of config `stem` say (profiles/<round>_<stem>_{kernel_stats.csv,
+    pmc_summary.json}, newest round; tools/profile_all.sh + tools/summarize_profile.py): the DOMINANT kernel of a step by
+    total time, the HBM bytes of one step (sum over all kernels of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches
+    per step; a step = one `adam_kernel` launch) and, for `kernel_substr`, that kernel's own bytes per launch.  PMC
+    counters can only be read by rocprofv3 around a process, so these figures are QUOTED from the named files, not
+    measured by this run."""
+    import csv
+    import glob
+
+    out = {}
+    try:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{stem}_pmc_summary.json")))
+        if not files:
+            return out
+        pmc = json.load(open(files[-1]))
+        out["source"] = os.path.relpath(files[-1], ROOT)
+        stats = files[-1].replace("_pmc_summary.json", "_kernel_stats.csv")
+        if os.path.exists(stats):
+            rows = [r for r in csv.DictReader(open(stats)) if "at::native" not in r["Name"] and "rocclr" not in r["Name"]]
+            tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+            top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+            out["dominant_kernel"] = {"name": top["Name"].split("(")[0][-70:], "share_of_kernel_time": float(top["TotalDurationNs"]) / tot,
+                                      "avg_us": float(top["AverageNs"]) / 1e3}
+        nstep = next((v.get("launches_pmc_fetch") for k, v in pmc.items() if k.startswith("adam_kernel")), None)
+        if once_per_step:  # one-constraint PINN step: every kernel type runs once (forward, epilogue, reductions, reverse, Adam)
+            nstep = 1
+        if nstep:
+            byts = sum(v.get("hbm_bytes_per_launch", 0.0) * (1 if once_per_step else v.get("launches_pmc_fetch", 0))
+                       for v in pmc.values()) / nstep
+            out["hbm_bytes_per_step"] = byts
+            if ms_per_step:
+                out["hbm_frac_of_8TBps_over_step"] = byts / (ms_per_step * 1e-3) / (PEAK_HBM_TBPS * 1e12)
+        if kernel_substr:
+            for k, v in pmc.items():
+                if kernel_substr in k:
+                    out["kernel_hbm_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
+    except Exception as e:  # noqa: BLE001 -- quoted context must never cost the measured line
+        out["error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
+
+
+def step_hbm_roofline(stem, t_step):
+    """Step-level HBM roofline of a config whose kernels are all HBM / latency-bound: achieved = (HBM bytes of one step,
+    summed over all its kernels from the committed PMC summary) / (the step time measured by THIS run); the entry names the
+    dominant kernel of the step from the committed rocprofv3 kernel statistics."""
+    prof = profile_info(stem, None, t_step * 1e3)
+    byts = prof.get("hbm_bytes_per_step")
+    dom = prof.get("dominant_kernel", {})
+    ach = byts / t_step / 1e12 if byts else None
+    return {"bound": "hbm", "scope": "whole step", "kernel": dom.get("name"), "dominant_kernel_share": dom.get("share_of_kernel_time"),
+            "dominant_kernel_avg_us": dom.get("avg_us"), "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+            "frac": ach / PEAK_HBM_TBPS if ach else None, "traffic": byts, "traffic_source": prof.get("source")}
 
 
 def time_events(fn, reps=20):
@@ -254,6 +312,8 @@ def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
         opt.step(solver.engine.grad)
 
     t = time_wall(step, steps, warmup)
+    if PURE:
+        return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps}
     t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))  # incl. the two small reduction kernels
     t_fwd = time_events(lambda: cc.fused.forward(solver.engine.params, True))
     ach = 4.0 * p_mat * S * n / t_bwd / 1e12
@@ -272,6 +332,9 @@ def secondary_laplace(tmp, steps, warmup, with_cpu):
     e = pinn_entry("cfg1 Laplace2D, MLP 2->20x3->1 tanh, 10 000 interior points, u_xx+u_yy, MSE-sum, Adam "
                    "(BASELINE.json configs[0]); launch/latency-bound: 625 tiles on 1 024 wave slots",
                    solver, opt, cc, 10_000, 2 * 20 + 2 * 400 + 20, 5, steps, warmup, "taylor_bwd_kernel<2, 2, 2, 0>")
+    e["step_profile"] = profile_info("laplace", None, e["ms_per_step"], once_per_step=True)
+    if PURE:
+        return e
     e["parity"] = api_parity("laplace2d_3x20", ("x", "y"), ("u",), [20] * 3, lambda: ppsci.equation.Laplace(2), "sum",
                              None, tmp)
     if with_cpu:
@@ -298,6 +361,9 @@ def secondary_ns(tmp, steps, warmup):
     e = pinn_entry("cfg3 shard: LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 125 000 points (rank 0 of 8 of the "
                    "1 M-point cloud), continuity + momentum_x + momentum_y, weights 1e-4, MSE-sum, Adam",
                    solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wx_kernel<8, 1, 5, 2, 2, 0>")
+    e["step_profile"] = profile_info("ns", None, e["ms_per_step"], once_per_step=True)
+    if PURE:
+        return e
     e["parity"] = api_parity("ns2d_5x128", ("x", "y"), ("u", "v", "p"), [128] * 5,
                              lambda: ppsci.equation.NavierStokes(0.01, 1.0, 2, False), "sum", 1e-4, tmp)
     return e
@@ -387,6 +453,9 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
         opt.step(model.flat_grad)
 
     t = time_wall(step, steps, warmup)
+    # the same step timed with HIP events on the launch stream (device-side duration of the replayed graph + Adam): the
+    # wall-clock figure of this ~60-node graph has been seen 3.6x higher on some boxes with identical kernel times
+    t_ev = time_events(step, reps=steps)
     layer = fno.SpectralConv2d(32, 32, (12, 12), fft_norm="forward").cuda()
     x_ft = torch.fft.rfftn(torch.randn(B, 32, H, W, device="cuda"), norm="forward", dim=(-2, -1))
     t_k = time_events(lambda: fno.spectral_contract(x_ft, layer.weight_real, layer.weight_imag))
@@ -395,10 +464,11 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
     return {"config": "cfg4 TFNO-2D Darcy shape: 64x64 grid, batch 16, in 3, hidden 32, lifting 256, projection 64, "
                       "4 layers, n_modes (12,12), group_norm; forward + MSE + backward + Adam",
             "value": B * H * W / t, "unit": "grid-points/s", "samples_per_s": B / t, "ms_per_step": t * 1e3, "steps": steps,
-            "roofline": {"bound": "hbm", "kernel": "spectral_contract_kernel (84 modes x [16 x 64]x[64 x 64] real GEMM on "
-                                                   "v_mfma_f32_16x16x4_f32)", "achieved": ach, "peak": PEAK_HBM_TBPS,
-                         "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS, "kernel_ms": t_k * 1e3,
-                         "note": "1.4 MB of operands, 11 MFLOP: launch/latency-bound at this size"},
+            "ms_per_step_hip_events": t_ev * 1e3,
+            "roofline": step_hbm_roofline("tfno", t),
+            "spectral_contract_kernel": {"kernel_ms": t_k * 1e3, "operand_TBps": ach,
+                                         "note": "84 modes x [16 x 64]x[64 x 64] real GEMM, 1.4 MB of operands, 11 MFLOP: "
+                                                 "launch/latency-bound at this size; 9.6 % of the step"},
             "native_forward_backward": eng.native is not None, "parity": parity}
 
 
@@ -425,6 +495,15 @@ def secondary_spinn(tmp, steps, warmup, nc=128):
         cc.bind(data, lab)
         return solver, opt, cc, xs, uc
 
+    if PURE:  # profiling run: nothing but the timed steps
+        solver, opt, cc, xs, uc = run(nc, True)
+
+        def pure_step():
+            solver.engine.forward_backward([cc])
+            opt.step(solver.engine.grad)
+
+        t = time_wall(pure_step, steps, warmup)
+        return {"value": nc ** 3 / t, "ms_per_step": t * 1e3, "steps": steps}
     # parity on a 24^3 grid (checker: oracle fp64 restatement of spinn.py / helmholtz.py, pinned by tests/golden/spinn.npz)
     from oracle import ref_torch as R
 
@@ -460,10 +539,10 @@ def secondary_spinn(tmp, steps, warmup, nc=128):
     return {"config": f"cfg5 SPINN Helmholtz3D: 3 x ModifiedMLP 1->64x4->32 tanh, {nc}^3 tensor-product grid, "
                       "k^2 u + u_xx + u_yy + u_zz - f, MSE-mean, Adam",
             "value": pts / t, "unit": "grid-points/s", "ms_per_step": t * 1e3, "steps": steps,
-            "roofline": {"bound": "hbm", "kernel": "3 x modmlp_fwd + spinn_grid_fwd_kernel (label read 4 B/grid point; the "
-                                                   "grid itself is never materialised)", "achieved": ach,
-                         "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": ach / PEAK_HBM_TBPS, "kernel_ms": t_g * 1e3,
-                         "note": "8.4 MB algorithmic read per step: latency-bound at this size"},
+            "roofline": step_hbm_roofline("spinn", t),
+            "grid_forward": {"kernel_ms": t_g * 1e3, "label_read_TBps": ach,
+                             "note": "3 x modmlp_fwd + spinn_grid_fwd_mfma_kernel: 8.4 MB algorithmic read (the grid itself is "
+                                     "never materialised): latency-bound at this size"},
             "parity": parity}
 
 
@@ -697,21 +776,10 @@ def main():
     flops_fwd = 2.0 * p_mat * S * N_PER_GPU   # F_R
     ach = flops_bwd / t_bwd / 1e12
 
-    # HBM traffic of the dominant kernel per launch: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, KiB) can only be read by
-    # rocprofv3 around the process, not from inside it: tools/profile_bench.sh collects them in separate --pmc passes of
-    # THIS command and tools/summarize_profile.py condenses them into profiles/*_bench_pmc_summary.json; the newest one
-    # is quoted here together with its file name (`traffic_source`), it is not measured by this run
-    traffic, traffic_src = None, None
-    try:
-        import glob
-
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_summary.json")))
-        if files:
-            for k, v in json.load(open(files[-1])).items():
-                if "taylor_bwd" in k and "<4, 2, 1, 0" in k:
-                    traffic, traffic_src = v.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
-    except Exception:  # noqa: BLE001
-        traffic = None
+    # HBM traffic of the dominant kernel per launch and of the whole step: quoted from the newest committed rocprofv3
+    # summary (tools/profile_bench.sh; separate --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md) with its file name
+    prof = profile_info("bench", "taylor_bwd_wx_kernel<4, 1, 4, 2, 1", dt / args.steps * 1e3, once_per_step=True)
+    traffic, traffic_src = prof.get("kernel_hbm_bytes_per_launch"), prof.get("source")
 
     strong = None
     import tempfile
@@ -744,10 +812,14 @@ def main():
                                    "residual+MSE-mean+grad+Adam (BASELINE.json configs[1])",
                        "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss,
                        "residual_only_points_per_s_per_gpu": N_PER_GPU / t_res},
-            "roofline": {"bound": "mfma", "kernel": "taylor_bwd_kernel<4, 2, 1, 0>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "taylor_bwd_wx_kernel<4, 1, 4, 2, 1, 0>", "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": t_bwd * 1e3,
-                         "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12},
+                         "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12,
+                         "arithmetic": "fp32 operands as three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per "
+                                       "K = 32 step, fp32 accumulate (error <= the fp32 MFMA's); `peak` is the fp32-input "
+                                       "MFMA peak the algorithmic flops are priced against",
+                         "step_profile": prof},
             "parity": parity,
         }
         if strong is not None:

@@ -148,9 +148,11 @@ const char* ppsci_last_error(void);
 /* Tuning/testing knob: cap the number of workgroups of the tile kernels (0 = automatic, the default).
  * Results do not depend on it beyond fp32 summation order. */
 void ppsci_set_max_grid(int max_blocks);
-/* Testing knob: nets whose padded width / 16 is at least this use the feature-split ("wide") kernels, in which
- * the waves of a workgroup share one 16-point tile.  Default 8 (width > 64); 16 keeps width <= 128 on the
- * single-wave kernels; width > 128 always uses the wide kernels. */
+/* Testing knob: nets whose padded width / 16 is at least this use the feature-split kernels, in which the waves
+ * of a workgroup share one 16-point tile.  Default 8: forward sweep feature-split for width > 64, reverse sweep
+ * (register-accumulating XDL kernel, 2..5 hidden layers, <= 5 streams) already for width > 32.  Any other value
+ * applies to both sweeps: 16 keeps width <= 128 on the single-wave kernels, 4 runs width 33..64 feature-split in the
+ * forward sweep too; width > 128 always uses the feature-split kernels. */
 void ppsci_set_wide_min_nb(int nb);
 /* Testing knob: 1 (default) lets ppsci_taylor_bwd accumulate the hidden-weight gradient per WORKGROUP in LDS when the
  * net allows it (padded width <= 64, fragments and accumulators fit LDS); 0 forces the per-tile streaming path that

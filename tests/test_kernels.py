@@ -96,7 +96,8 @@ def test_fwd_streams_match_oracle(hidden, dout, dirs, n2, act, N):
 
 
 @pytest.mark.parametrize("hidden,dout,n2,N,knob", [([100, 100, 100], 3, 2, 37, 8), ([100, 100, 100], 3, 2, 37, 16),
-                                                   ([200, 200], 2, 1, 21, 8), ([256, 256, 256], 1, 2, 16, 8)])
+                                                   ([200, 200], 2, 1, 21, 8), ([256, 256, 256], 1, 2, 16, 8),
+                                                   ([64, 64, 64, 64], 1, 1, 40, 4), ([50, 50, 50], 3, 2, 37, 4)])
 def test_fwd_wide_nets(hidden, dout, n2, N, knob):
     """Feature-split forward kernel (one tile per workgroup, NB/4 waves): width 100 -> NB = 8 with the knob at 8
     (wide) and at 16 (single-wave kernel), widths 200 / 256 -> NB = 16 (wide only)."""
@@ -247,6 +248,8 @@ def test_ns_config_shape_5x128_three_outputs():
     ([200, 200], 2, [[0, 1], [1, 0]], 1, 21, 8),      # NB = 16 (padded 256), four waves per tile
     ([256, 256, 256, 256], 1, [[0, 1], [1, 0]], 1, 33, 8),  # reference allen_cahn.yaml width
     ([72], 1, np.eye(2), 2, 19, 8),                   # single hidden layer: no hidden-to-hidden weights
+    ([64, 64, 64, 64], 1, [[0, 1], [1, 0]], 1, 70, 4),  # width <= 64 on the feature-split XDL kernels (knob 4): bench net
+    ([50, 50, 50], 3, np.eye(2), 2, 37, 4),
 ])
 def test_bwd_wide_nets(hidden, dout, dirs, n2, N, knob):
     """Feature-split reverse kernel against the fp64 oracle; one block only so that several tiles share it."""
@@ -592,6 +595,7 @@ def test_bwd_workgroup_accumulation_matches_streaming_and_oracle(hidden, dout, n
     ref = T.flat_grads(*T.taylor_backward(net32, cache, Ubar))
     got = {}
     _lib.lib().ppsci_set_max_grid(grid)
+    _lib.lib().ppsci_set_wide_min_nb(16)  # the single-wave kernels (by default width 33..64 runs feature-split)
     try:
         for mode in (1, 0):
             _lib.lib().ppsci_set_bwd_accum(mode)
@@ -599,6 +603,7 @@ def test_bwd_workgroup_accumulation_matches_streaming_and_oracle(hidden, dout, n
     finally:
         _lib.lib().ppsci_set_bwd_accum(1)
         _lib.lib().ppsci_set_max_grid(0)
+        _lib.lib().ppsci_set_wide_min_nb(8)
     assert _rel(got[1], ref) < 5e-6 and _rel(got[0], ref) < 5e-6
     assert _rel(got[1], got[0]) < 2e-6
 

@@ -5,6 +5,7 @@ import sys
 import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PPSCI_BENCH_PURE_STEPS"] = "1"  # nothing but the training steps (launches / steps = launches per step)
 import bench  # noqa: E402
 
 if __name__ == "__main__":

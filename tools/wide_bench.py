@@ -29,11 +29,13 @@ def main():
     dev = "cuda"
     shapes = [("NS 5x128 S5 125k", 2, 5, 128, 3, [[1.0, 0.0], [0.0, 1.0]], 2, 125_000),
               ("AC 4x256 S4 100k", 2, 4, 256, 1, [[0.0, 1.0], [1.0, 0.0]], 1, 100_000)]
+    if "--ac64" in sys.argv:  # the primary bench shape on the single-wave (knob 8) and feature-split (knob 4) kernels
+        shapes = [("AC 4x64 S4 100k", 2, 4, 64, 1, [[0.0, 1.0], [1.0, 0.0]], 1, 100_000)]
     ns_only = "--ns-only" in sys.argv  # profiling runs: the BASELINE config 3 shard on the default kernels only
     if ns_only:
         shapes = shapes[:1]
     for (label, d_raw, nh, w, m, dirs, n2, N) in shapes:
-        for knob in ((8,) if ns_only else (8, 16)):
+        for knob in ((8,) if ns_only else ((4, 8) if "--ac64" in sys.argv else (8, 16))):
             L.lib().ppsci_set_wide_min_nb(knob)
             try:
                 lay = hp.NetLayout(d_raw, nh, w, m, "tanh")
