@@ -21,7 +21,7 @@
 // * ppsci_gn_*: GroupNorm with one group (per-sample statistics over C*P) fused with the spectral bias, the affine
 //   map, the skip addition and GELU; backward with per-row sums, a tiny fixed-order finalisation and one apply pass.
 // All reductions have a fixed order (no float atomics): bit-reproducible.
-#include "ppsci_common.h"
+#include "taylor_tile.h"  // ppsci_split / PPSCI_XDL: fp32 GEMMs on the bf16 (XDL) matrix pipe
 
 #ifndef PPSCI_EMU
 #include <hip/hip_runtime.h>
@@ -60,7 +60,7 @@ struct PwArgs {
 #define PW_STAGE 16  // weight float4s in flight per thread while staging
 
 template <int PW_OC, int PW_WAVES>
-__global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
+__global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
   PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
   // several output-channel slabs in one launch: neighbouring workgroups take different slabs, so that the weight stage
   // of one workgroup on a CU overlaps the MFMA phase of another (64 KB slabs: two or more workgroups per CU)
@@ -70,6 +70,38 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
   a.nob = (a.Cout + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
+  if constexpr (PPSCI_XDL) {
+    // XDL: K = 32 steps.  Fragment (ob, q2) of lane (g, c): Weff[o = 16ob + c][k = 32 q2 + 8g + j], j = 0..7, split into
+    // three bf16 planes of 16 bytes per lane: smem[((ob * kq2 + q2) * 3 + plane) * 64 + lane] (u32x4).  The split is
+    // done here, once per workgroup and slab (a thread reads its eight weights: two float4 along k, or eight rows when
+    // the matrix is used transposed).
+    const int kq2 = (a.Cin + 31) / 32;
+    u32x4* fr = (u32x4*)smem;
+    for (int idx = tid; idx < a.nob * kq2 * 64; idx += blockDim.x) {
+      const int l = idx & 63, q2 = (idx >> 6) % kq2, ob = (idx >> 6) / kq2;
+      const int o = 16 * ob + (l & 15), k0 = 32 * q2 + 8 * (l >> 4);
+      f32x4 w0 = (f32x4){0.f, 0.f, 0.f, 0.f}, w1 = w0;
+      if (o < a.Cout) {
+        if (!a.transpose && a.vec && k0 + 7 < a.Cin) {
+          const float* src = &a.W[(long long)(a.co0 + o) * a.ldw + k0];
+          w0 = *(const f32x4*)src;
+          w1 = *(const f32x4*)(src + 4);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            const float w = k < a.Cin ? (a.transpose ? a.W[(long long)k * a.ldw + a.co0 + o] : a.W[(long long)(a.co0 + o) * a.ldw + k]) : 0.f;
+            if (j < 4) w0[j] = w;
+            else w1[j - 4] = w;
+          }
+        }
+      }
+      const ppsci_split4 s0 = ppsci_split(w0), s1 = ppsci_split(w1);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fr[((long long)(ob * kq2 + q2) * 3 + pl) * 64 + l] = (u32x4){s0.p[pl][0], s0.p[pl][1], s1.p[pl][0], s1.p[pl][1]};
+    }
+  } else
   // stage W as A-operand fragments: comp r of lane (g,c) for (ob, q): Weff[o = 16ob + c][k = 16q + 4r + g].
   // Fast paths (no integer division, 16-byte coalesced global loads, 16 loads in flight per thread): a thread reads
   // four consecutive elements along the matrix' contiguous axis and scatters them to the four lanes / components
@@ -157,6 +189,48 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
       for (int j = 0; j < PW_OC; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (PPSCI_XDL) {
+        // K = 32 step q2: lane (g, c) loads channels 32 q2 + 8g + j (j = 0..7), pixels p0..p0+3 (eight float4, each a
+        // 256-byte run per channel row over the 16 lanes of a group); pixel t of the float4s is the B operand of column
+        // tile t: its eight values are split into three bf16 planes in registers, then six products per (block, tile).
+        const int kq2 = (a.Cin + 31) / 32;
+        const u32x4* fr = (const u32x4*)smem;
+        f32x4 xn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * g + j;
+          xn[j] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int q2 = 0; q2 < kq2; ++q2) {
+          u32x4 bp[4][3];  // [tile][plane]
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const ppsci_split4 s0 = ppsci_split((f32x4){xn[0][t], xn[1][t], xn[2][t], xn[3][t]});
+            const ppsci_split4 s1 = ppsci_split((f32x4){xn[4][t], xn[5][t], xn[6][t], xn[7][t]});
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bp[t][pl] = (u32x4){s0.p[pl][0], s0.p[pl][1], s1.p[pl][0], s1.p[pl][1]};
+          }
+          if (q2 + 1 < kq2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int k = 32 * (q2 + 1) + 8 * g + j;
+              xn[j] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < PW_OC; ++j) {
+            if (ob0 + j < a.nob) {
+              const u32x4* f = &fr[((long long)((ob0 + j) * kq2 + q2) * 3) * 64 + lane];
+              const u32x4 ap[3] = {f[0], f[64], f[128]};
+#pragma unroll
+              for (int q = 0; q < PPSCI_XDL_NPROD; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  acc[j][t] = ppsci_xdl32aa(ap[ppsci_xdl_pa[q]], bp[t][ppsci_xdl_pb[q]], acc[j][t]);
+            }
+          }
+        }
+      } else {
       f32x4 xn[4];  // k-step r: channel 16q + 4r + g, pixels p0..p0+3; loaded one q ahead of its MFMA chains
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -184,6 +258,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES) pw_conv_kernel(PwArgs a) {
               for (int t = 0; t < 4; ++t) acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xv[r][t], acc[j][t], 0, 0, 0);
           }
         }
+      }
       }
       // D_t[row = 4g + rr][col = c]: channel 16(ob0+j) + 4g + rr, pixel p0 + t
 #pragma unroll
@@ -232,7 +307,9 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
   // workgroup's LDS when it is small (<= 64 KiB: FNO layers); otherwise slabs of about 64 KiB -- all of them in ONE
   // launch, two or more workgroups per CU with 8 waves each: the weight stage of one overlaps the MFMAs of the other.
   const int nob_all = (Cout + 15) / 16;
-  const long long blk = (long long)a.kq * 64 * 16;  // bytes of one 16-row block
+  // bytes of one 16-row block of fragments: fp32 16 B per lane and 16-channel slab; XDL three 16-byte planes per
+  // lane and 32-channel slab
+  const long long blk = PPSCI_XDL ? (long long)((Cin + 31) / 32) * 3 * 64 * 16 : (long long)a.kq * 64 * 16;
   if (blk > PPSCI_LDS_LIMIT_BYTES) {
     ppsci_set_error("pw_conv: a 16 x %d weight block does not fit LDS", Cin);
     return PPSCI_E_UNSUPPORTED;
@@ -260,7 +337,8 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
   // one workgroup per CU (a slab above 80 KiB): 8 waves of 2-block items so that every SIMD still holds two waves; otherwise
   // 4 waves of 4-block items (a 64-row slab = one item per chunk: the B operand is streamed once per slab)
   const bool wide = resident == 1;
-  const int oc = wide ? 2 : 4, waves = wide ? 8 : 4;
+  // (XDL: a work item always takes 4 output blocks, so that one split of the B operand feeds 96 MFMAs)
+  const int oc = (wide && !PPSCI_XDL) ? 2 : 4, waves = wide ? 8 : 4;
   const long long nchunk = (long long)B * ((P + 63) / 64);
   const long long nitem = nchunk * ((nob_slab + oc - 1) / oc);  // per slab
   long long wg_slab = (nitem + waves - 1) / waves;
@@ -269,8 +347,9 @@ extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, co
   const long long grid = wg_slab * nslab;
   int se;
   if (wide) {
-    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<2, 8>), (int)lds);
-    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<2, 8>), PwArgs, (int)grid, 64 * 8, (int)lds, stream, a);
+    constexpr int OCW = PPSCI_XDL ? 4 : 2;
+    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<OCW, 8>), (int)lds);
+    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<OCW, 8>), PwArgs, (int)grid, 64 * 8, (int)lds, stream, a);
   } else {
     se = PPSCI_SET_MAX_LDS((pw_conv_kernel<4, 4>), (int)lds);
     if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<4, 4>), PwArgs, (int)grid, 64 * 4, (int)lds, stream, a);
@@ -300,7 +379,7 @@ struct PwWArgs {
 // the L2 traffic of its operands (each wave streams 2 * 16TB rows x cpix pixels), which per flop falls as 1 / TB.
 // TB = 2 for small layers (a 32 x 32 FNO layer is ONE tile), TB = 4 from 128 x 128 on.
 template <int TB>
-__global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
+__global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int nibt = (a.nib + TB - 1) / TB, nobt = (a.nob + TB - 1) / TB;
   int id = blockIdx.x;
@@ -330,7 +409,33 @@ __global__ void __launch_bounds__(64) pw_wgrad_kernel(PwWArgs a) {
 #pragma unroll
   for (int u = 0; u < TB; ++u) bsum[u] = 0.f;
   const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
-  for (int p = p0; p < pend; p += 16) {
+  int pbeg = p0;
+  if constexpr (PPSCI_XDL) {
+    // K = 32 pixels per step: lane (g, c) holds pixels p + 8g .. + 7 of its row for both operands (two float4 each),
+    // split into three bf16 planes; six products per 16 x 16 block.  A 16-pixel remainder takes the fp32 loop below.
+    for (; pbeg + 32 <= pend; pbeg += 32) {
+      u32x4 gp[TB][3], xp[TB][3];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+        const f32x4 g0 = *(const f32x4*)&gr[u][pbeg + 8 * g] * mo[u], g1 = *(const f32x4*)&gr[u][pbeg + 8 * g + 4] * mo[u];
+        const f32x4 x0 = *(const f32x4*)&xr[u][pbeg + 8 * g] * mi[u], x1 = *(const f32x4*)&xr[u][pbeg + 8 * g + 4] * mi[u];
+        bsum[u] += ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]));
+        const ppsci_split4 a0 = ppsci_split(g0), a1 = ppsci_split(g1), b0 = ppsci_split(x0), b1 = ppsci_split(x1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          gp[u][pl] = (u32x4){a0.p[pl][0], a0.p[pl][1], a1.p[pl][0], a1.p[pl][1]};
+          xp[u][pl] = (u32x4){b0.p[pl][0], b0.p[pl][1], b1.p[pl][0], b1.p[pl][1]};
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PPSCI_XDL_NPROD; ++q)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+          for (int v = 0; v < TB; ++v) acc[u][v] = ppsci_xdl32aa(gp[u][ppsci_xdl_pa[q]], xp[v][ppsci_xdl_pb[q]], acc[u][v]);
+    }
+  }
+  for (int p = pbeg; p < pend; p += 16) {
     // k-step r <-> pixel p + 4g + r for both operands
     f32x4 gv[TB], xv[TB];
 #pragma unroll

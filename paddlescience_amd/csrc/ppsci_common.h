@@ -47,6 +47,11 @@ __device__ __forceinline__ f32x4 ppsci_xdl32a(u32x4 a, u32x2 b_lo, u32x2 b_hi, f
   const u32x4 b = {b_lo[0], b_lo[1], b_hi[0], b_hi[1]};
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
 }
+// both operands already paired
+__device__ __forceinline__ f32x4 ppsci_xdl32aa(u32x4 a, u32x4 b, f32x4 c) {
+  typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
 // ds_read_b64_tr_b16: 64 bits per lane with a 16-bit-element transpose inside each 16-lane group: element j of lane i
 // (i = lane & 15) is element (i & 3) of the 8 bytes that lane 4j + (i >> 2) of the same group addresses (checked on
 // MI355X, tools/microbench/tr_test.hip).  `p` must be 8-byte aligned LDS.

@@ -3,7 +3,11 @@
 (ppsci/arch/mlp.py:28-137, :530-820), autodiff/ad.py, utils/symbolic.py and loss/mse.py in float64 under the torch-backed
 paddle shim (tests/golden/make_piratenet_golden.py): network outputs, per-point residuals (u_t, u_xx, products of two
 outputs ...), loss terms and the gradient w.r.t. every named parameter incl. alpha, the Fourier kernel and the factorised
-weights.  Tolerances: fp32 kernels against fp64 reference values -- residual rel-L2 <= 2e-5, gradient rel-L2 <= 2e-4."""
+weights.  Tolerances: fp32 kernels against fp64 reference values -- residual rel-L2 <= 1e-5, gradient rel-L2 <= 1e-4
+(BASELINE.md section 4).  Where the error comes from: the reference ALGORITHM itself evaluated in fp32 (torch CPU,
+oracle/ref_torch.PirateNet(dtype=float32)) is 2.1e-6 / 7.5e-6 (residual / gradient) off the fp64 values on the `allen_cahn_rwf`
+case -- the Fourier features make u_xx a sum of large cancelling terms -- and 1e-7 .. 1e-6 on the others; the HIP path is held
+to within 3x of that fp32 floor on every case."""
 import os
 
 import numpy as np
@@ -56,12 +60,26 @@ def test_piratenet_matches_reference_run(name, dev, tmp_path):
         k = p.numel()
         ref = GOLD[f"{name}/grad/{n}"].ravel()
         if np.linalg.norm(ref) > 1e-6 * np.linalg.norm(gref):
-            assert rel(g[off:off + k], ref) < 5e-4, n
+            assert rel(g[off:off + k], ref) < 1e-4, n
         off += k
-    assert rel(g, gref) < 2e-4
+    assert rel(g, gref) < 1e-4
     res = solver.predict(inp, eqs, batch_size=None, return_numpy=True)
     for k in keys:
-        assert rel(res[k][:, 0], GOLD[f"{name}/res/{k}"]) < 2e-5, k
+        assert rel(res[k][:, 0], GOLD[f"{name}/res/{k}"]) < 1e-5, k
+    # ... and no worse than 3x the error of the reference algorithm itself in fp32 arithmetic (the conditioning of the case)
+    from oracle import ref_torch as R
+
+    state = {k.split("/", 2)[2]: GOLD[k] for k in GOLD.files if k.startswith(f"{name}/param/")}
+    m32 = R.PirateNet(c["inputs"], c["outputs"], state, c["act"], c["periods"], dtype=torch.float32)
+    c32 = dict(name="EQ", input={k: X[:, j:j + 1] for j, k in enumerate(c["inputs"])},
+               exprs={k: R.lambdify(e, m32) for k, e in eqs.items()},
+               label={k: GOLD[f"{name}/label/{k}"][:, None].astype(np.float32) for k in keys}, reduction=c["reduction"])
+    _, _, g32, o32 = R.loss_and_grads(m32, [c32])
+    if keys:
+        e_res32 = max(rel(o32[0][k].detach().numpy()[:, 0], GOLD[f"{name}/res/{k}"]) for k in keys)
+        e_res = max(rel(res[k][:, 0], GOLD[f"{name}/res/{k}"]) for k in keys)
+        assert e_res < max(3 * e_res32, 1e-6), (e_res, e_res32)
+    assert rel(g, gref) < max(3 * rel(g32, gref), 2e-6), (rel(g, gref), rel(g32, gref))
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -123,9 +141,9 @@ def test_piratenet_full_width_matches_oracle(dev, tmp_path, hidden, blocks, n):
     solver = ppsci.solver.Solver(model, {"EQ": c}, str(tmp_path), ppsci.optimizer.Adam(1e-3)(model), epochs=1, iters_per_epoch=1)
     solver.engine.forward_backward([solver._compiled["EQ"].fused])
     assert solver._compiled["EQ"].fused.losses()["allen_cahn"] == pytest.approx(losses["allen_cahn"], rel=1e-4)
-    assert rel(solver.engine.grad.cpu().numpy(), gref) < 3e-4
+    assert rel(solver.engine.grad.cpu().numpy(), gref) < 1e-4
     res = solver.predict(inp, eqs, batch_size=None, return_numpy=True)
-    assert rel(res["allen_cahn"][:, 0], outs[0]["allen_cahn"].detach().numpy()[:, 0]) < 3e-5
+    assert rel(res["allen_cahn"][:, 0], outs[0]["allen_cahn"].detach().numpy()[:, 0]) < 1e-5
 
 
 def test_model_list_of_an_mlp_and_a_piratenet(dev, tmp_path):
@@ -167,7 +185,7 @@ def test_model_list_of_an_mlp_and_a_piratenet(dev, tmp_path):
     n_mlp = mlp.flat_params.numel()
     assert rel(g[mlp._param_offset:mlp._param_offset + n_mlp], gref[:n_mlp]) < 1e-4
     n_p = pir.flat_params.numel()
-    assert rel(g[pir._param_offset:pir._param_offset + n_p], gref[n_mlp:]) < 3e-4
+    assert rel(g[pir._param_offset:pir._param_offset + n_p], gref[n_mlp:]) < 1e-4
     solver.train()
 
 
