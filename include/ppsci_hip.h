@@ -324,6 +324,10 @@ int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const floa
  * scratch, stats: [4*B] floats (kept for the backward).
  * backward: gt = gout * GELU'(t) (the skip branch's gradient), gv = dL/dv, ggamma / gbeta / gsbias = the [C] parameter
  * gradients (each may be NULL). */
+/* DomainPadding (/root/reference/ppsci/arch/fno_block.py:19-140) on n planes: unpad == 0 writes src [n, h, w] into
+ * dst [n, hp, wp] at offset (oh, ow) with zeros around it; unpad == 1 copies that window of src [n, hp, wp] back into
+ * dst [n, h, w].  Each is the other's backward. */
+int ppsci_pad2d(int n, int h, int w, int hp, int wp, int oh, int ow, int unpad, const float* src, float* dst, void* stream);
 int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
                        const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
                        float* y, void* stream);

@@ -827,7 +827,8 @@ def reference_spectral_conv2d(x, w_re, w_im, n_modes_x, fft_norm="backward", bia
     return y if bias is None else y + bias
 
 
-def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5):
+def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5, domain_padding=None,
+                domain_padding_mode="one-sided"):
     """FNONet.forward (tfnonet.py:179-193) with FNOBlocks.forward_with_postactivation (fno_block.py:1191-1220)
     and fno_block.MLP (:313-320) written out on plain tensors.  P: dict of parameters named like the torch
     modules of paddlescience_amd.arch.fno (lifting.fcs.i.weight [Co,Ci,1,1] ...)."""
@@ -846,6 +847,15 @@ def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5
 
     n_lift = sum(1 for k in P if k.startswith("lifting.fcs.") and k.endswith(".weight"))
     x = mlp(x, "lifting", n_lift)
+    # DomainPadding (fno_block.py:19-140): round(fraction * resolution) zero rows / columns behind (one-sided) or on both
+    # sides (symmetric) of every spatial axis, between lifting and the blocks; removed again in front of the projection
+    H0, W0 = x.shape[-2:]
+    ph = pw = 0
+    if domain_padding is not None:
+        fr = [float(domain_padding)] * 2 if not isinstance(domain_padding, (list, tuple)) else [float(v) for v in domain_padding]
+        ph, pw = round(fr[0] * H0), round(fr[1] * W0)
+        sym = domain_padding_mode == "symmetric"
+        x = F.pad(x, [pw if sym else 0, pw, ph if sym else 0, ph])
     for i in range(n_layers):
         skip = conv1x1(x, P[f"fno_blocks.fno_skips.{i}.weight"]) if f"fno_blocks.fno_skips.{i}.weight" in P else x
         y = reference_spectral_conv2d(x, P[f"fno_blocks.convs.{i}.weight_real"], P[f"fno_blocks.convs.{i}.weight_imag"],
@@ -858,4 +868,7 @@ def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5
         x = y + skip
         if i < n_layers - 1:
             x = F.gelu(x)
+    if ph or pw:
+        oh, ow = (ph, pw) if domain_padding_mode == "symmetric" else (0, 0)
+        x = x[..., oh:oh + H0, ow:ow + W0]
     return mlp(x, "projection", 2)

@@ -119,6 +119,7 @@ _SYMBOLS = {
     "ppsci_pw_conv_wgrad_chunks": (C.c_int64, [C.c_int, C.c_int]),
     "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "ppsci_pad2d": (C.c_int, [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_fno_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -182,8 +182,17 @@ class FNONet(base.Arch, torch.nn.Module):
                               ("max_n_modes", max_n_modes, None)):
             if val != ok:
                 raise NotImplementedError(f"FNONet({name}={val!r}) is not built")
-        if domain_padding is not None and (sum(domain_padding) if isinstance(domain_padding, list) else domain_padding) > 0:
-            raise NotImplementedError("FNONet(domain_padding=...) is not built")
+        # DomainPadding (fno_block.py:19-140, tfnonet.py:118-127): per-axis fractions of the resolution, or None
+        if domain_padding is not None and (sum(domain_padding) if isinstance(domain_padding, (list, tuple)) else domain_padding) > 0:
+            fr = list(domain_padding) if isinstance(domain_padding, (list, tuple)) else [float(domain_padding)] * 2
+            if len(fr) != 2:
+                raise ValueError("domain_padding length must match the number of spatial dimensions (2)")
+            mode = domain_padding_mode.lower()
+            if mode not in ("one-sided", "symmetric"):
+                raise ValueError(f"Got self.padding_mode = {mode}")
+            self.domain_padding = ([float(v) for v in fr], mode)
+        else:
+            self.domain_padding = None
         # `factorization`/`rank`: the reference's FactorizedTensor (fno_block.py:522-539) stores a DENSE complex
         # weight whatever the name says, so "Tucker" with rank 1.0 and None are the same parametrisation.
         self.input_keys, self.output_keys = tuple(input_keys), tuple(output_keys)
@@ -241,10 +250,25 @@ class FNONet(base.Arch, torch.nn.Module):
         return self.train(False)
 
     # ---- forward (tfnonet.py:179-193) ---------------------------------------------------------
+    def padding_of(self, H: int, W: int):
+        """(rows, columns, row offset, column offset) DomainPadding adds to an H x W plane: round(fraction * resolution)
+        behind each axis (one-sided) or on both sides (symmetric), fno_block.py:72-115."""
+        if self.domain_padding is None:
+            return 0, 0, 0, 0
+        (fh, fw), mode = self.domain_padding
+        ph, pw = round(fh * H), round(fw * W)
+        return (2 * ph, 2 * pw, ph, pw) if mode == "symmetric" else (ph, pw, 0, 0)
+
     def forward_tensor(self, x: torch.Tensor) -> torch.Tensor:
         x = self.lifting(x)
+        H, W = x.shape[-2:]
+        ah, aw, oh, ow = self.padding_of(H, W)
+        if ah or aw:
+            x = torch.nn.functional.pad(x, [ow, aw - ow, oh, ah - oh])
         for index in range(self.n_layers):
             x = self.fno_blocks(x, index)
+        if ah or aw:
+            x = x[..., oh:oh + H, ow:ow + W]
         return self.projection(x)
 
     def forward(self, x):

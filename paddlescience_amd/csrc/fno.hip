@@ -753,3 +753,47 @@ extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const
   }
   return PPSCI_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------ DomainPadding
+// fno_block.DomainPadding (/root/reference/ppsci/arch/fno_block.py:19-140): zero rows / columns around every [H, W] plane
+// between the lifting layer and the FNO blocks, removed again in front of the projection.  unpad == 0: dst [n, hp, wp] =
+// src [n, h, w] placed at (oh, ow), zero elsewhere; unpad == 1: dst [n, h, w] = src [n, hp, wp] window at (oh, ow).
+// The backward of one is the other.
+struct PadArgs {
+  const float* src;
+  float* dst;
+  int n, h, w, hp, wp, oh, ow, unpad;
+};
+__global__ void __launch_bounds__(256) pad2d_kernel(PadArgs a) {
+  const long long total = a.unpad ? (long long)a.n * a.h * a.w : (long long)a.n * a.hp * a.wp;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    if (a.unpad) {
+      const int j = (int)(idx % a.w), i = (int)((idx / a.w) % a.h);
+      const long long pl = idx / ((long long)a.w * a.h);
+      a.dst[idx] = a.src[(pl * a.hp + i + a.oh) * a.wp + j + a.ow];
+    } else {
+      const int j = (int)(idx % a.wp), i = (int)((idx / a.wp) % a.hp);
+      const long long pl = idx / ((long long)a.wp * a.hp);
+      const int ii = i - a.oh, jj = j - a.ow;
+      a.dst[idx] = (ii >= 0 && ii < a.h && jj >= 0 && jj < a.w) ? a.src[(pl * a.h + ii) * a.w + jj] : 0.f;
+    }
+  }
+}
+extern "C" int ppsci_pad2d(int n, int h, int w, int hp, int wp, int oh, int ow, int unpad, const float* src, float* dst,
+                           void* stream) {
+  if (n < 1 || h < 1 || w < 1 || hp < h + oh || wp < w + ow || oh < 0 || ow < 0 || !src || !dst) {
+    ppsci_set_error("pad2d: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  PadArgs a{src, dst, n, h, w, hp, wp, oh, ow, unpad};
+  const long long total = unpad ? (long long)n * h * w : (long long)n * hp * wp;
+  long long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  PPSCI_LAUNCH(pad2d_kernel, PadArgs, (int)grid, 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("pad2d: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

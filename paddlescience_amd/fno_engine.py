@@ -67,16 +67,27 @@ class FnoNative:
         m = self.m
         dev = m.flat_params.device
         f = dict(dtype=torch.float32, device=dev)
-        P, Ch, nl = H * W, m.hidden_channels, m.n_layers
-        if P % 16 != 0:
-            raise NotImplementedError(f"native FNO path: H*W = {P} must be a multiple of 16")
-        self.shape = (B, H, W)
-        self.P = P
+        Ch, nl = m.hidden_channels, m.n_layers
+        # DomainPadding (fno_block.py:19-140): the blocks run on the padded [Hp, Wp] planes, lifting / projection on [H0, W0]
+        H0, W0 = H, W
+        ah, aw, self.oh, self.ow = m.padding_of(H0, W0) if hasattr(m, "padding_of") else (0, 0, 0, 0)
+        H, W = H0 + ah, W0 + aw
+        self.padded = bool(ah or aw)
+        P, P0 = H * W, H0 * W0
+        if P % 16 != 0 or P0 % 16 != 0:
+            raise NotImplementedError(f"native FNO path: H*W = {P0} (padded: {P}) must be a multiple of 16")
+        self.shape = (B, H0, W0)
+        self.hw, self.hw0 = (H, W), (H0, W0)
+        self.P, self.P0 = P, P0
         lift, proj = m.lifting.fcs, m.projection.fcs
         self.c_lift = lift[0].out_channels if len(lift) == 2 else 0
         self.c_proj = proj[0].out_channels
         if self.c_lift:
-            self.z1, self.a1 = torch.empty((B, self.c_lift, P), **f), torch.empty((B, self.c_lift, P), **f)
+            self.z1, self.a1 = torch.empty((B, self.c_lift, P0), **f), torch.empty((B, self.c_lift, P0), **f)
+        if self.padded:
+            self.x0u = torch.empty((B, Ch, P0), **f)   # lifting output before padding
+            self.xou = torch.empty((B, Ch, P0), **f)   # blocks' output after unpadding
+            self.gpad = torch.empty((B, Ch, P), **f)   # padded gradient of the blocks' output
         self.x = [torch.empty((B, Ch, P), **f) for _ in range(nl + 1)]          # block inputs, x[nl] = blocks' output
         self.s = torch.empty((B, Ch, P), **f)                                    # skip branch of the current block
         self.t = [torch.empty((B, Ch, P), **f) for _ in range(nl)]              # pre-activations
@@ -89,15 +100,15 @@ class FnoNative:
         self.gsp = torch.empty((B, Ch, P), **f)
         self.rows = torch.empty(B * Ch * 4, **f)
         self.stats = [torch.empty(4 * B, **f) for _ in range(nl)]
-        self.z2, self.a2 = torch.empty((B, self.c_proj, P), **f), torch.empty((B, self.c_proj, P), **f)
-        self.y = torch.empty((B, m.out_channels, P), **f)
+        self.z2, self.a2 = torch.empty((B, self.c_proj, P0), **f), torch.empty((B, self.c_proj, P0), **f)
+        self.y = torch.empty((B, m.out_channels, P0), **f)
         # backward scratch
         cmax = max(Ch, self.c_lift, self.c_proj)
         self.ga = torch.empty((B, cmax, P), **f)
         self.gb = torch.empty((B, cmax, P), **f)
         self.gt = torch.empty((B, Ch, P), **f)
         self.gv = torch.empty((B, Ch, P), **f)
-        self.chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))
+        self.chunks = max(int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P)), int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0)))
         wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels))
         self.part_w = torch.empty(self.chunks * wmax, **f)
         self.part_b = torch.empty(self.chunks * cmax, **f)
@@ -107,21 +118,31 @@ class FnoNative:
         d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, Ch, Ch, H, Wf, mx, my
         self.inv_n = 1.0 / float(H * W)
 
+    def _pad(self, src, dst, unpad: bool) -> None:
+        B, Ch = self.shape[0], self.m.hidden_channels
+        (Hp, Wp), (H0, W0) = self.hw, self.hw0
+        L.check(L.lib().ppsci_pad2d(B * Ch, H0, W0, Hp, Wp, self.oh, self.ow, 1 if unpad else 0, _p(src), _p(dst),
+                                    _stream_ptr(dst)))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B, C_in, H, W] on the device -> y [B, C_out, H, W] (a buffer owned by the engine)."""
         m = self.m
-        B, _, H, W = x.shape
-        if self.shape != (B, H, W):
-            self._alloc(B, H, W)
-        P, Ch, nl = self.P, m.hidden_channels, m.n_layers
-        self.x_in = x.contiguous().view(B, m.in_channels, P)
+        B, _, H0, W0 = x.shape
+        if self.shape != (B, H0, W0):
+            self._alloc(B, H0, W0)
+        P, P0, Ch, nl = self.P, self.P0, m.hidden_channels, m.n_layers
+        H, W = self.hw
+        self.x_in = x.contiguous().view(B, m.in_channels, P0)
         lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
+        x0 = self.x0u if self.padded else self.x[0]
         if self.c_lift:
-            _pw_conv(B, m.in_channels, self.c_lift, P, self.x_in, lift[0].weight, self.z1, bias=lift[0].bias, act=self.a1)
-            _pw_conv(B, self.c_lift, Ch, P, self.a1, lift[1].weight, self.x[0], bias=lift[1].bias)
+            _pw_conv(B, m.in_channels, self.c_lift, P0, self.x_in, lift[0].weight, self.z1, bias=lift[0].bias, act=self.a1)
+            _pw_conv(B, self.c_lift, Ch, P0, self.a1, lift[1].weight, x0, bias=lift[1].bias)
         else:
-            _pw_conv(B, m.in_channels, Ch, P, self.x_in, lift[0].weight, self.x[0], bias=lift[0].bias)
+            _pw_conv(B, m.in_channels, Ch, P0, self.x_in, lift[0].weight, x0, bias=lift[0].bias)
+        if self.padded:
+            self._pad(x0, self.x[0], False)
         st = _stream_ptr(self.y)
         for l in range(nl):
             xl = self.x[l]
@@ -144,34 +165,47 @@ class FnoNative:
                 _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
                 _p(sk), _p(self.rows), _p(self.stats[l]), _p(self.t[l]), None if last else _p(self.x[l + 1]), st))
         xo = self.t[nl - 1]  # no activation behind the last block
-        _pw_conv(B, Ch, self.c_proj, P, xo, proj[0].weight, self.z2, bias=proj[0].bias, act=self.a2)
-        _pw_conv(B, self.c_proj, m.out_channels, P, self.a2, proj[1].weight, self.y, bias=proj[1].bias)
-        return self.y.view(B, m.out_channels, H, W)
+        if self.padded:
+            self._pad(xo, self.xou, True)
+            xo = self.xou
+        self.xo = xo
+        _pw_conv(B, Ch, self.c_proj, P0, xo, proj[0].weight, self.z2, bias=proj[0].bias, act=self.a2)
+        _pw_conv(B, self.c_proj, m.out_channels, P0, self.a2, proj[1].weight, self.y, bias=proj[1].bias)
+        return self.y.view(B, m.out_channels, H0, W0)
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param) -> None:
         L.check(L.lib().ppsci_pw_conv_wgrad(B, ci, co, P, _p(x), _p(gy), _p(self.part_w),
                                             _p(self.part_b) if b_param is not None else None, _stream_ptr(gy)))
-        hp.reduce_rows(self.part_w, self.chunks, co * ci, w_param.grad.view(-1), False)
+        chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))  # (P differs between the padded blocks and lifting / projection)
+        hp.reduce_rows(self.part_w, chunks, co * ci, w_param.grad.view(-1), False)
         if b_param is not None:
-            hp.reduce_rows(self.part_b, self.chunks, co, b_param.grad.view(-1), False)
+            hp.reduce_rows(self.part_b, chunks, co, b_param.grad.view(-1), False)
 
     def backward(self, gy: torch.Tensor) -> None:
         """gy = dL/dy [B, C_out, H, W]; writes dL/d(parameter) into every parameter's `.grad` (views of flat_grad)."""
         m = self.m
-        B, H, W = self.shape
-        P, Ch, nl = self.P, m.hidden_channels, m.n_layers
+        B = self.shape[0]
+        H, W = self.hw
+        P, P0, Ch, nl = self.P, self.P0, m.hidden_channels, m.n_layers
         lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
-        gy = gy.contiguous().view(B, m.out_channels, P)
+        gy = gy.contiguous().view(B, m.out_channels, P0)
         st = _stream_ptr(self.y)
         # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
-        self._wgrad(B, self.c_proj, m.out_channels, P, self.a2, gy, proj[1].weight, proj[1].bias)
-        gz2 = self.ga.view(-1)[:B * self.c_proj * P].view(B, self.c_proj, P)
-        _pw_conv(B, m.out_channels, self.c_proj, P, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
-        self._wgrad(B, Ch, self.c_proj, P, self.t[nl - 1], gz2, proj[0].weight, proj[0].bias)
+        self._wgrad(B, self.c_proj, m.out_channels, P0, self.a2, gy, proj[1].weight, proj[1].bias)
+        gz2 = self.ga.view(-1)[:B * self.c_proj * P0].view(B, self.c_proj, P0)
+        _pw_conv(B, m.out_channels, self.c_proj, P0, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
+        self._wgrad(B, Ch, self.c_proj, P0, self.xo, gz2, proj[0].weight, proj[0].bias)
         gx = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)  # dL/d(block output), ping-pongs with `gnext`
         gnext = self.ga.view(-1)[:B * Ch * P].view(B, Ch, P)
-        _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
+        if self.padded:  # the gradient of unpad is pad: zeros outside the window
+            gxu = self.xou  # (free: the forward value was consumed by the weight gradient above)
+            _pw_conv(B, self.c_proj, Ch, P0, gz2, proj[0].weight, gxu, transpose=True)
+            self._pad(gxu, self.gpad, False)
+            gx = self.gpad
+            gnext = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)
+        else:
+            _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
         for l in range(nl - 1, -1, -1):
             conv, skip = fb.convs[l], fb.fno_skips[l]
             nrm = fb.norm[l] if fb.norm is not None else None
@@ -195,12 +229,15 @@ class FnoNative:
             L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
             hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
             gx, gnext = gnext, gx
-        # lifting
+        # lifting (on the unpadded planes: the gradient of pad is unpad)
+        if self.padded:
+            self._pad(gx, self.x0u, True)
+            gx = self.x0u
         if self.c_lift:
-            self._wgrad(B, self.c_lift, Ch, P, self.a1, gx, lift[1].weight, lift[1].bias)
+            self._wgrad(B, self.c_lift, Ch, P0, self.a1, gx, lift[1].weight, lift[1].bias)
             gz1 = self.gb if gx.data_ptr() != self.gb.data_ptr() else self.ga
-            gz1 = gz1.view(-1)[:B * self.c_lift * P].view(B, self.c_lift, P)
-            _pw_conv(B, Ch, self.c_lift, P, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
-            self._wgrad(B, m.in_channels, self.c_lift, P, self.x_in, gz1, lift[0].weight, lift[0].bias)
+            gz1 = gz1.view(-1)[:B * self.c_lift * P0].view(B, self.c_lift, P0)
+            _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
+            self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
         else:
-            self._wgrad(B, m.in_channels, Ch, P, self.x_in, gx, lift[0].weight, lift[0].bias)
+            self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)

@@ -108,6 +108,8 @@ def install_fno_shim():
     nn.Dropout = S._act(lambda x: x)
     F.gelu = torch.nn.functional.gelu
     F.interpolate = None
+    # paddle.nn.functional.pad(x, [l, r, t, b], mode="constant") on NCHW pads the LAST axis first, like torch
+    F.pad = lambda x, pad, mode="constant", value=0.0, **k: torch.nn.functional.pad(x, list(pad), mode=mode, value=value)
     # ppsci.utils.initializer.normal_(tensor, mean, std) returns the tensor
     init = types.ModuleType("ppsci.utils.initializer")
 
@@ -130,6 +132,9 @@ def install_fno_shim():
     fno_block = importlib.import_module("ppsci.arch.fno_block")
     arch.fno_block = fno_block
     tfnonet = importlib.import_module("ppsci.arch.tfnonet")
+    # paddle's Tensor.shape is a python list, so DomainPadding.unpad's key f"{x.shape[2:]}" reads "[20, 24]"; under torch it
+    # would read "torch.Size([20, 24])" and miss the entry pad() stored: same lookup with the shape as a list
+    fno_block.DomainPadding.unpad = lambda self, x: x[self._unpad_indices[f"{list(x.shape[2:])}"]]
     return fno_block, tfnonet
 
 
@@ -152,19 +157,26 @@ def assign(ref_model, P):
 
 
 CASES = {
-    # name: (n_modes, hidden, lifting, projection, layers, norm, batch, H, W)
+    # name: (n_modes, hidden, lifting, projection, layers, norm, batch, H, W[, domain_padding, domain_padding_mode])
+    # (the per-case random stream is seeded by the LENGTH of the name: keep the lengths distinct)
     "tfno_gn_8x8": ((4, 4), 8, 16, 16, 2, "group_norm", 3, 8, 8),
     "tfno_plain_16x12": ((8, 6), 6, 12, 10, 3, None, 2, 16, 12),
+    # DomainPadding (fno_block.py:19-140): one-sided 4 rows / 8 columns -> 20 x 24; symmetric 4 + 4 -> 24 x 24
+    "tfno_pad1_16x16": ((4, 6), 6, 12, 10, 2, "group_norm", 2, 16, 16, [0.25, 0.5], "one-sided"),
+    "tfno_padsym_16x16": ((6, 4), 6, 12, 10, 2, None, 2, 16, 16, 0.25, "symmetric"),
 }
 
 
 def main():
     fno_block, tfnonet = install_fno_shim()
     out = {}
-    for cname, (modes, hid, lift, proj, nl, norm, B, H, W) in CASES.items():
+    for cname, case in CASES.items():
+        modes, hid, lift, proj, nl, norm, B, H, W = case[:9]
+        pad, pad_mode = (case[9], case[10]) if len(case) > 9 else (None, "one-sided")
         rng = np.random.default_rng(len(cname) * 977)
         model = tfnonet.TFNO2dNet(("x",), ("y",), modes[0], modes[1], hid, in_channels=3, out_channels=1,
-                                  lifting_channels=lift, projection_channels=proj, n_layers=nl, norm=norm)
+                                  lifting_channels=lift, projection_channels=proj, n_layers=nl, norm=norm,
+                                  domain_padding=pad, domain_padding_mode=pad_mode)
         my = modes[1] // 2 + 1
         shapes = {"lifting.fcs.0.weight": (lift, 3, 1, 1), "lifting.fcs.0.bias": (lift,),
                   "lifting.fcs.1.weight": (hid, lift, 1, 1), "lifting.fcs.1.bias": (hid,),
@@ -216,6 +228,8 @@ def main():
         out[f"{cname}/y"] = y.detach().numpy()
         out[f"{cname}/loss"] = np.asarray(float(loss.detach()))
         out[f"{cname}/config"] = np.asarray([modes[0], modes[1], hid, lift, proj, nl, 1 if norm else 0])
+        padl = [0.0, 0.0] if pad is None else ([float(pad)] * 2 if not isinstance(pad, list) else [float(v) for v in pad])
+        out[f"{cname}/domain_padding"] = np.asarray(padl + [1.0 if pad_mode == "symmetric" else 0.0])  # [frac_h, frac_w, symmetric]
         print(cname, "y", tuple(y.shape), "loss", float(loss.detach()))
     np.savez_compressed(os.path.join(HERE, "fno.npz"), **out)
     print("wrote", os.path.join(HERE, "fno.npz"), len(out), "arrays")

@@ -25,13 +25,21 @@ def _case(c):
     return (mx, my, hid, lift, proj, nl, "group_norm" if gn else None), P, Gr
 
 
+def _padding(c):
+    """DomainPadding of the case (fno_block.py:19-140): (fractions or None, mode)."""
+    fh, fw, sym = [float(v) for v in G[f"{c}/domain_padding"]]
+    return ([fh, fw] if fh or fw else None), ("symmetric" if sym else "one-sided")
+
+
 @pytest.mark.parametrize("c", CASES)
 def test_native_path_reproduces_reference_fno(c, dev):
     import ppsci
     from paddlescience_amd.fno_engine import FnoNative
 
     (mx, my, hid, lift, proj, nl, norm), P, Gr = _case(c)
-    model = ppsci.arch.TFNO2dNet(("x",), ("y",), mx, my, hid, 3, 1, lift, proj, nl, norm=norm)
+    pad, pad_mode = _padding(c)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), mx, my, hid, 3, 1, lift, proj, nl, norm=norm, domain_padding=pad,
+                                 domain_padding_mode=pad_mode)
     model.set_state_dict({k: v.astype(np.float32) for k, v in P.items()})
     d = model.flat_params.device
     x = torch.as_tensor(G[f"{c}/x"].astype(np.float32)).to(d)

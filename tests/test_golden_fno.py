@@ -24,11 +24,18 @@ def _case(c):
     return (mx, my, hid, lift, proj, nl, "group_norm" if gn else None), P, Gr
 
 
+def _padding(c):
+    """DomainPadding of the case (fno_block.py:19-140): (fractions or None, mode)."""
+    fh, fw, sym = [float(v) for v in G[f"{c}/domain_padding"]]
+    return ([fh, fw] if fh or fw else None), ("symmetric" if sym else "one-sided")
+
+
 @pytest.mark.parametrize("c", CASES)
 def test_oracle_reproduces_reference_fno(c):
     (mx, my, hid, lift, proj, nl, norm), P, Gr = _case(c)
     Pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in P.items()}
-    y = R.fno_forward(torch.tensor(G[f"{c}/x"]), Pt, nl, (mx, my), norm)
+    pad, pad_mode = _padding(c)
+    y = R.fno_forward(torch.tensor(G[f"{c}/x"]), Pt, nl, (mx, my), norm, domain_padding=pad, domain_padding_mode=pad_mode)
     np.testing.assert_allclose(y.detach().numpy(), G[f"{c}/y"], rtol=0, atol=1e-11)
     loss = ((y - torch.tensor(G[f"{c}/target"])) ** 2).mean()
     assert abs(float(loss.detach()) - float(G[f"{c}/loss"])) < 1e-12
@@ -42,7 +49,9 @@ def test_hip_path_reproduces_reference_fno(c, dev):
     import ppsci
 
     (mx, my, hid, lift, proj, nl, norm), P, Gr = _case(c)
-    model = ppsci.arch.TFNO2dNet(("x",), ("y",), mx, my, hid, 3, 1, lift, proj, nl, norm=norm)
+    pad, pad_mode = _padding(c)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), mx, my, hid, 3, 1, lift, proj, nl, norm=norm, domain_padding=pad,
+                                 domain_padding_mode=pad_mode)
     model.set_state_dict({k: v.astype(np.float32) for k, v in P.items()})
     d = model.flat_params.device
     y = model({"x": G[f"{c}/x"].astype(np.float32)})["y"]
