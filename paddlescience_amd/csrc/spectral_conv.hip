@@ -192,6 +192,28 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
                         const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
                         void* stream, float xscale = 1.f);
 
+// Clears n floats (n % 2 == 0: complex spectra) with a plain kernel.  Not hipMemsetAsync: as a node of a captured HIP graph
+// the runtime's fill path made every replay of the TFNO step host-bound at 3.5 ms (device time 0.98 ms) once the process
+// had returned memory to the driver (measured on MI355X / ROCm 7.0.2: bench.py's cfg 4 entry after the 1 M-point run).
+struct ZeroArgs {
+  float* p;
+  long long n;
+};
+__global__ void __launch_bounds__(256) spectral_zero_kernel(ZeroArgs a) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; i < a.n; i += (long long)gridDim.x * 512) {
+    a.p[i] = 0.f;
+    a.p[i + 1] = 0.f;
+  }
+}
+static int spectral_zero(float* p, long long n, void* stream) {
+  ZeroArgs a{p, n};
+  long long grid = (n / 2 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  PPSCI_LAUNCH(spectral_zero_kernel, ZeroArgs, (int)grid, 256, 0, stream, a);
+  return PPSCI_LAST_LAUNCH_ERROR() != 0 ? PPSCI_E_LAUNCH : PPSCI_OK;
+}
+
 // out_ft = scale * (x_ft . w) on the kept modes, after clearing the WHOLE output spectrum (`zero_fill` != 0): for callers
 // whose inverse transform destroys its input (hipFFT C2R, ppsci_fft2d_c2r) or that hand over uninitialised memory.
 extern "C" int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
@@ -201,15 +223,10 @@ extern "C" int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, co
     ppsci_set_error("spectral_conv2d_fwd_scaled: null pointer");
     return PPSCI_E_INVALID;
   }
-#ifndef PPSCI_EMU
-  if (zero_fill &&
-      hipMemsetAsync(out_ft, 0, (size_t)d->batch * d->c_out * d->h * d->wf * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    ppsci_set_error("spectral_conv2d_fwd_scaled: hipMemsetAsync failed");
+  if (zero_fill && spectral_zero(out_ft, (long long)d->batch * d->c_out * d->h * d->wf * 2, stream) != PPSCI_OK) {
+    ppsci_set_error("spectral_conv2d_fwd_scaled: clearing the spectrum failed");
     return PPSCI_E_LAUNCH;
   }
-#else
-  if (zero_fill) memset(out_ft, 0, (size_t)d->batch * d->c_out * d->h * d->wf * 2 * sizeof(float));
-#endif
   return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream, scale);
 }
 
@@ -222,15 +239,10 @@ extern "C" int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* 
     ppsci_set_error("spectral_conv2d_bwd_real_scaled: invalid argument");
     return PPSCI_E_INVALID;
   }
-#ifndef PPSCI_EMU
-  if (zero_fill &&
-      hipMemsetAsync(gx_ft, 0, (size_t)d->batch * d->c_in * d->h * d->wf * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    ppsci_set_error("spectral_conv2d_bwd_real_scaled: hipMemsetAsync failed");
+  if (zero_fill && spectral_zero(gx_ft, (long long)d->batch * d->c_in * d->h * d->wf * 2, stream) != PPSCI_OK) {
+    ppsci_set_error("spectral_conv2d_bwd_real_scaled: clearing the spectrum failed");
     return PPSCI_E_LAUNCH;
   }
-#else
-  if (zero_fill) memset(gx_ft, 0, (size_t)d->batch * d->c_in * d->h * d->wf * 2 * sizeof(float));
-#endif
   return spectral_bwd(d, x_ft, w_re, w_im, ghat_ft, gx_ft, gw_re, gw_im, wscale, w_full, stream, xscale);
 }
 

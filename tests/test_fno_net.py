@@ -62,7 +62,9 @@ def test_unbuilt_options_raise():
     with pytest.raises(NotImplementedError):
         ppsci.arch.TFNO1dNet(("x",), ("y",), 4, 8)
     with pytest.raises(NotImplementedError):
-        ppsci.arch.FNONet(("x",), ("y",), (4, 4), 8, domain_padding=0.1)
+        ppsci.arch.FNONet(("x",), ("y",), (4, 4), 8, preactivation=True)
+    # (domain_padding is built since round 3: tests/test_golden_fno.py pins it to reference-run fixtures)
+    assert ppsci.arch.FNONet(("x",), ("y",), (4, 4), 8, domain_padding=0.1).padding_of(16, 20) == (2, 2, 0, 0)
 
 
 def test_solver_trains_fno_like_oracle_adam(dev, tmp_path):
