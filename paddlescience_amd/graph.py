@@ -331,6 +331,7 @@ def _walk(roots: Iterable[Sym]) -> List[Sym]:
 # (n1, n2, n3, n4) combinations the kernels are instantiated for (taylor_fwd.inc / taylor_bwd.inc): first-order
 # directions, and how many of the FIRST of them also carry second / third / fourth-order streams
 _INSTANTIATED = [(0, 0, 0, 0), (1, 1, 0, 0), (2, 0, 0, 0), (2, 1, 0, 0), (2, 2, 0, 0), (3, 2, 0, 0), (3, 3, 0, 0),
+                 (4, 3, 0, 0),  # unsteady 3-D NavierStokes: first derivatives along x, y, z, t, second along x, y, z
                  (1, 1, 1, 0), (1, 1, 1, 1), (2, 2, 2, 2), (4, 4, 4, 4)]
 
 

@@ -623,6 +623,32 @@ def test_unsteady_navier_stokes_and_laplace_3d(tmp_path):
     assert rel(g3, gref3) < 5e-5
 
 
+def test_unsteady_navier_stokes_3d(tmp_path):
+    """NavierStokes(dim=3, time=True) (navier_stokes.py:70-151): four outputs, first derivatives along t, x, y, z and second
+    along x, y, z -> the (4, 3) stream set (S = 8), through the sympy path against the oracle's reverse-over-reverse."""
+    model = ppsci.arch.MLP(("t", "x", "y", "z"), ("u", "v", "w", "p"), 2, 24, "tanh")
+    net = T.make_net(4, [24, 24], 4, bias_scale=0.05)
+    set_model_weights(model, net)
+    N = 23
+    X = np.random.default_rng(34).uniform(-1, 1, (N, 4)).astype(np.float32)
+    eq = ppsci.equation.NavierStokes(0.02, 1.3, 3, True)
+    keys = ("continuity", "momentum_x", "momentum_y", "momentum_z")
+    inp = {k: X[:, j:j + 1] for j, k in enumerate(("t", "x", "y", "z"))}
+    cst = _sup_constraint(inp, {k: np.zeros((N, 1), np.float32) for k in keys}, eq.equations, ppsci.loss.MSELoss("sum"))
+    solver = _solver(tmp_path, model, {"EQ": cst})
+    g = _run(solver)
+    assert solver._compiled["EQ"].fused.streams.S == 8
+    omodel = R.MLP(("t", "x", "y", "z"), ("u", "v", "w", "p"), net.astype(np.float32).astype(np.float64))
+    oc = dict(name="EQ", input={k: v.astype(np.float64) for k, v in inp.items()},
+              exprs={k: R.lambdify(eq.equations[k], omodel) for k in keys}, label={k: np.zeros((N, 1)) for k in keys},
+              reduction="sum")
+    total, losses, gref, _ = R.loss_and_grads(omodel, [oc])
+    got = solver._compiled["EQ"].fused.losses()
+    for k in keys:
+        assert got[k] == pytest.approx(losses[k], rel=5e-5)
+    assert rel(g, gref) < 5e-5
+
+
 def test_periodic_constraint_batches_and_training_step(tmp_path):
     """PeriodicConstraint (periodic_constraint.py:60-166) on a time x rectangle domain: every batch is [half ; images
     of that half along the periodic key]; two training iterations (two different batches) against the oracle."""
