@@ -385,6 +385,13 @@ __device__ __forceinline__ void ppsci_stage_fragB(float* dst, const float* W, in
 // pt = 8 consecutive points), hits 64 distinct banks as well.
 __device__ __forceinline__ int ppsci_xchunk(int fg, int pt) { return fg * 16 + (pt ^ ((fg >> 1) << 3)); }
 
+// Exchange buffers that are read as B operands of K = 32 steps keep the chunks of a block PAIR (2j, 2j+1) side by side, so that
+// one ds_read_b128 delivers both halves of the operand (half the LDS instructions and twice the LDS rate of two 8-byte
+// reads): index, in 8-byte units, of chunk `ch` of plane `pl` of (stream s, block blk) in a buffer of NB blocks per stream.
+__device__ __forceinline__ int ppsci_xpair(int NB, int s, int blk, int pl, int ch) {
+  return (((s * (NB / 2) + (blk >> 1)) * 3 + pl) * 64 + ch) * 2 + (blk & 1);
+}
+
 // u32x4 units per hidden-to-hidden layer of the pre-split global fragments:
 //   gfrag[((rb * (NB/2) + kp) * 3 + plane) * 64 + lane] = the K = 32 A operand of row block rb, k-blocks (2kp | 2kp+1)
 #define PPSCI_GFRAG_PER_LAYER(NB) ((NB) * ((NB) / 2) * 3 * 64)
