@@ -184,7 +184,11 @@ extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_
   if (n_points <= 0 || fill_bwd(a, d, n_points) != PPSCI_OK) return 0;
   int grid = 0;
   if (run_bwd_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
-  const long long slots = bwd_wpart_slots(a, grid);
+  // Sized for BOTH layouts of the single-wave kernels (one slot per workgroup when they accumulate, one per tile + a spare
+  // when they stream): which one runs depends on the process-global ppsci_set_bwd_accum flag at LAUNCH time, and a buffer
+  // sized under one setting must not be overrun under the other.  The feature-split XDL kernels always accumulate.
+  long long slots = bwd_wpart_slots(a, grid);
+  if (!a.xdl_split && (long long)a.ntiles + 1 > slots) slots = (long long)a.ntiles + 1;
   const long long chunks = slots < PPSCI_WRED_CHUNKS ? slots : PPSCI_WRED_CHUNKS;
   // hidden-weight blocks per tile (+ the spare slot) or per workgroup | chunk sums | per-workgroup small-parameter
   // rows | their chunk sums

@@ -451,6 +451,7 @@ struct BwdArgs {
   int resident;
   int tile0;     // first tile of this launch (feature-split kernels; `ntiles` stays the END of the range)
   int accum;     // 1: hidden-weight gradient blocks accumulated per WORKGROUP (wpart has one slot per workgroup)
+  int xdl_split; // 1: planned onto the register-accumulating feature-split kernel (always one slot per workgroup)
   const void* xfrag;  // feature-split XDL kernels: pre-split hidden-weight fragments (ppsci_presplit)
 };
 

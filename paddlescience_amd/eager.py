@@ -207,11 +207,16 @@ class EagerConstraint:
 
         The op-by-op path is a few hundred tiny torch kernels (4 boundary points with fourth derivatives: 4 ms of launches); with
         static shapes the whole sequence -- forward, higher-order autograd, the gradient add -- is captured once into a HIP graph
-        and replayed (PPSCI_EAGER_GRAPH=0 or a failed capture: launched op by op)."""
+        and replayed when PPSCI_EAGER_GRAPH=1 asks for it (default, or a failed capture: launched op by op)."""
         import os
 
-        key = (grad.data_ptr(), float(dp_scale))
-        if not grad.is_cuda or os.environ.get("PPSCI_EAGER_GRAPH", "1") == "0" or self._graph is False:
+        # A replayed graph freezes whatever the user's expressions did on the HOST at capture time (Python branches,
+        # counters, closures over mutable state) and the device pointers of every tensor it touched: the capture is
+        # OPT-IN (PPSCI_EAGER_GRAPH=1; the reference re-runs the Python every step) and keyed by those pointers.
+        key = (grad.data_ptr(), float(dp_scale), self.model.flat_params.data_ptr(),
+               tuple(int(t.data_ptr()) for d in (self.inp, self.lab, self.w) if isinstance(d, dict)
+                     for t in d.values() if isinstance(t, torch.Tensor)))
+        if not grad.is_cuda or os.environ.get("PPSCI_EAGER_GRAPH", "0") != "1" or self._graph is False:
             return self._step(grad, dp_scale)
         if self._graph is not None and self._graph[0] == key:
             self._graph[1].replay()
