@@ -9,9 +9,9 @@ CSRC = os.path.join(ROOT, "paddlescience_amd", "csrc")
 EXTRA = os.environ.get("PPSCI_EMU_EXTRA_FLAGS", "").split()  # experiment builds (e.g. -DPPSCI_WAVE_ACC) get their own directory
 OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "_".join(f.lstrip("-D") for f in EXTRA) if EXTRA else ""))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
+SOURCES = ["taylor_bwd_b_tanh.hip", "taylor_bwd_b_tanh_fourier.hip", "taylor_bwd_b_silu.hip", "taylor_bwd_b_sin.hip", "taylor_bwd_b_cos.hip", "taylor_bwd_b_sigmoid.hip", "taylor_bwd_b_gelu.hip", "taylor_bwd_b_relu.hip", "taylor_bwd_b_leaky_relu.hip", "taylor_bwd_b_elu.hip", "taylor_bwd_b_selu.hip", "taylor_bwd_b_identity.hip", "taylor_bwd_b_swish.hip", "taylor_bwd_b_stan.hip", "taylor_bwd_wx_tanh.hip", "taylor_bwd_wx_tanh_fourier.hip", "taylor_bwd_wx_silu.hip", "taylor_bwd_wx_sin.hip", "taylor_bwd_wx_cos.hip", "taylor_bwd_wx_sigmoid.hip", "taylor_bwd_wx_gelu.hip", "taylor_bwd_wx_relu.hip", "taylor_bwd_wx_leaky_relu.hip", "taylor_bwd_wx_elu.hip", "taylor_bwd_wx_selu.hip", "taylor_bwd_wx_identity.hip", "taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
            "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "fft.hip", "spinn.hip", "pirate.hip", "comm.hip", "epilogue_optim.hip"]
-HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc", "taylor_fwd_wide.inc", "taylor_bwd_wide.inc", "taylor_fwd_wx.inc", "taylor_bwd_wx.inc"]
+HEADERS = ["ppsci_common.h", "taylor_tile.h", "taylor_fwd.inc", "taylor_bwd.inc", "taylor_fwd_wide.inc", "taylor_bwd_wide.inc", "taylor_fwd_wx.inc", "taylor_bwd_wx.inc", "taylor_bwd_wx_tu.inc"]
 
 
 def _newer(dst, srcs):
@@ -26,7 +26,7 @@ def build() -> str:
     lib = os.path.join(OUT, "libppsci_emu.so")
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "ppsci_hip.h"),
                                                        os.path.join(ROOT, "tests", "emu", "hip_emu.h")]
-    flags = EXTRA + ["-x", "c++", "-DPPSCI_EMU", "-DPPSCI_NUM_CU=4", "-O1", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+    flags = EXTRA + ["-x", "c++", "-DPPSCI_EMU", "-DPPSCI_NUM_CU=4", os.environ.get("PPSCI_EMU_OPT", "-O0"), "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
              "-I", os.path.join(ROOT, "tests", "emu")]
 
     def one(src):
