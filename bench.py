@@ -328,13 +328,25 @@ def api_parity(name, inputs, outputs, hidden, make_eq, reduction, weight, tmp):
 
 
 def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
-    def step():
-        solver.engine.forward_backward([cc.fused])
-        opt.step(solver.engine.grad)
+    def step():  # == the body of Solver.train()'s iteration for one constraint
+        if not solver._step_in_one_launch([cc.fused], [], 1.0):
+            solver.engine.forward_backward([cc.fused])
+            opt.step(solver.engine.grad)
 
     t = time_wall(step, steps, warmup)
     if PURE:
         return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps}
+    if solver.engine.one_launch_ready([cc.fused]):
+        # the whole step is ONE kernel (csrc/taylor_step.inc): forward (2 P S flops per point) + reverse (4 P S)
+        t_k = time_events(step)
+        ach = 6.0 * p_mat * S * n / t_k / 1e12
+        name = "taylor_step_kernel" + kernel_name[kernel_name.index("<"):]
+        return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
+                "launches_per_step": 1, "matrix_tflops_step": 6.0 * p_mat * S * n / t / 1e12,
+                "roofline": {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": t_k * 1e3,
+                             "note": "forward + epilogue + reverse + reduction tree + Adam in one launch; latency-bound at "
+                                     "this size (one 16-point tile per wave, one round)"}}
     t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))  # incl. the two small reduction kernels
     t_fwd = time_events(lambda: cc.fused.forward(solver.engine.params, True))
     ach = 4.0 * p_mat * S * n / t_bwd / 1e12

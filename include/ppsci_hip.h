@@ -213,6 +213,42 @@ int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_poi
                      const float* const* inputs_host, const float* Ubar, const void* stash,
                      void* workspace, float* grad_partials, void* stream);
 
+/* Adam hyper-parameters of ppsci_taylor_step (the same quantities as ppsci_adam_step's arguments). */
+typedef struct ppsci_adam_args {
+  float* m;
+  float* v;
+  float lr, beta1, beta2, eps, grad_scale;
+  int64_t step_t; /* 1-based */
+} ppsci_adam_args;
+
+/* One training step of one constraint in ONE launch, for batches of a few thousand points (tiles fit the chip in a
+ * round or two): ppsci_taylor_fwd -> ppsci_epilogue -> ppsci_taylor_bwd of every tile by the wave that owns it, a
+ * fixed-order tree reduction of the workgroups' partial sums by whichever workgroup finishes a group last, then
+ *   grad (+)= dL/dparams (accumulate != 0: the second and later constraints of a step),  loss_terms[k] = loss term k,
+ * and, with adam != NULL, the Adam update of `params` from `grad` (i.e. pass it with the LAST constraint of a step on a
+ * single rank).  Replaces one pass of train.py:82-184 for that constraint; results equal the separate calls' up to the
+ * summation order of the partial sums.  Buffers as for the separate calls (U, Ubar: [m*S, N]; residual_out may be NULL;
+ * stash: ppsci_stash_bytes()); workspace: ppsci_taylor_step_workspace_bytes() bytes, ZERO-filled before the first call
+ * and owned by this constraint from then on.  ppsci_taylor_step_workspace_bytes() == 0 / PPSCI_E_UNSUPPORTED: this
+ * network, stream set or program (learnable equation parameters) has no one-launch kernel -- use the separate calls. */
+int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
+/* The same with the argument block prepared once: a training loop launches the same constraint thousands of times
+ * with the same buffers, and at 20-40 us of device time per step the per-call planning (occupancy / attribute queries,
+ * argument checks) of ppsci_taylor_step would dominate.  _plan: NULL on error / unsupported (ppsci_last_error);
+ * _run: one kernel launch; _set_scales: takes over the residual scales of `e` (loss re-weighting between steps). */
+typedef struct ppsci_step_plan ppsci_step_plan;
+ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params,
+                                        int64_t n_points, const float* const* inputs_host, const float* const* aux_host,
+                                        float* U, float* Ubar, float* residual_out, void* stash, void* workspace,
+                                        float* loss_terms, float* grad);
+int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream);
+int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogue_desc* e);
+void ppsci_taylor_step_plan_free(ppsci_step_plan* plan);
+int ppsci_taylor_step(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params, int64_t n_points,
+                      const float* const* inputs_host, const float* const* aux_host, float* U, float* Ubar,
+                      float* residual_out, void* stash, void* workspace, float* loss_terms, float* grad, int accumulate,
+                      const ppsci_adam_args* adam, void* stream);
+
 /* out[j] (+)= sum_r partials[r, j], fixed summation order (deterministic).  Used for the
  * gradient (cols = P) and for the loss terms (cols = n_res; mtl/sum.py:45-60 adds them). */
 int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t cols, float* out, int accumulate,

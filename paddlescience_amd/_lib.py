@@ -75,6 +75,11 @@ class EpilogueDesc(C.Structure):
     ]
 
 
+class AdamArgs(C.Structure):  # ppsci_adam_args
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("grad_scale", C.c_float), ("step_t", C.c_int64)]
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libppsci_hip.so")
 _lib: Optional[C.CDLL] = None
@@ -101,6 +106,16 @@ _SYMBOLS = {
     "ppsci_taylor_bwd": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "ppsci_taylor_step_workspace_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_int64]),
+    "ppsci_taylor_step_plan": (C.c_void_p, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_void_p, C.c_int64,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_taylor_step_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p]),
+    "ppsci_taylor_step_plan_set_scales": (C.c_int, [C.c_void_p, C.POINTER(EpilogueDesc)]),
+    "ppsci_taylor_step_plan_free": (None, [C.c_void_p]),
+    "ppsci_taylor_step": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p]),
     "ppsci_spectral_conv2d_fwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
     "ppsci_spectral_conv2d_bwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,12 +1,6 @@
 // epilogue_optim.hip -- pointwise epilogue VM (+ fused MSE and its adjoint), row reduction, Adam.
 //
-// Epilogue: replaces the chain of tiny elementwise kernels the reference launches for
-//   OperatorNode / ConstantNode / DetachNode   /root/reference/ppsci/utils/symbolic.py:184-267,433-468,165-181
-//   AllenCahn closure body                     /root/reference/ppsci/equation/pde/allen_cahn.py:62
-//   MSELoss.forward                            /root/reference/ppsci/loss/mse.py:82-105
-// and the seed of total_loss.backward() (train.py:158) for the pointwise part.
-// One lane = one collocation point; all HBM traffic is coalesced SoA ([row][N] arrays).  The
-// program is uniform across lanes (no divergence); values live in a per-lane array.
+// Epilogue: the VM itself is in epilogue_vm.h (shared with the one-launch step kernel); here its stand-alone launch.
 // Adam: paddle.optimizer.Adam as configured by /root/reference/ppsci/optimizer/optimizer.py:225-248.
 #include "ppsci_common.h"
 
@@ -17,212 +11,12 @@
 #include <stdio.h>
 #include <string.h>
 
-#define EPI_BLOCK 256
+#include "epilogue_vm.h"
 
-struct EpiArgs {
-  ppsci_epilogue_desc e;
-  const float* x[PPSCI_MAX_IN];
-  const float* aux[PPSCI_MAX_AUX];
-  const float* U;
-  float* resid;     // may be null: [n_res, N]
-  float* Ubar;      // may be null: [n_streams, N]
-  float* partials;  // [gridDim.x, n_res]
-  const float* ep;  // [PPSCI_MAX_EPARAM] learnable equation parameters (may be null)
-  float* ep_part;   // [gridDim.x, PPSCI_MAX_EPARAM] (may be null)
-  long long N;
-  int iters;
-};
-
-// d/dx lgamma(x) (the adjoint of paddle.lgamma): reflection for x < 0.5, recurrence up to x >= 6, then the
-// asymptotic series ln x - 1/(2x) - 1/(12x^2) + 1/(120x^4) - 1/(252x^6)  (truncation < 1e-8 at x = 6).
-__device__ __forceinline__ float epi_digamma(float x) {
-  float refl = 0.f;
-  if (x < 0.5f) {
-    refl = -3.14159265358979f / tanf(3.14159265358979f * x);
-    x = 1.f - x;
-  }
-  float acc = 0.f;
-  while (x < 6.f) {
-    acc -= 1.f / x;
-    x += 1.f;
-  }
-  const float i1 = 1.f / x, i2 = i1 * i1;
-  return refl + acc + logf(x) - 0.5f * i1 - i2 * (1.f / 12.f - i2 * (1.f / 120.f - i2 * (1.f / 252.f)));
-}
-
+template <int MODE>
 __global__ void __launch_bounds__(EPI_BLOCK) epilogue_kernel(EpiArgs a) {
-  PPSCI_DYN_SMEM(red);  // [EPI_BLOCK]
-  const int tid = threadIdx.x;
-  const int n = a.e.n_instr;
-  float lsum[PPSCI_MAX_RES];
-  for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
-  float padj[PPSCI_MAX_EPARAM];  // adjoints of the equation parameters, summed over this lane's points
-#pragma unroll
-  for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
-
-  for (int it = 0; it < a.iters; ++it) {
-    const long long p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
-    const bool valid = p < a.N;
-    const long long pp = valid ? p : 0;
-    float v[PPSCI_MAX_PROG];
-    float adj[PPSCI_MAX_PROG];
-    // ---- forward
-    for (int i = 0; i < n; ++i) {
-      const ppsci_instr ins = a.e.prog[i];
-      float r;
-      switch (ins.op) {
-        case PPSCI_OP_LD_IN: r = a.x[ins.a][pp]; break;
-        case PPSCI_OP_LD_U: r = a.U[(long long)ins.a * a.N + pp]; break;
-        case PPSCI_OP_LD_AUX: r = a.aux[ins.a][pp]; break;
-        case PPSCI_OP_CONST: r = ins.c; break;
-        case PPSCI_OP_LD_PARAM: r = a.ep[ins.a]; break;
-        case PPSCI_OP_ADD: r = v[ins.a] + v[ins.b]; break;
-        case PPSCI_OP_SUB: r = v[ins.a] - v[ins.b]; break;
-        case PPSCI_OP_MUL: r = v[ins.a] * v[ins.b]; break;
-        case PPSCI_OP_DIV: r = v[ins.a] / v[ins.b]; break;
-        case PPSCI_OP_NEG: r = -v[ins.a]; break;
-        case PPSCI_OP_POW: r = powf(v[ins.a], v[ins.b]); break;
-        case PPSCI_OP_SIN: r = sinf(v[ins.a]); break;
-        case PPSCI_OP_COS: r = cosf(v[ins.a]); break;
-        case PPSCI_OP_TANH: r = tanhf(v[ins.a]); break;
-        case PPSCI_OP_EXP: r = expf(v[ins.a]); break;
-        case PPSCI_OP_LOG: r = logf(v[ins.a]); break;
-        case PPSCI_OP_SQRT: r = sqrtf(v[ins.a]); break;
-        case PPSCI_OP_ABS: r = fabsf(v[ins.a]); break;
-        case PPSCI_OP_SINH: r = sinhf(v[ins.a]); break;
-        case PPSCI_OP_COSH: r = coshf(v[ins.a]); break;
-        case PPSCI_OP_TAN: r = tanf(v[ins.a]); break;
-        case PPSCI_OP_MAX: r = fmaxf(v[ins.a], v[ins.b]); break;
-        case PPSCI_OP_MIN: r = fminf(v[ins.a], v[ins.b]); break;
-        case PPSCI_OP_SIGN: r = (v[ins.a] > 0.f) ? 1.f : ((v[ins.a] < 0.f) ? -1.f : 0.f); break;
-        case PPSCI_OP_HEAVISIDE: r = (v[ins.a] > 0.f) ? 1.f : 0.f; break;  // heaviside(x, y=0)
-        case PPSCI_OP_DETACH: r = v[ins.a]; break;
-        case PPSCI_OP_ASIN: r = asinf(v[ins.a]); break;
-        case PPSCI_OP_ACOS: r = acosf(v[ins.a]); break;
-        case PPSCI_OP_ATAN: r = atanf(v[ins.a]); break;
-        case PPSCI_OP_ATAN2: r = atan2f(v[ins.a], v[ins.b]); break;
-        case PPSCI_OP_ASINH: r = asinhf(v[ins.a]); break;
-        case PPSCI_OP_ACOSH: r = acoshf(v[ins.a]); break;
-        case PPSCI_OP_ATANH: r = atanhf(v[ins.a]); break;
-        case PPSCI_OP_ERF: r = erff(v[ins.a]); break;
-        case PPSCI_OP_LGAMMA: r = lgammaf(v[ins.a]); break;
-        case PPSCI_OP_CEIL: r = ceilf(v[ins.a]); break;
-        case PPSCI_OP_FLOOR: r = floorf(v[ins.a]); break;
-        default: r = 0.f; break;
-      }
-      v[i] = r;
-      adj[i] = 0.f;
-    }
-    // ---- residuals, loss terms and their seeds
-    for (int k = 0; k < a.e.n_res; ++k) {
-      const ppsci_residual rs = a.e.res[k];
-      const float rv = v[rs.value];
-      if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
-      const float lab = (rs.label >= 0) ? a.aux[rs.label][pp] : 0.f;
-      float w = 1.f;
-      if (rs.weight >= 0) w *= a.aux[rs.weight][pp];
-      if (rs.area >= 0 && rs.kind != PPSCI_LOSS_ABSREL) w *= a.aux[rs.area][pp];
-      const float diff = rv - lab;
-      if (valid) {
-        if (rs.kind == PPSCI_LOSS_MSE) {
-          w *= rs.scale;
-          lsum[k] += w * diff * diff;
-          adj[rs.value] += 2.f * w * diff;
-        } else {
-          float f = rs.scale * (rs.kind == PPSCI_LOSS_SQRTABS ? sqrtf(w) : w);
-          if (rs.kind == PPSCI_LOSS_ABSREL) f /= fabsf(lab);
-          lsum[k] += f * fabsf(diff);
-          adj[rs.value] += diff > 0.f ? f : (diff < 0.f ? -f : 0.f);
-        }
-      }
-    }
-    // ---- reverse
-    if (a.Ubar != nullptr) {
-      for (int i = n - 1; i >= 0; --i) {
-        const ppsci_instr ins = a.e.prog[i];
-        const float g = adj[i];
-        switch (ins.op) {
-          case PPSCI_OP_LD_U:
-            if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
-            break;
-          case PPSCI_OP_LD_PARAM:
-#pragma unroll
-            for (int k = 0; k < PPSCI_MAX_EPARAM; ++k)
-              if (ins.a == k) padj[k] += g;  // invalid lanes carry g = 0 (their seeds are never set)
-            break;
-          case PPSCI_OP_ADD: adj[ins.a] += g; adj[ins.b] += g; break;
-          case PPSCI_OP_SUB: adj[ins.a] += g; adj[ins.b] -= g; break;
-          case PPSCI_OP_MUL: adj[ins.a] += g * v[ins.b]; adj[ins.b] += g * v[ins.a]; break;
-          case PPSCI_OP_DIV: {
-            const float inv = 1.f / v[ins.b];
-            adj[ins.a] += g * inv;
-            adj[ins.b] -= g * v[i] * inv;
-          } break;
-          case PPSCI_OP_NEG: adj[ins.a] -= g; break;
-          case PPSCI_OP_POW: {
-            const float x = v[ins.a], y = v[ins.b];
-            adj[ins.a] += g * y * powf(x, y - 1.f);
-            if (x > 0.f) adj[ins.b] += g * v[i] * logf(x);
-          } break;
-          case PPSCI_OP_SIN: adj[ins.a] += g * cosf(v[ins.a]); break;
-          case PPSCI_OP_COS: adj[ins.a] -= g * sinf(v[ins.a]); break;
-          case PPSCI_OP_TANH: adj[ins.a] += g * (1.f - v[i] * v[i]); break;
-          case PPSCI_OP_EXP: adj[ins.a] += g * v[i]; break;
-          case PPSCI_OP_LOG: adj[ins.a] += g / v[ins.a]; break;
-          case PPSCI_OP_SQRT: adj[ins.a] += g * 0.5f / v[i]; break;
-          case PPSCI_OP_ABS: adj[ins.a] += g * ((v[ins.a] > 0.f) ? 1.f : ((v[ins.a] < 0.f) ? -1.f : 0.f)); break;
-          case PPSCI_OP_SINH: adj[ins.a] += g * coshf(v[ins.a]); break;
-          case PPSCI_OP_COSH: adj[ins.a] += g * sinhf(v[ins.a]); break;
-          case PPSCI_OP_TAN: adj[ins.a] += g * (1.f + v[i] * v[i]); break;
-          case PPSCI_OP_MAX:
-            if (v[ins.a] >= v[ins.b]) adj[ins.a] += g; else adj[ins.b] += g;
-            break;
-          case PPSCI_OP_MIN:
-            if (v[ins.a] <= v[ins.b]) adj[ins.a] += g; else adj[ins.b] += g;
-            break;
-          case PPSCI_OP_ASIN: adj[ins.a] += g / sqrtf(1.f - v[ins.a] * v[ins.a]); break;
-          case PPSCI_OP_ACOS: adj[ins.a] -= g / sqrtf(1.f - v[ins.a] * v[ins.a]); break;
-          case PPSCI_OP_ATAN: adj[ins.a] += g / (1.f + v[ins.a] * v[ins.a]); break;
-          case PPSCI_OP_ATAN2: {
-            const float y = v[ins.a], x = v[ins.b], inv = 1.f / (x * x + y * y);
-            adj[ins.a] += g * x * inv;
-            adj[ins.b] -= g * y * inv;
-          } break;
-          case PPSCI_OP_ASINH: adj[ins.a] += g / sqrtf(v[ins.a] * v[ins.a] + 1.f); break;
-          case PPSCI_OP_ACOSH: adj[ins.a] += g / sqrtf(v[ins.a] * v[ins.a] - 1.f); break;
-          case PPSCI_OP_ATANH: adj[ins.a] += g / (1.f - v[ins.a] * v[ins.a]); break;
-          case PPSCI_OP_ERF: adj[ins.a] += g * 1.1283791670955126f * expf(-v[ins.a] * v[ins.a]); break;
-          case PPSCI_OP_LGAMMA: adj[ins.a] += g * epi_digamma(v[ins.a]); break;
-          default: break;  // LD_IN, LD_AUX, CONST, SIGN, HEAVISIDE, DETACH, CEIL, FLOOR: no adjoint flows
-        }
-      }
-    }
-  }
-
-  // ---- block reduction of the loss terms (fixed tree order => deterministic)
-  for (int k = 0; k < a.e.n_res; ++k) {
-    __syncthreads();
-    red[tid] = lsum[k];
-    __syncthreads();
-    for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
-      __syncthreads();
-    }
-    if (tid == 0) a.partials[(long long)blockIdx.x * a.e.n_res + k] = red[0];
-  }
-  if (a.ep_part != nullptr) {
-#pragma unroll
-    for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) {
-      __syncthreads();
-      red[tid] = padj[k];
-      __syncthreads();
-      for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-      }
-      if (tid == 0) a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = red[0];
-    }
-  }
+  PPSCI_DYN_SMEM(red);  // [EPI_BLOCK] (+ EPI_RF_LDS: [2][n][EPI_BLOCK])
+  epilogue_body<MODE>(a, red);
 }
 
 // ---------------------------------------------------------------------------------- reduce / Adam
@@ -482,8 +276,14 @@ extern "C" int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_poi
   a.ep = eq_params;
   a.ep_part = (uses_params && Ubar != nullptr) ? eq_param_partials : nullptr;
   a.N = n_points;
+  epi_fill_loads(a);
   const int grid = epi_grid(n_points, &a.iters);
-  PPSCI_LAUNCH(epilogue_kernel, EpiArgs, grid, EPI_BLOCK, EPI_BLOCK * sizeof(float), stream, a);
+  if (a.e.n_instr <= EPI_LDS_PROG) {
+    const int lds = (EPI_BLOCK + 2 * a.e.n_instr * EPI_BLOCK) * (int)sizeof(float);
+    PPSCI_LAUNCH(epilogue_kernel<EPI_RF_LDS>, EpiArgs, grid, EPI_BLOCK, lds, stream, a);
+  } else {
+    PPSCI_LAUNCH(epilogue_kernel<EPI_RF_SCRATCH>, EpiArgs, grid, EPI_BLOCK, EPI_BLOCK * sizeof(float), stream, a);
+  }
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("epilogue: launch failed (hip error %d)", err);

@@ -1,0 +1,299 @@
+// epilogue_vm.h -- the pointwise epilogue VM (+ fused loss terms and their adjoints) as a device function, shared by
+// the stand-alone epilogue kernel (epilogue_optim.hip) and the one-launch step kernel (taylor_step.inc).
+//
+// Replaces the chain of tiny elementwise kernels the reference launches for
+//   OperatorNode / ConstantNode / DetachNode   /root/reference/ppsci/utils/symbolic.py:184-267,433-468,165-181
+//   AllenCahn closure body                     /root/reference/ppsci/equation/pde/allen_cahn.py:62
+//   MSELoss.forward                            /root/reference/ppsci/loss/mse.py:82-105
+// and the seed of total_loss.backward() (train.py:158) for the pointwise part.
+// One lane = one collocation point; all HBM traffic is coalesced SoA ([row][N] arrays).  The
+// program is uniform across lanes (no divergence).
+#pragma once
+#include "taylor_tile.h"
+
+#define EPI_BLOCK 256
+#define EPI_LDS_PROG 20  // longest program whose VM register file is kept in LDS (2 x 20 KiB per workgroup: 3 per CU)
+
+struct EpiArgs {
+  ppsci_epilogue_desc e;
+  const float* x[PPSCI_MAX_IN];
+  const float* aux[PPSCI_MAX_AUX];
+  const float* U;
+  float* resid;     // may be null: [n_res, N]
+  float* Ubar;      // may be null: [n_streams, N]
+  float* partials;  // [gridDim.x, n_res]
+  const float* ep;  // [PPSCI_MAX_EPARAM] learnable equation parameters (may be null)
+  float* ep_part;   // [gridDim.x, PPSCI_MAX_EPARAM] (may be null)
+  long long N;
+  int iters;
+  int ntiles;  // EPI_RF_TILED only
+  int nload;   // the program's load instructions (LD_IN / LD_U / LD_AUX), in program order: epi_fill_loads()
+  unsigned char load_idx[PPSCI_MAX_PROG];
+};
+
+// host: list the load instructions of a.e (after a.e is set)
+static inline void epi_fill_loads(EpiArgs& a) {
+  a.nload = 0;
+  for (int i = 0; i < a.e.n_instr; ++i) {
+    const int op = a.e.prog[i].op;
+    if (op == PPSCI_OP_LD_IN || op == PPSCI_OP_LD_U || op == PPSCI_OP_LD_AUX) a.load_idx[a.nload++] = (unsigned char)i;
+  }
+}
+
+// d/dx lgamma(x) (the adjoint of paddle.lgamma): reflection for x < 0.5, recurrence up to x >= 6, then the
+// asymptotic series ln x - 1/(2x) - 1/(12x^2) + 1/(120x^4) - 1/(252x^6)  (truncation < 1e-8 at x = 6).
+__device__ __forceinline__ float epi_digamma(float x) {
+  float refl = 0.f;
+  if (x < 0.5f) {
+    refl = -3.14159265358979f / tanf(3.14159265358979f * x);
+    x = 1.f - x;
+  }
+  float acc = 0.f;
+  while (x < 6.f) {
+    acc -= 1.f / x;
+    x += 1.f;
+  }
+  const float i1 = 1.f / x, i2 = i1 * i1;
+  return refl + acc + logf(x) - 0.5f * i1 - i2 * (1.f / 12.f - i2 * (1.f / 120.f - i2 * (1.f / 252.f)));
+}
+
+// The VM's register file (values and adjoints of the n instructions), by MODE:
+//   EPI_RF_SCRATCH  per-lane scratch memory (dynamic indexing: 1 040 bytes per lane, every access a scratch round trip)
+//   EPI_RF_LDS      LDS, [n][EPI_BLOCK] floats each (conflict-free: lane-consecutive), for programs of at most
+//                   EPI_LDS_PROG instructions -- the pointwise programs of the BASELINE PDEs (Laplace 3, Allen-Cahn 12)
+//   EPI_RF_TILED    inside the one-launch step kernel (taylor_step.inc): wave w runs the program for the 16 points of
+//                   ITS tile on lanes 0..15 (the tile the same wave's forward sweep has just produced and its reverse
+//                   sweep consumes next); register file in LDS, [n][16 * waves]
+// `red`: EPI_BLOCK floats of LDS for the loss reductions, followed by the register file (LDS modes).
+#define EPI_RF_SCRATCH 0
+#define EPI_RF_LDS 1
+#define EPI_RF_TILED 2
+template <int MODE>
+__device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
+  const int tid = threadIdx.x;
+  const int n = a.e.n_instr;
+  constexpr bool LDSRF = MODE != EPI_RF_SCRATCH;
+  float v_s[LDSRF ? 1 : PPSCI_MAX_PROG], adj_s[LDSRF ? 1 : PPSCI_MAX_PROG];
+  const int RS = MODE == EPI_RF_SCRATCH ? 1 : (MODE == EPI_RF_LDS ? EPI_BLOCK : (int)(blockDim.x >> 2));
+  const int slot = MODE == EPI_RF_TILED ? ((tid >> 6) * PPSCI_TILE + (tid & 15)) : tid;
+  float* const vp = LDSRF ? red + EPI_BLOCK + slot : v_s;
+  float* const ap = LDSRF ? red + EPI_BLOCK + (long long)n * RS + slot : adj_s;
+  float lsum[PPSCI_MAX_RES];
+  for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
+  float padj[PPSCI_MAX_EPARAM];  // adjoints of the equation parameters, summed over this lane's points
+#pragma unroll
+  for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
+
+  for (int it = 0; it < a.iters; ++it) {
+    if (MODE == EPI_RF_TILED && (tid & 63) >= PPSCI_TILE) break;  // lanes 0..15 of every wave run the tile's points
+    long long p;
+    bool valid;
+    if (MODE == EPI_RF_TILED) {
+      const int tile = ppsci_tile_index(it, (int)(blockDim.x >> 6));
+      p = (long long)tile * PPSCI_TILE + (tid & 15);
+      valid = tile < a.ntiles && p < a.N;
+    } else {
+      p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
+      valid = p < a.N;
+    }
+    const long long pp = valid ? p : 0;
+    // labels / weights / areas of the first two loss terms: requested now, used behind the forward pass (they come
+    // from HBM -- a round trip of their own when requested where they are used).  Named scalars: an array indexed by
+    // the term number ends up in scratch memory.
+#define EPI_PF(k_, L_, W_, A_)                                                   \
+  float L_ = 0.f, W_ = 0.f, A_ = 0.f;                                            \
+  if (k_ < a.e.n_res) {                                                          \
+    const ppsci_residual rs_ = a.e.res[k_];                                      \
+    if (rs_.label >= 0) L_ = a.aux[rs_.label][pp];                              \
+    if (rs_.weight >= 0) W_ = a.aux[rs_.weight][pp];                             \
+    if (rs_.area >= 0) A_ = a.aux[rs_.area][pp];                                 \
+  }
+    EPI_PF(0, pfl0, pfw0, pfa0)
+    EPI_PF(1, pfl1, pfw1, pfa1)
+#undef EPI_PF
+    // ---- forward, pass 1: every memory operand of the program, eight loads in flight at a time, straight into the
+    // register file (issued one per VM step, each load is a full round trip that the next instruction waits for:
+    // 5-6 us for the eight loads of a Laplace program with label and weight, against well under 1 us of arithmetic)
+    for (int base = 0; base < a.nload; base += 8) {
+      float tv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = a.load_idx[base + k < a.nload ? base + k : a.nload - 1];
+        const ppsci_instr ins = a.e.prog[i];
+        const float* src = ins.op == PPSCI_OP_LD_IN ? a.x[ins.a] : (ins.op == PPSCI_OP_LD_U ? a.U + (long long)ins.a * a.N : a.aux[ins.a]);
+        tv[k] = src[pp];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (base + k < a.nload) vp[(a.load_idx[base + k]) * RS] = tv[k];
+    }
+    // ---- forward, pass 2
+    for (int i = 0; i < n; ++i) {
+      const ppsci_instr ins = a.e.prog[i];
+      float r;
+      switch (ins.op) {
+        case PPSCI_OP_LD_IN:
+        case PPSCI_OP_LD_U:
+        case PPSCI_OP_LD_AUX: r = vp[(i) * RS]; break;  // pass 1
+        case PPSCI_OP_CONST: r = ins.c; break;
+        case PPSCI_OP_LD_PARAM: r = a.ep[ins.a]; break;
+        case PPSCI_OP_ADD: r = vp[(ins.a) * RS] + vp[(ins.b) * RS]; break;
+        case PPSCI_OP_SUB: r = vp[(ins.a) * RS] - vp[(ins.b) * RS]; break;
+        case PPSCI_OP_MUL: r = vp[(ins.a) * RS] * vp[(ins.b) * RS]; break;
+        case PPSCI_OP_DIV: r = vp[(ins.a) * RS] / vp[(ins.b) * RS]; break;
+        case PPSCI_OP_NEG: r = -vp[(ins.a) * RS]; break;
+        case PPSCI_OP_POW: r = powf(vp[(ins.a) * RS], vp[(ins.b) * RS]); break;
+        case PPSCI_OP_SIN: r = sinf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_COS: r = cosf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_TANH: r = tanhf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_EXP: r = expf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_LOG: r = logf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_SQRT: r = sqrtf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ABS: r = fabsf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_SINH: r = sinhf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_COSH: r = coshf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_TAN: r = tanf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_MAX: r = fmaxf(vp[(ins.a) * RS], vp[(ins.b) * RS]); break;
+        case PPSCI_OP_MIN: r = fminf(vp[(ins.a) * RS], vp[(ins.b) * RS]); break;
+        case PPSCI_OP_SIGN: r = (vp[(ins.a) * RS] > 0.f) ? 1.f : ((vp[(ins.a) * RS] < 0.f) ? -1.f : 0.f); break;
+        case PPSCI_OP_HEAVISIDE: r = (vp[(ins.a) * RS] > 0.f) ? 1.f : 0.f; break;  // heaviside(x, y=0)
+        case PPSCI_OP_DETACH: r = vp[(ins.a) * RS]; break;
+        case PPSCI_OP_ASIN: r = asinf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ACOS: r = acosf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ATAN: r = atanf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ATAN2: r = atan2f(vp[(ins.a) * RS], vp[(ins.b) * RS]); break;
+        case PPSCI_OP_ASINH: r = asinhf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ACOSH: r = acoshf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ATANH: r = atanhf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_ERF: r = erff(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_LGAMMA: r = lgammaf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_CEIL: r = ceilf(vp[(ins.a) * RS]); break;
+        case PPSCI_OP_FLOOR: r = floorf(vp[(ins.a) * RS]); break;
+        default: r = 0.f; break;
+      }
+      vp[(i) * RS] = r;
+      ap[(i) * RS] = 0.f;
+    }
+    // ---- residuals, loss terms and their seeds
+    for (int k = 0; k < a.e.n_res; ++k) {
+      const ppsci_residual rs = a.e.res[k];
+      float labl, wgtl, arel;
+      if (k == 0) labl = pfl0, wgtl = pfw0, arel = pfa0;
+      else if (k == 1) labl = pfl1, wgtl = pfw1, arel = pfa1;
+      else {  // label, weight and area in ONE round trip: unconditional loads from clamped rows, selected afterwards
+        labl = a.aux[rs.label >= 0 ? rs.label : 0] != nullptr ? a.aux[rs.label >= 0 ? rs.label : 0][pp] : 0.f;
+        wgtl = a.aux[rs.weight >= 0 ? rs.weight : 0] != nullptr ? a.aux[rs.weight >= 0 ? rs.weight : 0][pp] : 0.f;
+        arel = a.aux[rs.area >= 0 ? rs.area : 0] != nullptr ? a.aux[rs.area >= 0 ? rs.area : 0][pp] : 0.f;
+      }
+      const float rv = vp[(rs.value) * RS];
+      if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
+      const float lab = (rs.label >= 0) ? labl : 0.f;
+      float w = 1.f;
+      if (rs.weight >= 0) w *= wgtl;
+      if (rs.area >= 0 && rs.kind != PPSCI_LOSS_ABSREL) w *= arel;
+      const float diff = rv - lab;
+      if (valid) {
+        if (rs.kind == PPSCI_LOSS_MSE) {
+          w *= rs.scale;
+          lsum[k] += w * diff * diff;
+          ap[(rs.value) * RS] += 2.f * w * diff;
+        } else {
+          float f = rs.scale * (rs.kind == PPSCI_LOSS_SQRTABS ? sqrtf(w) : w);
+          if (rs.kind == PPSCI_LOSS_ABSREL) f /= fabsf(lab);
+          lsum[k] += f * fabsf(diff);
+          ap[(rs.value) * RS] += diff > 0.f ? f : (diff < 0.f ? -f : 0.f);
+        }
+      }
+    }
+    // ---- reverse
+    if (a.Ubar != nullptr) {
+      for (int i = n - 1; i >= 0; --i) {
+        const ppsci_instr ins = a.e.prog[i];
+        const float g = ap[(i) * RS];
+        switch (ins.op) {
+          case PPSCI_OP_LD_U:
+            if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
+            break;
+          case PPSCI_OP_LD_PARAM:
+#pragma unroll
+            for (int k = 0; k < PPSCI_MAX_EPARAM; ++k)
+              if (ins.a == k) padj[k] += g;  // invalid lanes carry g = 0 (their seeds are never set)
+            break;
+          case PPSCI_OP_ADD: ap[(ins.a) * RS] += g; ap[(ins.b) * RS] += g; break;
+          case PPSCI_OP_SUB: ap[(ins.a) * RS] += g; ap[(ins.b) * RS] -= g; break;
+          case PPSCI_OP_MUL: ap[(ins.a) * RS] += g * vp[(ins.b) * RS]; ap[(ins.b) * RS] += g * vp[(ins.a) * RS]; break;
+          case PPSCI_OP_DIV: {
+            const float inv = 1.f / vp[(ins.b) * RS];
+            ap[(ins.a) * RS] += g * inv;
+            ap[(ins.b) * RS] -= g * vp[(i) * RS] * inv;
+          } break;
+          case PPSCI_OP_NEG: ap[(ins.a) * RS] -= g; break;
+          case PPSCI_OP_POW: {
+            const float x = vp[(ins.a) * RS], y = vp[(ins.b) * RS];
+            ap[(ins.a) * RS] += g * y * powf(x, y - 1.f);
+            if (x > 0.f) ap[(ins.b) * RS] += g * vp[(i) * RS] * logf(x);
+          } break;
+          case PPSCI_OP_SIN: ap[(ins.a) * RS] += g * cosf(vp[(ins.a) * RS]); break;
+          case PPSCI_OP_COS: ap[(ins.a) * RS] -= g * sinf(vp[(ins.a) * RS]); break;
+          case PPSCI_OP_TANH: ap[(ins.a) * RS] += g * (1.f - vp[(i) * RS] * vp[(i) * RS]); break;
+          case PPSCI_OP_EXP: ap[(ins.a) * RS] += g * vp[(i) * RS]; break;
+          case PPSCI_OP_LOG: ap[(ins.a) * RS] += g / vp[(ins.a) * RS]; break;
+          case PPSCI_OP_SQRT: ap[(ins.a) * RS] += g * 0.5f / vp[(i) * RS]; break;
+          case PPSCI_OP_ABS: ap[(ins.a) * RS] += g * ((vp[(ins.a) * RS] > 0.f) ? 1.f : ((vp[(ins.a) * RS] < 0.f) ? -1.f : 0.f)); break;
+          case PPSCI_OP_SINH: ap[(ins.a) * RS] += g * coshf(vp[(ins.a) * RS]); break;
+          case PPSCI_OP_COSH: ap[(ins.a) * RS] += g * sinhf(vp[(ins.a) * RS]); break;
+          case PPSCI_OP_TAN: ap[(ins.a) * RS] += g * (1.f + vp[(i) * RS] * vp[(i) * RS]); break;
+          case PPSCI_OP_MAX:
+            if (vp[(ins.a) * RS] >= vp[(ins.b) * RS]) ap[(ins.a) * RS] += g; else ap[(ins.b) * RS] += g;
+            break;
+          case PPSCI_OP_MIN:
+            if (vp[(ins.a) * RS] <= vp[(ins.b) * RS]) ap[(ins.a) * RS] += g; else ap[(ins.b) * RS] += g;
+            break;
+          case PPSCI_OP_ASIN: ap[(ins.a) * RS] += g / sqrtf(1.f - vp[(ins.a) * RS] * vp[(ins.a) * RS]); break;
+          case PPSCI_OP_ACOS: ap[(ins.a) * RS] -= g / sqrtf(1.f - vp[(ins.a) * RS] * vp[(ins.a) * RS]); break;
+          case PPSCI_OP_ATAN: ap[(ins.a) * RS] += g / (1.f + vp[(ins.a) * RS] * vp[(ins.a) * RS]); break;
+          case PPSCI_OP_ATAN2: {
+            const float y = vp[(ins.a) * RS], x = vp[(ins.b) * RS], inv = 1.f / (x * x + y * y);
+            ap[(ins.a) * RS] += g * x * inv;
+            ap[(ins.b) * RS] -= g * y * inv;
+          } break;
+          case PPSCI_OP_ASINH: ap[(ins.a) * RS] += g / sqrtf(vp[(ins.a) * RS] * vp[(ins.a) * RS] + 1.f); break;
+          case PPSCI_OP_ACOSH: ap[(ins.a) * RS] += g / sqrtf(vp[(ins.a) * RS] * vp[(ins.a) * RS] - 1.f); break;
+          case PPSCI_OP_ATANH: ap[(ins.a) * RS] += g / (1.f - vp[(ins.a) * RS] * vp[(ins.a) * RS]); break;
+          case PPSCI_OP_ERF: ap[(ins.a) * RS] += g * 1.1283791670955126f * expf(-vp[(ins.a) * RS] * vp[(ins.a) * RS]); break;
+          case PPSCI_OP_LGAMMA: ap[(ins.a) * RS] += g * epi_digamma(vp[(ins.a) * RS]); break;
+          default: break;  // LD_IN, LD_AUX, CONST, SIGN, HEAVISIDE, DETACH, CEIL, FLOOR: no adjoint flows
+        }
+      }
+    }
+  }
+
+  // ---- block reduction of the loss terms (fixed tree order => deterministic)
+  for (int k = 0; k < a.e.n_res; ++k) {
+    __syncthreads();
+    red[tid] = lsum[k];
+    __syncthreads();
+    for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) {  // (inside the one-launch step kernel other workgroups read the row before the launch ends)
+      if (MODE == EPI_RF_TILED) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + k], red[0]);
+      else a.partials[(long long)blockIdx.x * a.e.n_res + k] = red[0];
+    }
+  }
+  if (a.ep_part != nullptr) {
+#pragma unroll
+    for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) {
+      __syncthreads();
+      red[tid] = padj[k];
+      __syncthreads();
+      for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+      }
+      if (tid == 0) a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = red[0];
+    }
+  }
+}
+

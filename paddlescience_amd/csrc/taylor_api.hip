@@ -1,7 +1,9 @@
 // taylor_api.hip -- C ABI entry points of the Taylor-mode forward / reverse kernels: argument
 // checks, derived sizes, and dispatch to the per-activation translation units.
 #include "taylor_tile.h"
+#include "taylor_step.h"
 
+#include <math.h>
 #include <string.h>
 
 // ---- pre-split hidden-weight fragments for the feature-split XDL kernels (taylor_fwd_wx.inc / taylor_bwd_wx.inc) ----
@@ -242,4 +244,208 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   // rows of W0 / biases / W_last, written in the canonical parameter layout
   return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_rows, grid, small_tmp, grad_partials,
                             stream);
+}
+
+// ------------------------------------------------------------------------------------ one-launch step
+static int run_step_act(StepArgs& a, void* stream, int launch, int* grid) {
+  if (a.f.d.fourier_half > 0) return PPSCI_E_UNSUPPORTED;
+  switch (a.f.d.activation) {
+    case PPSCI_ACT_TANH: return ppsci_step_run_tanh(a, stream, launch, grid);
+    case PPSCI_ACT_SILU: return ppsci_step_run_silu(a, stream, launch, grid);
+    case PPSCI_ACT_SIN: return ppsci_step_run_sin(a, stream, launch, grid);
+    default: ppsci_set_error("taylor_step: no one-launch kernel for activation %d", a.f.d.activation); return PPSCI_E_UNSUPPORTED;
+  }
+}
+
+// workspace layout (floats): rows_w [grid][per_tile] | rows_s [grid][psmall] | rows_l [grid][n_res] | tree rows | counters
+struct StepLayout {
+  long long rows_w, rows_s, rows_l, tree, counters, total;
+  int per_tile, psmall, rowlen, tree_rows;
+};
+static StepLayout step_layout(const StepArgs& a, int grid, int n_res) {
+  StepLayout y;
+  y.per_tile = (int)bwd_per_tile_floats(a.b);
+  y.psmall = ppsci_small_params(a.b.d, a.b.q);
+  y.rowlen = y.per_tile + ((y.psmall + 3) & ~3) + ((n_res + 3) & ~3);
+  y.tree_rows = 0;
+  for (int n = grid; n > 1;) {
+    n = (n + PPSCI_STEP_FAN - 1) / PPSCI_STEP_FAN;
+    y.tree_rows += n;
+  }
+  const auto pad4 = [](long long v) { return (v + 3) & ~3LL; };
+  y.rows_w = 0;
+  y.rows_s = y.rows_w + pad4((long long)grid * y.per_tile);
+  y.rows_l = y.rows_s + pad4((long long)grid * y.psmall);
+  y.tree = y.rows_l + pad4((long long)grid * (n_res > 0 ? n_res : 1));
+  y.counters = y.tree + (long long)y.tree_rows * y.rowlen;
+  y.total = y.counters + pad4(y.tree_rows + 1);
+  return y;
+}
+
+static int fill_step(StepArgs& a, const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points) {
+  memset(&a, 0, sizeof(a));
+  if (!d || !e || n_points <= 0 || fill_fwd(a.f, d, n_points) != PPSCI_OK || fill_bwd(a.b, d, n_points) != PPSCI_OK) return PPSCI_E_INVALID;
+  if (e->n_instr < 1 || e->n_instr > PPSCI_MAX_PROG || e->n_res < 0 || e->n_res > PPSCI_MAX_RES) return PPSCI_E_INVALID;
+  for (int i = 0; i < e->n_instr; ++i)
+    if (e->prog[i].op == PPSCI_OP_LD_PARAM) {
+      ppsci_set_error("taylor_step: learnable equation parameters take the separate launches");
+      return PPSCI_E_UNSUPPORTED;
+    }
+  a.e.e = *e;
+  epi_fill_loads(a.e);
+  a.e.N = n_points;
+  a.e.ntiles = a.f.ntiles;
+  return PPSCI_OK;
+}
+
+extern "C" int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points) {
+  StepArgs a;
+  int grid = 0;
+  if (fill_step(a, d, e, n_points) != PPSCI_OK || run_step_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
+  return step_layout(a, grid, e->n_res).total * 4;
+}
+
+struct ppsci_step_plan {
+  StepArgs a;
+};
+
+extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params,
+                                                   int64_t n_points, const float* const* inputs_host,
+                                                   const float* const* aux_host, float* U, float* Ubar, float* residual_out,
+                                                   void* stash, void* workspace, float* loss_terms, float* grad) {
+  if (!params || !inputs_host || !U || !Ubar || !stash || !workspace || !loss_terms || !grad) {
+    ppsci_set_error("taylor_step: invalid argument");
+    return nullptr;
+  }
+  ppsci_step_plan* plan = new ppsci_step_plan;
+  StepArgs& a = plan->a;
+  const auto fail = [&]() -> ppsci_step_plan* {
+    delete plan;
+    return nullptr;
+  };
+  int rc = fill_step(a, d, e, n_points);
+  if (rc != PPSCI_OK) {
+    if (rc == PPSCI_E_INVALID) ppsci_set_error("taylor_step: invalid argument");
+    return fail();
+  }
+  // the program is checked exactly as ppsci_epilogue does (indices into inputs / streams / aux / earlier values)
+  for (int i = 0; i < e->n_instr; ++i) {
+    const ppsci_instr& ins = e->prog[i];
+    bool ok = ins.op >= 0 && ins.op < PPSCI_OP_COUNT;
+    if (ok) {
+      if (ins.op == PPSCI_OP_LD_IN) ok = ins.a >= 0 && ins.a < e->n_in && ins.a < d->d_raw;
+      else if (ins.op == PPSCI_OP_LD_U) ok = ins.a >= 0 && ins.a < e->n_streams;
+      else if (ins.op == PPSCI_OP_LD_AUX) ok = ins.a >= 0 && ins.a < e->n_aux && aux_host;
+      else if (ins.op != PPSCI_OP_CONST) {
+        ok = ins.a >= 0 && ins.a < i;
+        const bool binary = ins.op == PPSCI_OP_ADD || ins.op == PPSCI_OP_SUB || ins.op == PPSCI_OP_MUL ||
+                            ins.op == PPSCI_OP_DIV || ins.op == PPSCI_OP_POW || ins.op == PPSCI_OP_MAX ||
+                            ins.op == PPSCI_OP_MIN || ins.op == PPSCI_OP_ATAN2;
+        if (binary) ok = ok && ins.b >= 0 && ins.b < i;
+      }
+    }
+    if (!ok) {
+      ppsci_set_error("taylor_step: bad instruction %d (op %d a %d b %d)", i, ins.op, ins.a, ins.b);
+      return fail();
+    }
+  }
+  for (int k = 0; k < e->n_res; ++k) {
+    const ppsci_residual& r = e->res[k];
+    if (r.value < 0 || r.value >= e->n_instr || r.label >= e->n_aux || r.weight >= e->n_aux || r.area >= e->n_aux ||
+        r.kind < PPSCI_LOSS_MSE || r.kind > PPSCI_LOSS_ABSREL || ((r.label >= 0 || r.weight >= 0 || r.area >= 0) && !aux_host)) {
+      ppsci_set_error("taylor_step: bad residual %d", k);
+      return fail();
+    }
+  }
+  if (e->n_streams != d->d_out * (1 + d->n1 + d->n2 + d->n3 + d->n4) || e->n_in > PPSCI_MAX_IN || e->n_aux > PPSCI_MAX_AUX) {
+    ppsci_set_error("taylor_step: the program's stream count does not match the network's");
+    return fail();
+  }
+  int grid = 0;
+  if (run_step_act(a, nullptr, 0, &grid) != PPSCI_OK) return fail();
+  const StepLayout y = step_layout(a, grid, e->n_res);
+  float* ws = (float*)workspace;
+  a.f.params = a.b.params = params;
+  for (int j = 0; j < d->d_raw; ++j) a.f.x[j] = a.b.x[j] = a.e.x[j] = inputs_host[j];
+  for (int j = 0; j < e->n_aux; ++j) a.e.aux[j] = aux_host[j];
+  a.f.U = U;
+  a.f.stash = (f32x4*)stash;
+  a.e.U = U;
+  a.e.Ubar = Ubar;
+  a.e.resid = residual_out;
+  a.e.partials = ws + y.rows_l;
+  a.b.Ubar = Ubar;
+  a.b.stash = (const f32x4*)stash;
+  a.b.partials = ws + y.rows_s;
+  a.b.wpart = (f32x4*)(ws + y.rows_w);
+  StepTail& t = a.t;
+  t.rows_w = ws + y.rows_w;
+  t.rows_s = ws + y.rows_s;
+  t.rows_l = ws + y.rows_l;
+  t.tree = ws + y.tree;
+  t.counters = (unsigned*)(ws + y.counters);
+  t.grad = grad;
+  t.loss_terms = loss_terms;
+  t.p = params;
+  t.per_tile = y.per_tile;
+  t.psmall = y.psmall;
+  t.n_res = e->n_res;
+  t.rowlen = y.rowlen;
+  return plan;
+}
+
+extern "C" void ppsci_taylor_step_plan_free(ppsci_step_plan* plan) { delete plan; }
+
+extern "C" int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogue_desc* e) {
+  if (!plan || !e || e->n_res != plan->a.e.e.n_res) {
+    ppsci_set_error("taylor_step_plan_set_scales: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  for (int k = 0; k < e->n_res; ++k) plan->a.e.e.res[k].scale = e->res[k].scale;
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream) {
+  if (!plan) {
+    ppsci_set_error("taylor_step_run: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  StepTail& t = plan->a.t;
+  t.accumulate = accumulate ? 1 : 0;
+  t.do_adam = 0;
+  if (adam) {
+    if (!adam->m || !adam->v || adam->step_t < 1) {
+      ppsci_set_error("taylor_step: invalid Adam arguments");
+      return PPSCI_E_INVALID;
+    }
+    const double b1t = pow((double)adam->beta1, (double)adam->step_t), b2t = pow((double)adam->beta2, (double)adam->step_t);
+    const double c2 = sqrt(1.0 - b2t);  // == ppsci_adam_step
+    t.do_adam = 1;
+    t.m = adam->m;
+    t.v = adam->v;
+    t.lr_t = (float)(adam->lr * c2 / (1.0 - b1t));
+    t.beta1 = adam->beta1;
+    t.beta2 = adam->beta2;
+    t.eps_t = (float)(adam->eps * c2);
+    t.grad_scale = adam->grad_scale;
+  }
+  int grid = 0;
+  return run_step_act(plan->a, stream, 2, &grid);
+}
+
+extern "C" int ppsci_taylor_step(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params, int64_t n_points,
+                                 const float* const* inputs_host, const float* const* aux_host, float* U, float* Ubar,
+                                 float* residual_out, void* stash, void* workspace, float* loss_terms, float* grad,
+                                 int accumulate, const ppsci_adam_args* adam, void* stream) {
+  ppsci_step_plan* plan = ppsci_taylor_step_plan(d, e, params, n_points, inputs_host, aux_host, U, Ubar, residual_out, stash,
+                                                 workspace, loss_terms, grad);
+  if (!plan) {
+    StepArgs a;
+    const int rc = fill_step(a, d, e, n_points);
+    int grid = 0;
+    return rc != PPSCI_OK ? rc : (run_step_act(a, nullptr, 0, &grid) != PPSCI_OK ? PPSCI_E_UNSUPPORTED : PPSCI_E_INVALID);
+  }
+  const int rc = ppsci_taylor_step_run(plan, accumulate, adam, stream);
+  ppsci_taylor_step_plan_free(plan);
+  return rc;
 }

@@ -175,6 +175,34 @@ class FusedConstraint:
             n = nt["layout"].n_params
             hp.reduce_rows(nt["grad_partials"], nt["grad_rows"], n, grad[nt["off"]:nt["off"] + n], accumulate)
 
+    def one_launch_ready(self) -> bool:
+        """Can this constraint's whole step run as ONE launch (hp.taylor_step)?  A single plain network fed by all the
+        constraint's inputs, a program without learnable equation parameters, none of the two-pass losses (causal,
+        periodic), and a one-launch kernel for the net / stream set; the workspace is allocated on the first yes."""
+        ok = getattr(self, "_one_launch", None)
+        if ok is None:
+            nt = self.nets[0]
+            ok = (len(self.nets) == 1 and "exec" not in nt and nt["pre"] is None and nt["off"] == 0
+                  and len(nt["inputs"]) == len(self.inputs)
+                  and all(a.data_ptr() == b.data_ptr() for a, b in zip(nt["inputs"], self.inputs))
+                  and self.edesc.n_res >= 1)
+            if ok:
+                nbytes = hp.taylor_step_workspace_bytes(nt["desc"], self.edesc, self.n)
+                ok = nbytes > 0
+                if ok:
+                    self._step_ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.U.device)
+            self._one_launch = ok
+        return (ok and not getattr(self, "causal", None) and not getattr(self, "periodic", None)
+                and getattr(self, "eq_store", None) is None)
+
+    def step_one_launch(self, params: torch.Tensor, grad: torch.Tensor, accumulate: bool, adam: Optional[dict]) -> None:
+        plan = getattr(self, "_step_plan", None)
+        if plan is None or plan.key != (params.data_ptr(), grad.data_ptr()):
+            nt = self.nets[0]
+            plan = self._step_plan = hp.StepPlan(nt["desc"], self.edesc, params, self.n, self.inputs, self.aux, self.U,
+                                                 self.Ubar, self.resid, nt["stash"], self._step_ws, self.loss_terms, grad)
+        plan.run(self.edesc, accumulate, adam)
+
     def losses(self) -> Dict[str, float]:
         vals = self.loss_terms.detach().cpu().tolist()  # one device->host sync, only when logging
         off = getattr(self, "loss_offsets", None) or {}  # constant parts of row-sliced terms (compile.CompiledConstraint)
@@ -295,6 +323,22 @@ class Engine:
         self.multi_stream = os.environ.get("PPSCI_MULTI_STREAM", "1") != "0"
         self.multi_stream_max_points = 16384  # a constraint this small cannot fill the chip on its own
         self._streams: List[torch.cuda.Stream] = []
+        # One launch per constraint (forward -> epilogue -> reverse -> reduction [-> Adam] in one kernel) for steps whose
+        # constraints are all small: 7 launches of 4-5 us dispatch + drain each become one.  PPSCI_ONE_LAUNCH=0 turns it off.
+        self.one_launch = os.environ.get("PPSCI_ONE_LAUNCH", "1") != "0"
+        self.one_launch_max_points = 16384
+
+    def one_launch_ready(self, constraints: Sequence[FusedConstraint]) -> bool:
+        return (self.one_launch and self.layout is not None and len(constraints) > 0
+                and all(isinstance(c, FusedConstraint) and c.n <= self.one_launch_max_points and c.one_launch_ready()
+                        for c in constraints))
+
+    def step_one_launch(self, constraints: Sequence[FusedConstraint], adam: Optional[dict] = None) -> None:
+        """Gradient (and loss terms) of the step, constraint by constraint in order, one launch each; `adam` (see
+        hp.taylor_step) makes the LAST launch apply the optimizer step as well -- single rank only."""
+        last = len(constraints) - 1
+        for i, c in enumerate(constraints):
+            c.step_one_launch(self.params, self.grad, i > 0, adam if i == last else None)
 
     def _forward_backward_eager(self, constraints: Sequence[FusedConstraint]) -> None:
         # Constraints are independent until their gradients are summed.  A small one (a boundary or initial
@@ -327,6 +371,8 @@ class Engine:
                 first = False
 
     def forward_backward(self, constraints: Sequence[FusedConstraint]) -> None:
+        if self.one_launch_ready(constraints):
+            return self.step_one_launch(constraints)
         if not self.use_graph:
             return self._forward_backward_eager(constraints)
         # launch-bound only: a replayed HIP graph adds ~1.5 us of dependency handling per kernel node, which costs
@@ -357,6 +403,10 @@ class Engine:
         hp.adam_step(self.params, self.grad, self.m, self.v, lr, self.t, self.beta1, self.beta2, self.eps, scale)
 
     def train_step(self, constraints: Sequence[FusedConstraint], lr: float) -> None:
+        if self.world == 1 and self.one_launch_ready(constraints):
+            self.t += 1
+            return self.step_one_launch(constraints, dict(m=self.m, v=self.v, lr=lr, beta1=self.beta1, beta2=self.beta2,
+                                                          eps=self.eps, grad_scale=1.0, t=self.t))
         self.forward_backward(constraints)
         self.allreduce()
         self.optimizer_step(lr)

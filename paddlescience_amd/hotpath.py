@@ -157,6 +157,55 @@ def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Ten
                                      _p(grad_partials), _stream_ptr(params)))
 
 
+def taylor_step_workspace_bytes(desc: L.MlpDesc, edesc: L.EpilogueDesc, n: int) -> int:
+    """0: this network / stream set / program has no one-launch step kernel (ppsci_taylor_step_workspace_bytes)."""
+    return int(L.lib().ppsci_taylor_step_workspace_bytes(C.byref(desc), C.byref(edesc), n))
+
+
+class StepPlan:
+    """ppsci_taylor_step_plan / _run: forward -> epilogue -> reverse -> fixed-order reduction (-> Adam) of one constraint
+    in one launch, with the argument block prepared once (every buffer is persistent).  adam: dict(m, v, lr, beta1,
+    beta2, eps, grad_scale, t) or None."""
+
+    def __init__(self, desc: L.MlpDesc, edesc: L.EpilogueDesc, params: torch.Tensor, n: int, inputs: Sequence[torch.Tensor],
+                 aux: Sequence[torch.Tensor], U: torch.Tensor, Ubar: torch.Tensor, resid: Optional[torch.Tensor],
+                 stash: torch.Tensor, workspace: torch.Tensor, loss_terms: torch.Tensor, grad: torch.Tensor):
+        _require_device(params)
+        _chk_f32(params, U, Ubar, resid, loss_terms, grad, workspace, *inputs, *aux)
+        ip = L.ptr_array([t.data_ptr() for t in inputs])
+        ap = L.ptr_array([t.data_ptr() for t in aux]) if aux else None
+        self._free = L.lib().ppsci_taylor_step_plan_free
+        self._run = L.lib().ppsci_taylor_step_run
+        self.handle = L.lib().ppsci_taylor_step_plan(C.byref(desc), C.byref(edesc), _p(params), n, ip, ap, _p(U), _p(Ubar),
+                                                     _p(resid), _p(stash), _p(workspace), _p(loss_terms), _p(grad))
+        if not self.handle:
+            raise RuntimeError("ppsci_taylor_step_plan: " + L.lib().ppsci_last_error().decode())
+        self.key = (params.data_ptr(), grad.data_ptr())
+        self._keep = (params, inputs, aux, U, Ubar, resid, stash, workspace, loss_terms, grad)  # the plan holds raw pointers
+        self._dev = params
+        self.scales = self._scales(edesc)
+
+    @staticmethod
+    def _scales(edesc: L.EpilogueDesc):
+        return tuple(edesc.res[k].scale for k in range(edesc.n_res))
+
+    def run(self, edesc: L.EpilogueDesc, accumulate: bool, adam: Optional[dict] = None) -> None:
+        sc = self._scales(edesc)
+        if sc != self.scales:  # loss re-weighting (GradNorm / NTK, Solver._apply_loss_weights) between steps
+            L.check(L.lib().ppsci_taylor_step_plan_set_scales(self.handle, C.byref(edesc)))
+            self.scales = sc
+        aa = None
+        if adam is not None:
+            aa = C.byref(L.AdamArgs(adam["m"].data_ptr(), adam["v"].data_ptr(), adam["lr"], adam["beta1"], adam["beta2"],
+                                    adam["eps"], adam.get("grad_scale", 1.0), adam["t"]))
+        L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev)))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self._free(h)
+
+
 def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor, accumulate: bool) -> None:
     _require_device(out)
     _chk_f32(partials, out)

@@ -300,6 +300,8 @@ class Solver:
                         return total, g * gscale if gscale != 1.0 else g
 
                     self.optimizer.step(closure)
+                elif self._step_in_one_launch(eng_csts, eager_csts, gscale):
+                    pass  # forward -> loss -> backward -> Adam of every constraint in one launch each (engine.step_one_launch)
                 else:
                     self._materialize()
                     if eng_csts:
@@ -412,6 +414,24 @@ class Solver:
     def _materialize(self) -> None:
         if self._reparam:
             self.model.materialize()
+
+    def _step_in_one_launch(self, eng_csts, eager_csts, gscale: float) -> bool:
+        """The whole iteration (train.py:82-184) as one launch per constraint, the optimizer step inside the last one,
+        when nothing sits between the gradient and the update: one rank, plain Adam (no clipping / decay / learnable
+        equation parameters), no re-parametrised weights, no gradient accumulation or per-loss gradients, and every
+        constraint small enough for the one-launch kernel (engine.one_launch_ready).  False: nothing was done."""
+        opt = self.optimizer
+        if (self.world_size != 1 or eager_csts or not eng_csts or self._reparam or self.update_freq > 1
+                or getattr(self.loss_aggregator, "per_loss_grad", False) or type(opt).__name__ != "_AdamState"
+                or opt.grad_clip is not None or opt.l2 != 0.0 or opt.eq_store is not None
+                or not hasattr(self.engine, "one_launch_ready") or opt.model.flat_params.data_ptr() != self.engine.params.data_ptr()
+                or not self.engine.one_launch_ready(eng_csts)):
+            return False
+        self._materialize()
+        opt.t += 1
+        self.engine.step_one_launch(eng_csts, dict(m=opt.m, v=opt.v, lr=opt.get_lr(), beta1=opt.beta1, beta2=opt.beta2,
+                                                   eps=opt.epsilon, grad_scale=gscale, t=opt.t))
+        return True
 
     def _train_grad(self) -> torch.Tensor:
         """Gradient w.r.t. the optimizer's (trainable) parameters."""

@@ -334,5 +334,11 @@ inline float atomicAdd(float* p, float v) {
   *p = old + v;
   return old;
 }
+inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  unsigned old = *p;
+  *p = old + v;
+  return old;
+}
+inline void __threadfence() {}  // blocks run one after the other: every earlier block's writes are visible
 
 typedef void* hipStream_t;
