@@ -23,14 +23,15 @@ dtype = "float32"
 def main():
     cfg = parse(dict(seed=42, output_dir="./output_allen_cahn_piratenet", epochs=2, iters_per_epoch=500, batch_size=8192,
                      num_blocks=3, hidden_size=256, learning_rate=1e-3, gamma=0.9, decay_steps=5000, log_freq=100,
-                     n_chunks=32, tol=1.0, grad_norm_update_freq=1000, grad_norm_momentum=0.9, grad_norm=True))
+                     n_chunks=32, tol=1.0, grad_norm_update_freq=1000, grad_norm_momentum=0.9, grad_norm=True,
+                     n_x=512, n_t_eval=101))
     ppsci.utils.misc.set_random_seed(cfg["seed"])
     logger.init_logger("ppsci", os.path.join(cfg["output_dir"], "train.log"))
     model = ppsci.arch.PirateNet(("t", "x"), ("u",), cfg["num_blocks"], cfg["hidden_size"], "tanh", periods={"x": [2.0, False]},
                                  fourier={"dim": cfg["hidden_size"], "scale": 2.0}, random_weight={"mean": 1.0, "std": 0.1})
     equation = {"AllenCahn": ppsci.equation.AllenCahn(eps=0.01)}
     t0, t1, x0, x1 = 0.0, 1.0, -1.0, 1.0
-    x_star = np.linspace(x0, x1, 512, endpoint=False, dtype=dtype)
+    x_star = np.linspace(x0, x1, cfg["n_x"], endpoint=False, dtype=dtype)
 
     def gen_input_batch():  # allen_cahn_piratenet.py:83-92: the causal loss needs the batch ordered in time
         tx = np.random.uniform([t0, x0], [t1, x1], (cfg["batch_size"], 2)).astype(dtype)
@@ -58,11 +59,11 @@ def main():
     solver = ppsci.solver.Solver(model, constraint, cfg["output_dir"], optimizer, lr_scheduler, cfg["epochs"],
                                  cfg["iters_per_epoch"], log_freq=cfg["log_freq"], equation=equation, loss_aggregator=aggregator)
     solver.train()
-    tx = ppsci.utils.misc.cartesian_product(np.linspace(t0, t1, 101, dtype=dtype), x_star)
+    tx = ppsci.utils.misc.cartesian_product(np.linspace(t0, t1, cfg["n_t_eval"], dtype=dtype), x_star)
     res = solver.predict({"t": tx[:, 0:1], "x": tx[:, 1:2]}, equation["AllenCahn"].equations, batch_size=None,
                          return_numpy=True)
     u0 = solver.predict(ic_input, batch_size=None, return_numpy=True)["u"]
-    logger.info(f"PDE residual RMS on a 101x512 grid: {float(np.sqrt(np.mean(res['allen_cahn'] ** 2))):.5e}; "
+    logger.info(f"PDE residual RMS on a {cfg['n_t_eval']}x{cfg['n_x']} grid: {float(np.sqrt(np.mean(res['allen_cahn'] ** 2))):.5e}; "
                 f"initial condition rel-L2: {float(np.linalg.norm(u0 - ic_label['u']) / np.linalg.norm(ic_label['u'])):.5e}")
 
 

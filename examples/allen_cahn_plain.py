@@ -23,7 +23,7 @@ dtype = "float32"
 
 
 def main():
-    cfg = parse(dict(seed=42, output_dir="./output_allen_cahn", epochs=5, iters_per_epoch=200, batch_size=4096,
+    cfg = parse(dict(n_x=512, n_t_eval=101, seed=42, output_dir="./output_allen_cahn", epochs=5, iters_per_epoch=200, batch_size=4096,
                      num_layers=4, hidden_size=256, learning_rate=1e-3, gamma=0.9, decay_steps=2000, log_freq=100,  # allen_cahn.yaml:38-42
                      period_x=True, causal=False, n_chunks=32, tol=1.0, fourier=False, rwf=False))
     ppsci.utils.misc.set_random_seed(cfg["seed"])
@@ -34,7 +34,7 @@ def main():
                            random_weight={"mean": 0.5, "std": 0.1} if cfg["rwf"] else None)
     equation = {"AllenCahn": ppsci.equation.AllenCahn(eps=0.01)}
     t0, t1, x0, x1 = 0.0, 1.0, -1.0, 1.0
-    x_star = np.linspace(x0, x1, 512, endpoint=False, dtype=dtype)
+    x_star = np.linspace(x0, x1, cfg["n_x"], endpoint=False, dtype=dtype)
 
     def gen_input_batch():
         tx = np.random.uniform([t0, x0], [t1, x1], (cfg["batch_size"], 2)).astype(dtype)
@@ -61,7 +61,7 @@ def main():
     solver = ppsci.solver.Solver(model, {pde.name: pde, ic.name: ic}, cfg["output_dir"], optimizer, lr_scheduler,
                                  cfg["epochs"], cfg["iters_per_epoch"], log_freq=cfg["log_freq"], equation=equation)
     solver.train()
-    tx = ppsci.utils.misc.cartesian_product(np.linspace(t0, t1, 101, dtype=dtype), x_star)
+    tx = ppsci.utils.misc.cartesian_product(np.linspace(t0, t1, cfg["n_t_eval"], dtype=dtype), x_star)
     res = solver.predict({"t": tx[:, 0:1], "x": tx[:, 1:2]}, equation["AllenCahn"].equations, batch_size=None,
                          return_numpy=True)
     logger.info(f"PDE residual RMS on a 101x512 grid: {float(np.sqrt(np.mean(res['allen_cahn'] ** 2))):.5e}")

@@ -31,7 +31,7 @@ def sample_points_on_square_boundary(num_pts_per_side, eps):  # ldc_2d_Re3200_so
 
 
 if __name__ == "__main__":
-    cfg = parse(dict(seed=42, output_dir="./output_ldc_2d_sota", Re="100,400,1000,3200", epochs="2,2,2,2", iters_per_epoch=200,
+    cfg = parse(dict(n_eval=101, seed=42, output_dir="./output_ldc_2d_sota", Re="100,400,1000,3200", epochs="2,2,2,2", iters_per_epoch=200,
                      num_layers=5, hidden_size=256, fourier_dim=128, fourier_scale=10.0, batch_pde=8192, batch_bc=256,
                      learning_rate=1e-3, gamma=0.9, decay_steps=10000, grad_norm_update_freq=1000, grad_norm_momentum=0.9,
                      log_freq=100))
@@ -75,7 +75,7 @@ if __name__ == "__main__":
                                      optimizer, lr_scheduler, ep, cfg["iters_per_epoch"], log_freq=cfg["log_freq"],
                                      equation=equation, loss_aggregator=grad_norm)
         solver.train()
-        g = np.linspace(0.0, 1.0, 101, dtype=dtype)
+        g = np.linspace(0.0, 1.0, cfg["n_eval"], dtype=dtype)
         xy = ppsci.utils.misc.cartesian_product(g, g)
         res = solver.predict({"x": xy[:, 0:1], "y": xy[:, 1:2]}, equation["NavierStokes"].equations, batch_size=None,
                              return_numpy=True)

@@ -268,32 +268,42 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
     }
   }
 
-  // ---- block reduction of the loss terms (fixed tree order => deterministic)
-  for (int k = 0; k < a.e.n_res; ++k) {
-    __syncthreads();
-    red[tid] = lsum[k];
-    __syncthreads();
-    for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
-      __syncthreads();
-    }
-    if (tid == 0) {  // (inside the one-launch step kernel other workgroups read the row before the launch ends)
-      if (MODE == EPI_RF_TILED) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + k], red[0]);
-      else a.partials[(long long)blockIdx.x * a.e.n_res + k] = red[0];
+  // ---- block reduction of the loss terms: a butterfly inside every wave (register shuffles), then the waves' sums in
+  // wave order -- a fixed shape, so deterministic; two LDS-only barriers in all (a 256-wide LDS tree with a full
+  // __syncthreads() per level costs ten barriers per term, the first of which also waits for every adjoint store)
+  const int wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
+  ppsci_block_sync_lds();  // LDS modes: the register file's last reads come first (`red` is its own region, but cheap)
+#pragma unroll
+  for (int k = 0; k < PPSCI_MAX_RES; ++k) {
+    if (k < a.e.n_res) {
+      float v = lsum[k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((tid & 63) == 0) red[k * 16 + wv] = v;
     }
   }
   if (a.ep_part != nullptr) {
 #pragma unroll
     for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) {
-      __syncthreads();
-      red[tid] = padj[k];
-      __syncthreads();
-      for (int s = EPI_BLOCK / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-      }
-      if (tid == 0) a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = red[0];
+      float v = padj[k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((tid & 63) == 0) red[(PPSCI_MAX_RES + k) * 16 + wv] = v;
     }
+  }
+  ppsci_block_sync_lds();
+  if (tid < a.e.n_res) {
+    float t = 0.f;
+    for (int w = 0; w < nwv; ++w) t += red[tid * 16 + w];
+    // (inside the one-launch step kernel other workgroups read the row before the launch ends)
+    if (MODE == EPI_RF_TILED) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + tid], t);
+    else a.partials[(long long)blockIdx.x * a.e.n_res + tid] = t;
+  }
+  if (a.ep_part != nullptr && tid >= 64 && tid < 64 + PPSCI_MAX_EPARAM) {
+    const int k = tid - 64;
+    float t = 0.f;
+    for (int w = 0; w < nwv; ++w) t += red[(PPSCI_MAX_RES + k) * 16 + w];
+    a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = t;
   }
 }
 

@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TINY = {
     "laplace2d.py": ["epochs=3", "npoint_interior=64", "npoint_bc=16", "log_freq=1"],
-    "allen_cahn_plain.py": ["epochs=1", "iters_per_epoch=2", "batch_size=32", "hidden_size=32", "num_layers=2", "log_freq=1"],
-    "allen_cahn_piratenet.py": ["epochs=1", "iters_per_epoch=2", "batch_size=32", "hidden_size=16", "num_blocks=1", "log_freq=1",
-                                "grad_norm_update_freq=1"],
+    "allen_cahn_plain.py": ["epochs=1", "iters_per_epoch=2", "batch_size=32", "hidden_size=32", "num_layers=2", "log_freq=1", "n_x=32", "n_t_eval=5"],
+    "allen_cahn_piratenet.py": ["epochs=1", "iters_per_epoch=1", "batch_size=32", "hidden_size=16", "num_blocks=1", "log_freq=1",
+                                "grad_norm_update_freq=1", "n_x=32", "n_t_eval=5"],
     "euler_beam.py": ["epochs=3", "log_freq=1"],
     "cylinder2d_unsteady.py": ["epochs=2", "npoint_pde=40", "npoint_inlet_cylinder=11", "npoint_outlet=5", "train_num_timestamps=3",
                                "num_timestamps=5", "log_freq=1"],
@@ -22,8 +22,8 @@ TINY = {
                              "resample_every=1"],
     "tfno_darcyflow.py": ["epochs=1", "n_train=4", "n_test=2", "batch_size=2", "n_modes=4", "hidden_channels=8", "lifting_channels=8",
                           "projection_channels=8", "n_layers=1", "log_freq=1"],
-    "ldc_2d_sota.py": ["epochs=1,1", "Re=100,400", "iters_per_epoch=2", "hidden_size=16", "num_layers=2", "fourier_dim=8", "batch_pde=32",
-                       "batch_bc=8", "log_freq=1", "grad_norm_update_freq=1"],
+    "ldc_2d_sota.py": ["epochs=1,1", "Re=100,400", "iters_per_epoch=1", "hidden_size=16", "num_layers=2", "fourier_dim=8", "batch_pde=32",
+                       "batch_bc=8", "log_freq=1", "grad_norm_update_freq=1", "n_eval=9"],
 }
 
 

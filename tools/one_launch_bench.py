@@ -35,3 +35,22 @@ if __name__ == "__main__":
             r = {"net": f"{len(hidden)}x{hidden[0]}", "points": n, "separate_us (wall, hip events)": laplace(tmp, hidden, n, False),
                  "one_launch_us (wall, hip events)": laplace(tmp, hidden, n, True)}
             print(json.dumps(r), flush=True)
+
+
+def two_constraints(one):
+    """Laplace2D example shape: 10 201 interior points (S = 5 streams) + 400 boundary points (S = 1), engine level."""
+    import torch
+    from paddlescience_amd import hotpath as hp
+    from paddlescience_amd.engine import Engine
+    from tests.test_one_launch import _constraint, _weights
+
+    lay = hp.NetLayout(2, 5, 20, 1, "tanh")
+    eng = Engine(lay, torch.tensor(_weights(lay, 1), device="cuda"))
+    eng.one_launch = one
+    csts = [_constraint("cuda", "laplace", lay, 10_201, 1), _constraint("cuda", "value", lay, 400, 2)]
+    return round(bench.time_wall(lambda: eng.train_step(csts, 1e-3), 300, 30) * 1e6, 2)
+
+
+if __name__ == "__main__":
+    print(json.dumps({"laplace2d example shape (5x20, 10201 + 400 points)": {"separate_us": two_constraints(False),
+                                                                            "one_launch_us": two_constraints(True)}}), flush=True)
