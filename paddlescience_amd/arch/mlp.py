@@ -69,7 +69,17 @@ class PeriodEmbedding:
         self.freqs_dict = {k: float(np.float32(2 * np.pi / float(p))) for k, (p, _) in periods.items()}
 
 
-class MLP(Arch):
+class _MLPMeta(type):
+    """`ppsci.arch.MLP(...)` may hand back the layer-by-layer class (see MLP.__new__): such an object IS an MLP to user code
+    (`isinstance(model, ppsci.arch.MLP)`), although it shares its implementation with PirateNet."""
+
+    def __instancecheck__(cls, obj):
+        if type.__instancecheck__(cls, obj):
+            return True
+        return cls.__name__ == "MLP" and type(obj).__name__ == "LayerwiseMLP"
+
+
+class MLP(Arch, metaclass=_MLPMeta):
     def __new__(cls, input_keys=None, output_keys=None, num_layers=None, hidden_size=None, *args, **kwargs):
         """Configurations outside the fused kernels' envelope (width > 256, a Fourier embedding whose dim differs from
         hidden_size, per-layer widths with factored layers) are served by the layer-by-layer class (arch/layerwise_mlp.py):

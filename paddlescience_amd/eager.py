@@ -58,7 +58,7 @@ def supports(model) -> Optional[str]:
 
     members = model.model_list if isinstance(model, ModelList) else [model]
     for m in members:
-        if not isinstance(m, MLP):
+        if not isinstance(m, MLP) or type(m).__name__ == "LayerwiseMLP":  # (the layer-by-layer MLP is an MLP to isinstance)
             return f"{type(m).__name__} models"
         if getattr(m, "reparam", False):
             return "factored / tied layers or learnable activations"

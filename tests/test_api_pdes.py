@@ -878,3 +878,14 @@ def test_one_row_slices_are_lowered_to_the_fused_kernels(tmp_path, reduction):
     for k in losses:
         assert mine[k] == pytest.approx(losses[k], rel=2e-4, abs=1e-8), k
     assert rel(g, gref) < 2e-4
+    if cc.fused.resid is not None:  # a sliced output is [1, 1] (the reference's `expr[a:a+1]`), a full one [n, 1]
+        vals = cc.values()
+        assert tuple(vals["u__x"].shape) == (1, 1) and tuple(vals["all"].shape) == (4, 1)
+    # re-binding the same arrays takes the cached columns (no recomputation, no device-to-host copies on the step path)
+    inp, labd, wd = {"x": Xb}, dict(lab), dict(wts)
+    cc.bind(inp, labd, wd)
+    first = cc._row_slice_cache
+    cc.bind(inp, labd, wd)
+    assert cc._row_slice_cache is first
+    solver.engine.forward_backward([cc.fused])
+    assert rel(solver.engine.grad.cpu().numpy().astype(np.float64), gref) < 2e-4

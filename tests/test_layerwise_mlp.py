@@ -84,6 +84,7 @@ def test_dispatch_rules(dev):
     assert mk(3, 64) == "MLP" and mk(4, 256) == "MLP" and mk(None, (20, 30, 20)) == "MLP"
     assert mk(2, 64, "tanh", fourier={"dim": 64, "scale": 1.0}) == "MLP"
     assert mk(2, 512) == "LayerwiseMLP"
+    assert isinstance(ppsci.arch.MLP(("x", "y"), ("u",), 2, 512), ppsci.arch.MLP)  # ... and still an MLP to user code
     assert mk(2, 64, "tanh", fourier={"dim": 32, "scale": 1.0}) == "LayerwiseMLP"
     assert mk(2, 64, "gelu", fourier={"dim": 64, "scale": 1.0}) == "LayerwiseMLP"
     assert mk(None, (20, 30), random_weight={"mean": 0.5, "std": 0.1}) == "LayerwiseMLP"
