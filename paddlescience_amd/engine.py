@@ -356,6 +356,11 @@ class Engine:
         if (self.multi_stream and len(constraints) > 1 and self.params.is_cuda
                 and min(c.n for c in constraints) <= self.multi_stream_max_points):
             def job(c):
+                if self.one_launch and c.n <= self.one_launch_max_points and c.one_launch_ready():
+                    # forward -> epilogue -> reverse -> reduction in ONE launch per constraint, the constraints' launches
+                    # as parallel branches; the gradient row lands where the separate kernels would leave it
+                    row = c.nets[0]["grad_partials"]
+                    return lambda: c.step_one_launch(self.params, row.view(-1), False, None)
                 return lambda: (c.forward(self.params, True), c.backward(self.params))
 
             run_on_streams(self._streams, [job(c) for c in constraints])

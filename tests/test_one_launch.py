@@ -67,15 +67,15 @@ def _constraint(d, kind, lay, n, seed):
     return FusedConstraint(kind, lay, streams, ed, xs, aux, keys, want_residual=True)
 
 
-def _run(d, lay, specs, flat, one_launch, steps, max_grid=0):
+def _run(d, lay, specs, flat, one_launch, steps, max_grid=0, max_constraints=4):
     L.lib().ppsci_set_max_grid(max_grid)
     try:
         params = torch.tensor(flat, device=d)
         eng = Engine(lay, params)
         eng.one_launch = one_launch
-        eng.one_launch_max_constraints = 4  # (default 1: several small constraints overlap better as separate kernels)
+        eng.one_launch_max_constraints = max_constraints  # (default 1: several small constraints run as parallel branches)
         csts = [_constraint(d, kind, lay, n, 100 + i) for i, (kind, n) in enumerate(specs)]
-        assert eng.one_launch_ready(csts) == one_launch
+        assert eng.one_launch_ready(csts) == (one_launch and len(csts) <= max_constraints)
         grads, losses = [], []
         for _ in range(steps):
             eng.train_step(csts, 1e-2)
@@ -154,3 +154,21 @@ def test_one_launch_unsupported_falls_to_separate_launches(dev):
     assert not eng.one_launch_ready([cst])
     eng.train_step([cst], 1e-3)
     assert np.isfinite(cst.loss_terms.cpu().numpy()).all()
+
+
+def test_one_launch_kernels_as_parallel_branches(dev):
+    """Default engine, a step of several small constraints: their one-launch kernels (gradient only) run as parallel
+    branches of the captured graph, each into its own gradient row; rows summed in constraint order, Adam behind."""
+    if dev != "gpu":
+        pytest.skip("streams and graph capture: GPU only")
+    d = device.get_device()
+    lay = hp.NetLayout(2, 3, 20, 1, "tanh")
+    flat = _weights(lay, 11)
+    specs = [("laplace", 3000), ("value", 400), ("allen_cahn", 1000)]
+    p_sep, g_sep, l_sep, _ = _run(d, lay, specs, flat, False, 6, max_constraints=1)
+    p_one, g_one, l_one, _ = _run(d, lay, specs, flat, True, 6, max_constraints=1)  # steps 1 / 2 / 3+: eager, capture, replay
+    assert rel(g_one[0], g_sep[0]) < 3e-6 and rel(p_one, p_sep) < 1e-4
+    for a, b in zip(l_one[0], l_sep[0]):
+        np.testing.assert_allclose(a, b, rtol=2e-5)
+    again = _run(d, lay, specs, flat, True, 6, max_constraints=1)
+    assert np.array_equal(again[0], p_one)

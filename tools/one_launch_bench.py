@@ -37,7 +37,7 @@ if __name__ == "__main__":
             print(json.dumps(r), flush=True)
 
 
-def two_constraints(one):
+def two_constraints(one, serial=False):
     """Laplace2D example shape: 10 201 interior points (S = 5 streams) + 400 boundary points (S = 1), engine level."""
     import torch
     from paddlescience_amd import hotpath as hp
@@ -47,10 +47,12 @@ def two_constraints(one):
     lay = hp.NetLayout(2, 5, 20, 1, "tanh")
     eng = Engine(lay, torch.tensor(_weights(lay, 1), device="cuda"))
     eng.one_launch = one
+    eng.one_launch_max_constraints = 4 if serial else 1  # 1 (default): the constraints' launches as parallel graph branches
     csts = [_constraint("cuda", "laplace", lay, 10_201, 1), _constraint("cuda", "value", lay, 400, 2)]
     return round(bench.time_wall(lambda: eng.train_step(csts, 1e-3), 300, 30) * 1e6, 2)
 
 
 if __name__ == "__main__":
     print(json.dumps({"laplace2d example shape (5x20, 10201 + 400 points)": {"separate_us": two_constraints(False),
-                                                                            "one_launch_us": two_constraints(True)}}), flush=True)
+                                                                            "one_launch_parallel_branches_us": two_constraints(True),
+                                                                            "one_launch_serial_with_adam_us": two_constraints(True, True)}}), flush=True)
