@@ -195,6 +195,13 @@ int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* 
 int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
                           const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                           float* loss_partials, const float* eq_params, float* eq_param_partials, void* stream);
+/* The same, and the loss terms themselves without a reduction launch behind it: loss_terms [n_res] = the column sums of
+ * loss_partials in a fixed order, written by whichever workgroup finishes last (counter: 4 bytes, zero before the first
+ * call, left at zero).  loss_terms == counter == NULL: exactly ppsci_epilogue_params. */
+int ppsci_epilogue_losses(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                          const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                          float* loss_partials, const float* eq_params, float* eq_param_partials, float* loss_terms,
+                          void* counter, void* stream);
 
 /* Causal weighting of CausalMSELoss.forward (mse.py:158-177) for one loss key: the batch is n_chunks
  * consecutive time windows of N / n_chunks points; with l_p = weight_p * area_p * (value_p - label_p)^2 and

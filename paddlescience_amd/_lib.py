@@ -100,6 +100,9 @@ _SYMBOLS = {
                                    C.c_void_p, C.c_void_p]),
     "ppsci_epilogue": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                  C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_epilogue_losses": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_epilogue_params": (C.c_int, [C.POINTER(EpilogueDesc), C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),

@@ -226,6 +226,18 @@ extern "C" int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_poi
                                      const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                                      float* loss_partials, const float* eq_params, float* eq_param_partials,
                                      void* stream) {
+  return ppsci_epilogue_losses(e, n_points, inputs_host, U, aux_host, residual_out, Ubar, loss_partials, eq_params,
+                               eq_param_partials, nullptr, nullptr, stream);
+}
+
+extern "C" int ppsci_epilogue_losses(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,
+                                     const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
+                                     float* loss_partials, const float* eq_params, float* eq_param_partials,
+                                     float* loss_terms, void* counter, void* stream) {
+  if ((loss_terms != nullptr) != (counter != nullptr)) {
+    ppsci_set_error("epilogue: loss_terms and counter come together");
+    return PPSCI_E_INVALID;
+  }
   if (!e || n_points <= 0 || !loss_partials || e->n_instr < 1 || e->n_instr > PPSCI_MAX_PROG || e->n_res < 0 ||
       e->n_res > PPSCI_MAX_RES || e->n_in < 0 || e->n_in > PPSCI_MAX_IN || e->n_aux < 0 || e->n_aux > PPSCI_MAX_AUX) {
     ppsci_set_error("epilogue: invalid argument");
@@ -276,6 +288,8 @@ extern "C" int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_poi
   a.ep = eq_params;
   a.ep_part = (uses_params && Ubar != nullptr) ? eq_param_partials : nullptr;
   a.N = n_points;
+  a.loss_out = loss_terms;
+  a.counter = (unsigned*)counter;
   epi_fill_loads(a);
   const int grid = epi_grid(n_points, &a.iters);
   if (a.e.n_instr <= EPI_LDS_PROG) {

@@ -27,6 +27,8 @@ struct EpiArgs {
   long long N;
   int iters;
   int ntiles;  // EPI_RF_TILED only
+  float* loss_out;     // may be null; else [n_res]: the loss terms, summed over all workgroups by the one that finishes last
+  unsigned* counter;   // with loss_out: one zero-initialised ticket counter (left at zero)
   int nload;   // the program's load instructions (LD_IN / LD_U / LD_AUX), in program order: epi_fill_loads()
   unsigned char load_idx[PPSCI_MAX_PROG];
 };
@@ -295,8 +297,8 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
   if (tid < a.e.n_res) {
     float t = 0.f;
     for (int w = 0; w < nwv; ++w) t += red[tid * 16 + w];
-    // (inside the one-launch step kernel other workgroups read the row before the launch ends)
-    if (MODE == EPI_RF_TILED) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + tid], t);
+    // (inside the one-launch step kernel, or with loss_out, another workgroup reads the row before the launch ends)
+    if (MODE == EPI_RF_TILED || a.loss_out != nullptr) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + tid], t);
     else a.partials[(long long)blockIdx.x * a.e.n_res + tid] = t;
   }
   if (a.ep_part != nullptr && tid >= 64 && tid < 64 + PPSCI_MAX_EPARAM) {
@@ -304,6 +306,34 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
     float t = 0.f;
     for (int w = 0; w < nwv; ++w) t += red[(PPSCI_MAX_RES + k) * 16 + w];
     a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = t;
+  }
+  if (MODE != EPI_RF_TILED && a.loss_out != nullptr) {
+    // ---- loss terms without a reduction launch: the workgroup that finishes LAST sums all workgroups' rows, in a fixed
+    // order (thread t: rows t, t + 256, ...; then the butterfly and the waves in order) -- deterministic whichever it is.
+    // Rows were written with agent-scope stores; the ticket is taken after they have completed (ppsci_common.h).
+    ppsci_block_sync_mem();
+    if (tid == 0) ((unsigned*)red)[0] = atomicAdd(a.counter, 1u);
+    ppsci_block_sync_lds();
+    const unsigned ticket = ((const unsigned*)red)[0];
+    ppsci_block_sync_lds();
+    if (ticket != gridDim.x - 1) return;
+    ppsci_acquire_agent();
+    if (tid == 0) *a.counter = 0u;
+    for (int k = 0; k < a.e.n_res; ++k) {
+      float v = 0.f;
+#pragma unroll 4
+      for (int r = tid; r < (int)gridDim.x; r += (int)blockDim.x) v += a.partials[(long long)r * a.e.n_res + k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((tid & 63) == 0) red[16 + wv] = v;
+      ppsci_block_sync_lds();
+      if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < nwv; ++w) t += red[16 + w];
+        a.loss_out[k] = t;
+      }
+      ppsci_block_sync_lds();
+    }
   }
 }
 

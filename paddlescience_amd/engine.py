@@ -20,6 +20,9 @@ from . import _lib as L
 from . import hotpath as hp
 
 
+_EPI_LOSSES = os.environ.get("PPSCI_EPI_LOSSES", "1") != "0"  # loss terms finished inside the epilogue launch
+
+
 class FusedConstraint:
     """Device-resident state of one constraint batch: inputs, aux arrays, streams, stash, partials.
 
@@ -89,6 +92,7 @@ class FusedConstraint:
         self._pre_partials = torch.zeros((self.loss_rows, L.MAX_RES), **f32)  # unused sums of the stream programs
         self.loss_partials = torch.zeros((self.loss_rows, max(1, edesc.n_res)), **f32)
         self.loss_terms = torch.zeros(max(1, edesc.n_res), **f32)
+        self._loss_counter = torch.zeros(1, dtype=torch.int32, device=dev)  # ticket counter of ppsci_epilogue_losses
         self.resid = torch.zeros((max(1, edesc.n_res), self.n), **f32) if want_residual else None
 
     def set_inputs(self, inputs: Sequence[torch.Tensor], aux: Optional[Sequence[torch.Tensor]] = None) -> None:
@@ -143,6 +147,11 @@ class FusedConstraint:
             for row, lab in periodic:
                 self.aux[lab][:h].copy_(self.resid[row][h:])
                 self.aux[lab][h:].copy_(self.resid[row][:h])
+        if not periodic and self.edesc.n_res >= 1 and _EPI_LOSSES:
+            # the loss terms come out of the epilogue launch itself (the workgroup that finishes last sums the rows)
+            hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
+                        self.loss_partials, *self._eq_args(train), loss_terms=self.loss_terms, counter=self._loss_counter)
+            return
         hp.epilogue(self.edesc, self.n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None,
                     self.loss_partials, *self._eq_args(train))
 

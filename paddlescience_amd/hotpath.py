@@ -130,13 +130,20 @@ def taylor_fwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Ten
 def epilogue(edesc: L.EpilogueDesc, n: int, inputs: Sequence[torch.Tensor], U: Optional[torch.Tensor],
              aux: Sequence[torch.Tensor], resid: Optional[torch.Tensor], Ubar: Optional[torch.Tensor],
              loss_partials: torch.Tensor, eq_params: Optional[torch.Tensor] = None,
-             eq_param_partials: Optional[torch.Tensor] = None) -> None:
+             eq_param_partials: Optional[torch.Tensor] = None, loss_terms: Optional[torch.Tensor] = None,
+             counter: Optional[torch.Tensor] = None) -> None:
     """eq_params / eq_param_partials: learnable equation parameters ([MAX_EPARAM]) and the per-block sums of their
-    adjoints ([rows, MAX_EPARAM]) for programs with OP_LD_PARAM (ppsci_epilogue_params)."""
+    adjoints ([rows, MAX_EPARAM]) for programs with OP_LD_PARAM (ppsci_epilogue_params).  loss_terms + counter (a zeroed
+    int32): the kernel finishes the loss reduction itself (ppsci_epilogue_losses)."""
     _require_device(loss_partials)
-    _chk_f32(U, resid, Ubar, loss_partials, eq_params, eq_param_partials, *inputs, *aux)
+    _chk_f32(U, resid, Ubar, loss_partials, eq_params, eq_param_partials, loss_terms, *inputs, *aux)
     ip = L.ptr_array([t.data_ptr() for t in inputs])
     ap = L.ptr_array([t.data_ptr() for t in aux])
+    if loss_terms is not None:
+        L.check(L.lib().ppsci_epilogue_losses(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar), _p(loss_partials),
+                                              _p(eq_params), _p(eq_param_partials), _p(loss_terms), _p(counter),
+                                              _stream_ptr(loss_partials)))
+        return
     if eq_params is None:
         L.check(L.lib().ppsci_epilogue(C.byref(edesc), n, ip, _p(U), ap, _p(resid), _p(Ubar), _p(loss_partials),
                                        _stream_ptr(loss_partials)))
