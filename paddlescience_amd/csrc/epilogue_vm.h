@@ -12,7 +12,8 @@
 #include "taylor_tile.h"
 
 #define EPI_BLOCK 256
-#define EPI_LDS_PROG 20  // longest program whose VM register file is kept in LDS (2 x 20 KiB per workgroup: 3 per CU)
+#define EPI_LDS_PROG 31  // longest program whose VM register file is kept in LDS (2 x 31 KiB + 1 KiB per workgroup: under the 64 KiB
+                         // that need no launch attribute; 2 workgroups per CU): covers NavierStokes 2-D (30 instructions)
 
 struct EpiArgs {
   ppsci_epilogue_desc e;
@@ -62,7 +63,7 @@ __device__ __forceinline__ float epi_digamma(float x) {
 // The VM's register file (values and adjoints of the n instructions), by MODE:
 //   EPI_RF_SCRATCH  per-lane scratch memory (dynamic indexing: 1 040 bytes per lane, every access a scratch round trip)
 //   EPI_RF_LDS      LDS, [n][EPI_BLOCK] floats each (conflict-free: lane-consecutive), for programs of at most
-//                   EPI_LDS_PROG instructions -- the pointwise programs of the BASELINE PDEs (Laplace 3, Allen-Cahn 12)
+//                   EPI_LDS_PROG instructions -- the pointwise programs of the BASELINE PDEs (Laplace 3, Allen-Cahn 12, NavierStokes 2-D 30)
 //   EPI_RF_TILED    inside the one-launch step kernel (taylor_step.inc): wave w runs the program for the 16 points of
 //                   ITS tile on lanes 0..15 (the tile the same wave's forward sweep has just produced and its reverse
 //                   sweep consumes next); register file in LDS, [n][16 * waves]
