@@ -25,7 +25,7 @@ def laplace(tmp, hidden, n, one):
             solver.engine.forward_backward([cc.fused])
             opt.step(solver.engine.grad)
 
-    return round(e["ms_per_step"] * 1e3, 2), round(bench.time_events(step, 50) * 1e3, 2)
+    return round(e["ms_per_step"] * 1e3, 2), round(bench.time_events(step, 50) * 1e6, 2)
 
 
 if __name__ == "__main__":
