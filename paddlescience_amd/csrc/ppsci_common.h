@@ -92,8 +92,12 @@ __device__ __forceinline__ void ppsci_block_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 // Workgroup barrier that also orders GLOBAL memory traffic among the waves of the workgroup (one CU, one L1: waiting for
-// the outstanding stores is enough -- no L2 write-back as an agent-scope __threadfence() would do).
+// the outstanding stores is enough -- no L2 write-back as an agent-scope __threadfence() would do).  The wait is spelled
+// out: a workgroup-scope release fence alone emits NO vmcnt wait on gfx950 outside threadgroup-split mode (checked in
+// the ISA), and the reduction tree's tickets (taylor_step.inc, ppsci_epilogue_losses) rely on this wave's agent-scope
+// stores having COMPLETED before the ticket atomic is issued (vmcnt counts stores as well as loads on gfx9).
 __device__ __forceinline__ void ppsci_block_sync_mem() {
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
