@@ -141,6 +141,19 @@ def test_one_launch_is_deterministic(dev):
     assert np.isfinite(a[0]).all()
 
 
+def test_loss_terms_from_the_epilogue_launch_are_reproducible(dev):
+    """Separate launches: the loss terms are summed by whichever epilogue workgroup finishes last (ppsci_epilogue_losses),
+    in a fixed order -- bit-identical run to run (on the GPU also the race detector of its ticket protocol)."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 3, 20, 1, "tanh")
+    flat = _weights(lay, 5)
+    steps, n = (2, 700) if dev != "gpu" else (200, 40_000)  # 157 epilogue workgroups
+    a = _run(d, lay, [("laplace", n)], flat, False, steps)
+    b = _run(d, lay, [("laplace", n)], flat, False, steps)
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(a[2], b[2])) and np.array_equal(a[0], b[0])
+    assert np.isfinite(a[2][-1][0]).all()
+
+
 def test_one_launch_unsupported_falls_to_separate_launches(dev):
     """No one-launch kernel (activation without an instantiation, learnable equation parameters): workspace query
     says 0 and the engine keeps the separate launches -- which are the same HIP kernels, not a fallback off the GPU."""
