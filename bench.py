@@ -46,6 +46,10 @@ if EMU:
     N_PER_GPU = 128
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (f32 in) peak == fp32 vector peak
 PEAK_HBM_TBPS = 8.0       # MI355X_MICROARCH.md: HBM3E
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+# The GEMMs run on the bf16 (XDL) pipe as six bf16 products per fp32 product: the pipe-true ceiling for ALGORITHMIC fp32 flops
+PEAK_PIPE_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+CLOCK_GHZ, N_SIMD = 2.4, 1024
 EPS = 0.01
 N_FIX = 2048              # points of the reference-run fixtures (tests/golden/bench_nets.npz)
 NS_TOTAL = 64 if EMU else 1_000_000  # BASELINE configs[2]
@@ -150,6 +154,32 @@ def profile_info(stem, kernel_substr=None, ms_per_step=None, once_per_step=False
             for k, v in pmc.items():
                 if kernel_substr in k:
                     out["kernel_hbm_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
+    except Exception as e:  # noqa: BLE001 -- quoted context must never cost the measured line
+        out["error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
+
+
+def pipe_roofline(ach_tflops, stem, kernel_substr):
+    """What VERDICT r03 asked for next to `frac`: the fraction of the ceiling of the pipe the GEMMs actually run on
+    (2 500 TF bf16 / 6 products), and -- QUOTED from the committed PMC summary of config `stem` -- how busy that pipe was:
+    SQ_VALU_MFMA_BUSY_CYCLES / (kernel duration x 2.4 GHz x 1 024 SIMDs) for the kernel whose name contains `kernel_substr`."""
+    import csv
+    import glob
+
+    out = {"pipe_peak": PEAK_PIPE_TFLOPS, "pipe_frac": ach_tflops / PEAK_PIPE_TFLOPS if ach_tflops else None,
+           "pipe": "v_mfma_f32_16x16x32_bf16, six products per fp32 product: 2 500 / 6 TFLOP/s of algorithmic fp32 flops"}
+    try:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{stem}_pmc_summary.json")))
+        if files:
+            pmc = json.load(open(files[-1]))
+            stats = files[-1].replace("_pmc_summary.json", "_kernel_stats.csv")
+            busy = next((v.get("SQ_VALU_MFMA_BUSY_CYCLES") for k, v in pmc.items() if kernel_substr in k), None)
+            ns = None
+            if os.path.exists(stats):
+                ns = next((float(r["AverageNs"]) for r in csv.DictReader(open(stats)) if kernel_substr in r["Name"]), None)
+            if busy and ns:
+                out["mfma_busy"] = busy / (ns * CLOCK_GHZ * N_SIMD)
+                out["mfma_busy_source"] = os.path.relpath(files[-1], ROOT)
     except Exception as e:  # noqa: BLE001 -- quoted context must never cost the measured line
         out["error"] = f"{type(e).__name__}: {e}"[:200]
     return out
@@ -327,7 +357,7 @@ def api_parity(name, inputs, outputs, hidden, make_eq, reduction, weight, tmp):
             "loss_rel": max(abs(losses[k] / float(G[f"{name}/loss/{k}"]) - 1.0) for k in keys)}
 
 
-def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
+def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name, stem=None):
     def step():  # == the body of Solver.train()'s iteration for one constraint
         if not solver._step_in_one_launch([cc.fused], [], 1.0):
             solver.engine.forward_backward([cc.fused])
@@ -344,7 +374,7 @@ def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
         return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
                 "launches_per_step": 1, "matrix_tflops_step": 6.0 * p_mat * S * n / t / 1e12,
                 "roofline": {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": t_k * 1e3,
+                             "frac": ach / PEAK_FP32_TFLOPS, **pipe_roofline(ach, stem, name.split("<")[0]), "kernel_ms": t_k * 1e3,
                              "note": "forward + epilogue + reverse + reduction tree + Adam in one launch; latency-bound at "
                                      "this size (one 16-point tile per wave, one round)"}}
     t_bwd = time_events(lambda: cc.fused.backward(solver.engine.params))  # incl. the two small reduction kernels
@@ -353,7 +383,8 @@ def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name):
     return {"config": label, "value": n / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps,
             "matrix_tflops_step": 6.0 * p_mat * S * n / t / 1e12,
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "kernel_ms": t_bwd * 1e3,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                         **pipe_roofline(ach, stem, kernel_name.split(",")[0]), "kernel_ms": t_bwd * 1e3,
                          "fwd_plus_epilogue_ms": t_fwd * 1e3}}
 
 
@@ -364,7 +395,7 @@ def secondary_laplace(tmp, steps, warmup, with_cpu):
     solver, opt, cc, flat = api_pinn("lap", ("x", "y"), ("u",), [20] * 3, ppsci.equation.Laplace(2), X, "sum", None, tmp)
     e = pinn_entry("cfg1 Laplace2D, MLP 2->20x3->1 tanh, 10 000 interior points, u_xx+u_yy, MSE-sum, Adam "
                    "(BASELINE.json configs[0]); launch/latency-bound: 625 tiles on 1 024 wave slots",
-                   solver, opt, cc, 10_000, 2 * 20 + 2 * 400 + 20, 5, steps, warmup, "taylor_bwd_kernel<2, 2, 2, 0>")
+                   solver, opt, cc, 10_000, 2 * 20 + 2 * 400 + 20, 5, steps, warmup, "taylor_bwd_kernel<2, 2, 2, 0>", "laplace")
     e["step_profile"] = profile_info("laplace", None, e["ms_per_step"], once_per_step=True)
     if PURE:
         return e
@@ -393,7 +424,7 @@ def secondary_ns(tmp, steps, warmup):
     solver, opt, cc, _ = ns_setup(tmp, X, "ns")
     e = pinn_entry("cfg3 shard: LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 125 000 points (rank 0 of 8 of the "
                    "1 M-point cloud), continuity + momentum_x + momentum_y, weights 1e-4, MSE-sum, Adam",
-                   solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wx_kernel<8, 1, 5, 2, 2, 0>")
+                   solver, opt, cc, X.shape[0], NS_PMAT, 5, steps, warmup, "taylor_bwd_wx_kernel<8, 1, 5, 2, 2, 0>", "ns")
     e["step_profile"] = profile_info("ns", None, e["ms_per_step"], once_per_step=True)
     if PURE:
         return e
@@ -797,22 +828,38 @@ def main():
     dt = float(tt[0])
     loss = cst.losses()["allen_cahn"]
 
-    # per-kernel timing of the dominant kernel (reverse sweep) with HIP events on the launch stream
-    t_fwd = time_events(lambda: hp.taylor_fwd(cst.desc, params, cst.inputs, cst.U, cst.stash))
-    # ppsci_taylor_bwd = the reverse kernel + the two small fixed-order reduction kernels behind it (~10 us): the
-    # roofline fraction below charges them to the dominant kernel (rocprofv3's per-kernel average is in profiles/)
-    t_bwd = time_events(lambda: cst.backward(params))
-    # SURVEY.md 8(d) "R": residual evaluation only (forward streams + epilogue, no stash, no adjoints)
-    t_res = time_events(lambda: cst.forward(params, False))
     p_mat = 2 * WIDTH + (HIDDEN - 1) * WIDTH * WIDTH + WIDTH  # matrix weights (P = 12 480)
     S = cst.streams.S
     flops_bwd = 4.0 * p_mat * S * N_PER_GPU   # reverse sweep: 2 GEMMs per layer  (F_T - F_R)
     flops_fwd = 2.0 * p_mat * S * N_PER_GPU   # F_R
-    ach = flops_bwd / t_bwd / 1e12
+    fused = cst.one_launch_ready() and getattr(cst, "_step_kind", 0) == hp.STEP_FUSED_TILE and eng.one_launch
+    # SURVEY.md 8(d) "R": residual evaluation only (forward streams + epilogue, no stash, no adjoints)
+    t_res = time_events(lambda: cst.forward(params, False))
+    if fused:
+        # the dominant kernel IS the step: forward + residual program + reverse of every tile in one kernel (F_T flops);
+        # HIP events on the launch stream around that kernel alone (no weight split, no reduction kernels)
+        kname = f"taylor_fused_kernel<4, {HIDDEN}, 2, 1, 0>"
+        t_main = time_events(cst._step_plan.run_main)
+        flops_main = flops_fwd + flops_bwd
+        ach = flops_main / t_main / 1e12
+        extra = {"kernel_ms": t_main * 1e3, "flops_per_launch": flops_main,
+                 "what": "forward Taylor streams + residual program + loss seeds + reverse sweep of every 16-point tile in one "
+                         "kernel: the activation stash never leaves the CU (registers), U / dL/dU live in LDS"}
+        ksub = "taylor_fused_kernel<4, 4, 2, 1"
+    else:
+        # per-kernel timing of the dominant kernel (reverse sweep) with HIP events on the launch stream;
+        # ppsci_taylor_bwd = the reverse kernel + the two small fixed-order reduction kernels behind it (~10 us)
+        kname = "taylor_bwd_wx_kernel<4, 1, 4, 2, 1, 0>"
+        t_fwd = time_events(lambda: hp.taylor_fwd(cst.desc, params, cst.inputs, cst.U, cst.stash))
+        t_bwd = time_events(lambda: cst.backward(params))
+        ach = flops_bwd / t_bwd / 1e12
+        extra = {"kernel_ms": t_bwd * 1e3, "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12,
+                 "flops_per_launch": flops_bwd}
+        ksub = "taylor_bwd_wx_kernel<4, 1, 4, 2, 1"
 
     # HBM traffic of the dominant kernel per launch and of the whole step: quoted from the newest committed rocprofv3
     # summary (tools/profile_bench.sh; separate --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md) with its file name
-    prof = profile_info("bench", "taylor_bwd_wx_kernel<4, 1, 4, 2, 1", dt / args.steps * 1e3, once_per_step=True)
+    prof = profile_info("bench", ksub, dt / args.steps * 1e3, once_per_step=True)
     traffic, traffic_src = prof.get("kernel_hbm_bytes_per_launch"), prof.get("source")
 
     strong = None
@@ -846,13 +893,18 @@ def main():
                                    "residual+MSE-mean+grad+Adam (BASELINE.json configs[1])",
                        "points_per_gpu": N_PER_GPU, "parallelism": f"dp{world}", "loss": loss,
                        "residual_only_points_per_s_per_gpu": N_PER_GPU / t_res},
-            "roofline": {"bound": "mfma", "kernel": "taylor_bwd_wx_kernel<4, 1, 4, 2, 1, 0>", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": ach,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": t_bwd * 1e3,
-                         "fwd_kernel_ms": t_fwd * 1e3, "fwd_achieved": flops_fwd / t_fwd / 1e12,
+                         **pipe_roofline(ach, "bench", ksub),
+                         "traffic": traffic, "traffic_source": traffic_src, **extra,
+                         "algorithmic_bytes_per_launch": 4.0 * (2 + 1 + 1) * N_PER_GPU,
                          "arithmetic": "fp32 operands as three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per "
                                        "K = 32 step, fp32 accumulate (error <= the fp32 MFMA's); `peak` is the fp32-input "
-                                       "MFMA peak the algorithmic flops are priced against",
+                                       "MFMA peak the algorithmic flops are priced against, `pipe_peak` the ceiling of the "
+                                       "pipe they actually run on",
+                         "residual_error_note": "residual rel-L2 vs the fp64 reference run is ~1.1e-6 = 2.5x the fp32 floor of "
+                                                "the reference algorithm itself (4.4e-7, SURVEY 8d): the 5-slot tanh "
+                                                "(1 - 2/(exp(2x)+1), abs error 1.2e-7), not the bf16 split",
                          "step_profile": prof},
             "parity": parity,
         }

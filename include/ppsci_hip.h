@@ -228,33 +228,57 @@ typedef struct ppsci_adam_args {
   int64_t step_t; /* 1-based */
 } ppsci_adam_args;
 
-/* One training step of one constraint in ONE launch, for batches of a few thousand points (tiles fit the chip in a
- * round or two): ppsci_taylor_fwd -> ppsci_epilogue -> ppsci_taylor_bwd of every tile by the wave that owns it, a
- * fixed-order tree reduction of the workgroups' partial sums by whichever workgroup finishes a group last, then
+/* One training step of one constraint behind ONE call.  Two kernel families (ppsci_taylor_step_kind):
+ *   1  padded width <= 32, batches of a few thousand points (tiles fit the chip in a round or two): ppsci_taylor_fwd ->
+ *      ppsci_epilogue -> ppsci_taylor_bwd of every tile by the wave that owns it, in ONE launch (csrc/taylor_step.inc);
+ *   2  padded width 33..64, any batch size: the fused tile kernel (csrc/taylor_fused.inc) -- a workgroup carries a
+ *      16-point tile from its inputs through forward streams, residual program, loss seeds and reverse sweep without
+ *      anything of the tile leaving the CU (the activation stash is registers, U / dL/dU are LDS): no stash traffic.
+ *      U, Ubar and stash may be NULL (U / Ubar: optional outputs; the stash is not used).
+ * Both end with a fixed-order reduction of the workgroups' partial sums -- a tree of "last one out" sums inside the
+ * launch, or (kind 2, large grids) the two reduction kernels behind it -- then
  *   grad (+)= dL/dparams (accumulate != 0: the second and later constraints of a step),  loss_terms[k] = loss term k,
  * and, with adam != NULL, the Adam update of `params` from `grad` (i.e. pass it with the LAST constraint of a step on a
- * single rank).  Replaces one pass of train.py:82-184 for that constraint; results equal the separate calls' up to the
+ * single rank).  Replaces one pass of /root/reference/ppsci/solver/train.py:82-184 for that constraint
+ * (utils/expression.py:89-126, loss/mse.py:82-105, train.py:158,175); results equal the separate calls' up to the
  * summation order of the partial sums.  Buffers as for the separate calls (U, Ubar: [m*S, N]; residual_out may be NULL;
  * stash: ppsci_stash_bytes()); workspace: ppsci_taylor_step_workspace_bytes() bytes, ZERO-filled before the first call
- * and owned by this constraint from then on.  ppsci_taylor_step_workspace_bytes() == 0 / PPSCI_E_UNSUPPORTED: this
- * network, stream set or program (learnable equation parameters) has no one-launch kernel -- use the separate calls. */
+ * and owned by this constraint from then on; `workspace_bytes` is checked against what the launch planned NOW needs (the
+ * grid depends on ppsci_set_max_grid).  ppsci_taylor_step_workspace_bytes() == 0 / ppsci_taylor_step_kind() == 0 /
+ * PPSCI_E_UNSUPPORTED: this network, stream set or program (learnable equation parameters) has neither kernel -- use
+ * the separate calls. */
 int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
+int ppsci_taylor_step_kind(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
+/* test / tool knobs (process-global): the fused tile kernel on (default) or off; how a fused launch ends: -1 by grid
+ * size (default), 0 the in-kernel reduction tree, 1 the reduction kernels behind the launch.  Both are read when a
+ * launch is PLANNED (workspace_bytes, _plan). */
+void ppsci_set_fused_step(int on);
+void ppsci_set_step_tail(int mode);
+/* kind 2: residual programs made of loads, constants, +, -, *, negation and detach under MSE terms (every BASELINE PDE)
+ * run pre-decoded (csrc/epilogue_vm.h epi_point_fast) instead of through the opcode interpreter; 0 forces the interpreter
+ * (tests compare the two). */
+void ppsci_set_fast_program(int on);
 /* The same with the argument block prepared once: a training loop launches the same constraint thousands of times
  * with the same buffers, and at 20-40 us of device time per step the per-call planning (occupancy / attribute queries,
  * argument checks) of ppsci_taylor_step would dominate.  _plan: NULL on error / unsupported (ppsci_last_error);
- * _run: one kernel launch; _set_scales: takes over the residual scales of `e` (loss re-weighting between steps). */
+ * _run: one kernel launch (kind 2: + the weight-split launch in front of it, and the reduction launches behind it for
+ * large grids); _set_scales: takes over the residual scales of `e` (loss re-weighting between steps). */
 typedef struct ppsci_step_plan ppsci_step_plan;
 ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params,
                                         int64_t n_points, const float* const* inputs_host, const float* const* aux_host,
                                         float* U, float* Ubar, float* residual_out, void* stash, void* workspace,
-                                        float* loss_terms, float* grad);
+                                        int64_t workspace_bytes, float* loss_terms, float* grad);
 int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream);
 int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogue_desc* e);
+/* measurement (bench.py's roofline entry): the MAIN kernel of the planned step alone -- kind 2: the fused tile kernel
+ * without the weight-split launch in front of it and without any reduction (the workgroups' rows stay in the workspace;
+ * the fragments are those of the last _run); kind 1: the whole launch without Adam. */
+int ppsci_taylor_step_run_main(ppsci_step_plan* plan, void* stream);
 void ppsci_taylor_step_plan_free(ppsci_step_plan* plan);
 int ppsci_taylor_step(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params, int64_t n_points,
                       const float* const* inputs_host, const float* const* aux_host, float* U, float* Ubar,
-                      float* residual_out, void* stash, void* workspace, float* loss_terms, float* grad, int accumulate,
-                      const ppsci_adam_args* adam, void* stream);
+                      float* residual_out, void* stash, void* workspace, int64_t workspace_bytes, float* loss_terms,
+                      float* grad, int accumulate, const ppsci_adam_args* adam, void* stream);
 
 /* out[j] (+)= sum_r partials[r, j], fixed summation order (deterministic).  Used for the
  * gradient (cols = P) and for the loss terms (cols = n_res; mtl/sum.py:45-60 adds them). */

@@ -81,7 +81,8 @@ class AdamArgs(C.Structure):  # ppsci_adam_args
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "libppsci_hip.so")
+# PPSCI_HIP_LIB: another gfx950 build of the same sources (tools/build_variant.py: timer / ablation builds for measurements)
+DEFAULT_LIB = os.environ.get("PPSCI_HIP_LIB") or os.path.join(_HERE, "libppsci_hip.so")
 _lib: Optional[C.CDLL] = None
 _injected = False
 
@@ -110,15 +111,20 @@ _SYMBOLS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "ppsci_taylor_step_workspace_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_int64]),
+    "ppsci_taylor_step_kind": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_int64]),
+    "ppsci_set_fused_step": (None, [C.c_int]),
+    "ppsci_set_step_tail": (None, [C.c_int]),
+    "ppsci_set_fast_program": (None, [C.c_int]),
     "ppsci_taylor_step_plan": (C.c_void_p, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ppsci_taylor_step_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p]),
     "ppsci_taylor_step_plan_set_scales": (C.c_int, [C.c_void_p, C.POINTER(EpilogueDesc)]),
+    "ppsci_taylor_step_run_main": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ppsci_taylor_step_plan_free": (None, [C.c_void_p]),
     "ppsci_taylor_step": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p]),
+                                    C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p]),
     "ppsci_spectral_conv2d_fwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
     "ppsci_spectral_conv2d_bwd": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

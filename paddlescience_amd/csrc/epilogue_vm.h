@@ -32,7 +32,48 @@ struct EpiArgs {
   unsigned* counter;   // with loss_out: one zero-initialised ticket counter (left at zero)
   int nload;   // the program's load instructions (LD_IN / LD_U / LD_AUX), in program order: epi_fill_loads()
   unsigned char load_idx[PPSCI_MAX_PROG];
+  // EPI_RF_FUSED: the pre-decoded arithmetic steps of a program that only adds, subtracts, multiplies, negates and
+  // detaches (every BASELINE PDE residual) -- epi_fast_encode(); device memory; null: the generic interpreter
+  const unsigned* fast;
+  int nfast;
 };
+
+// ---- pre-decoded programs for epi_point_fast.  One 32-bit word per arithmetic step (loads and constants are not steps):
+//   [0:6] a  [7:13] b  [14:20] destination i  [21] product  [22:23] sx  [24:25] sy  [26:27] rx  [28:29] ry  [30] a == b
+// value:   r = product ? v[a] v[b] : sx v[a] + sy v[b];   adjoints: abar += g (product ? v[b] : rx), bbar += g (product ? v[a] : ry)
+// with the two-bit codes 0 -> 0, 1 -> +1, 2 -> -1 (detach: sx = 1, rx = 0).
+#define EPI_FAST_MAX 96
+static inline unsigned epi_fast_word(int a, int b, int i, int prod, int sx, int sy, int rx, int ry) {
+  return (unsigned)a | ((unsigned)b << 7) | ((unsigned)i << 14) | ((unsigned)prod << 21) | ((unsigned)sx << 22) |
+         ((unsigned)sy << 24) | ((unsigned)rx << 26) | ((unsigned)ry << 28) | ((a == b ? 1u : 0u) << 30);
+}
+// host: returns the number of steps written to `out` (<= EPI_FAST_MAX), or -1 when the program (or one of its loss
+// terms) needs the generic interpreter
+static inline int epi_fast_encode(const ppsci_epilogue_desc& e, unsigned* out) {
+  if (e.n_instr > 127) return -1;
+  for (int k = 0; k < e.n_res; ++k)
+    if (e.res[k].kind != PPSCI_LOSS_MSE) return -1;
+  int n = 0;
+  for (int i = 0; i < e.n_instr; ++i) {
+    const ppsci_instr& ins = e.prog[i];
+    unsigned w;
+    switch (ins.op) {
+      case PPSCI_OP_LD_IN:
+      case PPSCI_OP_LD_U:
+      case PPSCI_OP_LD_AUX:
+      case PPSCI_OP_CONST: continue;
+      case PPSCI_OP_ADD: w = epi_fast_word(ins.a, ins.b, i, 0, 1, 1, 1, 1); break;
+      case PPSCI_OP_SUB: w = epi_fast_word(ins.a, ins.b, i, 0, 1, 2, 1, 2); break;
+      case PPSCI_OP_MUL: w = epi_fast_word(ins.a, ins.b, i, 1, 0, 0, 0, 0); break;
+      case PPSCI_OP_NEG: w = epi_fast_word(ins.a, ins.a, i, 0, 2, 0, 2, 0); break;     // (a == b: one accumulation of -g)
+      case PPSCI_OP_DETACH: w = epi_fast_word(ins.a, ins.a, i, 0, 1, 0, 0, 0); break;  // (no adjoint flows)
+      default: return -1;
+    }
+    if (n == EPI_FAST_MAX) return -1;
+    out[n++] = w;
+  }
+  return n;
+}
 
 // host: list the load instructions of a.e (after a.e is set)
 static inline void epi_fill_loads(EpiArgs& a) {
@@ -68,38 +109,30 @@ __device__ __forceinline__ float epi_digamma(float x) {
 //                   ITS tile on lanes 0..15 (the tile the same wave's forward sweep has just produced and its reverse
 //                   sweep consumes next); register file in LDS, [n][16 * waves]
 // `red`: EPI_BLOCK floats of LDS for the loss reductions, followed by the register file (LDS modes).
+//   EPI_RF_FUSED    inside the fused tile kernel (taylor_fused.inc): ONE 16-point tile per workgroup; lanes 0..15 of wave 0
+//                   run the program for it.  The tile's operands never leave the CU: LD_U sums the waves' partial sums
+//                   of the last linear layer from LDS, LD_IN reads the tile's inputs from LDS, and the adjoint of every
+//                   LD_U goes to the LDS rows the reverse sweep reads (EpiFused); register file in LDS, [n][16]
 #define EPI_RF_SCRATCH 0
 #define EPI_RF_LDS 1
 #define EPI_RF_TILED 2
-template <int MODE>
-__device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
-  const int tid = threadIdx.x;
-  const int n = a.e.n_instr;
-  constexpr bool LDSRF = MODE != EPI_RF_SCRATCH;
-  float v_s[LDSRF ? 1 : PPSCI_MAX_PROG], adj_s[LDSRF ? 1 : PPSCI_MAX_PROG];
-  const int RS = MODE == EPI_RF_SCRATCH ? 1 : (MODE == EPI_RF_LDS ? EPI_BLOCK : (int)(blockDim.x >> 2));
-  const int slot = MODE == EPI_RF_TILED ? ((tid >> 6) * PPSCI_TILE + (tid & 15)) : tid;
-  float* const vp = LDSRF ? red + EPI_BLOCK + slot : v_s;
-  float* const ap = LDSRF ? red + EPI_BLOCK + (long long)n * RS + slot : adj_s;
-  float lsum[PPSCI_MAX_RES];
-  for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
-  float padj[PPSCI_MAX_EPARAM];  // adjoints of the equation parameters, summed over this lane's points
-#pragma unroll
-  for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
+#define EPI_RF_FUSED 3
 
-  for (int it = 0; it < a.iters; ++it) {
-    if (MODE == EPI_RF_TILED && (tid & 63) >= PPSCI_TILE) break;  // lanes 0..15 of every wave run the tile's points
-    long long p;
-    bool valid;
-    if (MODE == EPI_RF_TILED) {
-      const int tile = ppsci_tile_index(it, (int)(blockDim.x >> 6));
-      p = (long long)tile * PPSCI_TILE + (tid & 15);
-      valid = tile < a.ntiles && p < a.N;
-    } else {
-      p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
-      valid = p < a.N;
-    }
-    const long long pp = valid ? p : 0;
+struct EpiFused {
+  const float* red;   // [W][mS][16]: per-wave partial sums of the last linear layer (fixed-order sum over w)
+  const float* bl;    // [m]: last bias (added to the value stream, s == 0)
+  const float* tinx;  // [d_raw][16]: the tile's raw inputs
+  float* tin;         // [mS][16]: dL/dU of the tile (rows the program never loads are zeroed here)
+  int W, mS, S;
+};
+
+// One point of the program: forward (memory operands first), loss terms and their seeds, reverse.
+//   vp / ap: this point's column of the register file (values / adjoints), row stride RS; n = program length;
+//   p / pp / valid: the point, its clamped index for loads, inside the batch; pt: the point's index in its tile (FUSED).
+template <int MODE>
+__device__ __forceinline__ void epi_point(const EpiArgs& a, float* const vp, float* const ap, const int RS, const int n,
+                                          const long long p, const long long pp, const bool valid, const int pt,
+                                          float (&lsum)[PPSCI_MAX_RES], float (&padj)[PPSCI_MAX_EPARAM], const EpiFused* fx) {
     // labels / weights / areas of the first two loss terms: requested now, used behind the forward pass (they come
     // from HBM -- a round trip of their own when requested where they are used).  Named scalars: an array indexed by
     // the term number ends up in scratch memory.
@@ -117,6 +150,21 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
     // ---- forward, pass 1: every memory operand of the program, eight loads in flight at a time, straight into the
     // register file (issued one per VM step, each load is a full round trip that the next instruction waits for:
     // 5-6 us for the eight loads of a Laplace program with label and weight, against well under 1 us of arithmetic)
+    if (MODE == EPI_RF_FUSED) {
+      // the tile's streams and inputs are in LDS; only LD_AUX goes to memory
+      for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
+      for (int k = 0; k < a.nload; ++k) {
+        const int i = a.load_idx[k];
+        const ppsci_instr ins = a.e.prog[i];
+        float v;
+        if (ins.op == PPSCI_OP_LD_U) {
+          v = (ins.a % fx->S == 0) ? fx->bl[ins.a / fx->S] : 0.f;
+          for (int w = 0; w < fx->W; ++w) v += fx->red[(w * fx->mS + ins.a) * PPSCI_TILE + pt];
+        } else if (ins.op == PPSCI_OP_LD_IN) v = fx->tinx[ins.a * PPSCI_TILE + pt];
+        else v = a.aux[ins.a][pp];
+        vp[i * RS] = v;
+      }
+    } else {
     for (int base = 0; base < a.nload; base += 8) {
       float tv[8];
 #pragma unroll
@@ -129,6 +177,7 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (base + k < a.nload) vp[(a.load_idx[base + k]) * RS] = tv[k];
+    }
     }
     // ---- forward, pass 2
     for (int i = 0; i < n; ++i) {
@@ -209,13 +258,16 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
       }
     }
     // ---- reverse
-    if (a.Ubar != nullptr) {
+    if (MODE == EPI_RF_FUSED || a.Ubar != nullptr) {
       for (int i = n - 1; i >= 0; --i) {
         const ppsci_instr ins = a.e.prog[i];
         const float g = ap[(i) * RS];
         switch (ins.op) {
           case PPSCI_OP_LD_U:
-            if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
+            if (MODE == EPI_RF_FUSED) {
+              fx->tin[ins.a * PPSCI_TILE + pt] = g;  // (invalid lanes carry g = 0: their seeds are never set)
+              if (valid && a.Ubar != nullptr) a.Ubar[(long long)ins.a * a.N + p] = g;
+            } else if (valid) a.Ubar[(long long)ins.a * a.N + p] = g;
             break;
           case PPSCI_OP_LD_PARAM:
 #pragma unroll
@@ -269,11 +321,115 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
         }
       }
     }
-  }
+}
 
-  // ---- block reduction of the loss terms: a butterfly inside every wave (register shuffles), then the waves' sums in
-  // wave order -- a fixed shape, so deterministic; two LDS-only barriers in all (a 256-wide LDS tree with a full
-  // __syncthreads() per level costs ten barriers per term, the first of which also waits for every adjoint store)
+// EPI_RF_FUSED, pre-decoded programs (EpiArgs::fast): the same arithmetic as epi_point, step for step and in the same
+// order, without the interpreter -- no opcode dispatch, every step a handful of branch-free VALU instructions between one
+// round of LDS reads and its writes.  (The interpreter costs ~600 cycles per step on the 16 lanes it runs on, with the
+// workgroup's other waves parked at the barrier behind it: 17 000 of a tile's 52 000 cycles on Allen-Cahn's 12
+// instructions.)  The constants of the program sit in the register file from the start of the kernel (epi_fast_init).
+__device__ __forceinline__ float epi_fast_code(unsigned c) { return (float)(c & 1u) - (float)(c >> 1); }
+
+__device__ __forceinline__ void epi_fast_init(const EpiArgs& a, float* const vp, const int RS) {
+  for (int i = 0; i < a.e.n_instr; ++i) {
+    const ppsci_instr ins = a.e.prog[i];
+    if (ins.op == PPSCI_OP_CONST) vp[i * RS] = ins.c;
+  }
+}
+
+// `lacc`: this point's column of the running loss sums in LDS ([PPSCI_MAX_RES][PPSCI_TILE], stride PPSCI_TILE).
+__device__ __forceinline__ void epi_point_fast(const EpiArgs& a, float* const vp, float* const ap, const int RS, const long long p,
+                                               const long long pp, const bool valid, const int pt, float* const lacc,
+                                               const EpiFused* fx) {
+  // label / weight / area of the first two loss terms: requested first (HBM), used behind the forward steps
+#define EPI_PF(k_, L_, W_)                                                       \
+  float L_ = 0.f, W_ = 1.f;                                                      \
+  if (k_ < a.e.n_res) {                                                          \
+    const ppsci_residual rs_ = a.e.res[k_];                                      \
+    if (rs_.label >= 0) L_ = a.aux[rs_.label][pp];                              \
+    if (rs_.weight >= 0) W_ = a.aux[rs_.weight][pp];                             \
+    if (rs_.area >= 0) W_ *= a.aux[rs_.area][pp];                               \
+  }
+  EPI_PF(0, lab0, w0)
+  EPI_PF(1, lab1, w1)
+#undef EPI_PF
+  // ---- memory operands; the adjoint of everything the reverse pass accumulates into starts at zero
+  for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
+  for (int k = 0; k < a.nload; ++k) {
+    const int i = a.load_idx[k];
+    const ppsci_instr ins = a.e.prog[i];
+    float v;
+    if (ins.op == PPSCI_OP_LD_U) {
+      v = (ins.a % fx->S == 0) ? fx->bl[ins.a / fx->S] : 0.f;
+      for (int w = 0; w < fx->W; ++w) v += fx->red[(w * fx->mS + ins.a) * PPSCI_TILE + pt];
+    } else if (ins.op == PPSCI_OP_LD_IN) v = fx->tinx[ins.a * PPSCI_TILE + pt];
+    else v = a.aux[ins.a][pp];
+    vp[i * RS] = v;
+    ap[i * RS] = 0.f;
+  }
+  // ---- forward steps
+  for (int k = 0; k < a.nfast; ++k) {
+    const unsigned w = a.fast[k];
+    const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
+    const float x = vp[ia * RS], y = vp[ib * RS];
+    const float lin = epi_fast_code((w >> 22) & 3u) * x + epi_fast_code((w >> 24) & 3u) * y;
+    vp[id * RS] = ((w >> 21) & 1u) ? x * y : lin;
+    ap[id * RS] = 0.f;
+  }
+  // ---- residuals, MSE terms and their seeds (epi_point, PPSCI_LOSS_MSE)
+  for (int k = 0; k < a.e.n_res; ++k) {
+    const ppsci_residual rs = a.e.res[k];
+    float lab, wk;
+    if (k == 0) lab = lab0, wk = w0;
+    else if (k == 1) lab = lab1, wk = w1;
+    else {
+      lab = rs.label >= 0 ? a.aux[rs.label][pp] : 0.f;
+      wk = rs.weight >= 0 ? a.aux[rs.weight][pp] : 1.f;
+      if (rs.area >= 0) wk *= a.aux[rs.area][pp];
+    }
+    const float rv = vp[rs.value * RS];
+    if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
+    const float diff = rv - lab;
+    if (valid) {
+      const float w = wk * rs.scale;
+      lacc[k * PPSCI_TILE] += w * diff * diff;
+      ap[rs.value * RS] += 2.f * w * diff;
+    }
+  }
+  // ---- reverse steps
+  for (int k = a.nfast - 1; k >= 0; --k) {
+    const unsigned w = a.fast[k];
+    const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
+    const float g = ap[id * RS], x = vp[ia * RS], y = vp[ib * RS];
+    const float ga = ap[ia * RS], gb = ap[ib * RS];
+    const bool prod = (w >> 21) & 1u;
+    const float ca = prod ? y : epi_fast_code((w >> 26) & 3u), cb = prod ? x : epi_fast_code((w >> 28) & 3u);
+    if ((w >> 30) & 1u) ap[ia * RS] = ga + g * ca + g * cb;  // a == b (u * u): ONE accumulation, the generic order a, then b
+    else {
+      ap[ia * RS] = ga + g * ca;
+      ap[ib * RS] = gb + g * cb;
+    }
+  }
+  for (int k = 0; k < a.nload; ++k) {
+    const int i = a.load_idx[k];
+    const ppsci_instr ins = a.e.prog[i];
+    if (ins.op == PPSCI_OP_LD_U) {
+      const float g = ap[i * RS];
+      fx->tin[ins.a * PPSCI_TILE + pt] = g;  // (invalid lanes carry g = 0: their seeds are never set)
+      if (valid && a.Ubar != nullptr) a.Ubar[(long long)ins.a * a.N + p] = g;
+    }
+  }
+}
+
+// Block reduction of the loss terms (and equation-parameter adjoints) the lanes have summed over their points: a butterfly
+// inside every wave (register shuffles), then the waves' sums in
+// wave order -- a fixed shape, so deterministic; two LDS-only barriers in all (a 256-wide LDS tree with a full
+// __syncthreads() per level costs ten barriers per term, the first of which also waits for every adjoint store).
+// `red`: (PPSCI_MAX_RES + PPSCI_MAX_EPARAM) * 16 floats of LDS.
+template <int MODE>
+__device__ __forceinline__ void epi_finale(const EpiArgs& a, float* red, float (&lsum)[PPSCI_MAX_RES],
+                                           float (&padj)[PPSCI_MAX_EPARAM]) {
+  const int tid = threadIdx.x;
   const int wv = tid >> 6, nwv = (int)(blockDim.x >> 6);
   ppsci_block_sync_lds();  // LDS modes: the register file's last reads come first (`red` is its own region, but cheap)
 #pragma unroll
@@ -299,7 +455,7 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
     float t = 0.f;
     for (int w = 0; w < nwv; ++w) t += red[tid * 16 + w];
     // (inside the one-launch step kernel, or with loss_out, another workgroup reads the row before the launch ends)
-    if (MODE == EPI_RF_TILED || a.loss_out != nullptr) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + tid], t);
+    if (MODE == EPI_RF_TILED || MODE == EPI_RF_FUSED || a.loss_out != nullptr) ppsci_store_agent(&a.partials[(long long)blockIdx.x * a.e.n_res + tid], t);
     else a.partials[(long long)blockIdx.x * a.e.n_res + tid] = t;
   }
   if (a.ep_part != nullptr && tid >= 64 && tid < 64 + PPSCI_MAX_EPARAM) {
@@ -308,7 +464,7 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
     for (int w = 0; w < nwv; ++w) t += red[(PPSCI_MAX_RES + k) * 16 + w];
     a.ep_part[(long long)blockIdx.x * PPSCI_MAX_EPARAM + k] = t;
   }
-  if (MODE != EPI_RF_TILED && a.loss_out != nullptr) {
+  if (MODE != EPI_RF_TILED && MODE != EPI_RF_FUSED && a.loss_out != nullptr) {
     // ---- loss terms without a reduction launch: the workgroup that finishes LAST sums all workgroups' rows, in a fixed
     // order (thread t: rows t, t + 256, ...; then the butterfly and the waves in order) -- deterministic whichever it is.
     // Rows were written with agent-scope stores; the ticket is taken after they have completed (ppsci_common.h).
@@ -338,3 +494,38 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
   }
 }
 
+// `red`: EPI_BLOCK floats of LDS for the loss reductions, followed by the register file (LDS modes).
+template <int MODE>
+__device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
+  static_assert(MODE != EPI_RF_FUSED, "the fused tile kernel calls epi_point / epi_finale itself");
+  const int tid = threadIdx.x;
+  const int n = a.e.n_instr;
+  constexpr bool LDSRF = MODE != EPI_RF_SCRATCH;
+  float v_s[LDSRF ? 1 : PPSCI_MAX_PROG], adj_s[LDSRF ? 1 : PPSCI_MAX_PROG];
+  const int RS = MODE == EPI_RF_SCRATCH ? 1 : (MODE == EPI_RF_LDS ? EPI_BLOCK : (int)(blockDim.x >> 2));
+  const int slot = MODE == EPI_RF_TILED ? ((tid >> 6) * PPSCI_TILE + (tid & 15)) : tid;
+  float* const vp = LDSRF ? red + EPI_BLOCK + slot : v_s;
+  float* const ap = LDSRF ? red + EPI_BLOCK + (long long)n * RS + slot : adj_s;
+  float lsum[PPSCI_MAX_RES];
+  for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = 0.f;
+  float padj[PPSCI_MAX_EPARAM];  // adjoints of the equation parameters, summed over this lane's points
+#pragma unroll
+  for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
+
+  for (int it = 0; it < a.iters; ++it) {
+    if (MODE == EPI_RF_TILED && (tid & 63) >= PPSCI_TILE) break;  // lanes 0..15 of every wave run the tile's points
+    long long p;
+    bool valid;
+    if (MODE == EPI_RF_TILED) {
+      const int tile = ppsci_tile_index(it, (int)(blockDim.x >> 6));
+      p = (long long)tile * PPSCI_TILE + (tid & 15);
+      valid = tile < a.ntiles && p < a.N;
+    } else {
+      p = ((long long)it * gridDim.x + blockIdx.x) * EPI_BLOCK + tid;
+      valid = p < a.N;
+    }
+    const long long pp = valid ? p : 0;
+    epi_point<MODE>(a, vp, ap, RS, n, p, pp, valid, tid & 15, lsum, padj, nullptr);
+  }
+  epi_finale<MODE>(a, red, lsum, padj);
+}

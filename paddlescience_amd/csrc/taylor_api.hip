@@ -38,6 +38,37 @@ __global__ void __launch_bounds__(256) ppsci_presplit_kernel(const float* params
   }
 }
 
+// Both directions in ONE launch into a caller-owned buffer (the fused tile kernel's step workspace): forward fragments
+// first, backward fragments PPSCI_GFRAG_PER_LAYER * (L - 1) u32x4 behind them.
+__global__ void __launch_bounds__(256) ppsci_presplit2_kernel(const float* params, ppsci_derived q, int H, int L, u32x4* out) {
+  const int NB = q.NB, NKP = NB / 2;
+  const int per_layer = NB * NKP * 64;
+  const int total = (L - 1) * per_layer;
+  for (int idx2 = blockIdx.x * blockDim.x + threadIdx.x; idx2 < 2 * total; idx2 += gridDim.x * blockDim.x) {
+    const int bwd = idx2 >= total ? 1 : 0, idx = idx2 - bwd * total;
+    const int l = 1 + idx / per_layer, rem = idx % per_layer;
+    const int lane = rem & 63, pair = rem >> 6, rb = pair / NKP, kp = pair - rb * NKP;
+    const int g = lane >> 4, c = lane & 15;
+    const float* W = params + q.offW[l];
+    ppsci_split4 sp[2];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const int kb = 2 * kp + hlf;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int in = bwd ? 16 * rb + c : 16 * kb + 4 * g + r, o = bwd ? 16 * kb + 4 * g + r : 16 * rb + c;
+        v[r] = (in < H && o < H) ? W[in * H + o] : 0.f;
+      }
+      sp[hlf] = ppsci_split(v);
+    }
+    u32x4* dst = out + (long long)bwd * (L - 1) * (NB * NKP * 3 * 64) + (long long)(l - 1) * (NB * NKP * 3 * 64) +
+                 (long long)(pair * 3) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * 64] = (u32x4){sp[0].p[p][0], sp[0].p[p][1], sp[1].p[p][0], sp[1].p[p][1]};
+  }
+}
+
 // Fragment cache: one device buffer per (parameter buffer, direction), allocated on first use (an eager call: the
 // engine captures HIP graphs only from the second step on) and re-filled by every launch that needs it -- the
 // parameters change every step.  Never freed: a handful of entries of <= a few MiB.
@@ -247,8 +278,29 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
 }
 
 // ------------------------------------------------------------------------------------ one-launch step
+// process-global knobs of the one-launch step (tests / tools): the fused tile kernel on or off; how a fused launch ends
+// (-1: by grid size, 0: the in-kernel reduction tree, 1: the host issues the reduction kernels behind the launch)
+static int g_fused_step = 1, g_step_tail = -1, g_fast_vm = 1;
+extern "C" void ppsci_set_fast_program(int on) { g_fast_vm = on ? 1 : 0; }
+extern "C" void ppsci_set_fused_step(int on) { g_fused_step = on ? 1 : 0; }
+extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = mode < 0 ? -1 : (mode ? 1 : 0); }
+// a tree over more rows than this is slower than the reduction kernels: every level is a ~10-20 us pass of ONE workgroup
+// over 16 rows of (L-1) * 16 KB, against ~12 us for the two kernels over all rows
+#define PPSCI_FUSED_TREE_MAX_GRID 48
+
 static int run_step_act(StepArgs& a, void* stream, int launch, int* grid) {
   if (a.f.d.fourier_half > 0) return PPSCI_E_UNSUPPORTED;
+  if (launch == 2 ? a.t.fused != 0 : g_fused_step != 0) {
+    int rc = PPSCI_E_UNSUPPORTED;
+    switch (a.f.d.activation) {
+      case PPSCI_ACT_TANH: rc = ppsci_fused_run_tanh(a, stream, launch, grid); break;
+      case PPSCI_ACT_SILU: rc = ppsci_fused_run_silu(a, stream, launch, grid); break;
+      case PPSCI_ACT_SIN: rc = ppsci_fused_run_sin(a, stream, launch, grid); break;
+      default: break;
+    }
+    if (rc != PPSCI_E_UNSUPPORTED || launch == 2) return rc;
+  }
+  a.t.fused = 0;
   switch (a.f.d.activation) {
     case PPSCI_ACT_TANH: return ppsci_step_run_tanh(a, stream, launch, grid);
     case PPSCI_ACT_SILU: return ppsci_step_run_silu(a, stream, launch, grid);
@@ -258,12 +310,14 @@ static int run_step_act(StepArgs& a, void* stream, int launch, int* grid) {
 }
 
 // workspace layout (floats): rows_w [grid][per_tile] | rows_s [grid][psmall] | rows_l [grid][n_res] | tree rows | counters
+// fused tile kernel: ... | pre-split fragments (both directions) | chunk sums of the reduction kernels | a spare gradient row
 struct StepLayout {
-  long long rows_w, rows_s, rows_l, tree, counters, total;
+  long long rows_w, rows_s, rows_l, tree, counters, frag, red_tmp, red_small, red_row, fastprog, total;
   int per_tile, psmall, rowlen, tree_rows;
 };
 static StepLayout step_layout(const StepArgs& a, int grid, int n_res) {
   StepLayout y;
+  memset(&y, 0, sizeof(y));
   y.per_tile = (int)bwd_per_tile_floats(a.b);
   y.psmall = ppsci_small_params(a.b.d, a.b.q);
   y.rowlen = y.per_tile + ((y.psmall + 3) & ~3) + ((n_res + 3) & ~3);
@@ -279,6 +333,15 @@ static StepLayout step_layout(const StepArgs& a, int grid, int n_res) {
   y.tree = y.rows_l + pad4((long long)grid * (n_res > 0 ? n_res : 1));
   y.counters = y.tree + (long long)y.tree_rows * y.rowlen;
   y.total = y.counters + pad4(y.tree_rows + 1);
+  if (a.t.fused) {
+    const long long chunks = grid < PPSCI_WRED_CHUNKS ? grid : PPSCI_WRED_CHUNKS;
+    y.frag = y.total;
+    y.red_tmp = y.frag + 2LL * (a.f.d.n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB) * 4;
+    y.red_small = y.red_tmp + chunks * y.per_tile;
+    y.red_row = y.red_small + pad4(PPSCI_WRED_CHUNKS * (long long)y.psmall);
+    y.fastprog = y.red_row + pad4(a.f.q.P);  // pre-decoded residual program (epi_fast_encode)
+    y.total = y.fastprog + EPI_FAST_MAX;
+  }
   return y;
 }
 
@@ -307,13 +370,23 @@ extern "C" int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, co
 
 struct ppsci_step_plan {
   StepArgs a;
+  StepLayout y;
+  float* ws;
 };
+
+extern "C" int ppsci_taylor_step_kind(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points) {
+  StepArgs a;
+  int grid = 0;
+  if (fill_step(a, d, e, n_points) != PPSCI_OK || run_step_act(a, nullptr, 0, &grid) != PPSCI_OK) return 0;
+  return a.t.fused ? 2 : 1;
+}
 
 extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params,
                                                    int64_t n_points, const float* const* inputs_host,
                                                    const float* const* aux_host, float* U, float* Ubar, float* residual_out,
-                                                   void* stash, void* workspace, float* loss_terms, float* grad) {
-  if (!params || !inputs_host || !U || !Ubar || !stash || !workspace || !loss_terms || !grad) {
+                                                   void* stash, void* workspace, int64_t workspace_bytes, float* loss_terms,
+                                                   float* grad) {
+  if (!params || !inputs_host || !workspace || !loss_terms || !grad) {
     ppsci_set_error("taylor_step: invalid argument");
     return nullptr;
   }
@@ -364,7 +437,41 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
   int grid = 0;
   if (run_step_act(a, nullptr, 0, &grid) != PPSCI_OK) return fail();
   const StepLayout y = step_layout(a, grid, e->n_res);
+  // the grid (hence the layout) depends on process-global knobs (ppsci_set_max_grid, the occupancy query): a workspace
+  // sized under other settings must not be overrun
+  if (y.total * 4 > workspace_bytes) {
+    ppsci_set_error("taylor_step: the workspace holds %lld B, the planned launch (%d workgroups) needs %lld B", (long long)workspace_bytes,
+                    grid, y.total * 4);
+    return fail();
+  }
+  if (!a.t.fused && (!U || !Ubar || !stash)) {  // (the fused tile kernel keeps them on the chip; there they are optional outputs)
+    ppsci_set_error("taylor_step: invalid argument");
+    return fail();
+  }
   float* ws = (float*)workspace;
+  plan->y = y;
+  plan->ws = ws;
+  if (a.t.fused) {
+    a.f.xfrag = ws + y.frag;
+    a.b.xfrag = (const u32x4*)(ws + y.frag) + (long long)(d->n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB);
+    a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 1 : 0);
+    unsigned fast[EPI_FAST_MAX];
+    const int nfast = g_fast_vm ? epi_fast_encode(a.e.e, fast) : -1;
+    a.e.fast = nullptr;
+    a.e.nfast = 0;
+    if (nfast >= 0) {  // (a synchronous copy of < 400 bytes; plans are made outside graph captures)
+#ifdef PPSCI_EMU
+      memcpy(ws + y.fastprog, fast, sizeof(unsigned) * (nfast > 0 ? nfast : 1));
+#else
+      if (hipMemcpy(ws + y.fastprog, fast, sizeof(unsigned) * (nfast > 0 ? nfast : 1), hipMemcpyHostToDevice) != hipSuccess) {
+        ppsci_set_error("taylor_step: cannot upload the pre-decoded residual program");
+        return fail();
+      }
+#endif
+      a.e.fast = (const unsigned*)(ws + y.fastprog);
+      a.e.nfast = nfast;
+    }
+  }
   a.f.params = a.b.params = params;
   for (int j = 0; j < d->d_raw; ++j) a.f.x[j] = a.b.x[j] = a.e.x[j] = inputs_host[j];
   for (int j = 0; j < e->n_aux; ++j) a.e.aux[j] = aux_host[j];
@@ -430,15 +537,73 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
     t.grad_scale = adam->grad_scale;
   }
   int grid = 0;
-  return run_step_act(plan->a, stream, 2, &grid);
+  if (!plan->a.t.fused) return run_step_act(plan->a, stream, 2, &grid);
+  // ---- fused tile kernel: split the (new) hidden-to-hidden matrices, run the tiles, and -- for large grids -- sum the
+  // workgroups' rows with the reduction kernels
+  StepArgs& a = plan->a;
+  const StepLayout& y = plan->y;
+  float* ws = plan->ws;
+  {
+    const int L = a.f.d.n_hidden, NB = a.f.q.NB;
+    const int total = 2 * (L - 1) * NB * (NB / 2) * 64;
+    struct PArgs {
+      const float* params;
+      ppsci_derived q;
+      int H, L;
+      u32x4* out;
+    };
+#ifdef PPSCI_EMU
+    PArgs pa{a.f.params, a.f.q, a.f.d.width, L, (u32x4*)(ws + y.frag)};
+    emu::launch(emu_dim3{(unsigned)((total + 255) / 256)}, emu_dim3{256u}, 0,
+                [](void* p) { PArgs& x = *(PArgs*)p; ppsci_presplit2_kernel(x.params, x.q, x.H, x.L, x.out); }, &pa);
+#else
+    hipLaunchKernelGGL(ppsci_presplit2_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a.f.params, a.f.q,
+                       a.f.d.width, L, (u32x4*)(ws + y.frag));
+    if (hipGetLastError() != hipSuccess) {
+      ppsci_set_error("taylor_step: presplit launch failed");
+      return PPSCI_E_LAUNCH;
+    }
+#endif
+  }
+  const int do_adam = t.do_adam;
+  if (t.external) t.do_adam = 0;
+  int rc = run_step_act(a, stream, 2, &grid);
+  t.do_adam = do_adam;
+  if (rc != PPSCI_OK || !t.external) return rc;
+  float* row = accumulate ? ws + y.red_row : t.grad;
+  rc = ppsci_wgrad_reduce(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, row, stream);
+  if (rc == PPSCI_OK && accumulate) rc = ppsci_reduce_rows(row, 1, a.b.q.P, t.grad, 1, stream);
+  if (rc == PPSCI_OK) rc = ppsci_reduce_rows(t.rows_l, t.grid, t.n_res, t.loss_terms, 0, stream);
+  if (rc == PPSCI_OK && adam)
+    rc = ppsci_adam_step(a.b.q.P, t.p, t.grad, adam->m, adam->v, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step_t,
+                         adam->grad_scale, stream);
+  return rc;
+}
+
+// measurement: the main kernel of the planned step alone (kind 2: the fused tile kernel without the weight split in front
+// of it and without any reduction -- the workgroups' rows stay in the workspace; kind 1: the whole launch)
+extern "C" int ppsci_taylor_step_run_main(ppsci_step_plan* plan, void* stream) {
+  if (!plan) {
+    ppsci_set_error("taylor_step_run_main: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  StepTail& t = plan->a.t;
+  const int ext = t.external, adam = t.do_adam;
+  if (t.fused) t.external = 1;
+  t.do_adam = 0;
+  int grid = 0;
+  const int rc = run_step_act(plan->a, stream, 2, &grid);
+  t.external = ext;
+  t.do_adam = adam;
+  return rc;
 }
 
 extern "C" int ppsci_taylor_step(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params, int64_t n_points,
                                  const float* const* inputs_host, const float* const* aux_host, float* U, float* Ubar,
-                                 float* residual_out, void* stash, void* workspace, float* loss_terms, float* grad,
-                                 int accumulate, const ppsci_adam_args* adam, void* stream) {
+                                 float* residual_out, void* stash, void* workspace, int64_t workspace_bytes,
+                                 float* loss_terms, float* grad, int accumulate, const ppsci_adam_args* adam, void* stream) {
   ppsci_step_plan* plan = ppsci_taylor_step_plan(d, e, params, n_points, inputs_host, aux_host, U, Ubar, residual_out, stash,
-                                                 workspace, loss_terms, grad);
+                                                 workspace, workspace_bytes, loss_terms, grad);
   if (!plan) {
     StepArgs a;
     const int rc = fill_step(a, d, e, n_points);

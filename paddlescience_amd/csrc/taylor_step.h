@@ -23,6 +23,9 @@ struct StepTail {
   int lds;             // host side only: dynamic LDS bytes of the planned launch
   int accumulate, do_adam;
   float lr_t, beta1, beta2, eps_t, grad_scale;
+  int fused;           // host side only: planned onto the fused tile kernel (taylor_fused.inc)
+  int external;        // fused tile kernel: 1 = the launch stops at the workgroups' rows; the host issues the two reduction kernels
+                       // (+ loss sum, Adam) behind it -- a 512-row tree of 48 KB rows is slower than those (taylor_api.hip)
 };
 
 struct StepArgs {
@@ -38,3 +41,8 @@ struct StepArgs {
 int ppsci_step_run_tanh(StepArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_step_run_silu(StepArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_step_run_sin(StepArgs& a, void* stream, int launch, int* grid_out);
+// the fused tile kernels (taylor_fused.inc, padded width 64): same contract; PPSCI_E_UNSUPPORTED without an error
+// message when the net / stream set has none
+int ppsci_fused_run_tanh(StepArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fused_run_silu(StepArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fused_run_sin(StepArgs& a, void* stream, int launch, int* grid_out);

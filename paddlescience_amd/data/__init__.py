@@ -29,7 +29,13 @@ def _world():
 
 class BatchSampler:
     """Index batches; `world`/`rank` give paddle.io.DistributedBatchSampler's rank-strided sharding
-    (total size padded to a multiple of world by wrapping around)."""
+    (total size padded to a multiple of world by wrapping around, /root/reference/ppsci/data/__init__.py:76-99).
+
+    The wrapped-around samples keep every rank in lock-step (same number of batches, same batch sizes) but are
+    DUPLICATES: `last_pad` tells the caller which positions of the batch just yielded are such padding -- (mask over
+    this rank's batch, number of padded samples in the GLOBAL batch, size of the global batch) -- so that the loss can
+    give them zero weight and normalise by the true sample count (Solver._shard_weights).  None: no
+    padding in this batch."""
 
     def __init__(self, n: int, batch_size: int, shuffle: bool = False, drop_last: bool = False, world: int = 1,
                  rank: int = 0, seed: int = 42):
@@ -38,6 +44,7 @@ class BatchSampler:
         self.epoch = 0
         self.rng = np.random.RandomState(seed)
         self.num_samples = int(np.ceil(n / world)) if world > 1 else n
+        self.last_pad = None
 
     def __iter__(self) -> Iterator[np.ndarray]:
         idx = np.arange(self.n)
@@ -55,6 +62,12 @@ class BatchSampler:
             b = idx[s: s + self.batch_size]
             if len(b) < self.batch_size and self.drop_last:
                 break
+            self.last_pad = None
+            if self.world > 1 and (s + len(b)) * self.world > self.n:
+                # local stream position j sits at global stream position rank + j * world; positions >= n are wrap-around
+                gpos = self.rank + (s + np.arange(len(b))) * self.world
+                npad = (s + len(b)) * self.world - max(self.n, s * self.world)
+                self.last_pad = (gpos >= self.n, int(npad), int(len(b) * self.world))
             yield b
 
     def __len__(self):
@@ -69,6 +82,7 @@ class DataLoader:
 
     def __iter__(self):
         for idx in self.batch_sampler:
+            self.last_pad = getattr(self.batch_sampler, "last_pad", None)
             yield self.dataset[idx]
 
     def __len__(self):

@@ -195,14 +195,21 @@ class FusedConstraint:
                   and len(nt["inputs"]) == len(self.inputs)
                   and all(a.data_ptr() == b.data_ptr() for a, b in zip(nt["inputs"], self.inputs))
                   and self.edesc.n_res >= 1)
+            self._step_kind = hp.STEP_NONE
             if ok:
                 nbytes = hp.taylor_step_workspace_bytes(nt["desc"], self.edesc, self.n)
                 ok = nbytes > 0
                 if ok:
+                    self._step_kind = hp.taylor_step_kind(nt["desc"], self.edesc, self.n)
                     self._step_ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.U.device)
             self._one_launch = ok
         return (ok and not getattr(self, "causal", None) and not getattr(self, "periodic", None)
                 and getattr(self, "eq_store", None) is None)
+
+    def one_launch_wins(self, max_points_single_wave: int) -> bool:
+        """one_launch_ready() and the one-launch kernel is the faster path at this batch size: the fused tile kernel
+        (padded width 64) at any size, the single-wave kernel (padded width 32) for small batches only."""
+        return self.one_launch_ready() and (self._step_kind == hp.STEP_FUSED_TILE or self.n <= max_points_single_wave)
 
     def step_one_launch(self, params: torch.Tensor, grad: torch.Tensor, accumulate: bool, adam: Optional[dict]) -> None:
         plan = getattr(self, "_step_plan", None)
@@ -343,7 +350,7 @@ class Engine:
 
     def one_launch_ready(self, constraints: Sequence[FusedConstraint]) -> bool:
         return (self.one_launch and self.layout is not None and 0 < len(constraints) <= self.one_launch_max_constraints
-                and all(isinstance(c, FusedConstraint) and c.n <= self.one_launch_max_points and c.one_launch_ready()
+                and all(isinstance(c, FusedConstraint) and c.one_launch_wins(self.one_launch_max_points)
                         for c in constraints))
 
     def step_one_launch(self, constraints: Sequence[FusedConstraint], adam: Optional[dict] = None) -> None:
@@ -365,7 +372,7 @@ class Engine:
         if (self.multi_stream and len(constraints) > 1 and self.params.is_cuda
                 and min(c.n for c in constraints) <= self.multi_stream_max_points):
             def job(c):
-                if self.one_launch and c.n <= self.one_launch_max_points and c.one_launch_ready():
+                if self.one_launch and c.one_launch_wins(self.one_launch_max_points):
                     # forward -> epilogue -> reverse -> reduction in ONE launch per constraint, the constraints' launches
                     # as parallel branches; the gradient row lands where the separate kernels would leave it
                     row = c.nets[0]["grad_partials"]
@@ -377,6 +384,11 @@ class Engine:
                 c.reduce_grads(self.grad, several or i > 0)
         else:
             for i, c in enumerate(constraints):
+                if (self.one_launch and not several and isinstance(c, FusedConstraint) and c.one_launch_ready()
+                        and c._step_kind == hp.STEP_FUSED_TILE):
+                    # padded width 64: the fused tile kernel (no stash round trip through HBM), gradient (+)= in place
+                    c.step_one_launch(self.params, self.grad, i > 0, None)
+                    continue
                 c.forward(self.params, True)
                 # the first constraint's gradient row goes straight into the flat gradient (no copy kernel)
                 if not c.backward(self.params, self.grad if (i == 0 and not several) else None):

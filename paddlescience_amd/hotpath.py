@@ -169,14 +169,25 @@ def taylor_step_workspace_bytes(desc: L.MlpDesc, edesc: L.EpilogueDesc, n: int) 
     return int(L.lib().ppsci_taylor_step_workspace_bytes(C.byref(desc), C.byref(edesc), n))
 
 
+STEP_NONE, STEP_SINGLE_WAVE, STEP_FUSED_TILE = 0, 1, 2
+
+
+def taylor_step_kind(desc: L.MlpDesc, edesc: L.EpilogueDesc, n: int) -> int:
+    """Which kernel ppsci_taylor_step runs for this network / stream set / program: STEP_SINGLE_WAVE (padded width 32; wins
+    for batches of a few thousand points only) or STEP_FUSED_TILE (padded width 64: forward -> program -> reverse per tile
+    with the stash on the chip; any batch size), STEP_NONE: the separate launches."""
+    return int(L.lib().ppsci_taylor_step_kind(C.byref(desc), C.byref(edesc), n))
+
+
 class StepPlan:
     """ppsci_taylor_step_plan / _run: forward -> epilogue -> reverse -> fixed-order reduction (-> Adam) of one constraint
     in one launch, with the argument block prepared once (every buffer is persistent).  adam: dict(m, v, lr, beta1,
     beta2, eps, grad_scale, t) or None."""
 
     def __init__(self, desc: L.MlpDesc, edesc: L.EpilogueDesc, params: torch.Tensor, n: int, inputs: Sequence[torch.Tensor],
-                 aux: Sequence[torch.Tensor], U: torch.Tensor, Ubar: torch.Tensor, resid: Optional[torch.Tensor],
-                 stash: torch.Tensor, workspace: torch.Tensor, loss_terms: torch.Tensor, grad: torch.Tensor):
+                 aux: Sequence[torch.Tensor], U: Optional[torch.Tensor], Ubar: Optional[torch.Tensor],
+                 resid: Optional[torch.Tensor], stash: Optional[torch.Tensor], workspace: torch.Tensor,
+                 loss_terms: torch.Tensor, grad: torch.Tensor):
         _require_device(params)
         _chk_f32(params, U, Ubar, resid, loss_terms, grad, workspace, *inputs, *aux)
         ip = L.ptr_array([t.data_ptr() for t in inputs])
@@ -184,7 +195,8 @@ class StepPlan:
         self._free = L.lib().ppsci_taylor_step_plan_free
         self._run = L.lib().ppsci_taylor_step_run
         self.handle = L.lib().ppsci_taylor_step_plan(C.byref(desc), C.byref(edesc), _p(params), n, ip, ap, _p(U), _p(Ubar),
-                                                     _p(resid), _p(stash), _p(workspace), _p(loss_terms), _p(grad))
+                                                     _p(resid), _p(stash), _p(workspace), workspace.numel() * 4,
+                                                     _p(loss_terms), _p(grad))
         if not self.handle:
             raise RuntimeError("ppsci_taylor_step_plan: " + L.lib().ppsci_last_error().decode())
         self.key = (params.data_ptr(), grad.data_ptr())
@@ -206,6 +218,10 @@ class StepPlan:
             aa = C.byref(L.AdamArgs(adam["m"].data_ptr(), adam["v"].data_ptr(), adam["lr"], adam["beta1"], adam["beta2"],
                                     adam["eps"], adam.get("grad_scale", 1.0), adam["t"]))
         L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev)))
+
+    def run_main(self) -> None:
+        """Measurement: the main kernel of the step alone (ppsci_taylor_step_run_main)."""
+        L.check(L.lib().ppsci_taylor_step_run_main(self.handle, _stream_ptr(self._dev)))
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None

@@ -228,6 +228,17 @@ class Solver:
                                           "rank); use drop_last")
             if len(cst.data_loader) == 1:
                 bsz = cst.data_loader.batch_sampler.num_samples
+            if self.world_size > 1 and cst.data_loader.batch_sampler.n % self.world_size != 0:
+                # Ragged shards: the sampler pads by wrapping around (data.BatchSampler, as the reference's
+                # DistributedBatchSampler does) so that all ranks run the same batches; the duplicates get ZERO weight and
+                # "mean" is taken over the true sample count, so the W-rank step equals the 1-rank step.
+                # That needs a weight column for every loss key (_shard_weights fills it at bind time).
+                if (getattr(cst.loss, "periodic", False) or getattr(cst.loss, "causal", None)
+                        or hasattr(cst.loss, "batch_weight") or getattr(cst.loss, "term_kind", 0) != 0):
+                    raise NotImplementedError(f"constraint {name}: {len(ds)} samples do not divide over {self.world_size} ranks; "
+                                              f"zero-weight padding is built for MSELoss only, not {type(cst.loss).__name__}")
+                self._ragged.add(name)
+                weight_keys = weight_keys + [k for k in label_keys if k not in weight_keys]
         try:
             cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
                                     bsz * self.world_size, self.device, train=True,
@@ -255,8 +266,27 @@ class Solver:
         self._static[name] = _is_full_static_batch(cst)
         if self._static[name]:
             inp, lab, w = next(cst.data_iter)
-            cc.bind(inp, lab, w)
+            cc.bind(inp, lab, self._shard_weights(name, cst, lab, w))
         return cc
+
+    def _shard_weights(self, name: str, cst, lab, w):
+        """Zero weight for the wrap-around duplicates of a ragged shard (data.BatchSampler.last_pad), and, for "mean"
+        losses, the other weights scaled so that the compiled 1 / (batch x world) becomes 1 / (true sample count)."""
+        if name not in self._ragged:
+            return w
+        pad = getattr(cst.data_loader, "last_pad", None)
+        out = dict(w or {})
+        n_loc = len(next(iter(lab.values())))
+        for k in lab:
+            col = np.ones((n_loc, 1), np.float32) if k not in out else np.array(
+                out[k].cpu().numpy() if isinstance(out[k], torch.Tensor) else out[k], dtype=np.float32).reshape(n_loc, 1)
+            if pad is not None:
+                mask, npad, nglob = pad
+                col[mask] = 0.0
+                if getattr(cst.loss, "reduction", "mean") == "mean":
+                    col *= np.float32(nglob / (nglob - npad))
+            out[k] = col
+        return out
 
     # ------------------------------------------------------------------ training
     def train(self) -> None:
@@ -279,7 +309,7 @@ class Solver:
                         if self._is_spinn:
                             cc.bind(inp, lab)
                         else:
-                            cc.bind(inp, lab, w)
+                            cc.bind(inp, lab, self._shard_weights(name, self.constraint[name], lab, w))
                 reader_cost = time.perf_counter() - reader_tic
                 eager_csts = [c for c in csts if getattr(c, "is_eager", False)]
                 eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts if c not in eager_csts]

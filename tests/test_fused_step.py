@@ -1,0 +1,161 @@
+"""Fused tile kernel (csrc/taylor_fused.inc: forward -> residual program -> reverse per 16-point tile, stash in
+registers, U / dL/dU in LDS; padded width 64) against the separate launches (ppsci_taylor_fwd -> ppsci_epilogue ->
+ppsci_taylor_bwd -> reductions -> ppsci_adam_step) on the same buffers.  The two compute the same sums in different
+orders (per-workgroup rows vs per-workgroup slots + chunks), so values agree to fp32 rounding.  The separate path is
+pinned to the reference by the golden tests; with the engine's default the golden tests of width 33..64 nets run
+through this kernel as well."""
+import numpy as np
+import pytest
+import torch
+
+from paddlescience_amd import _lib as L
+from paddlescience_amd import device
+from paddlescience_amd import hotpath as hp
+from paddlescience_amd.engine import Engine
+from tests.common import make_dev_fixture, rel
+from tests.test_one_launch import _constraint, _program, _weights
+
+dev = make_dev_fixture()
+
+
+def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints=4, fast_program=1):
+    lib = L.lib()
+    lib.ppsci_set_max_grid(max_grid)
+    lib.ppsci_set_step_tail(tail)
+    lib.ppsci_set_fast_program(fast_program)
+    try:
+        params = torch.tensor(flat, device=d)
+        eng = Engine(lay, params)
+        eng.one_launch = fused
+        eng.one_launch_max_constraints = max_constraints
+        csts = [_constraint(d, kind, lay, n, 100 + i) for i, (kind, n) in enumerate(specs)]
+        if fused:
+            assert all(c.one_launch_ready() and c._step_kind == hp.STEP_FUSED_TILE for c in csts)
+            assert eng.one_launch_ready(csts) == (len(csts) <= max_constraints)
+        grads, losses = [], []
+        for _ in range(steps):
+            eng.train_step(csts, 1e-2)
+            grads.append(eng.grad.detach().cpu().numpy().copy())
+            losses.append([c.loss_terms.detach().cpu().numpy().copy() for c in csts])
+        resid = [c.resid.detach().cpu().numpy().copy() for c in csts]
+        U = [c.U.detach().cpu().numpy().copy() for c in csts]
+        Ubar = [c.Ubar.detach().cpu().numpy().copy() for c in csts]
+        return params.detach().cpu().numpy(), grads, losses, resid, U, Ubar
+    finally:
+        lib.ppsci_set_max_grid(0)
+        lib.ppsci_set_step_tail(-1)
+        lib.ppsci_set_fast_program(1)
+
+
+CASES = [
+    # (activation, hidden layers, width, constraints [(program, points)], max_grid, tail: 0 tree / 1 reduction kernels)
+    ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 0),                # BASELINE configs[1]'s net; a ragged last tile
+    ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 1),
+    ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 0),                # several tiles per workgroup, a ragged last round
+    ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 1),
+    ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 0, 0),     # two constraints: the second accumulates, then Adam
+    ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 3, 1),
+    ("silu", 2, 40, [("allen_cahn", 500)], 0, 0),
+    ("sin", 5, 33, [("streams:1,1", 400)], 0, 1),                 # S = 3: the odd stream's K = 16 step
+    ("tanh", 2, 64, [("streams:0,0", 300)], 1, 0),                # a single workgroup: no tree at all
+    ("silu", 3, 64, [("streams:2,0", 500)], 0, 1),
+    ("tanh", 3, 48, [("streams:2,2", 500)], 0, 0),                # S = 5
+]
+
+
+@pytest.mark.parametrize("act,depth,width,specs,max_grid,tail", CASES)
+def test_fused_step_matches_separate_launches(dev, act, depth, width, specs, max_grid, tail):
+    d = device.get_device()
+    lay = hp.NetLayout(2, depth, width, 1, act)
+    flat = _weights(lay, 7)
+    steps = 3
+    if dev != "gpu":  # the emulator runs a few hundred points per second
+        specs = [(k, max(40, n // 6 + 3)) for k, n in specs]
+        steps = 2
+    p_sep, g_sep, l_sep, r_sep, u_sep, ub_sep = _run(d, lay, specs, flat, False, steps, max_grid)
+    p_one, g_one, l_one, r_one, u_one, ub_one = _run(d, lay, specs, flat, True, steps, max_grid, tail)
+    for s in range(steps):
+        # (later steps start from parameters that already differ by rounding)
+        assert rel(g_one[s], g_sep[s]) < (3e-6 if s == 0 else 1e-4), (s, rel(g_one[s], g_sep[s]))
+        for a, b in zip(l_one[s], l_sep[s]):
+            np.testing.assert_allclose(a, b, rtol=2e-5 if s == 0 else 1e-3)
+    for a, b in zip(r_one, r_sep):
+        assert rel(a, b) < 1e-3
+    for a, b in zip(u_one, u_sep):  # the optional outputs: streams and their adjoints of the last step
+        assert rel(a, b) < 1e-3
+    for a, b in zip(ub_one, ub_sep):
+        assert rel(a, b) < 1e-3
+    assert rel(p_one, p_sep) < 1e-4
+    assert rel(p_one, flat) > 1e-4  # the update is not a no-op (and the tree left its counters at zero)
+
+
+@pytest.mark.parametrize("kind", ["allen_cahn", "laplace", "streams:2,1"])
+def test_predecoded_program_equals_the_interpreter(dev, kind):
+    """Residual programs of loads / constants / + / - / * run pre-decoded (epi_point_fast) by default; the opcode
+    interpreter computes the same values in the same order: bit-identical gradients, loss terms and residuals."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 3, 64, 1, "tanh")
+    flat = _weights(lay, 13)
+    n = 90 if dev != "gpu" else 3000
+    a = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=1)
+    b = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=0)
+    assert np.array_equal(a[0], b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    assert all(np.array_equal(x[0], y[0]) for x, y in zip(a[2], b[2])) and np.array_equal(a[3][0], b[3][0])
+    assert np.array_equal(a[5][0], b[5][0]) and np.abs(a[1][0]).max() > 0
+
+
+def test_fused_step_is_deterministic(dev):
+    """Bit-identical run to run in both tail modes (on the GPU also the race detector of the reduction tree)."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 4, 64, 1, "tanh")
+    flat = _weights(lay, 3)
+    steps, n = (2, 200) if dev != "gpu" else (100, 20_000)
+    for tail in (0, 1):
+        a = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
+        b = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
+        assert np.array_equal(a[0], b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+        assert np.isfinite(a[0]).all()
+
+
+def test_fused_step_workspace_is_checked(dev):
+    """ppsci_taylor_step_plan refuses a workspace smaller than what the launch planned NOW needs (the grid depends on
+    ppsci_set_max_grid: a workspace sized under a smaller grid must not be overrun)."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 4, 64, 1, "tanh")
+    ed, streams, _ = _program("allen_cahn", 640)
+    desc = lay.desc(streams)
+    L.lib().ppsci_set_max_grid(1)
+    try:
+        small = hp.taylor_step_workspace_bytes(desc, ed, 640)
+    finally:
+        L.lib().ppsci_set_max_grid(0)
+    assert 0 < small < hp.taylor_step_workspace_bytes(desc, ed, 640)
+    cst = _constraint(d, "allen_cahn", lay, 640, 5)
+    params = torch.tensor(_weights(lay, 1), device=d)
+    grad = torch.zeros_like(params)
+    ws = torch.zeros(small // 4, dtype=torch.float32, device=d)
+    with pytest.raises(RuntimeError, match="workspace"):
+        hp.StepPlan(desc, ed, params, 640, cst.inputs, cst.aux, cst.U, cst.Ubar, cst.resid, None, ws, cst.loss_terms, grad)
+
+
+def test_fused_step_without_optional_outputs(dev):
+    """U, dL/dU and the stash are optional for the fused tile kernel: nothing of a tile has to leave the CU."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 3, 64, 1, "tanh")
+    n = 100 if dev != "gpu" else 5000
+    ed, streams, _ = _program("allen_cahn", n)
+    desc = lay.desc(streams)
+    flat = _weights(lay, 9)
+    cst = _constraint(d, "allen_cahn", lay, n, 5)
+    outs = []
+    for with_outputs in (True, False):
+        params = torch.tensor(flat, device=d)
+        grad = torch.zeros_like(params)
+        loss = torch.zeros(1, device=d)
+        ws = torch.zeros(hp.taylor_step_workspace_bytes(desc, ed, n) // 4, dtype=torch.float32, device=d)
+        plan = hp.StepPlan(desc, ed, params, n, cst.inputs, cst.aux, cst.U if with_outputs else None,
+                           cst.Ubar if with_outputs else None, None, None, ws, loss, grad)
+        plan.run(ed, False, None)
+        outs.append((grad.cpu().numpy().copy(), loss.cpu().numpy().copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.abs(outs[0][0]).max() > 0

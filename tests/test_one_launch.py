@@ -159,7 +159,8 @@ def test_one_launch_unsupported_falls_to_separate_launches(dev):
     says 0 and the engine keeps the separate launches -- which are the same HIP kernels, not a fallback off the GPU."""
     d = device.get_device()
     ed, streams, _ = _program("allen_cahn", 64)
-    assert hp.taylor_step_workspace_bytes(hp.NetLayout(2, 4, 64, 1, "tanh").desc(streams), ed, 64) == 0  # padded width 64
+    assert hp.taylor_step_kind(hp.NetLayout(2, 4, 64, 1, "tanh").desc(streams), ed, 64) == hp.STEP_FUSED_TILE  # padded width 64
+    assert hp.taylor_step_workspace_bytes(hp.NetLayout(2, 4, 128, 1, "tanh").desc(streams), ed, 64) == 0  # padded width 128
     lay = hp.NetLayout(2, 3, 20, 1, "gelu")
     assert hp.taylor_step_workspace_bytes(lay.desc(streams), ed, 64) == 0
     eng = Engine(lay, torch.tensor(_weights(lay, 1), device=d))
