@@ -449,15 +449,26 @@ def strong_ns(tmp, world, rank, steps, warmup, barrier):
         opt.step(eng.grad)
 
     t = time_wall(step, steps, warmup, barrier)
-    tt = torch.tensor([t], device="cpu" if EMU else "cuda", dtype=torch.float64)
+    # the collective alone (HIP events on the launch stream around eng.allreduce(); wall clock in the emulator test mode),
+    # after a barrier so that it measures the all-reduce, not the wait for the slowest rank's kernels
+    t_ar = None
+    if world > 1:
+        ts = []
+        for _ in range(5):
+            barrier()
+            ts.append(time_events(eng.allreduce, 1) if not EMU else time_wall(eng.allreduce, 1, 0))
+        t_ar = float(np.median(ts))
+    tt = torch.tensor([t, t_ar or 0.0], device="cpu" if EMU else "cuda", dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     t = float(tt[0])
+    t_ar = float(tt[1]) if world > 1 else None
     return {"workload": "LDC NavierStokes 2-D steady, MLP 2->128x5->3 tanh, 1 000 000 collocation points sharded "
                         "rank-strided over the ranks, SUM all-reduce of the flat gradient, Adam (BASELINE.json configs[2])",
             "value": NS_TOTAL / t, "unit": "points/s", "ms_per_step": t * 1e3, "steps": steps, "n_gpus": world,
             "scaling": "strong", "points_total": NS_TOTAL, "points_per_rank": n_local,
-            "allreduce_bytes": int(eng.grad.numel()) * 4, "comm_world_size": eng.world,
+            "allreduce_bytes": int(eng.grad.numel()) * 4, "allreduce_ms": None if t_ar is None else t_ar * 1e3,
+            "comm_world_size": eng.world,
             "comm_backend": torch.distributed.get_backend() if world > 1 else None,
             "matrix_tflops_per_gpu": 6.0 * NS_PMAT * 5 * n_local / t / 1e12}
 

@@ -429,16 +429,9 @@ int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
                            0 = P.  3P with the three pointers P apart interleaves the networks' rows [n][3][P], so that ONE
                            ppsci_reduce_rows(n, 3P) sums all three */, void* stream);
 
-/* ---- data-parallel collectives on RCCL (csrc/comm.hip): the fused gradient all-reduce of solver/train.py:168-171 and
- * the evaluation gather of utils/misc.py, on the ONE flat gradient buffer.  librccl is resolved lazily at
- * ppsci_comm_init (the copy already loaded into the process is preferred); one communicator per process = per GPU.
- * ppsci_comm_unique_id: 128 bytes, produced by rank 0 and shipped to the others by any host channel. */
-int ppsci_comm_unique_id(void* out128);
-int ppsci_comm_init(int rank, int world, const void* id128); /* collective; current HIP device = this rank's GPU */
-int ppsci_comm_world_size(void);                              /* 0 before ppsci_comm_init */
-int ppsci_allreduce_sum(float* buf, int64_t n, void* stream); /* in place, ordered on `stream` */
-int ppsci_allgather(const float* send, float* recv, int64_t n, void* stream); /* recv: [world][n] */
-int ppsci_comm_destroy(void);
+/* ---- data parallelism: no entry point here.  The step's one collective -- SUM all-reduce of the flat gradient
+ * (solver/train.py:168-171) -- is issued by the host through torch.distributed (RCCL) on the launch stream between the
+ * gradient kernels and ppsci_adam_step; every kernel above is rank-local. */
 
 /* ---- ppsci.arch.PirateNet (mlp.py:530-820), layer by layer on Taylor streams (csrc/pirate.hip) ---------------------
  * Every tensor is a stream block [S][C][NP]: S = 1 + n1 + n2 streams (value, first derivatives along n1 directions,

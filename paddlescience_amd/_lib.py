@@ -161,12 +161,6 @@ _SYMBOLS = {
     "ppsci_modmlp_bwd_batch": (C.c_int, [C.POINTER(ModMlpDesc), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.c_int64, C.c_void_p]),
-    "ppsci_comm_unique_id": (C.c_int, [C.c_void_p]),
-    "ppsci_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
-    "ppsci_comm_world_size": (C.c_int, []),
-    "ppsci_allreduce_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
-    "ppsci_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "ppsci_comm_destroy": (C.c_int, []),
     "ppsci_pirate_embed_fwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_pirate_embed_chunks": (C.c_int64, [C.c_int64]),
     "ppsci_pirate_embed_bwd": (C.c_int, [C.POINTER(PirateEmbedDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,

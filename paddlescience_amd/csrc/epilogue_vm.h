@@ -36,21 +36,55 @@ struct EpiArgs {
   // detaches (every BASELINE PDE residual) -- epi_fast_encode(); device memory; null: the generic interpreter
   const unsigned* fast;
   int nfast;
+  int nfast_loads;  // entries of the load table: the program's loads AND constants, in program order
 };
 
 // ---- pre-decoded programs for epi_point_fast.  One 32-bit word per arithmetic step (loads and constants are not steps):
 //   [0:6] a  [7:13] b  [14:20] destination i  [21] product  [22:23] sx  [24:25] sy  [26:27] rx  [28:29] ry  [30] a == b
 // value:   r = product ? v[a] v[b] : sx v[a] + sy v[b];   adjoints: abar += g (product ? v[b] : rx), bbar += g (product ? v[a] : ry)
 // with the two-bit codes 0 -> 0, 1 -> +1, 2 -> -1 (detach: sx = 1, rx = 0).
-#define EPI_FAST_MAX 96
 static inline unsigned epi_fast_word(int a, int b, int i, int prod, int sx, int sy, int rx, int ry) {
   return (unsigned)a | ((unsigned)b << 7) | ((unsigned)i << 14) | ((unsigned)prod << 21) | ((unsigned)sx << 22) |
          ((unsigned)sy << 24) | ((unsigned)rx << 26) | ((unsigned)ry << 28) | ((a == b ? 1u : 0u) << 30);
 }
-// host: returns the number of steps written to `out` (<= EPI_FAST_MAX), or -1 when the program (or one of its loss
-// terms) needs the generic interpreter
-static inline int epi_fast_encode(const ppsci_epilogue_desc& e, unsigned* out) {
+// The device buffer of a pre-decoded program (EPI_FAST_WORDS dwords): [0, 64) the arithmetic steps, [64, 128) the loads
+// and constants --
+//   [0:6] destination i  [7:13] index a (input / stream / aux array)  [14:15] 0 input, 1 stream, 2 aux, 3 constant --
+// [128, 136) the loss terms: [0:6] value  [7:11] label + 1  [12:16] weight + 1  [17:21] area + 1  (0: none), and
+// [192, 256) the constants' values (entry k belongs to load-table entry k).
+// A wave keeps the groups in four registers, entry k in lane k, and fetches an entry with v_readlane: no memory access
+// (a scalar load per step from the argument block cost ~300 cycles, more than the step itself).
+#define EPI_FAST_MAX 64
+#define EPI_FAST_WORDS (64 + 64 + 64 + 64)
+#define EPI_FAST_NREG 16  // programs of at most this many instructions keep the VM's register file in VGPRs (epi_tile_fast_regs)
+// host: fills `out` (EPI_FAST_WORDS dwords), *n_loads (entries of the load table) and returns the number of arithmetic
+// steps (<= EPI_FAST_MAX), or -1 when the program (or one of its loss terms) needs the generic interpreter
+static inline int epi_fast_encode(const ppsci_epilogue_desc& e, unsigned* out, int* n_loads) {
   if (e.n_instr > 127) return -1;
+  {
+    for (int k = 0; k < EPI_FAST_WORDS; ++k) out[k] = 0u;
+    int nl = 0;
+    for (int i = 0; i < e.n_instr; ++i) {
+      const ppsci_instr& ins = e.prog[i];
+      const int kind = ins.op == PPSCI_OP_LD_IN ? 0 : (ins.op == PPSCI_OP_LD_U ? 1 : (ins.op == PPSCI_OP_LD_AUX ? 2 : (ins.op == PPSCI_OP_CONST ? 3 : -1)));
+      if (kind < 0) continue;
+      if (nl == 64 || ins.a > 127 || ins.a < 0) return -1;
+      union {
+        float f;
+        unsigned u;
+      } cb;
+      cb.f = kind == 3 ? ins.c : 0.f;
+      const unsigned cbits = cb.u;
+      out[192 + nl] = cbits;
+      out[64 + nl++] = (unsigned)i | ((unsigned)(kind == 3 ? 0 : ins.a) << 7) | ((unsigned)kind << 14);
+    }
+    *n_loads = nl;
+    for (int k = 0; k < e.n_res; ++k) {
+      const ppsci_residual& r = e.res[k];
+      if (r.label > 30 || r.weight > 30 || r.area > 30) return -1;
+      out[128 + k] = (unsigned)r.value | ((unsigned)(r.label + 1) << 7) | ((unsigned)(r.weight + 1) << 12) | ((unsigned)(r.area + 1) << 17);
+    }
+  }
   for (int k = 0; k < e.n_res; ++k)
     if (e.res[k].kind != PPSCI_LOSS_MSE) return -1;
   int n = 0;
@@ -118,11 +152,25 @@ __device__ __forceinline__ float epi_digamma(float x) {
 #define EPI_RF_TILED 2
 #define EPI_RF_FUSED 3
 
+// -DPPSCI_FUSED_TIMERS (measurement builds only): cycle stamps inside the pre-decoded program, summed per phase in LDS
+#ifdef PPSCI_FUSED_TIMERS
+#define EPI_FT(k)                                                         \
+  if (threadIdx.x == 0) {                                                 \
+    const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();          \
+    fx->dbg[k] += now_ - fx->dbg[15];                                     \
+    fx->dbg[15] = now_;                                                   \
+  }
+#else
+#define EPI_FT(k)
+#endif
+
 struct EpiFused {
+  unsigned* dbg;      // PPSCI_FUSED_TIMERS: 16 counters in LDS ([15]: the last stamp)
   const float* red;   // [W][mS][16]: per-wave partial sums of the last linear layer (fixed-order sum over w)
   const float* bl;    // [m]: last bias (added to the value stream, s == 0)
   const float* tinx;  // [d_raw][16]: the tile's raw inputs
   float* tin;         // [mS][16]: dL/dU of the tile (rows the program never loads are zeroed here)
+  float* rres;        // epi_tile_fast: [n_res][16] residual values of the tile (another wave writes them out); may be null
   int W, mS, S;
 };
 
@@ -330,95 +378,230 @@ __device__ __forceinline__ void epi_point(const EpiArgs& a, float* const vp, flo
 // instructions.)  The constants of the program sit in the register file from the start of the kernel (epi_fast_init).
 __device__ __forceinline__ float epi_fast_code(unsigned c) { return (float)(c & 1u) - (float)(c >> 1); }
 
-__device__ __forceinline__ void epi_fast_init(const EpiArgs& a, float* const vp, const int RS) {
-  for (int i = 0; i < a.e.n_instr; ++i) {
-    const ppsci_instr ins = a.e.prog[i];
-    if (ins.op == PPSCI_OP_CONST) vp[i * RS] = ins.c;
+// the program's tables, entry k in lane k (loaded once per wave at the start of the kernel)
+struct EpiFastRegs {
+  unsigned steps, loads, terms;
+  float scale;  // lane k: res[k].scale (the argument block's value: ppsci_taylor_step_plan_set_scales changes it)
+  float cvals;  // lane k: the value of load-table entry k when it is a constant
+};
+
+// kernel start: the tables go to LDS (`tab`: EPI_FAST_WORDS + PPSCI_MAX_RES dwords), the constants into the register file
+__device__ __forceinline__ void epi_fast_init(const EpiArgs& a, unsigned* const tab, float* const vp, const int RS, const int tid,
+                                              const int nthr, const bool owner) {
+  for (int k = tid; k < EPI_FAST_WORDS; k += nthr) tab[k] = a.fast[k];
+  for (int k = tid; k < PPSCI_MAX_RES; k += nthr) tab[EPI_FAST_WORDS + k] = __builtin_bit_cast(unsigned, a.e.res[k].scale);
+  if (owner) {  // the constants sit in the register file for the whole launch
+    for (int i = 0; i < a.e.n_instr; ++i) {
+      const ppsci_instr ins = a.e.prog[i];
+      if (ins.op == PPSCI_OP_CONST) vp[i * RS] = ins.c;
+    }
   }
 }
+// per tile: the wave that runs the program takes the tables into three registers (one LDS round trip)
+__device__ __forceinline__ EpiFastRegs epi_fast_regs(const unsigned* const tab, const int lane) {
+  EpiFastRegs R;
+  R.steps = tab[lane & 63];
+  R.loads = tab[64 + (lane & 63)];
+  R.terms = tab[128 + (lane & 63)];
+  R.scale = __builtin_bit_cast(float, tab[EPI_FAST_WORDS + (lane & (PPSCI_MAX_RES - 1))]);
+  R.cvals = __builtin_bit_cast(float, tab[192 + (lane & 63)]);
+  return R;
+}
 
+// One tile; called by ALL lanes of the wave (the table look-ups are wave-wide), `act`: this lane runs point `pt`.
+// No global stores: dL/dU stays in fx->tin, the residual values go to fx->rres; the caller writes them out from another
+// wave (a store here would put an `s_waitcnt vmcnt(0)` -- a full HBM write round trip -- into the step loops).
 // `lacc`: this point's column of the running loss sums in LDS ([PPSCI_MAX_RES][PPSCI_TILE], stride PPSCI_TILE).
-__device__ __forceinline__ void epi_point_fast(const EpiArgs& a, float* const vp, float* const ap, const int RS, const long long p,
-                                               const long long pp, const bool valid, const int pt, float* const lacc,
-                                               const EpiFused* fx) {
+__device__ __forceinline__ void epi_tile_fast(const EpiArgs& a, const EpiFastRegs& R, float* const vp, float* const ap, const int RS,
+                                              const bool act, const long long p, const long long pp, const bool valid,
+                                              const int pt, float* const lacc, const EpiFused* fx) {
   // label / weight / area of the first two loss terms: requested first (HBM), used behind the forward steps
-#define EPI_PF(k_, L_, W_)                                                       \
-  float L_ = 0.f, W_ = 1.f;                                                      \
-  if (k_ < a.e.n_res) {                                                          \
-    const ppsci_residual rs_ = a.e.res[k_];                                      \
-    if (rs_.label >= 0) L_ = a.aux[rs_.label][pp];                              \
-    if (rs_.weight >= 0) W_ = a.aux[rs_.weight][pp];                             \
-    if (rs_.area >= 0) W_ *= a.aux[rs_.area][pp];                               \
+#define EPI_PF(k_, L_, W_)                                                             \
+  float L_ = 0.f, W_ = 1.f;                                                            \
+  if (k_ < a.e.n_res) {                                                                \
+    const unsigned t_ = ppsci_readlane(R.terms, k_);                                   \
+    const int lb_ = (int)((t_ >> 7) & 31u) - 1, wt_ = (int)((t_ >> 12) & 31u) - 1, ar_ = (int)((t_ >> 17) & 31u) - 1; \
+    if (act) {                                                                         \
+      if (lb_ >= 0) L_ = a.aux[lb_][pp];                                               \
+      if (wt_ >= 0) W_ = a.aux[wt_][pp];                                               \
+      if (ar_ >= 0) W_ *= a.aux[ar_][pp];                                              \
+    }                                                                                  \
   }
   EPI_PF(0, lab0, w0)
   EPI_PF(1, lab1, w1)
 #undef EPI_PF
   // ---- memory operands; the adjoint of everything the reverse pass accumulates into starts at zero
-  for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
-  for (int k = 0; k < a.nload; ++k) {
-    const int i = a.load_idx[k];
-    const ppsci_instr ins = a.e.prog[i];
-    float v;
-    if (ins.op == PPSCI_OP_LD_U) {
-      v = (ins.a % fx->S == 0) ? fx->bl[ins.a / fx->S] : 0.f;
-      for (int w = 0; w < fx->W; ++w) v += fx->red[(w * fx->mS + ins.a) * PPSCI_TILE + pt];
-    } else if (ins.op == PPSCI_OP_LD_IN) v = fx->tinx[ins.a * PPSCI_TILE + pt];
-    else v = a.aux[ins.a][pp];
-    vp[i * RS] = v;
-    ap[i * RS] = 0.f;
+  if (act)
+    for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
+  for (int k = 0; k < a.nfast_loads; ++k) {
+    const unsigned w = ppsci_readlane(R.loads, k);
+    const int i = w & 127u, ia = (w >> 7) & 127u, kind = (w >> 14) & 3u;
+    if (act && kind != 3) {  // (the constants sit in the LDS register file since epi_fast_init)
+      float v;
+      if (kind == 1) {
+        v = (ia % fx->S == 0) ? fx->bl[ia / fx->S] : 0.f;
+        for (int wv = 0; wv < fx->W; ++wv) v += fx->red[(wv * fx->mS + ia) * PPSCI_TILE + pt];
+      } else if (kind == 0) v = fx->tinx[ia * PPSCI_TILE + pt];
+      else v = a.aux[ia][pp];
+      vp[i * RS] = v;
+      ap[i * RS] = 0.f;
+    }
   }
   // ---- forward steps
   for (int k = 0; k < a.nfast; ++k) {
-    const unsigned w = a.fast[k];
+    const unsigned w = ppsci_readlane(R.steps, k);
     const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
-    const float x = vp[ia * RS], y = vp[ib * RS];
-    const float lin = epi_fast_code((w >> 22) & 3u) * x + epi_fast_code((w >> 24) & 3u) * y;
-    vp[id * RS] = ((w >> 21) & 1u) ? x * y : lin;
-    ap[id * RS] = 0.f;
+    if (act) {
+      const float x = vp[ia * RS], y = vp[ib * RS];
+      const float lin = epi_fast_code((w >> 22) & 3u) * x + epi_fast_code((w >> 24) & 3u) * y;
+      vp[id * RS] = ((w >> 21) & 1u) ? x * y : lin;
+      ap[id * RS] = 0.f;
+    }
   }
   // ---- residuals, MSE terms and their seeds (epi_point, PPSCI_LOSS_MSE)
   for (int k = 0; k < a.e.n_res; ++k) {
-    const ppsci_residual rs = a.e.res[k];
-    float lab, wk;
-    if (k == 0) lab = lab0, wk = w0;
-    else if (k == 1) lab = lab1, wk = w1;
-    else {
-      lab = rs.label >= 0 ? a.aux[rs.label][pp] : 0.f;
-      wk = rs.weight >= 0 ? a.aux[rs.weight][pp] : 1.f;
-      if (rs.area >= 0) wk *= a.aux[rs.area][pp];
-    }
-    const float rv = vp[rs.value * RS];
-    if (a.resid != nullptr && valid) a.resid[(long long)k * a.N + p] = rv;
-    const float diff = rv - lab;
-    if (valid) {
-      const float w = wk * rs.scale;
-      lacc[k * PPSCI_TILE] += w * diff * diff;
-      ap[rs.value * RS] += 2.f * w * diff;
+    const unsigned t = ppsci_readlane(R.terms, k);
+    const float scale = __builtin_bit_cast(float, ppsci_readlane(__builtin_bit_cast(unsigned, R.scale), k));
+    const int iv = t & 127u, lb = (int)((t >> 7) & 31u) - 1, wt = (int)((t >> 12) & 31u) - 1, ar = (int)((t >> 17) & 31u) - 1;
+    if (act) {
+      float lab, wk;
+      if (k == 0) lab = lab0, wk = w0;
+      else if (k == 1) lab = lab1, wk = w1;
+      else {
+        lab = lb >= 0 ? a.aux[lb][pp] : 0.f;
+        wk = wt >= 0 ? a.aux[wt][pp] : 1.f;
+        if (ar >= 0) wk *= a.aux[ar][pp];
+      }
+      const float rv = vp[iv * RS];
+      if (fx->rres != nullptr) fx->rres[k * PPSCI_TILE + pt] = rv;
+      const float diff = rv - lab;
+      if (valid) {
+        const float wgt = wk * scale;
+        lacc[k * PPSCI_TILE] += wgt * diff * diff;
+        ap[iv * RS] += 2.f * wgt * diff;
+      }
     }
   }
   // ---- reverse steps
   for (int k = a.nfast - 1; k >= 0; --k) {
-    const unsigned w = a.fast[k];
+    const unsigned w = ppsci_readlane(R.steps, k);
     const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
-    const float g = ap[id * RS], x = vp[ia * RS], y = vp[ib * RS];
-    const float ga = ap[ia * RS], gb = ap[ib * RS];
+    if (act) {
+      const float g = ap[id * RS], x = vp[ia * RS], y = vp[ib * RS];
+      const float ga = ap[ia * RS], gb = ap[ib * RS];
+      const bool prod = (w >> 21) & 1u;
+      const float ca = prod ? y : epi_fast_code((w >> 26) & 3u), cb = prod ? x : epi_fast_code((w >> 28) & 3u);
+      if ((w >> 30) & 1u) ap[ia * RS] = ga + g * ca + g * cb;  // a == b (u * u, -u): ONE accumulation, in the generic order
+      else {
+        ap[ia * RS] = ga + g * ca;
+        ap[ib * RS] = gb + g * cb;
+      }
+    }
+  }
+  for (int k = 0; k < a.nfast_loads; ++k) {
+    const unsigned w = ppsci_readlane(R.loads, k);
+    const int i = w & 127u, ia = (w >> 7) & 127u, kind = (w >> 14) & 3u;
+    if (act && kind == 1) fx->tin[ia * PPSCI_TILE + pt] = ap[i * RS];  // (invalid lanes carry 0: their seeds are never set)
+  }
+}
+
+// The same for programs of at most EPI_FAST_NREG instructions, with the VM's register file (values and adjoints) in VGPRs:
+// the operand of a step is a uniformly indexed register (s_set_gpr_idx), so a step has NO memory access at all -- under
+// load an LDS round trip per step (the other workgroup of the CU streams GEMM operands through the same LDS) was most
+// of the ~350 cycles a step of epi_tile_fast takes.  Lanes 16..63 compute the same values as lanes 0..15 (pt = lane & 15:
+// same addresses) and only the stores are predicated.  fx->uls: [mS][16] the tile's stream values (bias included).
+__device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFastRegs& R, const bool act, const long long p,
+                                                   const long long pp, const bool valid, const int pt, float* const lacc,
+                                                   const EpiFused* fx, const float* const uls) {
+  EPI_FT(0)
+  float rv[EPI_FAST_NREG], ra[EPI_FAST_NREG];
+#pragma unroll
+  for (int i = 0; i < EPI_FAST_NREG; ++i) rv[i] = 0.f, ra[i] = 0.f;
+#define EPI_PF(k_, L_, W_)                                                             \
+  float L_ = 0.f, W_ = 1.f;                                                            \
+  if (k_ < a.e.n_res) {                                                                \
+    const unsigned t_ = ppsci_readlane(R.terms, k_);                                   \
+    const int lb_ = (int)((t_ >> 7) & 31u) - 1, wt_ = (int)((t_ >> 12) & 31u) - 1, ar_ = (int)((t_ >> 17) & 31u) - 1; \
+    if (lb_ >= 0) L_ = a.aux[lb_][pp];                                                 \
+    if (wt_ >= 0) W_ = a.aux[wt_][pp];                                                 \
+    if (ar_ >= 0) W_ *= a.aux[ar_][pp];                                                \
+  }
+  EPI_PF(0, lab0, w0)
+  EPI_PF(1, lab1, w1)
+#undef EPI_PF
+  if (act)
+    for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
+  EPI_FT(1)
+  // ---- memory operands and constants, four at a time (one LDS round trip per four)
+  for (int k0 = 0; k0 < a.nfast_loads; k0 += 4) {
+    unsigned w[4];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + j < a.nfast_loads ? k0 + j : a.nfast_loads - 1;
+      w[j] = ppsci_readlane(R.loads, kk);
+      const float cv = __builtin_bit_cast(float, ppsci_readlane(__builtin_bit_cast(unsigned, R.cvals), kk));
+      const int ia = (w[j] >> 7) & 127u, kind = (w[j] >> 14) & 3u;
+      if (kind == 3) v[j] = cv;
+      else if (kind == 2) v[j] = a.aux[ia][pp];
+      else v[j] = (kind == 1 ? uls : fx->tinx)[ia * PPSCI_TILE + pt];
+    }
+    // (unconditional writes: a conditional write to a uniformly indexed register array is compiled as a copy of the whole
+    // array + a select per register; the clamped entries past the end rewrite the last entry with its own value)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rv[w[j] & 127u] = v[j];
+  }
+  EPI_FT(2)
+  // ---- forward steps
+  for (int k = 0; k < a.nfast; ++k) {
+    const unsigned w = ppsci_readlane(R.steps, k);
+    const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
+    const float x = rv[ia], y = rv[ib];
+    const float lin = epi_fast_code((w >> 22) & 3u) * x + epi_fast_code((w >> 24) & 3u) * y;
+    rv[id] = ((w >> 21) & 1u) ? x * y : lin;
+  }
+  EPI_FT(3)
+  // ---- residuals, MSE terms and their seeds (epi_point, PPSCI_LOSS_MSE)
+  for (int k = 0; k < a.e.n_res; ++k) {
+    const unsigned t = ppsci_readlane(R.terms, k);
+    const float scale = __builtin_bit_cast(float, ppsci_readlane(__builtin_bit_cast(unsigned, R.scale), k));
+    const int iv = t & 127u, lb = (int)((t >> 7) & 31u) - 1, wt = (int)((t >> 12) & 31u) - 1, ar = (int)((t >> 17) & 31u) - 1;
+    float lab, wk;
+    if (k == 0) lab = lab0, wk = w0;
+    else if (k == 1) lab = lab1, wk = w1;
+    else {
+      lab = lb >= 0 ? a.aux[lb][pp] : 0.f;
+      wk = wt >= 0 ? a.aux[wt][pp] : 1.f;
+      if (ar >= 0) wk *= a.aux[ar][pp];
+    }
+    const float rval = rv[iv];
+    if (act && fx->rres != nullptr) fx->rres[k * PPSCI_TILE + pt] = rval;
+    const float diff = rval - lab;
+    const float wgt = wk * scale;
+    if (act && valid) lacc[k * PPSCI_TILE] += wgt * diff * diff;
+    ra[iv] += valid ? 2.f * wgt * diff : 0.f;
+  }
+  EPI_FT(4)
+  // ---- reverse steps
+  for (int k = a.nfast - 1; k >= 0; --k) {
+    const unsigned w = ppsci_readlane(R.steps, k);
+    const int ia = w & 127u, ib = (w >> 7) & 127u, id = (w >> 14) & 127u;
+    const float g = ra[id], x = rv[ia], y = rv[ib];
     const bool prod = (w >> 21) & 1u;
     const float ca = prod ? y : epi_fast_code((w >> 26) & 3u), cb = prod ? x : epi_fast_code((w >> 28) & 3u);
-    if ((w >> 30) & 1u) ap[ia * RS] = ga + g * ca + g * cb;  // a == b (u * u): ONE accumulation, the generic order a, then b
-    else {
-      ap[ia * RS] = ga + g * ca;
-      ap[ib * RS] = gb + g * cb;
-    }
+    // two sequential read-modify-writes, no branch: with a == b (u * u, -u) the second one sees the first -- the generic
+    // order (abar + g ca) + g cb
+    ra[ia] = ra[ia] + g * ca;
+    ra[ib] = ra[ib] + g * cb;
   }
-  for (int k = 0; k < a.nload; ++k) {
-    const int i = a.load_idx[k];
-    const ppsci_instr ins = a.e.prog[i];
-    if (ins.op == PPSCI_OP_LD_U) {
-      const float g = ap[i * RS];
-      fx->tin[ins.a * PPSCI_TILE + pt] = g;  // (invalid lanes carry g = 0: their seeds are never set)
-      if (valid && a.Ubar != nullptr) a.Ubar[(long long)ins.a * a.N + p] = g;
-    }
+  EPI_FT(5)
+  for (int k = 0; k < a.nfast_loads; ++k) {
+    const unsigned w = ppsci_readlane(R.loads, k);
+    const int i = w & 127u, ia = (w >> 7) & 127u, kind = (w >> 14) & 3u;
+    const float g = ra[i];
+    if (act && kind == 1) fx->tin[ia * PPSCI_TILE + pt] = g;  // (invalid lanes carry 0: their seeds are never set)
   }
+  EPI_FT(6)
 }
 
 // Block reduction of the loss terms (and equation-parameter adjoints) the lanes have summed over their points: a butterfly

@@ -20,9 +20,19 @@
 #define ppsci_block_sync_lds() __syncthreads()
 #define ppsci_block_sync_mem() __syncthreads()
 #define ppsci_acquire_agent() ((void)0)
+#define ppsci_setprio(p) ((void)0)
 #define PPSCI_OPAQUE(v) ((void)0)
 static inline void ppsci_store_agent(float* p, float v) { *p = v; }
 static inline void ppsci_store_agent4(f32x4* p, f32x4 v) { *p = v; }
+// v_readlane_b32 with a wave-uniform lane index; EVERY lane of the wave must execute it (the emulator's collective)
+static inline unsigned ppsci_readlane(unsigned v, int lane) {
+  float f;
+  std::memcpy(&f, &v, 4);
+  const float* buf = emu::wave_publish(f);
+  unsigned r;
+  std::memcpy(&r, &buf[lane & 63], 4);
+  return r;
+}
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -118,6 +128,12 @@ __device__ __forceinline__ void ppsci_store_agent4(f32x4* p, f32x4 v) {
   __hip_atomic_store((unsigned long long*)p + 1, b[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void ppsci_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// s_setprio: instruction-issue priority of this wave among the waves of its SIMD (0 .. 3)
+#define ppsci_setprio(p) __builtin_amdgcn_s_setprio(p)
+// v_readlane_b32 with a wave-uniform lane index (the result is a scalar); executed by every lane of the wave
+__device__ __forceinline__ unsigned ppsci_readlane(unsigned v, int lane) {
+  return (unsigned)__builtin_amdgcn_readlane((int)v, lane);
+}
 #endif
 
 extern "C" int ppsci_get_max_grid(void);

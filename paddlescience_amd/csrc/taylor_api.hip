@@ -340,7 +340,7 @@ static StepLayout step_layout(const StepArgs& a, int grid, int n_res) {
     y.red_small = y.red_tmp + chunks * y.per_tile;
     y.red_row = y.red_small + pad4(PPSCI_WRED_CHUNKS * (long long)y.psmall);
     y.fastprog = y.red_row + pad4(a.f.q.P);  // pre-decoded residual program (epi_fast_encode)
-    y.total = y.fastprog + EPI_FAST_MAX;
+    y.total = y.fastprog + EPI_FAST_WORDS;
   }
   return y;
 }
@@ -455,21 +455,23 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
     a.f.xfrag = ws + y.frag;
     a.b.xfrag = (const u32x4*)(ws + y.frag) + (long long)(d->n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB);
     a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 1 : 0);
-    unsigned fast[EPI_FAST_MAX];
-    const int nfast = g_fast_vm ? epi_fast_encode(a.e.e, fast) : -1;
+    unsigned fast[EPI_FAST_WORDS];
+    int nfast_loads = 0;
+    const int nfast = g_fast_vm ? epi_fast_encode(a.e.e, fast, &nfast_loads) : -1;
     a.e.fast = nullptr;
-    a.e.nfast = 0;
+    a.e.nfast = a.e.nfast_loads = 0;
     if (nfast >= 0) {  // (a synchronous copy of < 400 bytes; plans are made outside graph captures)
 #ifdef PPSCI_EMU
-      memcpy(ws + y.fastprog, fast, sizeof(unsigned) * (nfast > 0 ? nfast : 1));
+      memcpy(ws + y.fastprog, fast, sizeof(fast));
 #else
-      if (hipMemcpy(ws + y.fastprog, fast, sizeof(unsigned) * (nfast > 0 ? nfast : 1), hipMemcpyHostToDevice) != hipSuccess) {
+      if (hipMemcpy(ws + y.fastprog, fast, sizeof(fast), hipMemcpyHostToDevice) != hipSuccess) {
         ppsci_set_error("taylor_step: cannot upload the pre-decoded residual program");
         return fail();
       }
 #endif
       a.e.fast = (const unsigned*)(ws + y.fastprog);
       a.e.nfast = nfast;
+      a.e.nfast_loads = nfast_loads;
     }
   }
   a.f.params = a.b.params = params;
@@ -570,14 +572,26 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
   int rc = run_step_act(a, stream, 2, &grid);
   t.do_adam = do_adam;
   if (rc != PPSCI_OK || !t.external) return rc;
-  float* row = accumulate ? ws + y.red_row : t.grad;
-  rc = ppsci_wgrad_reduce(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, row, stream);
-  if (rc == PPSCI_OK && accumulate) rc = ppsci_reduce_rows(row, 1, a.b.q.P, t.grad, 1, stream);
-  if (rc == PPSCI_OK) rc = ppsci_reduce_rows(t.rows_l, t.grid, t.n_res, t.loss_terms, 0, stream);
-  if (rc == PPSCI_OK && adam)
-    rc = ppsci_adam_step(a.b.q.P, t.p, t.grad, adam->m, adam->v, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step_t,
-                         adam->grad_scale, stream);
-  return rc;
+  // two launches: chunk sums of the workgroups' rows, then -- one thread per parameter -- the total, grad (+)= it, the Adam
+  // update; the loss terms by one more workgroup of the second launch
+  ppsci_wred_extras x;
+  memset(&x, 0, sizeof(x));
+  x.accumulate = accumulate ? 1 : 0;
+  x.loss_rows = t.rows_l;
+  x.loss_out = t.loss_terms;
+  x.loss_nrows = t.grid;
+  x.n_res = t.n_res;
+  if (adam) {
+    x.p = t.p;
+    x.m = t.m;
+    x.v = t.v;
+    x.lr_t = t.lr_t;
+    x.beta1 = t.beta1;
+    x.beta2 = t.beta2;
+    x.eps_t = t.eps_t;
+    x.grad_scale = t.grad_scale;
+  }
+  return ppsci_wgrad_reduce_ex(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, t.grad, x, stream);
 }
 
 // measurement: the main kernel of the planned step alone (kind 2: the fused tile kernel without the weight split in front

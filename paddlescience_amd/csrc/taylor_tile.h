@@ -466,6 +466,20 @@ __host__ __device__ inline int ppsci_small_params(const ppsci_mlp_desc& d, const
 // stage 1 sums chunks of tiles, stage 2 sums the chunks and writes the gradient in the canonical parameter
 // layout; the entries that are not hidden-to-hidden weights are taken from `small_sum` (compact order above).
 #define PPSCI_WRED_CHUNKS 64
+// What stage 2 can do in the same launch (the tail of a fused-tile step, taylor_api.hip): row (+)= the sums instead of
+// row = ; the loss terms from the workgroups' rows (one more workgroup); the Adam update of the parameters from the
+// finished gradient (p != null; lr_t / eps_t: bias-corrected as in ppsci_adam_step).
+struct ppsci_wred_extras {
+  int accumulate;
+  const float* loss_rows;  // [loss_nrows][n_res] or null
+  float* loss_out;         // [n_res]
+  int loss_nrows, n_res;
+  float *p, *m, *v;        // Adam (p == null: none)
+  float lr_t, beta1, beta2, eps_t, grad_scale;
+};
+int ppsci_wgrad_reduce_ex(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
+                          const float* small_rows, int nsmall_rows, float* tmp_small, float* row, const ppsci_wred_extras& x,
+                          void* stream);
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
                        const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream);
 

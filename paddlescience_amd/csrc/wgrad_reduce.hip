@@ -3,6 +3,8 @@
 // once with float4 loads, coalesced.
 #include "taylor_tile.h"
 
+#include <string.h>
+
 struct WRedArgs {
   const float* wpart;  // [ntiles][per_tile]
   float* tmp;          // [nchunks][per_tile]
@@ -14,6 +16,7 @@ struct WRedArgs {
   ppsci_derived q;
   int L, H, ntiles, nchunks, nb4;  // nb4 = workgroups per chunk (each covers 256 float4)
   long long per_tile;              // (L-1)*HP*HP floats
+  ppsci_wred_extras x;             // stage 2: row (+)= / loss terms / Adam in the same launch (taylor_tile.h)
 };
 
 // stage 1: tmp[chunk][j] = sum_{tile in chunk} wpart[tile][j]; the workgroups behind those do the same for the
@@ -47,6 +50,22 @@ __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(WRedArgs a) {
 
 // stage 2: one thread per parameter of the row
 __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
+  if ((int)blockIdx.x >= (a.q.P + 255) / 256) {
+    // one more workgroup: the loss terms, rows summed in a fixed order (thread t: rows t, t + 256, ...; then the waves in order)
+    __shared__ float red[4];
+    for (int k = 0; k < a.x.n_res; ++k) {
+      float v = 0.f;
+#pragma unroll 4
+      for (int r = threadIdx.x; r < a.x.loss_nrows; r += 256) v += a.x.loss_rows[(long long)r * a.x.n_res + k];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) a.x.loss_out[k] = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+    }
+    return;
+  }
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= a.q.P) return;
   float v = 0.f;
@@ -99,12 +118,30 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
     }
     v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
   }
+  if (a.x.accumulate) v += a.row[idx];
   a.row[idx] = v;
+  if (a.x.p != nullptr) {  // == adam_kernel (epilogue_optim.hip)
+    const float g = v * a.x.grad_scale;
+    const float mm = a.x.beta1 * a.x.m[idx] + (1.f - a.x.beta1) * g;
+    const float vv = a.x.beta2 * a.x.v[idx] + (1.f - a.x.beta2) * g * g;
+    a.x.m[idx] = mm;
+    a.x.v[idx] = vv;
+    a.x.p[idx] = a.x.p[idx] - a.x.lr_t * (mm / (sqrtf(vv) + a.x.eps_t));
+  }
 }
 
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
                        const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream) {
+  ppsci_wred_extras none;
+  memset(&none, 0, sizeof(none));
+  return ppsci_wgrad_reduce_ex(d, q, ntiles, wpart, tmp, small_rows, nsmall_rows, tmp_small, row, none, stream);
+}
+
+int ppsci_wgrad_reduce_ex(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
+                          const float* small_rows, int nsmall_rows, float* tmp_small, float* row, const ppsci_wred_extras& x,
+                          void* stream) {
   WRedArgs a;
+  a.x = x;
   a.small = small_rows;
   a.tmp_small = tmp_small;
   a.nsmall_rows = nsmall_rows;
@@ -131,7 +168,7 @@ int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntil
       return PPSCI_E_LAUNCH;
     }
   }
-  PPSCI_LAUNCH(wgrad_reduce2_kernel, WRedArgs, (q.P + 255) / 256, 256, 0, stream, a);
+  PPSCI_LAUNCH(wgrad_reduce2_kernel, WRedArgs, (q.P + 255) / 256 + (x.loss_rows != nullptr ? 1 : 0), 256, 0, stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) {
     ppsci_set_error("wgrad_reduce2: launch failed (hip error %d)", e);

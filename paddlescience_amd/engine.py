@@ -215,8 +215,13 @@ class FusedConstraint:
         plan = getattr(self, "_step_plan", None)
         if plan is None or plan.key != (params.data_ptr(), grad.data_ptr()):
             nt = self.nets[0]
-            plan = self._step_plan = hp.StepPlan(nt["desc"], self.edesc, params, self.n, self.inputs, self.aux, self.U,
-                                                 self.Ubar, self.resid, nt["stash"], self._step_ws, self.loss_terms, grad)
+            # the fused tile kernel keeps U, dL/dU and the stash on the chip; it writes U / dL/dU out only when asked to
+            # (`step_outputs`: tests, tools) -- a training step does not read them
+            outs = self._step_kind != hp.STEP_FUSED_TILE or getattr(self, "step_outputs", False)
+            plan = self._step_plan = hp.StepPlan(nt["desc"], self.edesc, params, self.n, self.inputs, self.aux,
+                                                 self.U if outs else None, self.Ubar if outs else None, self.resid,
+                                                 nt["stash"] if self._step_kind != hp.STEP_FUSED_TILE else None, self._step_ws,
+                                                 self.loss_terms, grad)
         plan.run(self.edesc, accumulate, adam)
 
     def losses(self) -> Dict[str, float]:
@@ -287,33 +292,6 @@ def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
             job()
     for st in streams[:len(jobs)]:
         cur.wait_stream(st)
-
-
-_NATIVE_COMM = None  # None: not decided yet; False: torch.distributed; True: ppsci_comm_* is initialised
-
-
-def native_comm_ready() -> bool:
-    """PPSCI_NATIVE_ALLREDUCE=1 on a multi-rank GPU job: create (once) the RCCL communicator of the C ABI -- rank 0's
-    128-byte id travels over the existing torch.distributed group -- and use ppsci_allreduce_sum for the gradient
-    all-reduce.  Default (unset / 0): torch.distributed.all_reduce, which is the same RCCL underneath."""
-    global _NATIVE_COMM
-    if _NATIVE_COMM is None:
-        dist = torch.distributed
-        if os.environ.get("PPSCI_NATIVE_ALLREDUCE", "0") != "1" or not dist.is_initialized() or dist.get_world_size() < 2 \
-                or not torch.cuda.is_available() or L.is_emulated():
-            _NATIVE_COMM = False
-        else:
-            import ctypes as C
-
-            lib = L.lib()
-            buf = C.create_string_buffer(128)
-            if dist.get_rank() == 0:
-                L.check(lib.ppsci_comm_unique_id(buf))
-            box = [buf.raw if dist.get_rank() == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            L.check(lib.ppsci_comm_init(dist.get_rank(), dist.get_world_size(), C.c_char_p(box[0])))
-            _NATIVE_COMM = True
-    return _NATIVE_COMM
 
 
 class Engine:
@@ -421,11 +399,10 @@ class Engine:
         self._step_graph.clear()
 
     def allreduce(self) -> None:
+        # ONE collective per step: the flat fp32 gradient, SUM, in place, through torch.distributed (backend "nccl" is RCCL
+        # over xGMI on ROCm; "gloo" in the CPU tests).  Matches fused_allreduce_gradients (/root/reference/ppsci/solver/train.py:168-171).
         if self.world > 1:
-            if native_comm_ready():  # PPSCI_NATIVE_ALLREDUCE=1: the C ABI's RCCL communicator (csrc/comm.hip)
-                L.check(L.lib().ppsci_allreduce_sum(hp._p(self.grad), self.grad.numel(), hp._stream_ptr(self.grad)))
-            else:
-                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
 
     def optimizer_step(self, lr: float) -> None:
         self.t += 1

@@ -163,6 +163,7 @@ class Solver:
         # ---- compile constraints (convert_expr, solver.py:496-535)
         self._compiled: Dict[str, CompiledConstraint] = {}
         self._static: Dict[str, bool] = {}
+        self._ragged: set = set()  # constraints whose sample count does not divide over the ranks (zero-weight padding)
         self._device_data: Dict[str, Tuple[dict, dict, dict]] = {}
         if self.constraint:
             for name, cst in self.constraint.items():

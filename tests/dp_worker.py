@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_solver(outdir, world_batch, reduction, steps, pirate=False):
+def build_solver(outdir, world_batch, reduction, steps, pirate=False, ragged=False):
     import ppsci
     from oracle import taylor_np as T
     from tests.common import set_model_weights
@@ -35,6 +35,9 @@ def build_solver(outdir, world_batch, reduction, steps, pirate=False):
     cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"t": X[:, :1], "x": X[:, 1:]},
                        "label": {"allen_cahn": lab}},
            "batch_size": N // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    if ragged:  # N % world != 0: one batch per epoch of ceil(N / world) samples per rank, the last rank's padded
+        cfg["batch_size"] = -(-N // world)
+        cfg["sampler"]["drop_last"] = False
     cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss(reduction), eq.equations, name="EQ")
     opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
     return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
@@ -128,7 +131,11 @@ def main():
     if world > 1:
         dist.init_process_group("gloo")
     pirate = reduction == "pirate"
-    solver, model = build_solver(outdir, 64, "mean" if pirate else reduction, 2, pirate=pirate)
+    ragged = reduction.startswith("ragged_")
+    if ragged:
+        solver, model = build_solver(outdir, 67, reduction[len("ragged_"):], 2, ragged=True)
+    else:
+        solver, model = build_solver(outdir, 64, "mean" if pirate else reduction, 2, pirate=pirate)
     solver.train()
     pred = solver.predict({"t": np.linspace(0, 1, 11, dtype=np.float32).reshape(-1, 1),
                            "x": np.linspace(-1, 1, 11, dtype=np.float32).reshape(-1, 1)}, batch_size=4, return_numpy=True)

@@ -33,6 +33,21 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert r["value"] > 0 and s["value"] > 0
 
 
+def test_bench_gpus8_as_the_driver_launches_it():
+    """The driver's 8-GPU run, first time right: eight ranks (here: emulator + gloo, tiny sizes), every rank a comm rank,
+    the 1 M-point strong-scaling entry sharded 8 ways with its all-reduce timed on its own."""
+    from tests.emu import build_emu
+
+    build_emu.build()
+    r = _run({}, ["--gpus", "8", "--steps", "1", "--warmup", "0"])
+    assert r["n_gpus"] == 8 and r["config"]["parallelism"] == "dp8" and r["scaling"] == "weak"
+    s = r["strong_scaling"]
+    assert s["n_gpus"] == 8 and s["comm_world_size"] == 8 and s["comm_backend"] == "gloo" and s["scaling"] == "strong"
+    assert s["points_per_rank"] * 8 == s["points_total"]
+    assert s["allreduce_ms"] is not None and s["allreduce_ms"] > 0 and s["allreduce_bytes"] == 4 * 66819
+    assert r["value"] > 0 and s["value"] > 0
+
+
 def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
     env = dict(os.environ, PPSCI_BENCH_EMU="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],

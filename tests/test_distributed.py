@@ -35,6 +35,18 @@ def test_two_ranks_reproduce_single_rank(tmp_path, reduction):
     assert np.isfinite(two["loss"])
 
 
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_ragged_shards_get_zero_weight_padding(tmp_path, reduction):
+    """67 samples on 2 ranks: the sampler pads rank 1's shard by wrapping around (as the reference's
+    DistributedBatchSampler does, /root/reference/ppsci/data/__init__.py:76-99); the duplicate gets zero weight and "mean"
+    divides by 67, not 68 -- so the 2-rank run still reproduces the 1-rank run."""
+    d = str(tmp_path)
+    one = _run(d, 1, "ragged_" + reduction)
+    two = _run(d, 2, "ragged_" + reduction)
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5, atol=1e-6)
+
+
 def test_two_ranks_reproduce_single_rank_piratenet(tmp_path):
     """PirateNet (layer-by-layer kernels, RWF, trainable Fourier kernel and alpha): the flat trainable-layout gradient is
     all-reduced like an MLP's."""

@@ -29,6 +29,8 @@ def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints
         eng.one_launch = fused
         eng.one_launch_max_constraints = max_constraints
         csts = [_constraint(d, kind, lay, n, 100 + i) for i, (kind, n) in enumerate(specs)]
+        for c in csts:
+            c.step_outputs = True  # U and dL/dU are optional outputs of the fused tile kernel
         if fused:
             assert all(c.one_launch_ready() and c._step_kind == hp.STEP_FUSED_TILE for c in csts)
             assert eng.one_launch_ready(csts) == (len(csts) <= max_constraints)
