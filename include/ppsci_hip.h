@@ -429,6 +429,27 @@ int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
                            0 = P.  3P with the three pointers P apart interleaves the networks' rows [n][3][P], so that ONE
                            ppsci_reduce_rows(n, 3P) sums all three */, void* stream);
 
+/* ---- losses on [rows][H][W] fields (rows = batch x channels) of the operator-learning path, value and adjoint
+ * (csrc/field_loss.hip).  LpLoss / H1Loss of /root/reference/examples/neuraloperator/metric.py:69-412 (p = 2, d = 2;
+ * central differences :36-55, wrapping around or one-sided at the ends under fix_x / fix_y) and MSELoss on fields
+ * (ppsci/loss/mse.py:82-105), plus what autograd derives from them in the reference.  With e = x - y:
+ *   _sums:    sums[2 r] = |e|^2 (+ |Dx e|^2 + |Dy e|^2, order 1),  sums[2 r + 1] = the same of y;  ihx / ihy = 1 / spacing
+ *             (order 2: the p = 1 norms -- sums of |e| and |y|, no differences)
+ *   _finish:  term(r) = sqrt(S_diff)/sqrt(S_y) (mode 0, rel) | sqrt(abs_const S_diff) (1, abs) | S_diff (2, squared) |
+ *             S_diff / S_y (3, rel p = 1) | abs_const S_diff (4, abs p = 1);
+ *             loss[0] = coef * sum_r term(r) (fixed order);  rowcoef[r] = coef * d term / d S_diff * 2 (may be NULL)
+ *   _adjoint: gx = rowcoef[r] (e + Dx^T Dx e + Dy^T Dy e) = d loss / d x */
+int ppsci_field_loss_sums(int rows, int H, int W, int order, float ihx, float ihy, int fix_x, int fix_y, const float* x,
+                          const float* y, float* sums, void* stream);
+int ppsci_field_loss_finish(int rows, int mode, float abs_const, float coef, const float* sums, float* loss, float* rowcoef,
+                            void* stream);
+int ppsci_field_loss_adjoint(int rows, int H, int W, int order, float ihx, float ihy, int fix_x, int fix_y, const float* x,
+                             const float* y, const float* rowcoef, float* gx, void* stream);
+/* FNOBlocks(stabilizer="tanh") (ppsci/arch/fno_block.py:1199): y = tanh(x) in front of the spectral convolution and its
+ * adjoint out (+)= g (1 - y^2) (y: the forward OUTPUT). */
+int ppsci_tanh_fwd(int64_t n, const float* x, float* y, void* stream);
+int ppsci_tanh_bwd(int64_t n, const float* y, const float* g, float* out, int accumulate, void* stream);
+
 /* ---- data parallelism: no entry point here.  The step's one collective -- SUM all-reduce of the flat gradient
  * (solver/train.py:168-171) -- is issued by the host through torch.distributed (RCCL) on the launch stream between the
  * gradient kernels and ppsci_adam_step; every kernel above is rank-local. */

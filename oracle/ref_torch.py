@@ -828,7 +828,7 @@ def reference_spectral_conv2d(x, w_re, w_im, n_modes_x, fft_norm="backward", bia
 
 
 def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5, domain_padding=None,
-                domain_padding_mode="one-sided"):
+                domain_padding_mode="one-sided", stabilizer=None):
     """FNONet.forward (tfnonet.py:179-193) with FNOBlocks.forward_with_postactivation (fno_block.py:1191-1220)
     and fno_block.MLP (:313-320) written out on plain tensors.  P: dict of parameters named like the torch
     modules of paddlescience_amd.arch.fno (lifting.fcs.i.weight [Co,Ci,1,1] ...)."""
@@ -858,7 +858,8 @@ def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5
         x = F.pad(x, [pw if sym else 0, pw, ph if sym else 0, ph])
     for i in range(n_layers):
         skip = conv1x1(x, P[f"fno_blocks.fno_skips.{i}.weight"]) if f"fno_blocks.fno_skips.{i}.weight" in P else x
-        y = reference_spectral_conv2d(x, P[f"fno_blocks.convs.{i}.weight_real"], P[f"fno_blocks.convs.{i}.weight_imag"],
+        xs = torch.tanh(x) if stabilizer == "tanh" else x  # fno_block.py:1199: the skip above sees x, the spectral branch tanh(x)
+        y = reference_spectral_conv2d(xs, P[f"fno_blocks.convs.{i}.weight_real"], P[f"fno_blocks.convs.{i}.weight_imag"],
                                       n_modes[0], fft_norm, P[f"fno_blocks.convs.{i}.bias"])
         if norm == "group_norm":  # nn.GroupNorm(num_groups=1): statistics over (C, H, W) per sample
             mu = y.mean(dim=(1, 2, 3), keepdim=True)
@@ -872,3 +873,33 @@ def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5
         oh, ow = (ph, pw) if domain_padding_mode == "symmetric" else (0, 0)
         x = x[..., oh:oh + H0, ow:ow + W0]
     return mlp(x, "projection", 2)
+
+
+def field_rel_error(x, y, order=0, p=2, spacing=(1.0, 1.0), fix=(False, False)):
+    """Per-row relative error of /root/reference/examples/neuraloperator/metric.py on [B, C, H, W] tensors: LpLoss.rel
+    (:148-160; order 0) and H1Loss.rel (:330-352; order 1: the squared norms of the central differences of :36-55 --
+    periodic wrap-around, one-sided at the first / last sample under fix -- are added before the square roots).  Returns
+    the [B, C] matrix of row terms (the classes then reduce it over `reduce_dims`)."""
+
+    def diff(v, dim, h, fx):
+        d = (torch.roll(v, -1, dims=dim) - torch.roll(v, 1, dims=dim)) / (2.0 * h)
+        if fx:
+            d = d.clone()
+            first, second = v.select(dim, 0), v.select(dim, 1)
+            last, prev = v.select(dim, -1), v.select(dim, -2)
+            d.select(dim, 0).copy_((second - first) / h)
+            d.select(dim, -1).copy_((last - prev) / h)
+        return d
+
+    def norm_p(v):
+        return v.flatten(-2).abs().pow(p).sum(-1)
+
+    e = x - y
+    if order == 0:
+        return (norm_p(e) / norm_p(y)) ** (1.0 / p) if p != 1 else norm_p(e) / norm_p(y)
+    sd, sy = norm_p(e), norm_p(y)
+    for dim, h, fx in ((-2, spacing[0], fix[0]), (-1, spacing[1], fix[1])):
+        sd = sd + norm_p(diff(x, dim, h, fx) - diff(y, dim, h, fx))
+        sy = sy + norm_p(diff(y, dim, h, fx))
+    return sd.sqrt() / sy.sqrt()
+

@@ -144,6 +144,11 @@ _SYMBOLS = {
     "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "ppsci_pad2d": (C.c_int, [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_field_loss_sums": (C.c_int, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "ppsci_field_loss_finish": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float] + [C.c_void_p] * 4),
+    "ppsci_field_loss_adjoint": (C.c_int, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "ppsci_tanh_fwd": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_tanh_bwd": (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ppsci_fno_tail_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -1,12 +1,12 @@
 from .base import Arch  # noqa: F401
-from .fno import FNONet, SpectralConv2d, TFNO1dNet, TFNO2dNet, TFNO3dNet, spectral_contract  # noqa: F401
+from .fno import FNONet, SpectralConv2d, TFNO1dNet, TFNO2dNet, TFNO3dNet  # noqa: F401
 from .mlp import MLP  # noqa: F401
 from .model_list import ModelList  # noqa: F401
 from .piratenet import PirateNet  # noqa: F401
 from .modified_mlp import ModifiedMLP  # noqa: F401
 from .spinn import SPINN  # noqa: F401
 
-__all__ = ["Arch", "MLP", "PirateNet", "ModifiedMLP", "ModelList", "SpectralConv2d", "spectral_contract", "SPINN", "FNONet", "TFNO1dNet", "TFNO2dNet", "TFNO3dNet",
+__all__ = ["Arch", "MLP", "PirateNet", "ModifiedMLP", "ModelList", "SpectralConv2d", "SPINN", "FNONet", "TFNO1dNet", "TFNO2dNet", "TFNO3dNet",
            "build_model"]
 
 

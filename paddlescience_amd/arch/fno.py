@@ -1,156 +1,114 @@
-"""FNO spectral convolution on the HIP MFMA kernel (BASELINE config 4).
+"""ppsci.arch.FNONet / TFNO2dNet (BASELINE config 4) on this framework's own kernels.
 
-`SpectralConv2d` follows FactorizedSpectralConv (dense, non-factorized weights, order 2) of
-/root/reference/ppsci/arch/fno_block.py:545-796: weights real/imag `[Ci, Co, n_modes[0], n_modes[1]//2+1]`
-drawn N(0, sqrt(2/(Ci+Co))) (:621-622, :522-532), optional bias `[Co, 1, 1]`, `fft_norm` forwarded to the
-FFTs.  The FFTs run in hipFFT through torch.fft (glue, as SURVEY.md allows); the per-mode complex channel
-contraction -- the part the reference does with four real einsums -- is `ppsci_spectral_conv2d_fwd/bwd`,
-wired into torch autograd so the layer can sit inside a larger torch module.
-
-`FNOBlocks`, `FNONet`, `TFNO2dNet` follow fno_block.py:1047-1255 and tfnonet.py:13-406 for the configuration of
-BASELINE config 4 (post-activation blocks, linear skips, optional GroupNorm, dense weights); the lifting /
-projection / skip 1x1 convolutions, GroupNorm and GELU are plain library ops (MIOpen / rocBLAS through torch).
-Options of the reference signature that are not built raise NotImplementedError."""
+The classes here hold PARAMETERS only -- spectral weights real / imag `[Ci, Co, n_modes[0], n_modes[1]//2+1]` drawn
+N(0, sqrt(2/(Ci+Co))) with a bias `[Co, 1, 1]` (/root/reference/ppsci/arch/fno_block.py:545-796, :621-622, :522-532), the
+1x1 convolutions of lifting / projection / skips (fno_block.MLP :263-320, skip :190-226), GroupNorm scale / shift -- with
+the reference's module tree and state-dict names.  Every forward (training, eval, predict, validators) and the whole
+backward run in `fno_engine.FnoNative`: MFMA 1x1 convolutions, raw hipFFT executions, the per-mode complex contraction,
+the fused GroupNorm + bias + skip + GELU block tail (csrc/fno.hip, csrc/fft.hip, csrc/spectral_conv.hip).  There is no
+second (library-op) implementation of the network; options of the reference signature that the kernels do not cover raise
+NotImplementedError with the reason."""
 from __future__ import annotations
 
-import ctypes as C
 import math
 from typing import Optional, Tuple
 
-import numpy as np
 import torch
 
-from .. import _lib as L
-from ..hotpath import _p, _require_device, _stream_ptr
 from . import base
 
 
-def _desc(B, ci, co, H, Wf, mx, my) -> L.SpectralDesc:
-    d = L.SpectralDesc()
-    d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, ci, co, H, Wf, mx, my
-    return d
+def gelu(x):
+    """The default `non_linearity` marker (paddle.nn.functional.gelu in the reference): the kernels fuse GELU into the
+    1x1-convolution epilogue and the block tail; the object itself is only compared by identity."""
+    raise NotImplementedError("fno.gelu names the activation fused into the kernels; it is not called")
 
 
-class _SpectralContract(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x_ft: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor):
-        _require_device(w_re)
-        B, ci, H, Wf = x_ft.shape
-        _, co, mx, my = w_re.shape
-        xr = torch.view_as_real(x_ft.contiguous()).contiguous()
-        out = torch.zeros((B, co, H, Wf, 2), dtype=torch.float32, device=x_ft.device)
-        d = _desc(B, ci, co, H, Wf, mx, my)
-        L.check(L.lib().ppsci_spectral_conv2d_fwd(C.byref(d), _p(xr), _p(w_re.contiguous()), _p(w_im.contiguous()),
-                                                  _p(out), _stream_ptr(out)))
-        ctx.save_for_backward(xr, w_re, w_im)
-        ctx.desc = d
-        return torch.view_as_complex(out)
-
-    @staticmethod
-    def backward(ctx, g_ft: torch.Tensor):
-        xr, w_re, w_im = ctx.saved_tensors
-        d = ctx.desc
-        g = torch.view_as_real(g_ft.contiguous()).contiguous()
-        gx = torch.zeros_like(xr)
-        gwr = torch.empty_like(w_re)
-        gwi = torch.empty_like(w_im)
-        L.check(L.lib().ppsci_spectral_conv2d_bwd(C.byref(d), _p(xr), _p(w_re.contiguous()), _p(w_im.contiguous()), _p(g),
-                                                  _p(gx), _p(gwr), _p(gwi), _stream_ptr(gx)))
-        return torch.view_as_complex(gx), gwr, gwi
+_GELUS = (gelu, torch.nn.functional.gelu)
 
 
-def spectral_contract(x_ft: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor) -> torch.Tensor:
-    """out_ft[b,o,r,c] = sum_i x_ft[b,i,r,c] * (w_re + i w_im)[i,o,m(r),c] on the kept modes, 0 elsewhere."""
-    return _SpectralContract.apply(x_ft, w_re, w_im)
+class Conv1x1(torch.nn.Module):
+    """Parameters of a 1x1 convolution (nn.Conv2D(..., 1) in fno_block.py:286-291 / :203): weight [Co, Ci, 1, 1], bias
+    [Co]; initialised like the framework default U(+-1/sqrt(Ci)).  Applied by ppsci_pw_conv (fno_engine)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        k = 1.0 / math.sqrt(in_channels)
+        self.weight = torch.nn.Parameter((torch.rand(out_channels, in_channels, 1, 1) * 2 - 1) * k)
+        self.bias = torch.nn.Parameter((torch.rand(out_channels) * 2 - 1) * k) if bias else None
+
+
+class GroupNorm1(torch.nn.Module):
+    """Parameters of nn.GroupNorm(num_groups=1, C) (fno_block.py:1157-1165): scale ones, shift zeros, eps 1e-5.  Applied
+    inside ppsci_fno_tail_fwd / _bwd."""
+
+    num_groups = 1
+
+    def __init__(self, num_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = torch.nn.Parameter(torch.ones(num_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(num_channels))
 
 
 class SpectralConv2d(torch.nn.Module):
+    """Parameters of one layer of FactorizedSpectralConv (dense weights, order 2)."""
+
     def __init__(self, in_channels: int, out_channels: int, n_modes: Tuple[int, int], bias: bool = True,
                  fft_norm: str = "backward", init_std: Optional[float] = None):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.n_modes = (int(n_modes[0]), int(n_modes[1]) // 2 + 1)  # fno_block.py:673-684
-        self.fft_norm = fft_norm
+        self.fft_norm = fft_norm  # (the rfftn / irfftn pair scales by 1/(H W) for every norm: folded into the contraction)
         std = (2 / (in_channels + out_channels)) ** 0.5 if init_std is None else init_std
         shape = (in_channels, out_channels, *self.n_modes)
         self.weight_real = torch.nn.Parameter(torch.randn(shape) * std)
         self.weight_imag = torch.nn.Parameter(torch.randn(shape) * std)
         self.bias = torch.nn.Parameter(std * torch.randn(out_channels, 1, 1)) if bias else None
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        H, W = x.shape[-2:]
-        x_ft = torch.fft.rfftn(x, norm=self.fft_norm, dim=(-2, -1))
-        out_ft = spectral_contract(x_ft, self.weight_real, self.weight_imag)
-        y = torch.fft.irfftn(out_ft, s=(H, W), dim=(-2, -1), norm=self.fft_norm)
-        if self.bias is not None:
-            y = y + self.bias
-        return y
-
-
-
 
 class ChannelMLP(torch.nn.Module):
     """fno_block.MLP (fno_block.py:263-320): n_layers 1x1 convolutions with the non-linearity in between."""
 
     def __init__(self, in_channels: int, out_channels: Optional[int] = None, hidden_channels: Optional[int] = None,
-                 n_layers: int = 2, non_linearity=torch.nn.functional.gelu):
+                 n_layers: int = 2, non_linearity=gelu):
         super().__init__()
         out_channels = in_channels if out_channels is None else out_channels
         hidden_channels = in_channels if hidden_channels is None else hidden_channels
         self.n_layers = n_layers
         self.non_linearity = non_linearity
         dims = [in_channels] + [hidden_channels] * (n_layers - 1) + [out_channels]
-        self.fcs = torch.nn.ModuleList([torch.nn.Conv2d(dims[i], dims[i + 1], 1) for i in range(n_layers)])
-
-    def forward(self, x):
-        for i, fc in enumerate(self.fcs):
-            x = fc(x)
-            if i < self.n_layers - 1:
-                x = self.non_linearity(x)
-        return x
+        self.fcs = torch.nn.ModuleList([Conv1x1(dims[i], dims[i + 1]) for i in range(n_layers)])
 
 
 class FNOBlocks(torch.nn.Module):
     """fno_block.FNOBlocks, post-activation form (fno_block.py:1191-1220): per layer
-    x <- act( norm(SpectralConv_i(x)) + skip_i(x) ), no activation after the last layer."""
+    x <- act( norm(SpectralConv_i(stab(x))) + skip_i(x) ), stab = tanh with `stabilizer="tanh"` (:1199), no activation
+    after the last layer."""
 
     def __init__(self, in_channels: int, out_channels: int, n_modes: Tuple[int, int], n_layers: int = 1,
-                 non_linearity=torch.nn.functional.gelu, stabilizer: Optional[str] = None, norm: Optional[str] = None,
+                 non_linearity=gelu, stabilizer: Optional[str] = None, norm: Optional[str] = None,
                  fno_skip: str = "linear", fft_norm: str = "forward"):
         super().__init__()
         if in_channels != out_channels:
             raise NotImplementedError("FNOBlocks with in_channels != out_channels")
         if fno_skip not in ("linear", "identity"):
             raise NotImplementedError(f"fno_skip={fno_skip!r} (built: 'linear', 'identity')")
-        if norm not in (None, "group_norm", "instance_norm"):
-            raise NotImplementedError(f"norm={norm!r} (built: None, 'group_norm', 'instance_norm')")
+        if norm not in (None, "group_norm"):
+            raise NotImplementedError(f"norm={norm!r}: the block-tail kernel normalises over one group (built: None, 'group_norm')")
         if stabilizer not in (None, "tanh"):
             raise ValueError(f"stabilizer={stabilizer!r}")
+        if non_linearity not in _GELUS:
+            raise NotImplementedError("non_linearity: GELU is the activation fused into the kernels")
         self.n_layers, self.non_linearity, self.stabilizer = n_layers, non_linearity, stabilizer
         # FactorizedSpectralConv holds the weights of all layers; bias per layer (fno_block.py:652-663)
         self.convs = torch.nn.ModuleList([SpectralConv2d(in_channels, out_channels, n_modes, bias=True, fft_norm=fft_norm)
                                           for _ in range(n_layers)])
         self.fno_skips = torch.nn.ModuleList([
-            torch.nn.Conv2d(in_channels, out_channels, 1, bias=False) if fno_skip == "linear" else torch.nn.Identity()
+            Conv1x1(in_channels, out_channels, bias=False) if fno_skip == "linear" else torch.nn.Identity()
             for _ in range(n_layers)])
-        if norm == "group_norm":
-            self.norm = torch.nn.ModuleList([torch.nn.GroupNorm(1, out_channels) for _ in range(n_layers)])
-        elif norm == "instance_norm":
-            self.norm = torch.nn.ModuleList([torch.nn.InstanceNorm2d(out_channels) for _ in range(n_layers)])
-        else:
-            self.norm = None
-
-    def forward(self, x, index: int = 0):
-        x_skip = self.fno_skips[index](x)
-        if self.stabilizer == "tanh":
-            x = torch.tanh(x)
-        x_fno = self.convs[index](x)
-        if self.norm is not None:
-            x_fno = self.norm[index](x_fno)
-        x = x_fno + x_skip
-        if index < self.n_layers - 1:
-            x = self.non_linearity(x)
-        return x
+        self.norm = torch.nn.ModuleList([GroupNorm1(out_channels) for _ in range(n_layers)]) if norm == "group_norm" else None
 
 
 class FNONet(base.Arch, torch.nn.Module):
@@ -161,12 +119,12 @@ class FNONet(base.Arch, torch.nn.Module):
     The parameters live in ONE flat fp32 buffer (`flat_params`, module parameters are views into it) so that
     the data-parallel all-reduce and the fused Adam kernel act on a single tensor, as for the PINN path."""
 
-    is_operator = True  # Solver: train through torch autograd around the HIP spectral kernel
+    is_operator = True  # Solver: the operator engine (hand-written forward + backward, fno_engine.FnoNative)
 
     def __init__(self, input_keys: Tuple[str, ...], output_keys: Tuple[str, ...], n_modes: Tuple[int, ...],
                  hidden_channels: int, in_channels: int = 3, out_channels: int = 1, lifting_channels: int = 256,
                  projection_channels: int = 256, n_layers: int = 4, use_mlp: bool = False, mlp=None,
-                 max_n_modes=None, non_linearity=torch.nn.functional.gelu, stabilizer: Optional[str] = None,
+                 max_n_modes=None, non_linearity=gelu, stabilizer: Optional[str] = None,
                  norm: Optional[str] = None, ada_in_features=None, preactivation: bool = False,
                  fno_skip: str = "linear", mlp_skip: str = "soft-gating", separable: bool = False,
                  factorization: Optional[str] = None, rank: float = 1.0, joint_factorization: bool = False,
@@ -204,6 +162,8 @@ class FNONet(base.Arch, torch.nn.Module):
             self.lifting = ChannelMLP(in_channels, hidden_channels, lifting_channels, 2)
         else:
             self.lifting = ChannelMLP(in_channels, hidden_channels, hidden_channels, 1)
+        if non_linearity not in _GELUS:
+            raise NotImplementedError("non_linearity: GELU is the activation fused into the kernels")
         self.projection = ChannelMLP(hidden_channels, out_channels, projection_channels, 2, non_linearity)
         self.flat_params: Optional[torch.Tensor] = None
         self.flat_grad: Optional[torch.Tensor] = None
@@ -215,6 +175,7 @@ class FNONet(base.Arch, torch.nn.Module):
     def to_device(self, device):
         """Moves the model and (re)packs every parameter as a view into `flat_params` / `flat_grad`."""
         torch.nn.Module.to(self, device)
+        self._native = None  # (its buffers live on the old device)
         ps = [p for p in torch.nn.Module.parameters(self)]
         n = sum(p.numel() for p in ps)
         flat = torch.empty(n, dtype=torch.float32, device=device)
@@ -259,17 +220,18 @@ class FNONet(base.Arch, torch.nn.Module):
         ph, pw = round(fh * H), round(fw * W)
         return (2 * ph, 2 * pw, ph, pw) if mode == "symmetric" else (ph, pw, 0, 0)
 
+    def native(self):
+        """The kernels' executor for this model (buffers per batch shape); shared by training, eval and predict."""
+        nat = getattr(self, "_native", None)
+        if nat is None:
+            from ..fno_engine import FnoNative
+
+            nat = self._native = FnoNative(self)
+        return nat
+
     def forward_tensor(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.lifting(x)
-        H, W = x.shape[-2:]
-        ah, aw, oh, ow = self.padding_of(H, W)
-        if ah or aw:
-            x = torch.nn.functional.pad(x, [ow, aw - ow, oh, ah - oh])
-        for index in range(self.n_layers):
-            x = self.fno_blocks(x, index)
-        if ah or aw:
-            x = x[..., oh:oh + H, ow:ow + W]
-        return self.projection(x)
+        """[B, C_in, H, W] -> [B, C_out, H, W] (a fresh tensor; the executor owns its buffers)."""
+        return self.native().forward(x.to(dtype=torch.float32).contiguous()).clone()
 
     def forward(self, x):
         if self._input_transform is not None:
@@ -291,7 +253,7 @@ class TFNO2dNet(FNONet):
     def __init__(self, input_keys: Tuple[str, ...], output_keys: Tuple[str, ...], n_modes_height: int,
                  n_modes_width: int, hidden_channels: int, in_channels: int = 3, out_channels: int = 1,
                  lifting_channels: int = 256, projection_channels: int = 256, n_layers: int = 4,
-                 non_linearity=torch.nn.functional.gelu, use_mlp: bool = False, mlp=None, norm: Optional[str] = None,
+                 non_linearity=gelu, use_mlp: bool = False, mlp=None, norm: Optional[str] = None,
                  skip: str = "soft-gating", separable: bool = False, preactivation: bool = False,
                  factorization: str = "Tucker", rank: float = 1.0, joint_factorization: bool = False,
                  implementation: str = "factorized", domain_padding=None, domain_padding_mode: str = "one-sided",

@@ -87,76 +87,66 @@ class PositionalEmbedding2D:
 
 
 class DarcyFlowDataset:
-    """darcyflow_dataset.py:168-296 (same constructor arguments and item layout)."""
+    """ppsci.data.dataset.DarcyFlowDataset (darcyflow_dataset.py:168-296): constructor arguments, item layout and the
+    `input_encoder` / `output_encoder` attributes of the reference; organised around ONE served split.
+
+    `data_split` picks what `__getitem__` serves: "train" (`darcy_train_<train_resolution>.npy`), "test_16x16" (the FIRST
+    entry of `test_resolutions`) or anything else (the SECOND) -- the reference's rule.  The normalisation statistics
+    always come from the training file; the output encoding is applied to the training labels only (validators compare in
+    physical units).  Only the training file and the served split are read (the reference reads all three every time)."""
 
     batch_index: bool = True
+    _SPLIT_OF = {"train": None, "test_16x16": 0}  # anything else: the second test resolution
 
     def __init__(self, input_keys: Tuple[str, ...], label_keys: Tuple[str, ...], data_dir: str,
                  weight_dict: Optional[Dict[str, float]] = None, test_resolutions: Sequence[int] = (32,),
                  train_resolution: int = 32, grid_boundaries=((0, 1), (0, 1)), positional_encoding: bool = True,
                  encode_input: bool = False, encode_output: bool = True, encoding: str = "channel-wise",
                  channel_dim: int = 1, data_split: str = "train"):
-        for res in test_resolutions:
-            if res not in [16, 32]:
-                raise ValueError(f"Only 32 and 64 are supported for test resolution, but got {test_resolutions}")
+        bad = [r for r in test_resolutions if r not in (16, 32)]
+        if bad:
+            raise ValueError(f"test resolutions must be 16 or 32 (the published Darcy test sets), but got {list(test_resolutions)}")
+        if encoding not in ("channel-wise", "pixel-wise"):
+            raise ValueError(f"encoding={encoding!r}")
         self.input_keys, self.label_keys, self.data_dir = tuple(input_keys), tuple(label_keys), data_dir
-        self.weight_dict = {} if weight_dict is None else weight_dict
-        if weight_dict is not None:
-            self.weight_dict = {key: 1.0 for key in self.label_keys}
-            self.weight_dict.update(weight_dict)
+        self.weight_dict = dict({k: 1.0 for k in self.label_keys}, **weight_dict) if weight_dict is not None else {}
         self.weight = self.weight_dict  # the array datasets' attribute name (Solver)
         self.test_resolutions, self.train_resolution = list(test_resolutions), train_resolution
         self.grid_boundaries, self.positional_encoding = grid_boundaries, positional_encoding
         self.encode_input, self.encode_output, self.encoding = encode_input, encode_output, encoding
         self.channel_dim, self.data_split = channel_dim, data_split
 
-        self.x_train, self.y_train = self.read_data(Path(data_dir).joinpath(f"darcy_train_{train_resolution}.npy").as_posix())
-        self.x_test_1, self.y_test_1 = self.read_data(
-            Path(data_dir).joinpath(f"darcy_test_{self.test_resolutions[0]}.npy").as_posix())
-        self.x_test_2, self.y_test_2 = self.read_data(
-            Path(data_dir).joinpath(f"darcy_test_{self.test_resolutions[1]}.npy").as_posix())
-        if self.encode_input:
-            self.input_encoder = self.encode_data(self.x_train)
-            self.x_train = self.input_encoder.encode(self.x_train)
-            self.x_test_1 = self.input_encoder.encode(self.x_test_1)
-            self.x_test_2 = self.input_encoder.encode(self.x_test_2)
+        root = Path(data_dir)
+        x_train, y_train = self._read(root / f"darcy_train_{train_resolution}.npy")
+        which = self._SPLIT_OF.get(data_split, 1)
+        if which is None:
+            xs, ys = x_train, y_train
         else:
-            self.input_encoder = None
-        if self.encode_output:
-            self.output_encoder = self.encode_data(self.y_train)
-            self.y_train = self.output_encoder.encode(self.y_train)
-        else:
-            self.output_encoder = None
+            xs, ys = self._read(root / f"darcy_test_{self.test_resolutions[which]}.npy")
+        # statistics of the TRAINING split; "channel-wise": one mean / std over everything, "pixel-wise": per pixel
+        axes = list(range(x_train.ndim)) if encoding == "channel-wise" else [0]
+        self.input_encoder = UnitGaussianNormalizer(x_train, reduce_dim=axes) if encode_input else None
+        self.output_encoder = UnitGaussianNormalizer(y_train, reduce_dim=axes) if encode_output else None
+        if self.input_encoder is not None:
+            xs = self.input_encoder.encode(xs)
+        if self.output_encoder is not None and which is None:
+            ys = self.output_encoder.encode(ys)
+        self._x, self._y = xs, ys
         self.transform_x = PositionalEmbedding2D(grid_boundaries) if positional_encoding else None
 
-    def read_data(self, path: str):
-        data = np.load(path, allow_pickle=True).item()
+    def _read(self, path: Path):
+        """`.npy` holding a pickled dict {"x": [n, H, W] permeability, "y": [n, H, W] pressure}; the channel axis is inserted
+        at `channel_dim`, the input is fp32 (darcyflow_dataset.py:253-264)."""
+        data = np.load(path.as_posix(), allow_pickle=True).item()
         x = np.expand_dims(np.asarray(data["x"]), self.channel_dim).astype(np.float32)
         y = np.expand_dims(np.asarray(data["y"]), self.channel_dim).copy()
         return x, y
 
-    def encode_data(self, data: np.ndarray) -> UnitGaussianNormalizer:
-        if self.encoding == "channel-wise":
-            reduce_dims = list(range(data.ndim))
-        elif self.encoding == "pixel-wise":
-            reduce_dims = [0]
-        else:
-            raise ValueError(f"encoding={self.encoding!r}")
-        return UnitGaussianNormalizer(data, reduce_dim=reduce_dims)
-
-    def _split(self):
-        if self.data_split == "train":
-            return self.x_train, self.y_train
-        if self.data_split == "test_16x16":
-            return self.x_test_1, self.y_test_1
-        return self.x_test_2, self.y_test_2
-
     def __len__(self):
-        return self._split()[0].shape[0]
+        return self._x.shape[0]
 
     def __getitem__(self, index):
-        xs, ys = self._split()
-        x, y = xs[index], ys[index]
+        x, y = self._x[index], self._y[index]
         if self.transform_x is not None:
             x = self.transform_x(x)
         return {self.input_keys[0]: x}, {self.label_keys[0]: y}, self.weight_dict

@@ -13,10 +13,10 @@ clones, no normalisation kernels; they are linear, so their adjoints are FFTs ag
 everything else is ppsci_pw_conv / ppsci_pw_conv_wgrad / ppsci_fno_tail_* / ppsci_spectral_conv2d_* / ppsci_reduce_rows.
 The 1/(H*W) of the rfftn / irfftn pair -- the same for every `fft_norm` -- is folded into the spectral contraction.  Gradients are written straight into the views of `model.flat_grad`.
 
-Supported configuration (`supports`): the one the reference's TFNO examples use -- 2-D, dense spectral weights, GELU,
-post-activation blocks, linear or identity skip, GroupNorm(1 group) or no norm, two-layer (or one-layer) lifting and a
-two-layer projection, no stabilizer.  Anything else trains through torch autograd around the spectral kernel
-(paddlescience_amd/operator_engine.py), as before."""
+Covered configuration: 2-D, dense spectral weights, GELU, post-activation blocks (optionally with the tanh stabilizer),
+linear or identity skip, GroupNorm(1 group) or no norm, DomainPadding, two-layer (or one-layer) lifting and a two-layer
+projection.  This executor is the ONLY implementation of the network: training, evaluation and prediction all run through
+it (arch/fno.py holds parameters, not operations); what it does not cover is refused when the model is built."""
 from __future__ import annotations
 
 import ctypes as C
@@ -26,26 +26,19 @@ import torch
 
 from . import _lib as L
 from . import hotpath as hp
+from .arch import fno as fno_arch
 from .hotpath import _p, _stream_ptr
 
 
 def supports(model) -> Optional[str]:
-    """None when the native path can run `model`, else the reason it cannot."""
+    """None when the kernels cover `model`, else the reason they do not (the constructors of arch/fno.py already refuse
+    the options without a kernel: other norms / activations / skips, preactivation, use_mlp, 1-D / 3-D)."""
     from .arch import fno
 
     if not isinstance(model, fno.FNONet):
         return "not an FNONet"
-    fb = model.fno_blocks
-    if fb.non_linearity is not torch.nn.functional.gelu or model.projection.non_linearity is not torch.nn.functional.gelu:
-        return "non-GELU activation"
-    if fb.stabilizer is not None:
-        return "stabilizer"
-    if fb.norm is not None and not all(isinstance(n, torch.nn.GroupNorm) and n.num_groups == 1 for n in fb.norm):
-        return "norm other than GroupNorm(1 group)"
     if model.lifting.n_layers not in (1, 2) or model.projection.n_layers != 2:
         return "lifting / projection depth"
-    if model._input_transform is not None or model._output_transform is not None:
-        return "input / output transform"
     return None
 
 
@@ -89,6 +82,9 @@ class FnoNative:
             self.xou = torch.empty((B, Ch, P0), **f)   # blocks' output after unpadding
             self.gpad = torch.empty((B, Ch, P), **f)   # padded gradient of the blocks' output
         self.x = [torch.empty((B, Ch, P), **f) for _ in range(nl + 1)]          # block inputs, x[nl] = blocks' output
+        self.stab = m.fno_blocks.stabilizer == "tanh"
+        if self.stab:
+            self.xs = [torch.empty((B, Ch, P), **f) for _ in range(nl)]        # tanh(x_l): the spectral branch's input
         self.s = torch.empty((B, Ch, P), **f)                                    # skip branch of the current block
         self.t = [torch.empty((B, Ch, P), **f) for _ in range(nl)]              # pre-activations
         Wf = W // 2 + 1
@@ -148,12 +144,15 @@ class FnoNative:
             xl = self.x[l]
             conv = fb.convs[l]
             skip = fb.fno_skips[l]
-            if isinstance(skip, torch.nn.Conv2d):
+            if isinstance(skip, fno_arch.Conv1x1):
                 _pw_conv(B, Ch, Ch, P, xl, skip.weight, self.s)
                 sk = self.s
             else:
                 sk = xl
             xft, v = self.xft[l], self.v[l]
+            if self.stab:  # fno_block.py:1199: x = tanh(x) in front of the spectral convolution (the skip sees x)
+                L.check(L.lib().ppsci_tanh_fwd(B * Ch * P, _p(xl), _p(self.xs[l]), st))
+                xl = self.xs[l]
             L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
             L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
                                                              _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
@@ -216,7 +215,7 @@ class FnoNative:
                 _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
                 _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
             # skip branch: s = Wskip x_l  (identity: the gradient passes straight through)
-            if isinstance(skip, torch.nn.Conv2d):
+            if isinstance(skip, fno_arch.Conv1x1):
                 self._wgrad(B, Ch, Ch, P, self.x[l], self.gt, skip.weight, None)
                 _pw_conv(B, Ch, Ch, P, self.gt, skip.weight, gnext, transpose=True)
             else:
@@ -227,7 +226,10 @@ class FnoNative:
                 C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat), _p(self.gx_ft),
                 _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, 1, st))
             L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
-            hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
+            if self.stab:  # gnext += gsp * (1 - tanh(x_l)^2)
+                L.check(L.lib().ppsci_tanh_bwd(B * Ch * P, _p(self.xs[l]), _p(self.gsp), _p(gnext), 1, st))
+            else:
+                hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
             gx, gnext = gnext, gx
         # lifting (on the unpadded planes: the gradient of pad is unpad)
         if self.padded:

@@ -43,6 +43,20 @@ class MSELoss(Loss):
         return losses
 
 
+def _mse_value_and_grad(self, y_net, label, key):
+    """Operator-learning path (operator_engine.OperatorConstraint): the loss on a [B, C, H, W] network output and its adjoint
+    from the field-loss kernels (loss/field.py, mode "sq"): weight * sum or mean of (y - label)^2."""
+    from . import field
+
+    plan = self.__dict__.setdefault("_field_plan", field.FieldLossPlan(0, field.SQ))
+    coef = self.key_weight(key) / (y_net.numel() if self.reduction == "mean" else 1.0)
+    loss, g = plan.value_and_grad(y_net, label, coef)
+    return {key: loss.reshape(())}, g
+
+
+MSELoss.value_and_grad = _mse_value_and_grad
+
+
 class CausalMSELoss(MSELoss):
     """mse.py:109-189: the batch is `n_chunks` consecutive time windows; window i is weighted with
     exp(-tol * sum of the mean losses of the windows before it) (a constant w.r.t. the parameters).
@@ -56,6 +70,8 @@ class CausalMSELoss(MSELoss):
         self.n_chunks, self.tol = n_chunks, tol
         self.causal = {"n_chunks": n_chunks, "tol": tol}
         self.acc_mat = torch.tril(torch.ones(n_chunks, n_chunks), -1)
+
+    value_and_grad = None  # (fields are not time-windowed batches)
 
     def forward(self, output_dict, label_dict, weight_dict=None) -> Dict[str, torch.Tensor]:
         losses = {}

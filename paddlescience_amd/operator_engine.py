@@ -1,7 +1,8 @@
-"""Training engine of the operator-learning path (FNO): forward + loss + backward through torch autograd
-around the HIP spectral-convolution kernel, gradients accumulated into the model's flat buffer, one SUM
-all-reduce of that buffer per step and the fused Adam kernel on it -- the same contract
-(`forward_backward`, `allreduce`, `grad`, `dp_reduce`) as `engine.Engine` for the PINN path.
+"""Training engine of the operator-learning path (FNO): network forward + hand-written backward on this framework's
+kernels (fno_engine.FnoNative), the loss and its adjoint w.r.t. the network output from the loss object's own kernels
+(loss.field: LpLoss / H1Loss / MSELoss on fields) -- gradients land in the model's flat buffer, one SUM all-reduce of that
+buffer per step and the fused Adam kernel on it: the same contract (`forward_backward`, `allreduce`, `grad`,
+`dp_reduce`) as `engine.Engine` for the PINN path.
 
 Mirrors ExpressionSolver.train_forward + train_epoch_func for a supervised constraint
 (/root/reference/ppsci/utils/expression.py:60-131, ppsci/solver/train.py:58-213)."""
@@ -62,31 +63,48 @@ class OperatorConstraint:
         data = {**self.inp, **out}
         return {k: f(data) for k, f in self.output_expr.items()}
 
-    def forward_loss(self) -> torch.Tensor:
-        vals = self.outputs()
+    def forward_backward_native(self, native) -> None:
+        """Network forward + backward on the hand-written kernels (fno_engine.FnoNative).  dL/dy comes from the loss
+        object itself when it has kernels for fields (`value_and_grad`: LpLoss / H1Loss / MSELoss on the raw network
+        output); any other loss / output expression -- arbitrary Python on the network OUTPUT -- is differentiated by
+        torch w.r.t. that one tensor (nothing of the network is on an autograd tape)."""
+        m = self.model
+        if m._input_transform is not None or m._output_transform is not None:
+            raise NotImplementedError("training an FNONet with registered input / output transforms")
+        xs = [self.inp[k] for k in m.input_keys]
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+        key = m.output_keys[0]
+        y = native.forward(x)
+        raw = (not self.output_expr or (list(self.output_expr) == [key] and getattr(self.output_expr[key], "is_identity", False))
+               or self._expr_is_identity(key, y))
+        if raw and hasattr(self.loss_fn, "value_and_grad") and list(self.lab) == [key] and not self.w:
+            losses, gy = self.loss_fn.value_and_grad(y, self.lab[key], key)
+            self._last = {k: v.detach() for k, v in losses.items()}
+            native.backward(gy)
+            return
+        y = y.detach().requires_grad_(True)
+        data = {**self.inp, key: y}
+        vals = {k: f(data) for k, f in self.output_expr.items()}
         losses = self.loss_fn(vals, self.lab, self.w)
         self._last = {k: v.detach() for k, v in losses.items()}
         total = None
         for v in losses.values():  # mtl.Sum: left fold in insertion order
             total = v if total is None else total + v
-        return total
-
-    def forward_backward_native(self, native) -> None:
-        """Network forward + backward on the hand-written kernels (fno_engine.FnoNative); only the user's loss
-        expression -- arbitrary Python on the network OUTPUT -- is differentiated by torch, which yields dL/dy."""
-        m = self.model
-        xs = [self.inp[k] for k in m.input_keys]
-        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
-        y = native.forward(x).detach().requires_grad_(True)
-        data = {**self.inp, m.output_keys[0]: y}
-        vals = {k: f(data) for k, f in self.output_expr.items()}
-        losses = self.loss_fn(vals, self.lab, self.w)
-        self._last = {k: v.detach() for k, v in losses.items()}
-        total = None
-        for v in losses.values():
-            total = v if total is None else total + v
         (gy,) = torch.autograd.grad(total, y)
         native.backward(gy)
+
+    def _expr_is_identity(self, key: str, y: torch.Tensor) -> bool:
+        """Is output_expr == {key: lambda out: out[key]} (the reference examples' form)?  Probed once with a marker."""
+        hit = getattr(self, "_identity", None)
+        if hit is None:
+            hit = False
+            if list(self.output_expr) == [key]:
+                try:
+                    hit = self.output_expr[key]({**self.inp, key: y}) is y
+                except Exception:  # noqa: BLE001 -- an expression that needs more than the output is not the identity
+                    hit = False
+            self._identity = hit
+        return hit
 
     def losses(self) -> Dict[str, float]:
         return {k: float(v) for k, v in self._last.items()}
@@ -102,26 +120,20 @@ class OperatorEngine:
         from .engine import StepGraph
 
         self._step_graph = StepGraph(self.grad.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0")
-        # FNO / TFNO in the supported configuration: forward and backward on this framework's own kernels, no autograd
-        # graph (fno_engine.py); PPSCI_FNO_NATIVE=0 keeps the torch-autograd path around the spectral kernel
-        self.native = None
-        if os.environ.get("PPSCI_FNO_NATIVE", "1") != "0":
-            from . import fno_engine
+        # forward and backward on this framework's own kernels, no autograd graph of the network (fno_engine.py)
+        from . import fno_engine
 
-            why = fno_engine.supports(model)
-            if why is None:
-                self.native = fno_engine.FnoNative(model)
-            else:
-                from .utils import logger
-
-                logger.message(f"FNO: native forward/backward not used ({why}); training through torch autograd")
+        why = fno_engine.supports(model)
+        if why is not None:
+            raise NotImplementedError(f"operator engine: {why}")
+        self.native = model.native()
 
     def _forward_backward_eager(self, constraints: List[OperatorConstraint]):
-        if self.native is not None and len(constraints) == 1:
-            return constraints[0].forward_backward_native(self.native)
-        self.grad.zero_()
-        for c in constraints:
-            c.forward_loss().backward()
+        if len(constraints) != 1:
+            # (the hand-written backward WRITES the parameter gradients; several constraints on one operator model would
+            # need an accumulating variant -- the reference's FNO examples train one supervised constraint)
+            raise NotImplementedError("the operator engine trains one constraint per model")
+        constraints[0].forward_backward_native(self.native)
 
     def forward_backward(self, constraints: List[OperatorConstraint]):
         # An FNO step is ~200 kernels of ~10 us (FFTs, the spectral contraction, 1x1 convolutions, norms, their

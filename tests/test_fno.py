@@ -1,15 +1,47 @@
-"""FNO spectral convolution (BASELINE config 4): the HIP per-mode complex contraction (+ its gradients)
-against a plain-torch restatement of FactorizedSpectralConv.forward
+"""FNO spectral convolution (BASELINE config 4): rfftn -> per-mode complex contraction -> irfftn (+ bias) through the
+C ABI (ppsci_fft2d_r2c / ppsci_spectral_conv2d_fwd_scaled / ppsci_fft2d_c2r) and its hand-written adjoint
+(ppsci_spectral_conv2d_bwd_real_scaled) against a plain-torch restatement of FactorizedSpectralConv.forward
 (/root/reference/ppsci/arch/fno_block.py:707-796, _contract_dense_trick :346-372) in fp64."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ref_torch as R
+from paddlescience_amd import _lib as L
 from paddlescience_amd.arch import fno
+from paddlescience_amd.hotpath import _p, _stream_ptr
 from tests.common import make_dev_fixture, rel
 
 dev = make_dev_fixture()
+
+
+def _layer(layer, x, g):
+    """y = irfftn(contract(rfftn(x))) + bias and the adjoints (gx, gw_re, gw_im) of <y, g>, as fno_engine.FnoNative runs them."""
+    B, ci, H, W = x.shape
+    co, Wf = layer.out_channels, W // 2 + 1
+    lib = L.lib()
+    st = _stream_ptr(x)
+    f = dict(dtype=torch.float32, device=x.device)
+    d = L.SpectralDesc()
+    d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, ci, co, H, Wf, *layer.n_modes
+    xft, oft = torch.empty((B, ci, H, Wf, 2), **f), torch.empty((B, co, H, Wf, 2), **f)
+    y = torch.empty((B, co, H, W), **f)
+    inv_n = 1.0 / (H * W)
+    L.check(lib.ppsci_fft2d_r2c(B * ci, H, W, _p(x), _p(xft), st))
+    L.check(lib.ppsci_spectral_conv2d_fwd_scaled(C.byref(d), _p(xft), _p(layer.weight_real), _p(layer.weight_imag), _p(oft),
+                                                 inv_n, 1, st))
+    L.check(lib.ppsci_fft2d_c2r(B * co, H, W, _p(oft), _p(y), st))
+    y = y + layer.bias.detach().view(1, -1, 1, 1)
+    ghat, gxft = torch.empty((B, co, H, Wf, 2), **f), torch.empty((B, ci, H, Wf, 2), **f)
+    gx = torch.empty_like(x)
+    gwr, gwi = torch.empty_like(layer.weight_real), torch.empty_like(layer.weight_imag)
+    L.check(lib.ppsci_fft2d_r2c(B * co, H, W, _p(g.contiguous()), _p(ghat), st))
+    L.check(lib.ppsci_spectral_conv2d_bwd_real_scaled(C.byref(d), _p(xft), _p(layer.weight_real), _p(layer.weight_imag), _p(ghat),
+                                                      _p(gxft), _p(gwr), _p(gwi), inv_n, W, inv_n, 1, st))
+    L.check(lib.ppsci_fft2d_c2r(B * ci, H, W, _p(gxft), _p(gx), st))
+    return y, gx, gwr, gwi
 
 
 @pytest.mark.parametrize("B,ci,co,H,W,modes", [(3, 5, 7, 16, 16, (8, 8)), (16, 32, 32, 64, 64, (12, 12)), (2, 4, 4, 8, 12, (8, 6))])
@@ -21,10 +53,9 @@ def test_spectral_conv_forward_and_gradients(B, ci, co, H, W, modes, dev):
     d = get_device()
     torch.manual_seed(0)
     layer = fno.SpectralConv2d(ci, co, modes, bias=True, fft_norm="forward").to(d)
-    x = torch.randn(B, ci, H, W, device=d, requires_grad=True)
-    y = layer(x)
-    g = torch.randn_like(y)
-    gx, gwr, gwi = torch.autograd.grad(y, [x, layer.weight_real, layer.weight_imag], g)
+    x = torch.randn(B, ci, H, W, device=d)
+    g = torch.randn(B, co, H, W, device=d)
+    y, gx, gwr, gwi = _layer(layer, x, g)
     # fp64 reference
     x64 = x.detach().double().cpu().requires_grad_(True)
     wr = layer.weight_real.detach().double().cpu().requires_grad_(True)
@@ -38,8 +69,10 @@ def test_spectral_conv_forward_and_gradients(B, ci, co, H, W, modes, dev):
 
 
 def test_odd_sizes_are_rejected(dev):
+    """A width that the half-spectrum layout does not cover is refused by the C ABI, not executed."""
     from paddlescience_amd.device import get_device
 
     layer = fno.SpectralConv2d(2, 2, (4, 4)).to(get_device())
+    x = torch.randn(1, 2, 9, 8, device=get_device())
     with pytest.raises(RuntimeError):
-        layer(torch.randn(1, 2, 9, 8, device=get_device()))
+        _layer(layer, x, torch.randn(1, 2, 9, 8, device=get_device()))

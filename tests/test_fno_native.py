@@ -60,33 +60,37 @@ def test_native_path_reproduces_reference_fno(c, dev):
         assert rel(p.grad.cpu().numpy(), Gr[n]) < 2e-4, n
 
 
-def test_native_path_matches_autograd_path_and_is_reproducible(dev):
-    """Darcy-like shape (16x16, batch 4, 16 hidden channels, 2 blocks): same output and gradients as the torch-autograd
-    path; a second run gives bit-identical gradients (fixed-order reductions)."""
+@pytest.mark.parametrize("stabilizer", [None, "tanh"])
+def test_native_path_matches_oracle_and_is_reproducible(dev, stabilizer):
+    """Darcy-like shape (16x16, batch 4, 16 hidden channels, 2 blocks), with and without the tanh stabilizer
+    (fno_block.py:1199): output and gradients against the fp64 restatement (oracle/ref_torch.fno_forward), loss value and
+    adjoint from the field-loss kernels; a second run gives bit-identical gradients (fixed-order reductions)."""
     import ppsci
-    from paddlescience_amd.fno_engine import FnoNative
+    from oracle import ref_torch as R
 
     torch.manual_seed(3)
-    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 8, 8, 16, 3, 1, 24, 20, 2, norm="group_norm")
+    model = ppsci.arch.FNONet(("x",), ("y",), (8, 8), 16, 3, 1, 24, 20, 2, norm="group_norm", stabilizer=stabilizer)
     d = model.flat_params.device
     rng = np.random.default_rng(0)
     x = torch.as_tensor(rng.standard_normal((4, 3, 16, 16)).astype(np.float32)).to(d)
     tgt = torch.as_tensor(rng.standard_normal((4, 1, 16, 16)).astype(np.float32)).to(d)
-    model.flat_grad.zero_()
-    ya = model.forward_tensor(x)
-    ((ya - tgt) ** 2).mean().backward()
-    ga = model.flat_grad.clone()
-    eng = FnoNative(model)
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.fno_forward(x.cpu().double(), P, 2, (8, 8), "group_norm", stabilizer=stabilizer)
+    lo = ((yo - tgt.cpu().double()) ** 2).mean()
+    names = [n for n, _ in torch.nn.Module.named_parameters(model)]
+    go = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(lo, [P[n] for n in names])])
+    eng = model.native()
+    mse = ppsci.loss.MSELoss("mean")
     runs = []
     for _ in range(2):
         y = eng.forward(x)
-        yl = y.detach().clone().requires_grad_(True)
-        (gy,) = torch.autograd.grad(((yl - tgt) ** 2).mean(), yl)
+        losses, gy = mse.value_and_grad(y, tgt, "y")
         model.flat_grad.fill_(float("nan"))
         eng.backward(gy)
         runs.append(model.flat_grad.clone())
-    assert rel(y.cpu().numpy(), ya.detach().cpu().numpy()) < 1e-5
-    assert rel(runs[0].cpu().numpy(), ga.cpu().numpy()) < 1e-4
+    assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    assert rel(runs[0].cpu().numpy(), go) < 2e-4
     assert torch.equal(runs[0], runs[1])
 
 

@@ -31,11 +31,16 @@ def test_tfno2d_forward_and_gradients_match_oracle(norm, dev):
     rng = np.random.default_rng(42)
     x = rng.standard_normal((3, 3, 8, 8)).astype(np.float32)
     tgt = rng.standard_normal((3, 1, 8, 8)).astype(np.float32)
-    out = model({"x": x})["y"]
+    out = model({"x": x})["y"]  # FNONet.forward runs the kernels' executor (the only implementation of the network)
     assert out.shape == (3, 1, 8, 8)
-    loss = ((out - torch.as_tensor(tgt).to(d)) ** 2).mean()
-    model.flat_grad.zero_()
-    loss.backward()
+    import ppsci
+
+    nat = model.native()
+    y = nat.forward(torch.as_tensor(x).to(d))
+    assert torch.equal(y, out)
+    _, gy = ppsci.loss.MSELoss("mean").value_and_grad(y, torch.as_tensor(tgt).to(d), "y")
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
     P = _params64(model)
     ref = R.fno_forward(torch.as_tensor(x).double(), P, 2, (4, 4), norm)
     assert rel(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5

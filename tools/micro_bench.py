@@ -11,7 +11,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ppsci  # noqa: E402
-from paddlescience_amd.arch import fno  # noqa: E402
 
 
 def timeit(fn, reps=20, warm=5):
@@ -53,53 +52,6 @@ def spinn(nc=128):
                       "algorithmic_label_GBps": pts * 4 / t / 1e9}), flush=True)
 
 
-def spectral(B=16, C=32, H=64, W=64, modes=(12, 12)):
-    layer = fno.SpectralConv2d(C, C, modes, fft_norm="forward").cuda()
-    x = torch.randn(B, C, H, W, device="cuda")
-    x_ft = torch.fft.rfftn(x, norm="forward", dim=(-2, -1))
-    t_k = timeit(lambda: fno.spectral_contract(x_ft, layer.weight_real, layer.weight_imag))
-    t_l = timeit(lambda: layer(x))
-    eq = "abcd,becd->aecd"
-    xs = x_ft[:, :, 26:38, :7].contiguous()
-
-    def ref():
-        return (torch.einsum(eq, xs.real, layer.weight_real) - torch.einsum(eq, xs.imag, layer.weight_imag),
-                torch.einsum(eq, xs.imag, layer.weight_real) + torch.einsum(eq, xs.real, layer.weight_imag))
-
-    t_r = timeit(ref)
-    flops = 8.0 * B * C * C * modes[0] * (modes[1] // 2 + 1)
-    byts = 4.0 * (2 * C * C * 84 + 2 * 2 * B * C * 84)
-    print(json.dumps({"bench": "fno_spectral_contract", "ms_kernel_path": t_k * 1e3, "ms_layer_incl_fft": t_l * 1e3,
-                      "ms_torch_4_einsums": t_r * 1e3, "MFLOP": flops / 1e6, "operand_MB": byts / 1e6}), flush=True)
-
-
-def tfno(B=16, H=64, W=64):
-    """BASELINE config 4 / SURVEY 8(d): TFNO2dNet in 3, hidden 32, lifting 256, projection 64, 4 layers,
-    n_modes (12, 12), group_norm, fft_norm forward; one training step = forward + MSE + backward + fused Adam."""
-    torch.manual_seed(0)
-    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
-                                 lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm")
-    rng = np.random.default_rng(42)
-    x = torch.as_tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
-    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, H, W)).astype(np.float32)).cuda()
-    opt = ppsci.optimizer.Adam(1e-3)(model)
-
-    def fwd():
-        with torch.no_grad():
-            return model.forward_tensor(x)
-
-    def step():
-        model.flat_grad.zero_()
-        loss = ((model.forward_tensor(x) - y) ** 2).mean()
-        loss.backward()
-        opt.step(model.flat_grad)
-
-    t_f = timeit(fwd)
-    t_s = timeit(step)
-    print(json.dumps({"bench": "tfno2d_darcy_64x64", "batch": B, "params": int(model.flat_params.numel()),
-                      "ms_forward": t_f * 1e3, "ms_train_step": t_s * 1e3, "samples_per_s": B / t_s}), flush=True)
-
-
 def ns(n=125_000):
     """BASELINE config 3 per-GPU shard: LDC NavierStokes 2-D steady, MLP 2 -> 128 x 5 -> 3 tanh, 125 000
     collocation points (1 M / 8 GPUs), continuity + momentum_x + momentum_y, MSE-sum with weight 1e-4, Adam."""
@@ -131,5 +83,3 @@ def ns(n=125_000):
 if __name__ == "__main__":
     ns()
     spinn(int(sys.argv[1]) if len(sys.argv) > 1 else 128)
-    spectral()
-    tfno()
