@@ -116,3 +116,123 @@ def test_empty_batch(dev):
     rc = L.lib().ppsci_taylor_bwd(C.byref(desc), params.data_ptr(), 0, ptrs, params.data_ptr(), params.data_ptr(),
                                   params.data_ptr(), params.data_ptr(), None)
     assert rc != 0 and b"invalid" in L.lib().ppsci_last_error()
+
+
+def test_spinn_full_size_128(dev, tmp_path):
+    """BASELINE configs[4] at its full size -- 128^3 tensor-product grid, three ModifiedMLP 1 -> 64 x 4 -> 32 branches --
+    against the fp64 oracle (oracle/ref_torch.spinn_helmholtz, pinned by the reference-run fixture tests/golden/spinn.npz;
+    separable, so the whole grid takes seconds): u on every grid point, the loss, and the gradient of every parameter."""
+    if dev != "gpu":
+        pytest.skip("full BASELINE sizes run on the GPU only")
+    import ppsci
+    from oracle import ref_torch as R
+
+    nc = 128
+    np.random.seed(111)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), 32, 4, 64, "tanh")
+    eq = ppsci.equation.Helmholtz(3, 1.0)
+    eq.model = model
+    rng = np.random.default_rng(42)
+    xs = [rng.uniform(-1, 1, (nc, 1)).astype(np.float32) for _ in range(3)]
+    uc = rng.standard_normal((nc, nc, nc, 1)).astype(np.float32)
+    data = {"x": xs[0], "y": xs[1], "z": xs[2], "uc": uc}
+    lab = {"helmholtz": uc}
+    pde = ppsci.constraint.SupervisedConstraint(
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: data, "label": lambda d: lab}},
+        output_expr=eq.equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"PDE": pde}, str(tmp_path), opt, epochs=1, iters_per_epoch=1)
+    cc = solver._compiled["PDE"]
+    cc.bind(data, lab)
+    solver.engine.forward_backward([cc])
+    grad = solver.engine.grad.detach().cpu().numpy().astype(np.float64)
+    sd = {k: np.asarray(v.detach().cpu().numpy(), np.float64) for k, v in model.state_dict().items()}
+    nets, names = [], []
+    for b in range(3):
+        P = {k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"branch_nets.{b}.")}
+        nl = sum(1 for k in P if k.startswith("linears.") and k.endswith(".weight"))
+        nets.append(R.ModifiedMLP1(dict(wu=P["embed_u.0.weight"], bu=P["embed_u.0.bias"], wv=P["embed_v.0.weight"],
+                                        bv=P["embed_v.0.bias"], w=[P[f"linears.{l}.weight"] for l in range(nl)],
+                                        b=[P[f"linears.{l}.bias"] for l in range(nl)], wl=P["last_fc.weight"],
+                                        bl=P["last_fc.bias"]), "tanh"))
+    xt = [torch.tensor(a.astype(np.float64), requires_grad=True) for a in xs]
+    uo, ro = R.spinn_helmholtz(nets, xt, 1.0)
+    loss = ((ro - torch.tensor(uc[..., 0].astype(np.float64))) ** 2).mean()
+    pred = solver.predict({"x": xs[0], "y": xs[1], "z": xs[2]}, batch_size=None, return_numpy=True)["u"]
+    assert K._rel(pred[..., 0].astype(np.float64), uo.detach().numpy()) < 5e-6
+    assert abs(cc.loss() / float(loss.detach()) - 1.0) < 1e-5
+    # the flat gradient follows model.parameters() order; the oracle's branch parameters are listed in the same order
+    go = torch.autograd.grad(loss, [p for net in nets for p in net.parameters()])
+    flat_ref = np.concatenate([g.numpy().ravel() for g in go])
+    assert grad.shape == flat_ref.shape
+    assert K._rel(grad, flat_ref) < 1e-4, K._rel(grad, flat_ref)
+
+
+def test_fused_tile_step_full_size_100k(dev):
+    """BASELINE configs[1] through the fused tile kernel (csrc/taylor_fused.inc) at its full size: the gradient of the 100 000
+    point batch equals the separate launches' (which the test above holds to the oracle point by point), shard additivity,
+    and the loss equals the mean of the squared residuals it writes out."""
+    if dev != "gpu":
+        pytest.skip("full BASELINE sizes run on the GPU only")
+    from paddlescience_amd import hotpath as hp
+    from paddlescience_amd.engine import Engine
+    from tests.test_one_launch import _constraint, _weights
+
+    d = torch.device("cuda")
+    lay = hp.NetLayout(2, 4, 64, 1, "tanh")
+    flat = _weights(lay, 7)
+    N = 100_000
+    out = {}
+    for fused in (False, True):
+        eng = Engine(lay, torch.tensor(flat, device=d))
+        eng.one_launch = fused
+        c = _constraint(d, "allen_cahn", lay, N, 100)
+        eng.forward_backward([c])
+        torch.cuda.synchronize()
+        out[fused] = (eng.grad.cpu().numpy().astype(np.float64), c.loss_terms.cpu().numpy().copy(), c.resid.cpu().numpy().copy(), c)
+    assert out[True][3]._step_kind == hp.STEP_FUSED_TILE
+    assert K._rel(out[True][0], out[False][0]) < 3e-6
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=2e-5)
+    np.testing.assert_allclose(out[True][1][0], np.mean(out[True][2][0].astype(np.float64) ** 2), rtol=1e-5)
+    # additivity over two ragged shards of the same points (each normalised by ITS size: rescale to the whole batch)
+    c_all = out[True][3]
+    h = (N // 2 // 16) * 16 + 5
+    g = np.zeros_like(out[True][0])
+    for lo, hi in ((0, h), (h, N)):
+        eng = Engine(lay, torch.tensor(flat, device=d))
+        cs = _constraint(d, "allen_cahn", lay, hi - lo, 100)
+        for dst, src in zip(cs.inputs, c_all.inputs):
+            dst.copy_(src[lo:hi])
+        eng.forward_backward([cs])
+        g += eng.grad.cpu().numpy().astype(np.float64) * (hi - lo) / N
+    assert K._rel(g, out[True][0]) < 2e-5
+
+
+def test_tfno_full_size_batch16_64x64(dev):
+    """BASELINE configs[3] at its full size (batch 16, 64 x 64, hidden 32, lifting 256, projection 64, 4 blocks, GroupNorm)
+    against the fp64 oracle (oracle/ref_torch.fno_forward, pinned by tests/golden/fno.npz): output, loss, every gradient."""
+    if dev != "gpu":
+        pytest.skip("full BASELINE sizes run on the GPU only")
+    import ppsci
+    from oracle import ref_torch as R
+
+    torch.manual_seed(0)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
+                                 lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm")
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((16, 3, 64, 64)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((16, 1, 64, 64)).astype(np.float32)).cuda()
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.fno_forward(x.cpu().double(), P, 4, (12, 12), "group_norm")
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    yh = nat.forward(x)
+    losses, gy = ppsci.loss.MSELoss("mean").value_and_grad(yh, y, "y")
+    assert K._rel(yh.cpu().numpy(), yo.detach().numpy()) < 2e-6
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    for n, p in torch.nn.Module.named_parameters(model):
+        assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 2e-5, n
+

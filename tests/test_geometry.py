@@ -107,3 +107,34 @@ def test_quasi_random_samplers(method, ndim):
     assert pts["x"].shape == (50, 1) and (pts["x"] > 0).all() and (pts["x"] < 2).all()
     with pytest.raises(ValueError):
         sampler.sample(4, 2, "Foo")
+
+
+def test_halton_restatement_is_pinned_to_an_independent_implementation():
+    """Third-party pin (the reference's skopt is absent): our radical-inverse Halton points == scipy.stats.qmc.Halton
+    (unscrambled) at the indices the reference's call site asks for (sampler.py:71-73, 90-92: skip the all-zero point)."""
+    from scipy.stats import qmc
+
+    from paddlescience_amd.geometry import sampler
+
+    for ndim in (1, 2, 3, 5):
+        ref = qmc.Halton(d=ndim, scramble=False).random(257 + 1)[1:]
+        np.testing.assert_allclose(sampler._halton(257, ndim, 1), ref, rtol=0, atol=1e-15)
+        got = sampler.quasirandom(257, ndim, "Halton")
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
+    np.testing.assert_allclose(sampler.radical_inverse(np.arange(1, 9), 2), [0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875, 0.0625])
+    ham = sampler.quasirandom(9, 3, "Hammersley")  # (i / N, phi_2(i), phi_3(i)), i = 1 .. 9, N = 10
+    np.testing.assert_allclose(ham[:, 0], np.arange(1, 10) / 10.0, rtol=1e-6)
+    np.testing.assert_array_equal(ham[:, 1:], sampler._halton(9, 2, 1).astype(np.float32))
+
+
+def test_sobol_points_are_the_published_sequence():
+    """The first points of the unscrambled 2-D Sobol' sequence with the Joe-Kuo direction numbers (scipy.stats.qmc.Sobol's
+    documented example): the reference drops the first one (sampler.py:84-88)."""
+    from paddlescience_amd.geometry import sampler
+
+    known = np.array([[0.5, 0.5], [0.75, 0.25], [0.25, 0.75], [0.375, 0.375], [0.875, 0.875], [0.625, 0.125], [0.125, 0.625]])
+    np.testing.assert_array_equal(sampler.quasirandom(7, 2, "Sobol"), known.astype(np.float32))
+    p3 = sampler.quasirandom(6, 3, "Sobol")  # three dimensions: [0, 0, 0] AND [0.5, 0.5, 0.5] dropped
+    assert not np.any(np.all(p3 == 0.5, axis=1)) and not np.any(np.all(p3 == 0.0, axis=1))
+    np.testing.assert_array_equal(p3[0, :2], [0.75, 0.25])
+
