@@ -510,9 +510,12 @@ __device__ __forceinline__ void epi_tile_fast(const EpiArgs& a, const EpiFastReg
 // load an LDS round trip per step (the other workgroup of the CU streams GEMM operands through the same LDS) was most
 // of the ~350 cycles a step of epi_tile_fast takes.  Lanes 16..63 compute the same values as lanes 0..15 (pt = lane & 15:
 // same addresses) and only the stores are predicated.  fx->uls: [mS][16] the tile's stream values (bias included).
+// GLOBAL (the one-launch step kernel of padded width 32, EPI_RF_TILED: every wave runs the program of ITS tile): streams,
+// inputs and dL/dU are the [row][N] arrays in memory; `lacc` has stride `lstride`.
+template <bool GLOBAL>
 __device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFastRegs& R, const bool act, const long long p,
                                                    const long long pp, const bool valid, const int pt, float* const lacc,
-                                                   const EpiFused* fx, const float* const uls) {
+                                                   const int lstride, const EpiFused* fx, const float* const uls) {
   EPI_FT(0)
   float rv[EPI_FAST_NREG], ra[EPI_FAST_NREG];
 #pragma unroll
@@ -529,7 +532,7 @@ __device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFa
   EPI_PF(0, lab0, w0)
   EPI_PF(1, lab1, w1)
 #undef EPI_PF
-  if (act)
+  if (!GLOBAL && act)
     for (int q = pt; q < fx->mS * PPSCI_TILE; q += PPSCI_TILE) fx->tin[q] = 0.f;
   EPI_FT(1)
   // ---- memory operands and constants, four at a time (one LDS round trip per four)
@@ -544,6 +547,7 @@ __device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFa
       const int ia = (w[j] >> 7) & 127u, kind = (w[j] >> 14) & 3u;
       if (kind == 3) v[j] = cv;
       else if (kind == 2) v[j] = a.aux[ia][pp];
+      else if (GLOBAL) v[j] = kind == 1 ? a.U[(long long)ia * a.N + pp] : a.x[ia][pp];
       else v[j] = (kind == 1 ? uls : fx->tinx)[ia * PPSCI_TILE + pt];
     }
     // (unconditional writes: a conditional write to a uniformly indexed register array is compiled as a copy of the whole
@@ -575,10 +579,12 @@ __device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFa
       if (ar >= 0) wk *= a.aux[ar][pp];
     }
     const float rval = rv[iv];
-    if (act && fx->rres != nullptr) fx->rres[k * PPSCI_TILE + pt] = rval;
+    if (GLOBAL) {
+      if (act && valid && a.resid != nullptr) a.resid[(long long)k * a.N + p] = rval;
+    } else if (act && fx->rres != nullptr) fx->rres[k * PPSCI_TILE + pt] = rval;
     const float diff = rval - lab;
     const float wgt = wk * scale;
-    if (act && valid) lacc[k * PPSCI_TILE] += wgt * diff * diff;
+    if (act && valid) lacc[k * lstride] += wgt * diff * diff;
     ra[iv] += valid ? 2.f * wgt * diff : 0.f;
   }
   EPI_FT(4)
@@ -599,7 +605,9 @@ __device__ __forceinline__ void epi_tile_fast_regs(const EpiArgs& a, const EpiFa
     const unsigned w = ppsci_readlane(R.loads, k);
     const int i = w & 127u, ia = (w >> 7) & 127u, kind = (w >> 14) & 3u;
     const float g = ra[i];
-    if (act && kind == 1) fx->tin[ia * PPSCI_TILE + pt] = g;  // (invalid lanes carry 0: their seeds are never set)
+    if (GLOBAL) {
+      if (act && valid && kind == 1 && a.Ubar != nullptr) a.Ubar[(long long)ia * a.N + p] = g;
+    } else if (act && kind == 1) fx->tin[ia * PPSCI_TILE + pt] = g;  // (invalid lanes carry 0: their seeds are never set)
   }
   EPI_FT(6)
 }
@@ -695,6 +703,30 @@ __device__ __forceinline__ void epilogue_body(const EpiArgs& a, float* red) {
 #pragma unroll
   for (int k = 0; k < PPSCI_MAX_EPARAM; ++k) padj[k] = 0.f;
 
+  if (MODE == EPI_RF_TILED && a.fast != nullptr && n <= EPI_FAST_NREG) {
+    // pre-decoded program on a register file in VGPRs (epi_tile_fast_regs): no interpreter, no LDS round trip per step.
+    // All 64 lanes of a wave go through the steps (the table look-ups are wave-wide); lanes 0..15 own the tile's points.
+    const int lane = tid & 63;
+    EpiFastRegs R;
+    R.steps = a.fast[lane];
+    R.loads = a.fast[64 + lane];
+    R.terms = a.fast[128 + lane];
+    R.cvals = __builtin_bit_cast(float, a.fast[192 + lane]);
+    R.scale = a.e.res[lane & (PPSCI_MAX_RES - 1)].scale;
+    float* const lacc = red + EPI_BLOCK + slot;  // [PPSCI_MAX_RES][RS]: the (unused) LDS register file
+    if (lane < PPSCI_TILE)
+      for (int k = 0; k < PPSCI_MAX_RES; ++k) lacc[k * RS] = 0.f;
+    for (int it = 0; it < a.iters; ++it) {
+      const int tile = ppsci_tile_index(it, (int)(blockDim.x >> 6));
+      const long long p = (long long)tile * PPSCI_TILE + (lane & 15);
+      const bool valid = tile < a.ntiles && p < a.N;
+      epi_tile_fast_regs<true>(a, R, lane < PPSCI_TILE, p, valid ? p : 0, valid, lane & 15, lacc, RS, nullptr, nullptr);
+    }
+#pragma unroll
+    for (int k = 0; k < PPSCI_MAX_RES; ++k) lsum[k] = lane < PPSCI_TILE ? lacc[k * RS] : 0.f;
+    epi_finale<MODE>(a, red, lsum, padj);
+    return;
+  }
   for (int it = 0; it < a.iters; ++it) {
     if (MODE == EPI_RF_TILED && (tid & 63) >= PPSCI_TILE) break;  // lanes 0..15 of every wave run the tile's points
     long long p;

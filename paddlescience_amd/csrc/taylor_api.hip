@@ -341,6 +341,9 @@ static StepLayout step_layout(const StepArgs& a, int grid, int n_res) {
     y.red_row = y.red_small + pad4(PPSCI_WRED_CHUNKS * (long long)y.psmall);
     y.fastprog = y.red_row + pad4(a.f.q.P);  // pre-decoded residual program (epi_fast_encode)
     y.total = y.fastprog + EPI_FAST_WORDS;
+  } else {
+    y.fastprog = y.total;
+    y.total += EPI_FAST_WORDS;
   }
   return y;
 }
@@ -455,6 +458,8 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
     a.f.xfrag = ws + y.frag;
     a.b.xfrag = (const u32x4*)(ws + y.frag) + (long long)(d->n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB);
     a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 1 : 0);
+  }
+  {
     unsigned fast[EPI_FAST_WORDS];
     int nfast_loads = 0;
     const int nfast = g_fast_vm ? epi_fast_encode(a.e.e, fast, &nfast_loads) : -1;

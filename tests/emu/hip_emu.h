@@ -38,7 +38,7 @@ struct emu_dim3 {
 namespace emu {
 
 constexpr int kWave = 64;
-constexpr size_t kStack = 256 * 1024;
+constexpr size_t kStack = 1024 * 1024;  // (the one-launch kernels inline forward + program + reverse: ~300 KB of -O0 frame)
 
 struct Barrier {
   int n = 0, count = 0, gen = 0;
