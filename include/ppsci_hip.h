@@ -160,6 +160,14 @@ void ppsci_set_wide_min_nb(int nb);
 void ppsci_set_bwd_accum(int on);
 /* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
 int ppsci_is_device_build(void);
+/* Frees the pre-split weight-fragment buffers the library keeps per parameter buffer for the feature-split kernels
+ * of padded width > 32 (allocated on first use by ppsci_taylor_fwd / ppsci_taylor_bwd).  Call it before freeing
+ * `params`; waits for the device. */
+void ppsci_release_fragments(const float* params);
+/* PPSCI_OK when the current HIP device is a gfx950 (the kernels' cross-workgroup reductions rely on its store / vmcnt
+ * behaviour, and the code object holds no other ISA); PPSCI_E_UNSUPPORTED with the device's name otherwise.  The Python
+ * host side calls it once when it loads the library on a machine with a GPU. */
+int ppsci_check_device(void);
 
 /* Number of fp32 parameters of the MLP (W and b of every linear). */
 int64_t ppsci_param_count(const ppsci_mlp_desc* d);
@@ -372,8 +380,8 @@ int ppsci_fft2d_c2r(int batch, int H, int W, float* in, float* out, void* stream
 
 /* ---- the rest of an FNO block / channel MLP, forward and hand-written backward (csrc/fno.hip) ---------------------
  * 1x1 convolutions (fno_block.MLP fno_block.py:263-320, linear skip :190-226) as MFMA GEMMs over [B, C, P] (NCHW,
- * P = H*W, a multiple of 4), and the block tail of forward_with_postactivation (fno_block.py:1191-1220):
- * GroupNorm(1 group) + spectral bias + skip + GELU.
+ * P = H*W; 16-byte accesses when P is a multiple of 4, element accesses otherwise), and the block tail of
+ * forward_with_postactivation (fno_block.py:1191-1220): GroupNorm(1 group) + spectral bias + skip + GELU.
  *
  * ppsci_pw_conv: out[b,o,p] = sum_i Weff[o,i] x[b,i,p] (+ bias[o]) (* GELU'(zmul[b,o,p])) (+ out if accumulate);
  *   act (optional) = GELU(out).  W is the torch / paddle Conv2D weight [Co, Ci] (row-major); transpose != 0 uses it
@@ -381,7 +389,8 @@ int ppsci_fft2d_c2r(int batch, int H, int W, float* in, float* out, void* stream
 int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* W, int transpose, const float* bias,
                   const float* zmul, int accumulate, float* out, float* act, void* stream);
 /* gW[o,i] = sum_{b,p} gy[b,o,p] x[b,i,p], gb[o] = sum_{b,p} gy[b,o,p] as per-chunk partial rows: partials
- * [ppsci_pw_conv_wgrad_chunks(B, P)][Co*Ci] and partials_b [chunks][Co] (or NULL); P a multiple of 16.  Sum each with
+ * [ppsci_pw_conv_wgrad_chunks(B, P)][Co*Ci] and partials_b [chunks][Co] (or NULL); any P >= 1 (16-byte accesses when P is a
+ * multiple of 4).  Sum each with
  * ppsci_reduce_rows (fixed order). */
 int64_t ppsci_pw_conv_wgrad_chunks(int B, int P);
 int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials, float* partials_b,

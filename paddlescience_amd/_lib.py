@@ -89,6 +89,8 @@ _injected = False
 _SYMBOLS = {
     "ppsci_last_error": (C.c_char_p, []),
     "ppsci_is_device_build": (C.c_int, []),
+    "ppsci_check_device": (C.c_int, []),
+    "ppsci_release_fragments": (None, [C.c_void_p]),
     "ppsci_set_max_grid": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),
     "ppsci_set_bwd_accum": (None, [C.c_int]),
@@ -221,6 +223,10 @@ def lib() -> C.CDLL:
         l = _bind(DEFAULT_LIB)
         if l.ppsci_is_device_build() != 1:
             raise RuntimeError(f"{DEFAULT_LIB} is not a gfx950 device build")
+        import torch
+
+        if torch.cuda.is_available() and l.ppsci_check_device() != 0:
+            raise RuntimeError(l.ppsci_last_error().decode())
         _lib = l
     return _lib
 

@@ -6,6 +6,7 @@ This is the counterpart of `Solver.__init__`'s `convert_expr` (/root/reference/p
 what the reference re-executes op by op every iteration is decided here once."""
 from __future__ import annotations
 
+import zlib
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -200,7 +201,16 @@ class CompiledConstraint:
 
         # same label / weight / area objects as the last bind (a static batch re-bound, or a loader that yields the same
         # arrays): the columns and the constant are unchanged -- no device-to-host copies on the step path
-        key = tuple(id(label.get(k)) for k in self._row_slices) + tuple(id(weight.get(k)) for k in self._row_slices) + (id(input.get("area")),)
+        # The key is identity AND content: a loader may refill the same buffers in place (tensors: the autograd version
+        # counter, bumped by every in-place write; host arrays: a CRC of the bytes -- no device traffic either way)
+        def stamp(a):
+            if isinstance(a, torch.Tensor):
+                return ("t", id(a), a._version)
+            if isinstance(a, np.ndarray):
+                return ("n", id(a), zlib.crc32(memoryview(np.ascontiguousarray(a)).cast("B")))
+            return ("v", id(a), repr(a))
+
+        key = tuple(stamp(label.get(k)) for k in self._row_slices) + tuple(stamp(weight.get(k)) for k in self._row_slices) + (stamp(input.get("area")),)
         sources = ([label.get(k) for k in self._row_slices], [weight.get(k) for k in self._row_slices], input.get("area"))
         cached = getattr(self, "_row_slice_cache", None)
         if cached is not None and cached[0] == key:

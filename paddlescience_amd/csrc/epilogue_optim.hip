@@ -188,6 +188,28 @@ extern "C" int ppsci_is_device_build(void) {
 #endif
 }
 
+// The cross-workgroup "last one out" reductions (taylor_step_tail.h, epilogue_vm.h, taylor_fused.inc) publish their rows
+// with agent-scope stores + s_waitcnt vmcnt(0) + a relaxed ticket: that is gfx950 behaviour (write-through stores
+// counted by vmcnt, no threadgroup-split mode), not the HIP memory model.  The code object only holds gfx950 ISA, so
+// another device could not run it anyway; this check turns that into a readable error before the first launch.
+extern "C" int ppsci_check_device(void) {
+#ifdef PPSCI_EMU
+  return PPSCI_OK;
+#else
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    ppsci_set_error("no HIP device");
+    return PPSCI_E_LAUNCH;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    ppsci_set_error("device %d is %s: this library is written for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  return PPSCI_OK;
+#endif
+}
+
 extern "C" int64_t ppsci_param_count(const ppsci_mlp_desc* d) {
   ppsci_derived q;
   if (!d || ppsci_derive(d, &q) != PPSCI_OK) return -1;

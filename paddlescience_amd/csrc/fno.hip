@@ -37,6 +37,30 @@ __device__ __forceinline__ float fno_gelu_grad(float t) {
   return 0.5f * (1.f + erff(t * 0.7071067811865476f)) + t * 0.3989422804014327f * expf(-0.5f * t * t);
 }
 
+// Four neighbouring pixels p .. p + 3 of one [.., P] row, zero beyond `lim`.  al (P a multiple of 4, 16-byte aligned
+// buffers: every FNO resolution that is not an odd DomainPadding size): one 16-byte access, all four or none; otherwise
+// element by element (rows of such planes do not start on 16-byte boundaries).
+__device__ __forceinline__ f32x4 fno_ld4(const float* row, long long p, long long lim, bool al) {
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (al) {
+    if (p + 3 < lim) v = *(const f32x4*)&row[p];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (p + t < lim) v[t] = row[p + t];
+  }
+  return v;
+}
+__device__ __forceinline__ void fno_st4(float* row, long long p, long long lim, bool al, f32x4 v) {
+  if (al) {
+    if (p + 3 < lim) *(f32x4*)&row[p] = v;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (p + t < lim) row[p + t] = v[t];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ 1x1 convolution
 struct PwArgs {
   const float* x;      // [B, Cin, P]
@@ -181,7 +205,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
     const int ob0 = (int)(item - ch * ngrp) * PW_OC;
     const int b = (int)(ch / chunks_per_b);
     const int p0 = (int)(ch - (long long)b * chunks_per_b) * 64 + 4 * c;  // this lane's 4 pixels
-    const bool pok = p0 + 3 < a.P;  // P is a multiple of 4 (checked on the host): all four or none
+    const bool al = (a.P & 3) == 0;  // 16-byte accesses (all four pixels or none); see fno_ld4
     const float* xb = a.x + (long long)b * a.Cin * a.P;
     {
       f32x4 acc[PW_OC][4];
@@ -199,7 +223,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 8 * g + j;
-          xn[j] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          xn[j] = k < a.Cin ? fno_ld4(xb + (long long)k * a.P, p0, a.P, al) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         for (int q2 = 0; q2 < kq2; ++q2) {
           u32x4 bp[4][3];  // [tile][plane]
@@ -214,7 +238,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int k = 32 * (q2 + 1) + 8 * g + j;
-              xn[j] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+              xn[j] = k < a.Cin ? fno_ld4(xb + (long long)k * a.P, p0, a.P, al) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
           }
 #pragma unroll
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 4 * r + g;
-        xn[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        xn[r] = k < a.Cin ? fno_ld4(xb + (long long)k * a.P, p0, a.P, al) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       for (int q = 0; q < a.kq; ++q) {
         f32x4 xv[4];
@@ -245,7 +269,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int k = 16 * (q + 1) + 4 * r + g;
-            xn[r] = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            xn[r] = k < a.Cin ? fno_ld4(xb + (long long)k * a.P, p0, a.P, al) : (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
 #pragma unroll
@@ -267,22 +291,22 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int o = 16 * (ob0 + j) + 4 * g + rr;
-          if (o >= a.Cout || !pok) continue;
-          const long long off = ((long long)b * a.CoutT + a.co0 + o) * a.P + p0;
+          if (o >= a.Cout || p0 >= a.P) continue;
+          const long long off = ((long long)b * a.CoutT + a.co0 + o) * a.P;  // this row
           f32x4 v = (f32x4){acc[j][0][rr], acc[j][1][rr], acc[j][2][rr], acc[j][3][rr]};
           if (a.bias) v += a.bias[a.co0 + o];
           if (a.zmul) {
-            const f32x4 z = *(const f32x4*)&a.zmul[off];
+            const f32x4 z = fno_ld4(a.zmul + off, p0, a.P, al);
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] *= fno_gelu_grad(z[t]);
           }
-          if (a.accumulate) v += *(const f32x4*)&a.out[off];
-          *(f32x4*)&a.out[off] = v;
+          if (a.accumulate) v += fno_ld4(a.out + off, p0, a.P, al);
+          fno_st4(a.out + off, p0, a.P, al, v);
           if (a.act) {
             f32x4 y;
 #pragma unroll
             for (int t = 0; t < 4; ++t) y[t] = fno_gelu(v[t]);
-            *(f32x4*)&a.act[off] = y;
+            fno_st4(a.act + off, p0, a.P, al, y);
           }
         }
       }
@@ -292,8 +316,8 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 
 extern "C" int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* W, int transpose,
                              const float* bias, const float* zmul, int accumulate, float* out, float* act, void* stream) {
-  if (B < 1 || Cin < 1 || Cout < 1 || P < 4 || (P & 3) || !x || !W || !out) {
-    ppsci_set_error("pw_conv: invalid argument (P must be a positive multiple of 4)");
+  if (B < 1 || Cin < 1 || Cout < 1 || P < 1 || !x || !W || !out) {
+    ppsci_set_error("pw_conv: invalid argument");
     return PPSCI_E_INVALID;
   }
   PwArgs a;
@@ -409,11 +433,12 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
 #pragma unroll
   for (int u = 0; u < TB; ++u) bsum[u] = 0.f;
   const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
+  const bool al = (a.P & 3) == 0;  // see fno_ld4; the remainder loop zero-fills beyond pend
   int pbeg = p0;
   if constexpr (PPSCI_XDL) {
     // K = 32 pixels per step: lane (g, c) holds pixels p + 8g .. + 7 of its row for both operands (two float4 each),
     // split into three bf16 planes; six products per 16 x 16 block.  A 16-pixel remainder takes the fp32 loop below.
-    for (; pbeg + 32 <= pend; pbeg += 32) {
+    for (; al && pbeg + 32 <= pend; pbeg += 32) {
       u32x4 gp[TB][3], xp[TB][3];
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
@@ -440,8 +465,8 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
     f32x4 gv[TB], xv[TB];
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
-      gv[u] = *(const f32x4*)&gr[u][p + 4 * g] * mo[u];
-      xv[u] = *(const f32x4*)&xr[u][p + 4 * g] * mi[u];
+      gv[u] = fno_ld4(gr[u], p + 4 * g, pend, al) * mo[u];
+      xv[u] = fno_ld4(xr[u], p + 4 * g, pend, al) * mi[u];
     }
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
@@ -488,8 +513,8 @@ extern "C" int64_t ppsci_pw_conv_wgrad_chunks(int B, int P) {
 // part_w: [chunks][Co*Ci], part_b: [chunks][Co] (or null); sum each with ppsci_reduce_rows(part, chunks, cols, out)
 extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials,
                                    float* partials_b, void* stream) {
-  if (B < 1 || Ci < 1 || Co < 1 || P < 16 || (P & 15) || !x || !gy || !partials) {
-    ppsci_set_error("pw_conv_wgrad: invalid argument (P must be a positive multiple of 16)");
+  if (B < 1 || Ci < 1 || Co < 1 || P < 1 || !x || !gy || !partials) {
+    ppsci_set_error("pw_conv_wgrad: invalid argument");
     return PPSCI_E_INVALID;
   }
   PwWArgs a;
@@ -557,8 +582,14 @@ __global__ void __launch_bounds__(256) gn_rowstats_kernel(GnArgs a) {
   const float* vr = a.v + (long long)row * a.P;
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
+  const bool al = (a.P & 3) == 0;
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
-    const f32x4 u = *(const f32x4*)&vr[p] + sb;
+    f32x4 u = fno_ld4(vr, p, a.P, al) + sb;
+    if (!al) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k >= a.P) u[k] = 0.f;
+    }
     s1 += (u[0] + u[1]) + (u[2] + u[3]);
     s2 += (u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]);
   }
@@ -587,24 +618,28 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(GnArgs a) {
 }
 
 __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
-  const long long n4 = (long long)a.B * a.C * a.P / 4;
+  // work item: four neighbouring pixels of one row (the last item of a row is ragged when P is not a multiple of 4)
+  const bool al = (a.P & 3) == 0;
+  const int p4 = (a.P + 3) / 4;
+  const long long n4 = (long long)a.B * a.C * p4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const long long e = i * 4, row = e / a.P;
+    const long long row = i / p4, base = row * a.P;
+    const int p = 4 * (int)(i - row * p4);
     const int c = (int)(row % a.C), b = (int)(row / a.C);
-    f32x4 u = *(const f32x4*)&a.v[e] + (a.sbias ? a.sbias[c] : 0.f);
+    f32x4 u = fno_ld4(a.v + base, p, a.P, al) + (a.sbias ? a.sbias[c] : 0.f);
     if (a.norm) {
       const float mean = a.stats[2 * b], rstd = a.stats[2 * b + 1];
       u = (u - mean) * (rstd * a.gamma[c]) + a.beta[c];
     }
-    if (a.skip) u += *(const f32x4*)&a.skip[e];
-    *(f32x4*)&a.t[e] = u;
+    if (a.skip) u += fno_ld4(a.skip + base, p, a.P, al);
+    fno_st4(a.t + base, p, a.P, al, u);
     if (a.y) {
       f32x4 y = u;
       if (a.gelu) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = fno_gelu(u[k]);
       }
-      *(f32x4*)&a.y[e] = y;
+      fno_st4(a.y + base, p, a.P, al, y);
     }
   }
 }
@@ -617,15 +652,21 @@ __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   const float mean = a.norm ? a.stats[2 * b] : 0.f, rstd = a.norm ? a.stats[2 * b + 1] : 1.f;
   float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+  const bool al = (a.P & 3) == 0;
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
-    f32x4 g4 = *(const f32x4*)&a.gout[base + p];
+    f32x4 g4 = fno_ld4(a.gout + base, p, a.P, al);  // zero beyond the row: such elements add nothing to r1, r2
     if (a.gelu) {
-      const f32x4 t4 = *(const f32x4*)&a.t[base + p];
+      const f32x4 t4 = fno_ld4(a.t + base, p, a.P, al);
 #pragma unroll
       for (int k = 0; k < 4; ++k) g4[k] *= fno_gelu_grad(t4[k]);
     }
-    *(f32x4*)&a.gt[base + p] = g4;
-    const f32x4 xh = (*(const f32x4*)&a.v[base + p] + sb - mean) * rstd;
+    fno_st4(a.gt + base, p, a.P, al, g4);
+    f32x4 xh = (fno_ld4(a.v + base, p, a.P, al) + sb - mean) * rstd;
+    if (!al) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k >= a.P) xh[k] = 0.f;
+    }
     r1 += (g4[0] + g4[1]) + (g4[2] + g4[3]);
     r2 += (g4[0] * xh[0] + g4[1] * xh[1]) + (g4[2] * xh[2] + g4[3] * xh[3]);
     r3 += (xh[0] + xh[1]) + (xh[2] + xh[3]);
@@ -677,25 +718,28 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(GnArgs a) {
 
 // backward pass 2: gv = rstd (gamma gt - m1 - xh m2)   (norm == 0: gv = gt)
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnArgs a) {
-  const long long n4 = (long long)a.B * a.C * a.P / 4;
+  const bool al = (a.P & 3) == 0;
+  const int p4 = (a.P + 3) / 4;
+  const long long n4 = (long long)a.B * a.C * p4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const long long e = i * 4, row = e / a.P;
+    const long long row = i / p4, base = row * a.P;
+    const int p = 4 * (int)(i - row * p4);
     const int c = (int)(row % a.C), b = (int)(row / a.C);
-    const f32x4 g4 = *(const f32x4*)&a.gt[e];
+    const f32x4 g4 = fno_ld4(a.gt + base, p, a.P, al);
     if (!a.norm) {
-      *(f32x4*)&a.gv[e] = g4;
+      fno_st4(a.gv + base, p, a.P, al, g4);
       continue;
     }
     const float mean = a.stats[2 * b], rstd = a.stats[2 * b + 1];
     const float m1 = a.stats[2 * a.B + 2 * b], m2 = a.stats[2 * a.B + 2 * b + 1];
-    const f32x4 xh = (*(const f32x4*)&a.v[e] + (a.sbias ? a.sbias[c] : 0.f) - mean) * rstd;
-    *(f32x4*)&a.gv[e] = (g4 * a.gamma[c] - m1 - xh * m2) * rstd;
+    const f32x4 xh = (fno_ld4(a.v + base, p, a.P, al) + (a.sbias ? a.sbias[c] : 0.f) - mean) * rstd;
+    fno_st4(a.gv + base, p, a.P, al, (g4 * a.gamma[c] - m1 - xh * m2) * rstd);
   }
 }
 
 static int gn_check(int B, int C, int P) {
-  if (B < 1 || C < 1 || P < 4 || (P & 3)) {
-    ppsci_set_error("fno block tail: invalid shape (P must be a positive multiple of 4)");
+  if (B < 1 || C < 1 || P < 1) {
+    ppsci_set_error("fno block tail: invalid shape");
     return PPSCI_E_INVALID;
   }
   return PPSCI_OK;
@@ -717,7 +761,7 @@ extern "C" int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float
     PPSCI_LAUNCH(gn_rowstats_kernel, GnArgs, B * C, 256, 0, stream, a);
     PPSCI_LAUNCH(gn_finalize_kernel, GnArgs, (B + 63) / 64, 64, 0, stream, a);
   }
-  const long long n4 = (long long)B * C * P / 4;
+  const long long n4 = (long long)B * C * ((P + 3) / 4);
   long long grid = (n4 + 255) / 256;
   if (grid > 8 * PPSCI_NUM_CU) grid = 8 * PPSCI_NUM_CU;
   PPSCI_LAUNCH(gn_apply_kernel, GnArgs, (int)grid, 256, 0, stream, a);
@@ -743,7 +787,7 @@ extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu;
   PPSCI_LAUNCH(gn_bwd_rows_kernel, GnArgs, B * C, 256, 0, stream, a);
   PPSCI_LAUNCH(gn_bwd_finalize_kernel, GnArgs, 1, 256, 0, stream, a);
-  const long long n4 = (long long)B * C * P / 4;
+  const long long n4 = (long long)B * C * ((P + 3) / 4);
   long long grid = (n4 + 255) / 256;
   if (grid > 8 * PPSCI_NUM_CU) grid = 8 * PPSCI_NUM_CU;
   PPSCI_LAUNCH(gn_bwd_apply_kernel, GnArgs, (int)grid, 256, 0, stream, a);

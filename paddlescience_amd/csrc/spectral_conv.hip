@@ -8,8 +8,8 @@
 //  -> write into a zero spectrum -> fftshift -> irfftn).  The FFTs themselves stay in hipFFT (torch.fft).
 //
 // The shift + crop is folded into index arithmetic on the UNSHIFTED spectrum: weight row m of the kept block
-// sits at shifted row c0 + m, i.e. unshifted row r = (c0 + m + H/2) mod H (H even), and the reference's second
-// fftshift puts the result back to the same r.
+// sits at shifted row c0 + m, i.e. unshifted row (c0 + m - H//2) mod H, and the reference's second fftshift puts the
+// result to row (c0 + m + H//2) mod H: the same row for even H, the row before it for odd H (spec_row_in / _out).
 //
 // Per kept mode the complex product  out[b,o] = sum_i x[b,i] * w[i,o]  is one real GEMM
 //   [B x 2Ci] . [[wr, wi], [-wi, wr]]  ->  [B x 2Co]
@@ -37,7 +37,14 @@ struct SpecArgs {
   float scale;      // applied to the result (1/(H*W) when the FFTs around the contraction are unscaled hipFFT calls)
 };
 
-__device__ __forceinline__ int spec_row(const ppsci_spectral_desc& d, int c0, int m) {
+// Kept mode m sits in row c0 + m of the fftshift-ed spectrum (c0 = (H - modes_x) // 2).  The reference shifts the input
+// spectrum by H // 2, writes the products into the same rows of a cleared buffer and shifts that by H // 2 AGAIN
+// (fno_block.py:721, :791 -- fftshift both times, not ifftshift): input row (c0 + m - H // 2) mod H, output row
+// (c0 + m + H // 2) mod H.  The same row when H is even; one row apart when H is odd (DomainPadding sizes like 69).
+__device__ __forceinline__ int spec_row_in(const ppsci_spectral_desc& d, int c0, int m) {
+  return (c0 + m + d.h - d.h / 2) % d.h;
+}
+__device__ __forceinline__ int spec_row_out(const ppsci_spectral_desc& d, int c0, int m) {
   return (c0 + m + d.h / 2) % d.h;
 }
 
@@ -67,9 +74,11 @@ __global__ void __launch_bounds__(64) spectral_contract_kernel(SpecArgs a) {
   const int tb = id % a.ntile_b;
   const int mode = id / a.ntile_b;
   const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
-  const int r = spec_row(a.d, a.c0, mx);
+  // forward: reads the input rows, writes the output rows; data gradient (conj_t): the other way round
+  const int r_src = a.conj_t ? spec_row_out(a.d, a.c0, mx) : spec_row_in(a.d, a.c0, mx);
+  const int r_dst = a.conj_t ? spec_row_in(a.d, a.c0, mx) : spec_row_out(a.d, a.c0, mx);
   const long long plane = (long long)a.d.h * a.d.wf * 2;
-  const long long pix = ((long long)r * a.d.wf + my) * 2;
+  const long long pix = ((long long)r_src * a.d.wf + my) * 2, pix_dst = ((long long)r_dst * a.d.wf + my) * 2;
   const int K = 2 * a.cin;
   const int brow = tb * 16 + c;       // A operand row (batch index) for this lane
   const bool bok = brow < a.d.batch;
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(64) spectral_contract_kernel(SpecArgs a) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int b = tb * 16 + 4 * g + rr;
-      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix + part] = acc[rr] * a.scale;
+      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix_dst + part] = acc[rr] * a.scale;
     }
   }
 }
@@ -117,13 +126,13 @@ __global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
   const long long io = t / ms;
   const int o = (int)(io % a.d.c_out), i = (int)(io / a.d.c_out);
   const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
-  const int r = spec_row(a.d, a.c0, mx);
   const long long plane = (long long)a.d.h * a.d.wf * 2;
-  const long long pix = ((long long)r * a.d.wf + my) * 2;
+  const long long pix_x = ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
+  const long long pix_g = ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
   float sr = 0.f, si = 0.f;
   for (int b = 0; b < a.d.batch; ++b) {
-    const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix;
-    const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix;
+    const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix_x;
+    const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix_g;
     const float xr = xp[0], xi = xp[1], gr = gp[0], gi = gp[1];
     sr += xr * gr + xi * gi;
     si += xr * gi - xi * gr;
@@ -143,12 +152,7 @@ static int spec_check(const ppsci_spectral_desc* d, int* c0) {
     ppsci_set_error("spectral_conv: invalid descriptor");
     return PPSCI_E_INVALID;
   }
-  if ((d->h & 1) || ((d->h - d->modes_x) & 1)) {
-    // odd sizes: the reference's centre-crop slices / double fftshift are not inverse to each other
-    ppsci_set_error("spectral_conv: H (%d) and H - modes_x (%d) must be even", d->h, d->h - d->modes_x);
-    return PPSCI_E_UNSUPPORTED;
-  }
-  *c0 = (d->h - d->modes_x) / 2;
+  *c0 = (d->h - d->modes_x) / 2;  // `start // 2` of the reference's slice (fno_block.py:749-752), any parity
   return PPSCI_OK;
 }
 

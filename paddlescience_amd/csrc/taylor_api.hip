@@ -4,7 +4,10 @@
 #include "taylor_step.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 // ---- pre-split hidden-weight fragments for the feature-split XDL kernels (taylor_fwd_wx.inc / taylor_bwd_wx.inc) ----
 // One thread per (layer, row block, k-pair, lane): the two 4-value halves of the K = 32 A operand, split into three bf16
@@ -69,21 +72,33 @@ __global__ void __launch_bounds__(256) ppsci_presplit2_kernel(const float* param
   }
 }
 
-// Fragment cache: one device buffer per (parameter buffer, direction), allocated on first use (an eager call: the
-// engine captures HIP graphs only from the second step on) and re-filled by every launch that needs it -- the
-// parameters change every step.  Never freed: a handful of entries of <= a few MiB.
+// Fragment cache of the separate (non-fused) feature-split kernels: one device buffer per (parameter buffer, direction),
+// allocated on first use (an eager call: the engine captures HIP graphs only from the second step on) and re-filled by
+// every launch that needs it -- the parameters change every step.  (The fused tile kernel keeps its fragments in the
+// caller-owned step workspace instead.)  A buffer lives until its parameter buffer is released
+// (ppsci_release_fragments, called by the engine that owns the parameters) or until the table is full, in which case
+// the oldest entry is freed -- hipFree waits for the device, so no launch that reads it is still in flight.
 struct FragEntry {
   const void* key;
   int bwd;
   size_t bytes;
   void* dev;
 };
-static FragEntry g_frag[64];
-static int g_nfrag = 0;
+#define PPSCI_FRAG_SLOTS 64
+static FragEntry g_frag[PPSCI_FRAG_SLOTS];
+static int g_nfrag = 0, g_frag_next = 0;
+static std::mutex g_frag_mutex;
+static void frag_free(void* dev) {
+#ifdef PPSCI_EMU
+  free(dev);
+#else
+  (void)hipFree(dev);
+#endif
+}
 static void* frag_cache_get(const void* key, int bwd, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_frag_mutex);
   for (int i = 0; i < g_nfrag; ++i)
     if (g_frag[i].key == key && g_frag[i].bwd == bwd && g_frag[i].bytes >= bytes) return g_frag[i].dev;
-  if (g_nfrag == 64) g_nfrag = 0;  // recycle the table (the old buffers stay allocated: their launches may be in flight)
   void* dev = nullptr;
 #ifdef PPSCI_EMU
   dev = malloc(bytes);
@@ -91,8 +106,26 @@ static void* frag_cache_get(const void* key, int bwd, size_t bytes) {
   if (hipMalloc(&dev, bytes) != hipSuccess) dev = nullptr;
 #endif
   if (!dev) return nullptr;
-  g_frag[g_nfrag++] = FragEntry{key, bwd, bytes, dev};
+  int slot = g_nfrag;
+  if (g_nfrag < PPSCI_FRAG_SLOTS) {
+    ++g_nfrag;
+  } else {  // full: the oldest entry goes
+    slot = g_frag_next;
+    g_frag_next = (g_frag_next + 1) % PPSCI_FRAG_SLOTS;
+    frag_free(g_frag[slot].dev);
+  }
+  g_frag[slot] = FragEntry{key, bwd, bytes, dev};
   return dev;
+}
+extern "C" void ppsci_release_fragments(const float* params) {
+  std::lock_guard<std::mutex> lock(g_frag_mutex);
+  int n = 0;
+  for (int i = 0; i < g_nfrag; ++i) {
+    if (g_frag[i].key == (const void*)params) frag_free(g_frag[i].dev);
+    else g_frag[n++] = g_frag[i];
+  }
+  g_nfrag = n;
+  g_frag_next = 0;
 }
 
 const void* ppsci_presplit(const float* params, const ppsci_mlp_desc& d, const ppsci_derived& q, int bwd, void* stream) {

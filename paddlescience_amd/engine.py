@@ -12,6 +12,7 @@ one RCCL all-reduce (torch.distributed, SUM) of that flat buffer when world_size
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -294,12 +295,22 @@ def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
         cur.wait_stream(st)
 
 
+def _release_fragments(ptr: int) -> None:
+    try:
+        L.lib().ppsci_release_fragments(ptr)
+    except Exception:  # interpreter shutdown
+        pass
+
+
 class Engine:
     def __init__(self, layout: hp.NetLayout, params: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8,
                  dp_reduce: str = "sum"):
         assert layout is None or params.numel() == layout.n_params  # None: several networks (ModelList)
         self.layout = layout
         self.params = params
+        # the library keeps pre-split weight fragments per parameter buffer (feature-split kernels): released with the engine
+        fin = weakref.finalize(self, _release_fragments, params.data_ptr())
+        fin.atexit = False
         self.grad = torch.zeros_like(params)
         self.m = torch.zeros_like(params)
         self.v = torch.zeros_like(params)

@@ -67,8 +67,6 @@ class FnoNative:
         H, W = H0 + ah, W0 + aw
         self.padded = bool(ah or aw)
         P, P0 = H * W, H0 * W0
-        if P % 16 != 0 or P0 % 16 != 0:
-            raise NotImplementedError(f"native FNO path: H*W = {P0} (padded: {P}) must be a multiple of 16")
         self.shape = (B, H0, W0)
         self.hw, self.hw0 = (H, W), (H0, W0)
         self.P, self.P0 = P, P0

@@ -889,3 +889,9 @@ def test_one_row_slices_are_lowered_to_the_fused_kernels(tmp_path, reduction):
     assert cc._row_slice_cache is first
     solver.engine.forward_backward([cc.fused])
     assert rel(solver.engine.grad.cpu().numpy().astype(np.float64), gref) < 2e-4
+    # ... but a loader that refills the SAME buffers in place does not: the key is identity and content
+    off0 = dict(cc.fused.loss_offsets)
+    labd["u0"][:] = labd["u0"] + 1.0
+    cc.bind(inp, labd, wd)
+    assert cc._row_slice_cache is not first and cc.fused.loss_offsets["u0"] != off0["u0"]
+    lab["u0"][:] = lab["u0"] - 1.0  # (labd holds the same arrays)

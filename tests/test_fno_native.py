@@ -43,8 +43,6 @@ def test_native_path_reproduces_reference_fno(c, dev):
     model.set_state_dict({k: v.astype(np.float32) for k, v in P.items()})
     d = model.flat_params.device
     x = torch.as_tensor(G[f"{c}/x"].astype(np.float32)).to(d)
-    if (x.shape[-1] * x.shape[-2]) % 16:
-        pytest.skip("native path needs H*W % 16 == 0")
     eng = FnoNative(model)
     y = eng.forward(x)
     assert rel(y.cpu().numpy(), G[f"{c}/y"]) < 2e-5
@@ -94,11 +92,43 @@ def test_native_path_matches_oracle_and_is_reproducible(dev, stabilizer):
     assert torch.equal(runs[0], runs[1])
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 37, 48), (3, 256, 256, 80), (2, 200, 176, 64), (1, 64, 1, 32), (2, 36, 260, 16)])
+@pytest.mark.parametrize("hw,pad", [((10, 10), 0.1), ((9, 7), None), ((14, 14), [0.078125, 0.0])])
+def test_native_path_on_plane_sizes_that_are_not_multiples_of_16(dev, hw, pad):
+    """DomainPadding fractions like the reference yaml's 0.078125 (64 -> 69) or 0.1 (64 -> 70) give planes whose size is
+    not a multiple of 16 or even odd (rows then do not start on 16-byte boundaries): 10 x 10 -> 11 x 11, 9 x 7 unpadded,
+    14 x 14 -> 15 x 14.  Output, loss and every gradient against the fp64 restatement."""
+    import ppsci
+    from oracle import ref_torch as R
+
+    torch.manual_seed(5)
+    H, W = hw
+    model = ppsci.arch.FNONet(("x",), ("y",), (4, 4), 12, 3, 1, 20, 16, 2, norm="group_norm", domain_padding=pad)
+    d = model.flat_params.device
+    rng = np.random.default_rng(2)
+    x = torch.as_tensor(rng.standard_normal((3, 3, H, W)).astype(np.float32)).to(d)
+    tgt = torch.as_tensor(rng.standard_normal((3, 1, H, W)).astype(np.float32)).to(d)
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.fno_forward(x.cpu().double(), P, 2, (4, 4), "group_norm", domain_padding=pad)
+    lo = ((yo - tgt.cpu().double()) ** 2).mean()
+    names = [n for n, _ in torch.nn.Module.named_parameters(model)]
+    go = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(lo, [P[n] for n in names])])
+    eng = model.native()
+    y = eng.forward(x)
+    losses, gy = ppsci.loss.MSELoss("mean").value_and_grad(y, tgt, "y")
+    model.flat_grad.fill_(float("nan"))
+    eng.backward(gy)
+    assert rel(y.cpu().numpy(), yo.detach().numpy()) < 1e-5
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    assert rel(model.flat_grad.cpu().numpy(), go) < 2e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 37, 48), (3, 256, 256, 80), (2, 200, 176, 64), (1, 64, 1, 32), (2, 36, 260, 16),
+                                   (2, 5, 37, 75), (1, 40, 24, 100), (1, 33, 17, 301)])
 def test_pw_conv_and_tail_kernels_known_answers(dev, shape):
     """(B, Ci, Co, P): small ragged channels (scalar weight staging), 256 x 256 (two output-channel slabs, 16-byte staging,
-    2 x 2 weight-gradient tiles), channel counts that are not multiples of 16 on the vector path, one output channel, and more
-    output channels than one slab with a ragged tail."""
+    2 x 2 weight-gradient tiles), channel counts that are not multiples of 16 on the vector path, one output channel, more
+    output channels than one slab with a ragged tail; plane sizes that are odd (75, 301: two weight-gradient chunks) or a
+    multiple of 4 but not of 16 (100)."""
     import ctypes as C
 
     from paddlescience_amd import _lib as L
