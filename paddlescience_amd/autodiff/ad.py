@@ -9,26 +9,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple, Union
 
-import torch
 
 from ..graph import Sym, diff
-
-
-def _tensor_grad(ys: torch.Tensor, xs: torch.Tensor, i: int, j: Optional[int], create_graph: bool,
-                 retain_graph: Optional[bool]) -> torch.Tensor:
-    """The reference's eager semantics on real tensors (ad.py:56-77): d ys[:, i] / d xs with the implicit all-ones
-    cotangent -- the per-point derivative, because points are independent -- optionally column j of it.  Used by the
-    eager fallback (paddlescience_amd/eager.py) for expressions the tracer cannot lower."""
-    if not (0 <= i < ys.shape[-1]):
-        raise ValueError(f"i({i}) should in range [0, {ys.shape[-1]}).")
-    if j is not None and not (0 <= j < xs.shape[-1]):
-        raise ValueError(f"j({j}) should in range [0, {xs.shape[-1]}).")
-    y = ys[:, i:i + 1] if ys.shape[-1] > 1 else ys
-    (g,) = torch.autograd.grad(y, xs, grad_outputs=torch.ones_like(y), create_graph=create_graph,
-                               retain_graph=create_graph if retain_graph is None else retain_graph, allow_unused=True)
-    if g is None:
-        g = torch.zeros_like(xs)
-    return g if j is None or xs.shape[-1] == 1 else g[:, j:j + 1]
 
 
 def _check_x(x):
@@ -55,22 +37,12 @@ class Jacobians:
 
     def __call__(self, ys: Sym, xs: Union[Sym, List[Sym]], i: int = 0, j: Optional[int] = None,
                  retain_graph: Optional[bool] = None, create_graph: bool = True):
-        if isinstance(ys, torch.Tensor):  # eager fallback: autograd on real tensors
-            one = lambda x: self._tensor_one(ys, x, i, j, create_graph, retain_graph)  # noqa: E731
-            return one(xs) if not isinstance(xs, (list, tuple)) else [one(x) for x in xs]
         if not isinstance(ys, Sym):
-            raise TypeError("jacobian: `ys` must be a traced expression (output of model(...) or an expression of it)")
+            raise TypeError("jacobian: `ys` must be a traced expression (output of model(...) or an expression of it); numeric "
+                            "tensors carry no derivative graph here -- derivatives are streams of the Taylor-mode kernels")
         if not isinstance(xs, (list, tuple)):
             return self._one(ys, xs, i, j)
         return [self._one(ys, x, i, j) for x in xs]
-
-    def _tensor_one(self, ys, x, i, j, create_graph, retain_graph):
-        if not isinstance(x, torch.Tensor):
-            raise TypeError("jacobian: `xs` must be tensors when `ys` is a tensor")
-        key = (id(ys), id(x), i, j)  # cached per object pair like the reference (ad.py:100-137)
-        if key not in self.Js:
-            self.Js[key] = (_tensor_grad(ys, x, i, j, create_graph, retain_graph), ys, x)  # keep ys / x alive: ids stay unique
-        return self.Js[key][0]
 
     def _clear(self):
         self.Js = {}
@@ -83,14 +55,6 @@ class Hessians:
 
     def __call__(self, ys: Sym, xs: Sym, component: Optional[int] = None, i: int = 0, j: int = 0,
                  grad_y: Optional[Sym] = None, retain_graph: Optional[bool] = None, create_graph: bool = True) -> Sym:
-        if isinstance(ys, torch.Tensor):  # eager fallback (ad.py:181-236)
-            if ys.shape[-1] == 1 and component is not None:
-                raise ValueError(f"component{component} should be set to None when dim_y(1)=1.")
-            if ys.shape[-1] > 1 and component is None:
-                raise ValueError("component should not be None when dim_y > 1.")
-            if grad_y is None:
-                grad_y = self._jac(ys, xs, i=component or 0, j=None)
-            return self._jac(grad_y, xs, i, j, retain_graph, create_graph)
         if component is not None:  # every traced field is [N, 1]  (ad.py:214-218)
             raise ValueError(f"component{component} should be set to None when dim_y(1)=1.")
         key = (id(ys), id(xs), component)

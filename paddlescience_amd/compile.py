@@ -21,8 +21,19 @@ LABEL_PREFIX, WEIGHT_PREFIX, CAUSAL_PREFIX = "label:", "weight:", "causal:"
 
 
 def trace_exprs(model, input_keys: Sequence[str], exprs: Dict[str, Callable],
-                extra_parameters: Sequence = ()) -> Dict[str, Sym]:
-    """expression.py:96-102 on proxies: model forward, then every named expression on the data dict."""
+                extra_parameters: Sequence = (), batch: Optional[Dict[str, object]] = None,
+                concretized: Optional[List[str]] = None) -> Dict[str, Sym]:
+    """expression.py:96-102 on proxies: model forward, then every named expression on the data dict.  `batch`: the input
+    columns of the ONE batch this trace will ever run on (a static constraint) -- Python control flow on their values is
+    then followed (graph.batch_values); what was asked is appended to `concretized`."""
+    with graph.batch_values(batch) as st:
+        out = _trace_exprs(model, input_keys, exprs, extra_parameters)
+        if concretized is not None:
+            concretized.extend(st.concretized)
+    return out
+
+
+def _trace_exprs(model, input_keys, exprs, extra_parameters) -> Dict[str, Sym]:
     data: Dict[str, object] = {}
     for k in input_keys:
         data[k] = Sym.input(k) if k in model.input_keys else Sym.aux(k)
@@ -59,9 +70,12 @@ class CompiledConstraint:
     def __init__(self, name: str, model, exprs: Dict[str, Callable], input_keys: Sequence[str],
                  label_keys: Sequence[str], weight_keys: Sequence[str], loss, batch_size: int, n_global: int,
                  device, train: bool = True, want_values: bool = False, extra_outputs: Sequence[str] = (),
-                 extra_parameters: Sequence = ()):
+                 extra_parameters: Sequence = (), static_batch: Optional[Dict[str, object]] = None):
         self.name, self.model, self.loss = name, model, loss
-        outputs = trace_exprs(model, input_keys, exprs, extra_parameters)
+        # static_batch: the input columns of the one batch this constraint will ever be bound to; the value requests the
+        # expressions made of it (`if float(d["x"][0]) == 0.0:` ...) -- non-empty: the program is specialised to that batch
+        self.specialised_to: List[str] = []
+        outputs = trace_exprs(model, input_keys, exprs, extra_parameters, static_batch, self.specialised_to)
         # Row slices `expr[a:a+1]` as whole outputs (examples/euler_beam/euler_beam.py:49-54).  The reference's loss then
         # broadcasts the [1, 1] value against the [n, 1] label / weight columns (mse.py:82-105):
         #     sum_p w_p (v_a - l_p)^2  =  W (v_a - lbar)^2 + const,   W = sum w_p,  lbar = sum w_p l_p / W,

@@ -15,6 +15,7 @@ computes numerically (ad.py:73-75).
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -98,6 +99,8 @@ class Sym:
         if self.kind == "net":
             k = self.model.output_keys[self.comp]
             return k + "".join(f"__{d}" for d in self.dirs)
+        if self.kind == "rows":
+            return f"{self.args[0]!r}[{self.comp[0]}:{'' if self.comp[1] is None else self.comp[1]}]"
         return f"{self.op}({', '.join(map(repr, self.args))})"
 
     # ---- arithmetic
@@ -114,20 +117,63 @@ class Sym:
     def __neg__(self): return apply("neg", self)
     def __pos__(self): return self
 
+    # ---- values at trace time: data-dependent Python control flow (see `batch_values`)
+    def _scalar(self, what: str):
+        v = concrete_values(self, what)
+        if v.size != 1:
+            raise TypeError(f"{what} of a traced expression with {v.size} values: only one-element values convert to Python scalars")
+        _TRACE.concretized.append(f"{what}({self!r})")
+        return v.reshape(-1)[0]
+
     def __bool__(self):
-        raise TypeError("a traced expression has no truth value: data-dependent Python control flow cannot be "
-                        "lowered to the fused HIP path")
+        return bool(self._scalar("bool") != 0)
 
     def __float__(self):
-        raise TypeError("a traced expression has no value at trace time: float(...) of it cannot be lowered to the fused HIP path")
+        return float(self._scalar("float"))
+
+    def __int__(self):
+        return int(self._scalar("int"))
+
+    def item(self):
+        return float(self._scalar("item"))
+
+    def _compare(self, o, f, what):
+        if isinstance(o, Sym):
+            o = concrete_values(o, what)
+        elif not isinstance(o, (int, float, np.floating, np.integer)):
+            return NotImplemented
+        v = f(concrete_values(self, what), np.float32(o))
+        _TRACE.concretized.append(f"{what}({self!r})")
+        return v if v.size != 1 else bool(v.reshape(-1)[0])
+
+    def __lt__(self, o): return self._compare(o, np.less, "lt")
+    def __le__(self, o): return self._compare(o, np.less_equal, "le")
+    def __gt__(self, o): return self._compare(o, np.greater, "gt")
+    def __ge__(self, o): return self._compare(o, np.greater_equal, "ge")
+
+    def __eq__(self, o):
+        # two traced values: identity (nodes are hash-consed: the same structure IS the same object); a number: the comparison
+        # of the reference's tensors, on the batch the trace is specialised to
+        if isinstance(o, Sym):
+            return self is o
+        return self._compare(o, np.equal, "eq")
+
+    def __ne__(self, o):
+        r = self.__eq__(o)
+        return r if r is NotImplemented else (not r if isinstance(r, bool) else ~r)
+
+    __hash__ = object.__hash__
 
     def __getitem__(self, key):
         """`expr[a:b]`: ROWS a..b of the batch (examples/euler_beam/euler_beam.py:49-54 picks the boundary point each condition
-        belongs to).  Legal only as the whole of an output expression; compile.CompiledConstraint turns a one-row slice into a
-        per-point weight mask (see there).  Anything else with it raises and the constraint takes the eager path."""
+        belongs to).  Legal as the whole of an output expression -- compile.CompiledConstraint turns a one-row slice into a
+        per-point weight mask (see there) -- or under float() / bool() / a comparison (its value at trace time).  Anything
+        else with it raises."""
+        if isinstance(key, (int, np.integer)):  # x[k]: the reference's [1]-shaped row k
+            key = slice(int(key), int(key) + 1 if int(key) != -1 else None)
         if isinstance(key, slice) and key.step in (None, 1) and all(isinstance(v, (int, type(None))) for v in (key.start, key.stop)):
             return Sym("rows", comp=(key.start or 0, key.stop), args=(self,))
-        raise TypeError("a traced expression can only be indexed by a contiguous row slice x[a:b]")
+        raise TypeError("a traced expression can only be indexed by a row x[k] or a contiguous row slice x[a:b]")
 
     def sin(self): return apply("sin", self)
     def cos(self): return apply("cos", self)
@@ -137,6 +183,68 @@ class Sym:
     def sqrt(self): return apply("sqrt", self)
     def abs(self): return apply("abs", self)
     def pow(self, o): return apply("pow", self, _lift(o))
+
+
+# ---- the batch a trace is specialised to ------------------------------------------------------------------------------
+# The reference evaluates expressions on real tensors, so Python may branch on their values (`if float(d["x"][0]) == 0:`,
+# utils/expression.py:96-102 just calls the user function).  A trace cannot follow a value that changes from step to step;
+# but a constraint whose batch is FIXED (full batch, no shuffling: the boundary / initial-condition sets such code looks
+# at) has one answer for every step.  `batch_values(...)` gives the trace those values: float() / bool() / comparisons
+# of expressions of the INPUT columns evaluate on them (fp32, the reference's dtype), the branch taken is the one the
+# reference takes on every step, and the trace stays a per-point program for the kernels.  Values that depend on the
+# network (they change as it trains) still raise.  `_TRACE.concretized` records what was asked, so that the caller can
+# refuse to reuse such a trace for a batch with other values.
+class _TraceState:
+    values: Optional[Dict[str, np.ndarray]] = None
+    concretized: List[str] = []
+
+
+_TRACE = _TraceState()
+
+
+@contextlib.contextmanager
+def batch_values(values: Optional[Dict[str, object]]):
+    """values: column name -> array of the bound batch (None: no specialisation, value requests raise)."""
+    def host(a):
+        a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+        return a.astype(np.float32).reshape(-1)
+
+    prev = (_TRACE.values, _TRACE.concretized)
+    _TRACE.values = None if values is None else {k: host(v) for k, v in values.items()}
+    _TRACE.concretized = []
+    try:
+        yield _TRACE
+    finally:
+        _TRACE.values, _TRACE.concretized = prev
+
+
+_NUMPY_OPS = {"add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "pow": np.power, "max": np.maximum,
+              "min": np.minimum, "atan2": np.arctan2, "sin": np.sin, "cos": np.cos, "tanh": np.tanh, "exp": np.exp,
+              "log": np.log, "sqrt": np.sqrt, "abs": np.abs, "sinh": np.sinh, "cosh": np.cosh, "tan": np.tan,
+              "neg": np.negative, "sign": np.sign, "detach": lambda v: v, "asin": np.arcsin, "acos": np.arccos,
+              "atan": np.arctan, "asinh": np.arcsinh, "acosh": np.arccosh, "atanh": np.arctanh, "ceil": np.ceil,
+              "floor": np.floor}
+
+
+def concrete_values(s: "Sym", what: str = "value") -> np.ndarray:
+    """fp32 values of an expression of the input columns on the batch the trace is specialised to."""
+    if _TRACE.values is None:
+        raise TypeError(f"{what}() of the traced expression {s!r}: data-dependent Python control flow can only be followed for a "
+                        "constraint whose batch is fixed (one full batch, no shuffling); this one changes every iteration")
+    if s.kind in ("in", "aux"):
+        if s.name not in _TRACE.values:
+            raise TypeError(f"{what}() of {s!r}: the bound batch has no column {s.name!r}")
+        return _TRACE.values[s.name]
+    if s.kind == "const":
+        return np.float32(s.value).reshape(1)
+    if s.kind == "rows":
+        a, b = s.comp
+        return concrete_values(s.args[0], what)[a:b]
+    if s.kind == "op" and s.op in _NUMPY_OPS:
+        with np.errstate(all="ignore"):
+            return np.asarray(_NUMPY_OPS[s.op](*[concrete_values(a, what) for a in s.args]), dtype=np.float32)
+    raise TypeError(f"{what}() of the traced expression {s!r}: it depends on the network (or a learnable parameter), whose value "
+                    "changes every step -- data-dependent Python control flow on it cannot be lowered to the fused HIP path")
 
 
 def _lift(v) -> Sym:

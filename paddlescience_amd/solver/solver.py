@@ -240,33 +240,24 @@ class Solver:
                                               f"zero-weight padding is built for MSELoss only, not {type(cst.loss).__name__}")
                 self._ragged.add(name)
                 weight_keys = weight_keys + [k for k in label_keys if k not in weight_keys]
+        # A static constraint (one full batch, not shuffled) is bound ONCE, here: its expressions may then look at the values
+        # of that batch (Python control flow on the input columns: graph.batch_values)
+        self._static[name] = _is_full_static_batch(cst)
+        first = next(cst.data_iter) if self._static[name] else None
         try:
             cc = CompiledConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
                                     bsz * self.world_size, self.device, train=True,
-                                    extra_parameters=self._extra_parameters())
+                                    extra_parameters=self._extra_parameters(),
+                                    static_batch=first[0] if first is not None else None)
         except (NotImplementedError, TypeError) as e:
-            # the expressions cannot be lowered to the fused kernels (row slices, tensor methods, control flow, a derivative
-            # set beyond the instantiated stream sets ...): this constraint runs the reference's own execution model --
-            # op-by-op tensors + autograd (eager.py); the others stay fused
-            from ..eager import EagerConstraint
-
-            # OPT-IN (PPSCI_EAGER_FALLBACK=1): by default a constraint that cannot run on this framework's kernels
-            # raises with the reason instead of silently training on torch library kernels
-            if os.environ.get("PPSCI_EAGER_FALLBACK", "0") != "1":
-                raise NotImplementedError(
-                    f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e}).  Set "
-                    "PPSCI_EAGER_FALLBACK=1 to run this constraint op by op through torch autograd (slow, library "
-                    "kernels)") from e
-            if self._extra_parameters() or getattr(self.loss_aggregator, "per_loss_grad", False) or \
-                    getattr(self.optimizer, "is_lbfgs", False):
-                raise
-            cc = EagerConstraint(name, self.model, cst.output_expr, input_keys, label_keys, weight_keys, cst.loss, bsz,
-                                 bsz * self.world_size, self.device, reason=f"{type(e).__name__}: {e}")
-            logger.warning(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e}); "
-                           "it trains through the eager fallback (torch autograd, slow)")
-        self._static[name] = _is_full_static_batch(cst)
-        if self._static[name]:
-            inp, lab, w = next(cst.data_iter)
+            # the expressions are not a per-point program (arithmetic on row windows, tensor methods that reduce over the
+            # batch, control flow on values that change every step, a derivative set beyond the instantiated stream sets
+            # ...): refused with the reason -- there is no op-by-op fallback
+            raise NotImplementedError(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e})") from e
+        if cc.specialised_to:
+            logger.info(f"constraint {name}: traced for the values of its (fixed) batch: {', '.join(cc.specialised_to)}")
+        if first is not None:
+            inp, lab, w = first
             cc.bind(inp, lab, self._shard_weights(name, cst, lab, w))
         return cc
 
@@ -312,8 +303,7 @@ class Solver:
                         else:
                             cc.bind(inp, lab, self._shard_weights(name, self.constraint[name], lab, w))
                 reader_cost = time.perf_counter() - reader_tic
-                eager_csts = [c for c in csts if getattr(c, "is_eager", False)]
-                eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts if c not in eager_csts]
+                eng_csts = csts if (self._is_spinn or self._is_operator) else [c.fused for c in csts]
                 gscale = (1.0 / self.world_size) if (self.engine.dp_reduce == "mean" and self.world_size > 1) else 1.0
                 if getattr(self.optimizer, "is_lbfgs", False):
                     # train_LBFGS_epoch_func (solver/train.py:216-315): the optimizer re-evaluates loss + gradient
@@ -331,17 +321,11 @@ class Solver:
                         return total, g * gscale if gscale != 1.0 else g
 
                     self.optimizer.step(closure)
-                elif self._step_in_one_launch(eng_csts, eager_csts, gscale):
+                elif self._step_in_one_launch(eng_csts, gscale):
                     pass  # forward -> loss -> backward -> Adam of every constraint in one launch each (engine.step_one_launch)
                 else:
                     self._materialize()
-                    if eng_csts:
-                        self.engine.forward_backward(eng_csts)
-                    else:
-                        self.engine.grad.zero_()
-                    for ec in eager_csts:  # eager fallback constraints add their gradient before the all-reduce
-                        mean = getattr(ec.loss, "reduction", "mean") == "mean"
-                        ec.forward_backward(self.engine.grad, (1.0 / self.world_size) if mean else 1.0)
+                    self.engine.forward_backward(eng_csts)
                     self.engine.allreduce()
                     self._allreduce_eq_params()
                     if getattr(self.loss_aggregator, "per_loss_grad", False):
@@ -446,13 +430,13 @@ class Solver:
         if self._reparam:
             self.model.materialize()
 
-    def _step_in_one_launch(self, eng_csts, eager_csts, gscale: float) -> bool:
+    def _step_in_one_launch(self, eng_csts, gscale: float) -> bool:
         """The whole iteration (train.py:82-184) as one launch per constraint, the optimizer step inside the last one,
         when nothing sits between the gradient and the update: one rank, plain Adam (no clipping / decay / learnable
         equation parameters), no re-parametrised weights, no gradient accumulation or per-loss gradients, and every
         constraint small enough for the one-launch kernel (engine.one_launch_ready).  False: nothing was done."""
         opt = self.optimizer
-        if (self.world_size != 1 or eager_csts or not eng_csts or self._reparam or self.update_freq > 1
+        if (self.world_size != 1 or not eng_csts or self._reparam or self.update_freq > 1
                 or getattr(self.loss_aggregator, "per_loss_grad", False) or type(opt).__name__ != "_AdamState"
                 or opt.grad_clip is not None or opt.l2 != 0.0 or opt.eq_store is not None
                 or not hasattr(self.engine, "one_launch_ready") or opt.model.flat_params.data_ptr() != self.engine.params.data_ptr()
@@ -497,12 +481,8 @@ class Solver:
                 vals = cc.losses()  # keys are whatever the loss returns (FunctionalLoss), not the label keys
                 keys = list(vals.keys())
             else:
-                if getattr(cc, "is_eager", False):
-                    vals = cc.losses()
-                    keys = list(vals.keys())
-                else:
-                    vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
-                    keys = cc.label_keys
+                vals = {cc.label_key: cc.loss()} if self._is_spinn else cc.fused.losses()
+                keys = cc.label_keys
                 if getattr(self.loss_aggregator, "per_loss_grad", False) and hasattr(cc, "_base_scales"):
                     # the kernels applied the aggregator's weights through the residual scales: report raw terms
                     order = self._loss_key_order()

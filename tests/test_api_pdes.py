@@ -703,11 +703,14 @@ def test_periodic_constraint_batches_and_training_step(tmp_path):
     assert rel(model.flat_params.cpu().numpy()[:p.size], p) < 1e-5
 
 
-def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path, monkeypatch):
-    """examples/euler_beam/euler_beam.py: the PDE u_xxxx + 1 = 0 runs on the fused kernels (fourth-order streams); its
-    boundary terms pick ROWS of the batch (`d["u"][0:1]`, `jacobian(...)[1:2]`, ...), which no per-point program can
-    express: that constraint falls back to the eager path (op-by-op tensors + autograd, the reference's execution model).
-    Loss terms and the summed parameter gradient against the oracle's reverse-over-reverse restatement."""
+def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
+    """examples/euler_beam/euler_beam.py with a twist: the PDE u_xxxx + 1 = 0 runs on the fused kernels (fourth-order
+    streams); its boundary terms pick ROWS of the batch, and `u0` picks the row by a data-dependent Python branch
+    (`if float(d["x"][0]) == 0.0`) -- in the reference that is plain eager code on tensors.  (The name is historic: up to
+    round 3 this constraint ran op by op through torch autograd.)  The boundary set is one fixed batch, so the trace is
+    specialised to its values (graph.batch_values): the branch the reference takes on every step is traced, everything
+    runs on the fused kernels, and nothing of the step is on an autograd tape.  Loss terms and the summed parameter
+    gradient against the oracle's reverse-over-reverse restatement; a batch that changes every step is refused."""
     from ppsci.autodiff import hessian, jacobian
 
     model = ppsci.arch.MLP(("x",), ("u",), 3, 20, "tanh")
@@ -718,27 +721,21 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path, monkey
     Xb = np.asarray([[0.0], [0.0], [1.0], [1.0]], np.float32)
     eq = ppsci.equation.Biharmonic(1, -1.0, 1.0)
     pde = _sup_constraint({"x": Xi}, {"biharmonic": np.zeros((32, 1), np.float32)}, eq.equations, ppsci.loss.MSELoss("mean"), name="EQ")
-    # (one-row slices alone are lowered since round 2 -- see the next test; the data-dependent branch in u0 is what no tracer
-    # can follow)
     bc_exprs = {"u0": lambda d: d["u"][0:1] if float(d["x"][0]) == 0.0 else d["u"][3:4],
-                "u__x": lambda d: jacobian(d["u"], d["x"])[1:2],
+                "u__x": lambda d: jacobian(d["u"], d["x"])[1:2] if d["x"][1] < 0.5 else jacobian(d["u"], d["x"])[2:3],
                 "u__x__x": lambda d: hessian(d["u"], d["x"])[2:3],
                 "u__x__x__x": lambda d: jacobian(hessian(d["u"], d["x"]), d["x"])[3:4]}
     bc = _sup_constraint({"x": Xb}, {k: np.zeros((4, 1), np.float32) for k in bc_exprs}, bc_exprs, ppsci.loss.MSELoss("sum"),
                          name="BC")
-    # the reroute is OPT-IN: by default the constraint is refused with the reason
-    monkeypatch.delenv("PPSCI_EAGER_FALLBACK", raising=False)
-    with pytest.raises(NotImplementedError, match="PPSCI_EAGER_FALLBACK=1"):
-        _solver(tmp_path, model, {"EQ": pde, "BC": bc})
-    monkeypatch.setenv("PPSCI_EAGER_FALLBACK", "1")
     solver = _solver(tmp_path, model, {"EQ": pde, "BC": bc})
-    assert getattr(solver._compiled["BC"], "is_eager", False) and not getattr(solver._compiled["EQ"], "is_eager", False)
+    cc = solver._compiled["BC"]
+    assert cc.specialised_to == ["float(x[0:1])", "lt(x[1:2])"] and not solver._compiled["EQ"].specialised_to
+    assert cc._row_slices == {"u0": 0, "u__x": 1, "u__x__x": 2, "u__x__x__x": 3}
     p0 = model.flat_params.clone()
-    solver.train()  # one Adam step through both paths
+    solver.train()  # one Adam step
     assert torch.isfinite(model.flat_params).all() and not torch.equal(model.flat_params, p0)
     model.flat_params.copy_(p0)
-    solver.engine.forward_backward([solver._compiled["EQ"].fused])
-    solver._compiled["BC"].forward_backward(solver.engine.grad)
+    solver.engine.forward_backward([solver._compiled["EQ"].fused, cc.fused])
     g = solver.engine.grad.cpu().numpy().astype(np.float64)
 
     omodel = R.MLP(("x",), ("u",), net.astype(np.float32).astype(np.float64))
@@ -749,17 +746,33 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path, monkey
     def d1(d): return ograd(d["u"], d["x"])  # noqa: E704
     def d2(d): return ograd(d1(d), d["x"])  # noqa: E704
     def d3(d): return ograd(d2(d), d["x"])  # noqa: E704
+    # the oracle runs the SAME branching code eagerly on tensors
     oc = [dict(name="EQ", input={"x": Xi.astype(np.float64)}, exprs={k: R.lambdify(e, omodel) for k, e in eq.equations.items()},
                label={"biharmonic": np.zeros((32, 1))}, reduction="mean"),
           dict(name="BC", input={"x": Xb.astype(np.float64)},
-               exprs={"u0": lambda d: d["u"][0:1], "u__x": lambda d: d1(d)[1:2], "u__x__x": lambda d: d2(d)[2:3],
+               exprs={"u0": lambda d: d["u"][0:1] if float(d["x"][0]) == 0.0 else d["u"][3:4],
+                      "u__x": lambda d: d1(d)[1:2] if d["x"][1] < 0.5 else d1(d)[2:3], "u__x__x": lambda d: d2(d)[2:3],
                       "u__x__x__x": lambda d: d3(d)[3:4]},
                label={k: np.zeros((4, 1)) for k in bc_exprs}, reduction="sum")]
     total, losses, gref, _ = R.loss_and_grads(omodel, oc)
-    mine = {**solver._compiled["EQ"].fused.losses(), **solver._compiled["BC"].losses()}
+    mine = {**solver._compiled["EQ"].fused.losses(), **cc.fused.losses()}
     for k in losses:
         assert mine[k] == pytest.approx(losses[k], rel=2e-4, abs=1e-9), k
     assert rel(g, gref) < 2e-4
+
+    # a constraint whose batch changes every iteration has no single answer: refused with the reason
+    import ppsci.constraint as C
+    moving = C.SupervisedConstraint(
+        {"dataset": {"name": "NamedArrayDataset", "input": {"x": Xi}, "label": {"u0": np.zeros((32, 1), np.float32)}},
+         "batch_size": 8, "sampler": {"name": "BatchSampler", "shuffle": True, "drop_last": True}},
+        ppsci.loss.MSELoss("mean"), {"u0": bc_exprs["u0"]}, name="MOV")
+    with pytest.raises(NotImplementedError, match="changes every iteration"):
+        _solver(tmp_path, model, {"MOV": moving})
+    # ... and so has a value that depends on the network
+    netdep = _sup_constraint({"x": Xb}, {"u0": np.zeros((4, 1), np.float32)},
+                             {"u0": lambda d: d["u"] if float(d["u"][0]) > 0 else -d["u"]}, ppsci.loss.MSELoss("sum"), name="ND")
+    with pytest.raises(NotImplementedError, match="depends on the network"):
+        _solver(tmp_path, model, {"ND": netdep})
 
 
 @pytest.mark.parametrize("act", ["tanh", "sigmoid"])
@@ -857,7 +870,7 @@ def test_one_row_slices_are_lowered_to_the_fused_kernels(tmp_path, reduction):
     bc = _sup_constraint({"x": Xb}, lab, bc_exprs, ppsci.loss.MSELoss(reduction), weights=wts, name="BC")
     solver = _solver(tmp_path, model, {"BC": bc})
     cc = solver._compiled["BC"]
-    assert not getattr(cc, "is_eager", False) and cc._row_slices == {"u0": 0, "u__x": 1, "u__x__x": 2, "u__x__x__x": 3}
+    assert not cc.specialised_to and cc._row_slices == {"u0": 0, "u__x": 1, "u__x__x": 2, "u__x__x__x": 3}
     solver.engine.forward_backward([cc.fused])
     g = solver.engine.grad.cpu().numpy().astype(np.float64)
     omodel = R.MLP(("x",), ("u",), net.astype(np.float32).astype(np.float64))
