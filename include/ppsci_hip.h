@@ -392,14 +392,40 @@ int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* 
  * [ppsci_pw_conv_wgrad_chunks(B, P)][Co*Ci] and partials_b [chunks][Co] (or NULL); any P >= 1 (16-byte accesses when P is a
  * multiple of 4).  Sum each with
  * ppsci_reduce_rows (fixed order). */
+/* An operand that is a FUNCTION of a stored tensor, evaluated when the kernel loads it instead of being stored by the
+ * producer and read back (the 256-channel hidden tensors of the lifting / projection MLPs are 8 x the size of a block
+ * tensor: at the BASELINE shape 67 MB each):
+ *   mode 0  the tensor itself;
+ *   mode 1  GELU(tensor)                      -- the tensor holds pre-activations;
+ *   mode 2  GELU(W0 x0 + b0), never stored    -- x0 [B, K0, P] with K0 <= 4 input channels (the lifting layer's input),
+ *                                                W0 [C, K0], b0 [C] or NULL; as `zmul`: GELU'(W0 x0 + b0).
+ * ppsci_pw_conv_v / ppsci_pw_conv_wgrad_v: ppsci_pw_conv / ppsci_pw_conv_wgrad with such an `x` (xv; NULL = mode 0;
+ * `x` may be NULL in mode 2) and, for the convolution, such a `zmul` (zv: mode 0 or 2). */
+typedef struct {
+  int32_t mode;
+  int32_t K0;
+  const float* x0;
+  const float* W0;
+  const float* b0;
+} ppsci_pw_virtual;
+int ppsci_pw_conv_v(int B, int Cin, int Cout, int P, const float* x, const ppsci_pw_virtual* xv, const float* W, int transpose,
+                    const float* bias, const float* zmul, const ppsci_pw_virtual* zv, int accumulate, float* out, float* act,
+                    void* stream);
+int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv, const float* gy,
+                          float* partials, float* partials_b, void* stream);
+/* Testing / tuning knob: pixels per lane of ppsci_pw_conv's work items (1, 2 or 4; 0 = chosen from the problem size: fewer
+ * pixels per lane give small problems more waves). */
+void ppsci_set_pw_pixels_per_lane(int npx);
 int64_t ppsci_pw_conv_wgrad_chunks(int B, int P);
 int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials, float* partials_b,
                         void* stream);
 /* Block tail.  forward: u = v + sbias[c]; norm: u = (u - mean_b) rstd_b gamma[c] + beta[c] (statistics over C*P per
  * sample, eps inside the square root); t = u + skip; y = gelu ? GELU(t) : t (y may be NULL).  rows: [B*C*4] floats of
  * scratch, stats: [4*B] floats (kept for the backward).
- * backward: gt = gout * GELU'(t) (the skip branch's gradient), gv = dL/dv, ggamma / gbeta / gsbias = the [C] parameter
- * gradients (each may be NULL). */
+ * backward: gt = (gout + gout2) * GELU'(t) (the skip branch's gradient; gout2 may be NULL -- it saves the caller a
+ * separate addition of two gradient branches), gv = dL/dv, ggamma / gbeta / gsbias = the [C] parameter gradients
+ * (each may be NULL).  The per-sample statistics are finished inside the apply kernels from the row sums (two launches
+ * forward, two backward). */
 /* DomainPadding (/root/reference/ppsci/arch/fno_block.py:19-140) on n planes: unpad == 0 writes src [n, h, w] into
  * dst [n, hp, wp] at offset (oh, ow) with zeros around it; unpad == 1 copies that window of src [n, hp, wp] back into
  * dst [n, h, w].  Each is the other's backward. */
@@ -408,8 +434,8 @@ int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const
                        const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
                        float* y, void* stream);
 int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
-                       const float* t, const float* gout, float* rows, float* stats, float* gt, float* gv, float* ggamma,
-                       float* gbeta, float* gsbias, void* stream);
+                       const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
+                       float* gv, float* ggamma, float* gbeta, float* gsbias, void* stream);
 
 /* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
  * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it

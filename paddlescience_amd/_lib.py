@@ -41,6 +41,11 @@ class SpectralDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "c_in", "c_out", "h", "wf", "modes_x", "modes_y")]
 
 
+class PwVirtual(C.Structure):
+    """ppsci_pw_virtual: an operand evaluated on load (mode 1: GELU(tensor); mode 2: GELU(W0 x0 + b0), never stored)."""
+    _fields_ = [("mode", C.c_int32), ("K0", C.c_int32), ("x0", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p)]
+
+
 class ModMlpDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_hidden", "width", "d_out", "activation")]
 
@@ -142,6 +147,11 @@ _SYMBOLS = {
     "ppsci_fft2d_c2r": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_pw_conv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pw_conv_v": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(PwVirtual), C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.POINTER(PwVirtual), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_pw_conv_wgrad_v": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(PwVirtual), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_set_pw_pixels_per_lane": (None, [C.c_int]),
     "ppsci_pw_conv_wgrad_chunks": (C.c_int64, [C.c_int, C.c_int]),
     "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
@@ -156,7 +166,7 @@ _SYMBOLS = {
                                      C.c_void_p]),
     "ppsci_fno_tail_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_modmlp_param_count": (C.c_int64, [C.POINTER(ModMlpDesc)]),
     "ppsci_modmlp_stash_floats": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
     "ppsci_modmlp_fwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -35,6 +35,10 @@ struct SpecArgs {
                     // 1: out = x . conj(w)^T    (gradient w.r.t. the input spectrum)
   int c0, ntile_b, nblk_n, cin, cout;
   float scale;      // applied to the result (1/(H*W) when the FFTs around the contraction are unscaled hipFFT calls)
+  int zero_fill;    // > 0: that many EXTRA workgroups (behind the mode workgroups) clear every position of `out` that
+                    // no kept mode writes
+  int nmode_wg;     // modes x batch tiles
+  int w_lds;        // weights of the mode staged in LDS
 };
 
 // Kept mode m sits in row c0 + m of the fftshift-ed spectrum (c0 = (H - modes_x) // 2).  The reference shifts the input
@@ -66,41 +70,96 @@ __device__ __forceinline__ float spec_w(const SpecArgs& a, int kk, int jj, int m
   return jj < ci ? a.wi[idx] : a.wr[idx];
 }
 
-__global__ void __launch_bounds__(64) spectral_contract_kernel(SpecArgs a) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  int id = blockIdx.x;
-  const int nb = id % a.nblk_n;
-  id /= a.nblk_n;
-  const int tb = id % a.ntile_b;
-  const int mode = id / a.ntile_b;
+// ONE workgroup (4 waves) per (mode, 16-row batch tile): the mode's operands -- 16 x Cin complex inputs and the Ci x Co
+// complex weights, all of them 4 / 8-byte gathers with strides of a whole plane / the mode count -- are fetched by 256
+// threads at once into LDS (one memory latency; round 3's one-wave-per-column-block kernel paid one per k-step: 12.8 us
+// at the BASELINE shape B 16, 32 -> 32 channels, 84 modes), then wave w runs the MFMA chain of column blocks w, w + 4, ...
+// Weights that do not fit LDS (`w_lds` == 0: more than ~ 90 x 90 channels) are read from global memory per k-step.
+// With `zero_fill` extra workgroups of the same launch clear every position of the output spectrum that no kept mode
+// writes (disjoint from the product stores: no ordering needed) -- no separate clearing launch in front of the
+// contraction, and the clearing overlaps the operand gathers of the mode workgroups.
+// LDS: xs [16][2 Cin + 1] | wrs [Ci][Co + 1] | wis [Ci][Co + 1]   (odd row strides: conflict-free both ways round)
+__device__ __forceinline__ float spec_w_lds(const SpecArgs& a, const float* wrs, const float* wis, int kk, int jj) {
+  const int ci = a.d.c_in, co = a.d.c_out, ld = co + 1;
+  if (!a.conj_t) {
+    const int i = kk < ci ? kk : kk - ci, o = jj < co ? jj : jj - co;
+    const int idx = i * ld + o;
+    if (kk < ci) return jj < co ? wrs[idx] : wis[idx];
+    return jj < co ? -wis[idx] : wrs[idx];
+  }
+  const int o = kk < co ? kk : kk - co, i = jj < ci ? jj : jj - ci;
+  const int idx = i * ld + o;
+  if (kk < co) return jj < ci ? wrs[idx] : -wis[idx];
+  return jj < ci ? wis[idx] : wrs[idx];
+}
+
+__global__ void __launch_bounds__(256) spectral_mode_kernel(SpecArgs a) {
+  PPSCI_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  if ((int)blockIdx.x >= a.nmode_wg) {
+    // clearing workgroups: one [h, wf] plane at a time.  Rows that some kept mode writes: ((r - c0 - shift) mod h) <
+    // modes_x with the shift of r_dst below; columns my < modes_y.  Disjoint from the product stores: no ordering needed.
+    const int shift = a.conj_t ? a.d.h - a.d.h / 2 : a.d.h / 2;
+    const int nplane = a.d.batch * a.cout, per = a.d.h * a.d.wf;
+    for (int pl = (int)blockIdx.x - a.nmode_wg; pl < nplane; pl += a.zero_fill) {
+      float* o = a.out + (long long)pl * per * 2;
+      for (int e = tid; e < per; e += 256) {
+        const int r = e / a.d.wf, col = e - r * a.d.wf;
+        const int rel = ((r - a.c0 - shift) % a.d.h + a.d.h) % a.d.h;
+        if (col < a.d.modes_y && rel < a.d.modes_x) continue;
+        o[2 * e] = 0.f;
+        o[2 * e + 1] = 0.f;
+      }
+    }
+    return;
+  }
+  const int tb = (int)blockIdx.x % a.ntile_b, mode = (int)blockIdx.x / a.ntile_b;
   const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
-  // forward: reads the input rows, writes the output rows; data gradient (conj_t): the other way round
   const int r_src = a.conj_t ? spec_row_out(a.d, a.c0, mx) : spec_row_in(a.d, a.c0, mx);
   const int r_dst = a.conj_t ? spec_row_in(a.d, a.c0, mx) : spec_row_out(a.d, a.c0, mx);
   const long long plane = (long long)a.d.h * a.d.wf * 2;
   const long long pix = ((long long)r_src * a.d.wf + my) * 2, pix_dst = ((long long)r_dst * a.d.wf + my) * 2;
-  const int K = 2 * a.cin;
-  const int brow = tb * 16 + c;       // A operand row (batch index) for this lane
-  const bool bok = brow < a.d.batch;
-  const int jj = nb * 16 + c;         // B operand column for this lane
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const int kk = k0 + g;  // this lane's k index for A[i=c][k=g] and B[k=g][j=c]
-    float av = 0.f, bv = 0.f;
-    if (kk < K) {
-      const int ch = kk < a.cin ? kk : kk - a.cin, part = kk < a.cin ? 0 : 1;
-      if (bok) av = a.x[((long long)brow * a.cin + ch) * plane + pix + part];
-      if (jj < 2 * a.cout) bv = spec_w(a, kk, jj, mode);
+  const int K = 2 * a.cin, ldx = K + 1, ci = a.d.c_in, co = a.d.c_out, ldw = co + 1;
+  float* xs = smem;
+  float* wrs = xs + 16 * ldx;
+  float* wis = wrs + ci * ldw;
+  for (int idx = tid; idx < 16 * a.cin; idx += 256) {
+    const int row = idx / a.cin, ch = idx - row * a.cin, b = tb * 16 + row;
+    float re = 0.f, im = 0.f;
+    if (b < a.d.batch) {
+      const float* src = &a.x[((long long)b * a.cin + ch) * plane + pix];
+      re = src[0];
+      im = src[1];
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    xs[row * ldx + ch] = re;
+    xs[row * ldx + a.cin + ch] = im;
   }
-  // D[row = 4g + rr][col = c]: batch row, expanded output column
-  if (jj < 2 * a.cout) {
-    const int ch = jj < a.cout ? jj : jj - a.cout, part = jj < a.cout ? 0 : 1;
+  const long long ms = (long long)a.d.modes_x * a.d.modes_y;
+  for (int idx = tid; a.w_lds && idx < ci * co; idx += 256) {
+    const int i = idx / co, o = idx - i * co;
+    wrs[i * ldw + o] = a.wr[(long long)idx * ms + mode];
+    wis[i * ldw + o] = a.wi[(long long)idx * ms + mode];
+  }
+  __syncthreads();
+  for (int nb = wave; nb < a.nblk_n; nb += 4) {
+    const int jj = nb * 16 + c;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int kk = k0 + g;
+      float av = 0.f, bv = 0.f;
+      if (kk < K) {
+        av = xs[c * ldx + kk];
+        if (jj < 2 * a.cout) bv = a.w_lds ? spec_w_lds(a, wrs, wis, kk, jj) : spec_w(a, kk, jj, mode);
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (jj < 2 * a.cout) {
+      const int ch = jj < a.cout ? jj : jj - a.cout, part = jj < a.cout ? 0 : 1;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int b = tb * 16 + 4 * g + rr;
-      if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix_dst + part] = acc[rr] * a.scale;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int b = tb * 16 + 4 * g + rr;
+        if (b < a.d.batch) a.out[((long long)b * a.cout + ch) * plane + pix_dst + part] = acc[rr] * a.scale;
+      }
     }
   }
 }
@@ -157,7 +216,7 @@ static int spec_check(const ppsci_spectral_desc* d, int* c0) {
 }
 
 static int launch_contract(const ppsci_spectral_desc* d, const float* x, const float* wr, const float* wi, float* out,
-                           int conj_t, void* stream, float scale = 1.f) {
+                           int conj_t, void* stream, float scale = 1.f, int zero_fill = 0) {
   SpecArgs a;
   memset(&a, 0, sizeof(a));
   int rc = spec_check(d, &a.c0);
@@ -173,8 +232,24 @@ static int launch_contract(const ppsci_spectral_desc* d, const float* x, const f
   a.cout = conj_t ? d->c_in : d->c_out;
   a.ntile_b = (d->batch + 15) / 16;
   a.nblk_n = (2 * a.cout + 15) / 16;
-  const int grid = d->modes_x * d->modes_y * a.ntile_b * a.nblk_n;
-  PPSCI_LAUNCH(spectral_contract_kernel, SpecArgs, grid, 64, 0, stream, a);
+  a.nmode_wg = d->modes_x * d->modes_y * a.ntile_b;
+  if (zero_fill) {
+    const long long nplane = (long long)d->batch * a.cout;
+    a.zero_fill = (int)(nplane < 4096 ? nplane : 4096);
+  }
+  const long long lds_x = 16LL * (2 * a.cin + 1) * 4, lds_w = 2LL * d->c_in * (d->c_out + 1) * 4;
+  if (lds_x > 64 * 1024) {
+    ppsci_set_error("spectral_conv: %d channels: one batch tile of a mode does not fit LDS", a.cin);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  a.w_lds = lds_x + lds_w <= 64 * 1024 ? 1 : 0;
+  const long long lds = lds_x + (a.w_lds ? lds_w : 0);
+  const int grid = a.nmode_wg + a.zero_fill;
+  if (PPSCI_SET_MAX_LDS(spectral_mode_kernel, (int)lds) != 0) {
+    ppsci_set_error("spectral_conv: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  PPSCI_LAUNCH(spectral_mode_kernel, SpecArgs, grid, 256, (int)lds, stream, a);
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) {
     ppsci_set_error("spectral_conv: launch failed (hip error %d)", e);
@@ -194,32 +269,13 @@ extern "C" int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const flo
 
 static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                         const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
-                        void* stream, float xscale = 1.f);
+                        void* stream, float xscale = 1.f, int zero_fill = 0);
 
-// Clears n floats (n % 2 == 0: complex spectra) with a plain kernel.  Not hipMemsetAsync: as a node of a captured HIP graph
-// the runtime's fill path made every replay of the TFNO step host-bound at 3.5 ms (device time 0.98 ms) once the process
-// had returned memory to the driver (measured on MI355X / ROCm 7.0.2: bench.py's cfg 4 entry after the 1 M-point run).
-struct ZeroArgs {
-  float* p;
-  long long n;
-};
-__global__ void __launch_bounds__(256) spectral_zero_kernel(ZeroArgs a) {
-  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; i < a.n; i += (long long)gridDim.x * 512) {
-    a.p[i] = 0.f;
-    a.p[i + 1] = 0.f;
-  }
-}
-static int spectral_zero(float* p, long long n, void* stream) {
-  ZeroArgs a{p, n};
-  long long grid = (n / 2 + 255) / 256;
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
-  PPSCI_LAUNCH(spectral_zero_kernel, ZeroArgs, (int)grid, 256, 0, stream, a);
-  return PPSCI_LAST_LAUNCH_ERROR() != 0 ? PPSCI_E_LAUNCH : PPSCI_OK;
-}
-
-// out_ft = scale * (x_ft . w) on the kept modes, after clearing the WHOLE output spectrum (`zero_fill` != 0): for callers
-// whose inverse transform destroys its input (hipFFT C2R, ppsci_fft2d_c2r) or that hand over uninitialised memory.
+// out_ft = scale * (x_ft . w) on the kept modes; `zero_fill` != 0: every other position of the output spectrum is cleared
+// by the same launch -- for callers whose inverse transform destroys its input (hipFFT C2R, ppsci_fft2d_c2r) or that hand
+// over uninitialised memory.  (Cleared by kernel stores, not hipMemsetAsync: as a node of a captured HIP graph the
+// runtime's fill path made every replay of the TFNO step host-bound at 3.5 ms once the process had returned memory to
+// the driver -- measured on MI355X / ROCm 7.0.2.)
 extern "C" int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
                                                 const float* w_im, float* out_ft, float scale, int zero_fill,
                                                 void* stream) {
@@ -227,11 +283,7 @@ extern "C" int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, co
     ppsci_set_error("spectral_conv2d_fwd_scaled: null pointer");
     return PPSCI_E_INVALID;
   }
-  if (zero_fill && spectral_zero(out_ft, (long long)d->batch * d->c_out * d->h * d->wf * 2, stream) != PPSCI_OK) {
-    ppsci_set_error("spectral_conv2d_fwd_scaled: clearing the spectrum failed");
-    return PPSCI_E_LAUNCH;
-  }
-  return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream, scale);
+  return launch_contract(d, x_ft, w_re, w_im, out_ft, 0, stream, scale, zero_fill ? 1 : 0);
 }
 
 // ppsci_spectral_conv2d_bwd_real with the input-spectrum gradient scaled by `xscale` and its buffer cleared first
@@ -243,11 +295,7 @@ extern "C" int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* 
     ppsci_set_error("spectral_conv2d_bwd_real_scaled: invalid argument");
     return PPSCI_E_INVALID;
   }
-  if (zero_fill && spectral_zero(gx_ft, (long long)d->batch * d->c_in * d->h * d->wf * 2, stream) != PPSCI_OK) {
-    ppsci_set_error("spectral_conv2d_bwd_real_scaled: clearing the spectrum failed");
-    return PPSCI_E_LAUNCH;
-  }
-  return spectral_bwd(d, x_ft, w_re, w_im, ghat_ft, gx_ft, gw_re, gw_im, wscale, w_full, stream, xscale);
+  return spectral_bwd(d, x_ft, w_re, w_im, ghat_ft, gx_ft, gw_re, gw_im, wscale, w_full, stream, xscale, zero_fill ? 1 : 0);
 }
 
 extern "C" int ppsci_spectral_conv2d_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
@@ -274,13 +322,13 @@ extern "C" int ppsci_spectral_conv2d_bwd_real(const ppsci_spectral_desc* d, cons
 
 static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                         const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
-                        void* stream, float xscale) {
+                        void* stream, float xscale, int zero_fill) {
   if (!x_ft || !w_re || !w_im || !gout_ft) {
     ppsci_set_error("spectral_conv2d_bwd: null pointer");
     return PPSCI_E_INVALID;
   }
   if (gx_ft) {
-    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale);
+    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale, zero_fill);
     if (rc != PPSCI_OK) return rc;
   }
   if (gw_re && gw_im) {

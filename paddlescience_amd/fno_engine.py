@@ -42,9 +42,20 @@ def supports(model) -> Optional[str]:
     return None
 
 
-def _pw_conv(B, cin, cout, P, x, W, out, bias=None, zmul=None, act=None, transpose=False, accumulate=False):
-    L.check(L.lib().ppsci_pw_conv(B, cin, cout, P, _p(x), _p(W), 1 if transpose else 0, _p(bias), _p(zmul),
-                                  1 if accumulate else 0, _p(out), _p(act), _stream_ptr(out)))
+def _pw_conv(B, cin, cout, P, x, W, out, bias=None, zmul=None, act=None, transpose=False, accumulate=False, xv=None, zv=None):
+    """xv / zv: L.PwVirtual -- x / zmul as functions of a stored tensor, evaluated on load (include/ppsci_hip.h)."""
+    L.check(L.lib().ppsci_pw_conv_v(B, cin, cout, P, _p(x), C.byref(xv) if xv is not None else None, _p(W),
+                                    1 if transpose else 0, _p(bias), _p(zmul), C.byref(zv) if zv is not None else None,
+                                    1 if accumulate else 0, _p(out), _p(act), _stream_ptr(out)))
+
+
+def _virtual(mode, x0=None, W0=None, b0=None):
+    v = L.PwVirtual()
+    v.mode = mode
+    if mode == 2:
+        v.K0 = W0.shape[1]
+        v.x0, v.W0, v.b0 = x0.data_ptr(), W0.data_ptr(), (b0.data_ptr() if b0 is not None else None)
+    return v
 
 
 class FnoNative:
@@ -73,7 +84,11 @@ class FnoNative:
         lift, proj = m.lifting.fcs, m.projection.fcs
         self.c_lift = lift[0].out_channels if len(lift) == 2 else 0
         self.c_proj = proj[0].out_channels
-        if self.c_lift:
+        # The hidden tensors of the two channel MLPs are 8 x a block tensor (256 channels): the lifting layer's
+        # GELU(W1 x + b1) is recomputed from its <= 4 input channels wherever it is an operand (never stored); of the
+        # projection's only the pre-activation z2 is stored, GELU(z2) is applied on load
+        self.lift_virtual = bool(self.c_lift) and m.in_channels <= 4
+        if self.c_lift and not self.lift_virtual:
             self.z1, self.a1 = torch.empty((B, self.c_lift, P0), **f), torch.empty((B, self.c_lift, P0), **f)
         if self.padded:
             self.x0u = torch.empty((B, Ch, P0), **f)   # lifting output before padding
@@ -94,7 +109,8 @@ class FnoNative:
         self.gsp = torch.empty((B, Ch, P), **f)
         self.rows = torch.empty(B * Ch * 4, **f)
         self.stats = [torch.empty(4 * B, **f) for _ in range(nl)]
-        self.z2, self.a2 = torch.empty((B, self.c_proj, P0), **f), torch.empty((B, self.c_proj, P0), **f)
+        self.z2 = torch.empty((B, self.c_proj, P0), **f)
+        self.gelu_on_load = _virtual(1)
         self.y = torch.empty((B, m.out_channels, P0), **f)
         # backward scratch
         cmax = max(Ch, self.c_lift, self.c_proj)
@@ -130,7 +146,10 @@ class FnoNative:
         self.x_in = x.contiguous().view(B, m.in_channels, P0)
         lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
         x0 = self.x0u if self.padded else self.x[0]
-        if self.c_lift:
+        if self.lift_virtual:
+            self.a1_virtual = _virtual(2, self.x_in, lift[0].weight, lift[0].bias)
+            _pw_conv(B, self.c_lift, Ch, P0, None, lift[1].weight, x0, bias=lift[1].bias, xv=self.a1_virtual)
+        elif self.c_lift:
             _pw_conv(B, m.in_channels, self.c_lift, P0, self.x_in, lift[0].weight, self.z1, bias=lift[0].bias, act=self.a1)
             _pw_conv(B, self.c_lift, Ch, P0, self.a1, lift[1].weight, x0, bias=lift[1].bias)
         else:
@@ -166,14 +185,15 @@ class FnoNative:
             self._pad(xo, self.xou, True)
             xo = self.xou
         self.xo = xo
-        _pw_conv(B, Ch, self.c_proj, P0, xo, proj[0].weight, self.z2, bias=proj[0].bias, act=self.a2)
-        _pw_conv(B, self.c_proj, m.out_channels, P0, self.a2, proj[1].weight, self.y, bias=proj[1].bias)
+        _pw_conv(B, Ch, self.c_proj, P0, xo, proj[0].weight, self.z2, bias=proj[0].bias)
+        _pw_conv(B, self.c_proj, m.out_channels, P0, self.z2, proj[1].weight, self.y, bias=proj[1].bias, xv=self.gelu_on_load)
         return self.y.view(B, m.out_channels, H0, W0)
 
     # ------------------------------------------------------------------ backward
-    def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param) -> None:
-        L.check(L.lib().ppsci_pw_conv_wgrad(B, ci, co, P, _p(x), _p(gy), _p(self.part_w),
-                                            _p(self.part_b) if b_param is not None else None, _stream_ptr(gy)))
+    def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param, xv=None) -> None:
+        L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
+                                              _p(self.part_w), _p(self.part_b) if b_param is not None else None,
+                                              _stream_ptr(gy)))
         chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))  # (P differs between the padded blocks and lifting / projection)
         hp.reduce_rows(self.part_w, chunks, co * ci, w_param.grad.view(-1), False)
         if b_param is not None:
@@ -189,7 +209,7 @@ class FnoNative:
         gy = gy.contiguous().view(B, m.out_channels, P0)
         st = _stream_ptr(self.y)
         # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
-        self._wgrad(B, self.c_proj, m.out_channels, P0, self.a2, gy, proj[1].weight, proj[1].bias)
+        self._wgrad(B, self.c_proj, m.out_channels, P0, self.z2, gy, proj[1].weight, proj[1].bias, xv=self.gelu_on_load)
         gz2 = self.ga.view(-1)[:B * self.c_proj * P0].view(B, self.c_proj, P0)
         _pw_conv(B, m.out_channels, self.c_proj, P0, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
         self._wgrad(B, Ch, self.c_proj, P0, self.xo, gz2, proj[0].weight, proj[0].bias)
@@ -203,13 +223,14 @@ class FnoNative:
             gnext = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)
         else:
             _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
+        gx2 = None  # a second addend of dL/d(block output): the spectral branch's share, added by the consumer on load
         for l in range(nl - 1, -1, -1):
             conv, skip = fb.convs[l], fb.fno_skips[l]
             nrm = fb.norm[l] if fb.norm is not None else None
             last = l == nl - 1
             L.check(L.lib().ppsci_fno_tail_bwd(
                 B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
-                _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(self.rows), _p(self.stats[l]),
+                _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows), _p(self.stats[l]),
                 _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
                 _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
             # skip branch: s = Wskip x_l  (identity: the gradient passes straight through)
@@ -226,6 +247,9 @@ class FnoNative:
             L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
             if self.stab:  # gnext += gsp * (1 - tanh(x_l)^2)
                 L.check(L.lib().ppsci_tanh_bwd(B * Ch * P, _p(self.xs[l]), _p(self.gsp), _p(gnext), 1, st))
+                gx2 = None
+            elif l > 0:
+                gx2 = self.gsp  # dL/dx_l = gnext + gsp: the next block tail adds them on load (gsp is rewritten after it)
             else:
                 hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
             gx, gnext = gnext, gx
@@ -234,10 +258,14 @@ class FnoNative:
             self._pad(gx, self.x0u, True)
             gx = self.x0u
         if self.c_lift:
-            self._wgrad(B, self.c_lift, Ch, P0, self.a1, gx, lift[1].weight, lift[1].bias)
             gz1 = self.gb if gx.data_ptr() != self.gb.data_ptr() else self.ga
             gz1 = gz1.view(-1)[:B * self.c_lift * P0].view(B, self.c_lift, P0)
-            _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
+            if self.lift_virtual:
+                self._wgrad(B, self.c_lift, Ch, P0, None, gx, lift[1].weight, lift[1].bias, xv=self.a1_virtual)
+                _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, transpose=True, zv=self.a1_virtual)
+            else:
+                self._wgrad(B, self.c_lift, Ch, P0, self.a1, gx, lift[1].weight, lift[1].bias)
+                _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
             self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
         else:
             self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)

@@ -124,7 +124,8 @@ def test_native_path_on_plane_sizes_that_are_not_multiples_of_16(dev, hw, pad):
 
 @pytest.mark.parametrize("shape", [(2, 5, 37, 48), (3, 256, 256, 80), (2, 200, 176, 64), (1, 64, 1, 32), (2, 36, 260, 16),
                                    (2, 5, 37, 75), (1, 40, 24, 100), (1, 33, 17, 301)])
-def test_pw_conv_and_tail_kernels_known_answers(dev, shape):
+@pytest.mark.parametrize("npx", [0, 1, 2, 4])
+def test_pw_conv_and_tail_kernels_known_answers(dev, shape, npx):
     """(B, Ci, Co, P): small ragged channels (scalar weight staging), 256 x 256 (two output-channel slabs, 16-byte staging,
     2 x 2 weight-gradient tiles), channel counts that are not multiples of 16 on the vector path, one output channel, more
     output channels than one slab with a ragged tail; plane sizes that are odd (75, 301: two weight-gradient chunks) or a
@@ -137,6 +138,9 @@ def test_pw_conv_and_tail_kernels_known_answers(dev, shape):
     d = device.get_device()
     rng = np.random.default_rng(1)
     B, Ci, Co, P = shape
+    if dev != "gpu" and npx in (1, 2) and Ci * Co > 20000:
+        pytest.skip("covered at the other sizes (emulator time)")
+    L.lib().ppsci_set_pw_pixels_per_lane(npx)  # work items of 16 npx pixels (0: chosen from the problem size)
     x = torch.as_tensor(rng.standard_normal((B, Ci, P)).astype(np.float32)).to(d)
     W = torch.as_tensor(rng.standard_normal((Co, Ci)).astype(np.float32)).to(d)
     b = torch.as_tensor(rng.standard_normal(Co).astype(np.float32)).to(d)
@@ -165,3 +169,55 @@ def test_pw_conv_and_tail_kernels_known_answers(dev, shape):
     hp.reduce_rows(pb, chunks, Co, gb, False)
     assert rel(gW.cpu().numpy().reshape(Co, Ci), torch.einsum("bop,bip->oi", gy.double(), x.double()).cpu().numpy()) < 1e-6
     assert rel(gb.cpu().numpy(), gy.double().sum((0, 2)).cpu().numpy()) < 1e-6
+    L.lib().ppsci_set_pw_pixels_per_lane(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 40, 24, 100), (1, 4, 256, 32, 77), (2, 2, 33, 17, 64)])
+def test_pw_conv_operands_evaluated_on_load(dev, shape):
+    """ppsci_pw_virtual (B, K0, hidden C, Co, P): a 1x1 convolution / weight gradient whose input is GELU(z) of a stored
+    pre-activation z (mode 1) or GELU(W0 x0 + b0) of the K0 <= 4 channel tensor x0, never stored (mode 2), and a data
+    gradient multiplied by GELU'(W0 x0 + b0) -- against the same calls on the materialised tensors."""
+    import ctypes as C
+
+    from paddlescience_amd import _lib as L
+    from paddlescience_amd import device, hotpath as hp
+    from paddlescience_amd.fno_engine import _virtual
+
+    d = device.get_device()
+    rng = np.random.default_rng(4)
+    B, K0, Ch, Co, P = shape
+    t = lambda *sh: torch.as_tensor(rng.standard_normal(sh).astype(np.float32)).to(d)  # noqa: E731
+    x0, W0, b0, W, bias, gy = t(B, K0, P), t(Ch, K0), t(Ch), t(Co, Ch), t(Co), t(B, Co, P)
+    p = lambda v: None if v is None else C.c_void_p(v.data_ptr())  # noqa: E731
+    lib = L.lib()
+    # materialised: z = W0 x0 + b0, a = GELU(z)
+    z = torch.empty((B, Ch, P), device=d)
+    a = torch.empty((B, Ch, P), device=d)
+    L.check(lib.ppsci_pw_conv(B, K0, Ch, P, p(x0), p(W0), 0, p(b0), None, 0, p(z), p(a), None))
+    ref = torch.empty((B, Co, P), device=d)
+    L.check(lib.ppsci_pw_conv(B, Ch, Co, P, p(a), p(W), 0, p(bias), None, 0, p(ref), None, None))
+    v1, v2 = _virtual(1), _virtual(2, x0, W0, b0)
+    for x, xv in ((z, v1), (None, v2)):
+        out = torch.full((B, Co, P), float("nan"), device=d)
+        L.check(lib.ppsci_pw_conv_v(B, Ch, Co, P, p(x), C.byref(xv), p(W), 0, p(bias), None, None, 0, p(out), None, None))
+        assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    # data gradient x GELU'(z): zmul = z against the virtual zmul
+    gref = torch.empty((B, Ch, P), device=d)
+    L.check(lib.ppsci_pw_conv(B, Co, Ch, P, p(gy), p(W), 1, None, p(z), 0, p(gref), None, None))
+    gout = torch.full((B, Ch, P), float("nan"), device=d)
+    L.check(lib.ppsci_pw_conv_v(B, Co, Ch, P, p(gy), None, p(W), 1, None, None, C.byref(v2), 0, p(gout), None, None))
+    assert rel(gout.cpu().numpy(), gref.cpu().numpy()) < 1e-6
+    # weight gradient with x = a
+    chunks = int(lib.ppsci_pw_conv_wgrad_chunks(B, P))
+    res = []
+    for x, xv in ((a, None), (z, v1), (None, v2)):
+        pw = torch.full((chunks * Co * Ch,), float("nan"), device=d)
+        pb = torch.full((chunks * Co,), float("nan"), device=d)
+        L.check(lib.ppsci_pw_conv_wgrad_v(B, Ch, Co, P, p(x), C.byref(xv) if xv is not None else None, p(gy), p(pw), p(pb), None))
+        gW, gb = torch.zeros(Co * Ch, device=d), torch.zeros(Co, device=d)
+        hp.reduce_rows(pw, chunks, Co * Ch, gW, False)
+        hp.reduce_rows(pb, chunks, Co, gb, False)
+        res.append((gW.cpu().numpy(), gb.cpu().numpy()))
+    for gW, gb in res[1:]:
+        assert rel(gW, res[0][0]) < 1e-6 and rel(gb, res[0][1]) < 1e-6
+

@@ -17,12 +17,28 @@ model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_chan
 x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
 y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, H, W)).astype(np.float32)).cuda()
 opt = ppsci.optimizer.Adam(1e-3)(model)
-cst = OperatorConstraint("Sup", model, {"y": lambda d: d["y"]}, ppsci.loss.FunctionalLoss(
-    lambda o, l, w=None: {"y": ((o["y"] - l["y"]) ** 2).mean()}), x.device, ["y"], B)
+cst = OperatorConstraint("Sup", model, {"y": lambda d: d["y"]}, ppsci.loss.MSELoss("mean"), x.device, ["y"], B)
 cst.bind({"x": x}, {"y": y})
 eng = OperatorEngine(model)
-for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
+
+
+def step():
     eng.forward_backward([cst])
     opt.step(model.flat_grad)
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+if os.environ.get("PPSCI_PW_NPX"):  # tuning: pixels per lane of the 1x1 convolutions (default: chosen per call)
+    from paddlescience_amd import _lib as L
+
+    L.lib().ppsci_set_pw_pixels_per_lane(int(os.environ["PPSCI_PW_NPX"]))
+for i in range(n):
+    step()
 torch.cuda.synchronize()
-print("native:", eng.native is not None, "loss", cst.losses())
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(n):
+    step()
+e1.record()
+torch.cuda.synchronize()
+print("native:", eng.native is not None, "loss", cst.losses(), "ms_per_step_hip_events", e0.elapsed_time(e1) / n)
