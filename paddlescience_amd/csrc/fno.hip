@@ -151,13 +151,22 @@ __device__ __forceinline__ f32x4 pw_virtual(f32x4 w0, float bk, const f32x4 (&x0
 }
 
 // the B operand of channel k (< Cin, else zero) at this lane's 4 pixels
-template <int N>
+// VM (compile time, so that the plain convolution's load loop has no branches): 0 plain operands, 1 x = GELU(stored),
+// 2 x = GELU(W0 x0 + b0), 3 zmul = GELU'(W0 x0 + b0)
+template <int N, int VM>
 __device__ __forceinline__ f32x4 pw_bop(const PwArgs& a, const float* xb, int k, int p0, bool al, const f32x4 (&x0q)[4],
                                         const f32x4* w0t, const float* b0t) {
-  if (k >= a.Cin) return (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (a.xmode == 2) return pw_virtual<N>(w0t[k], b0t[k], x0q, false);
-  f32x4 v = fno_ldn<N>(xb + (long long)k * a.P, p0, a.P, al);
-  if (a.xmode == 1) {
+  if constexpr (VM == 2) return k < a.Cin ? pw_virtual<N>(w0t[k], b0t[k], x0q, false) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 v;
+  if constexpr (N == 4) {
+    // (one select per load on flags computed once per item: the compiler keeps the eight loads of a k-step together)
+    const bool pok = al && p0 + 3 < a.P;
+    if (al) v = (pok && k < a.Cin) ? *(const f32x4*)&xb[(long long)k * a.P + p0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    else v = k < a.Cin ? fno_ld4(xb + (long long)k * a.P, p0, a.P, false) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else {
+    v = k < a.Cin ? fno_ldn<N>(xb + (long long)k * a.P, p0, a.P, al) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (VM == 1) {
 #pragma unroll
     for (int t = 0; t < N; ++t) v[t] = fno_gelu(v[t]);
   }
@@ -169,7 +178,7 @@ __device__ __forceinline__ f32x4 pw_bop(const PwArgs& a, const float* xb, int k,
                      // one wave's MFMA chains cover the other's operand waits
 #define PW_STAGE 16  // weight float4s in flight per thread while staging
 
-template <int PW_OC, int PW_WAVES, int NPX>
+template <int PW_OC, int PW_WAVES, int NPX, int VM, bool AL>
 __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
   PPSCI_DYN_SMEM(smem);  // weight fragments: [(ob * kq + q) * 64 + lane] float4
   // several output-channel slabs in one launch: neighbouring workgroups take different slabs, so that the weight stage
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
   // virtual operands: rows of W0 (zero padded to 4) and b0 behind the weight fragments
   f32x4* w0t = (f32x4*)(smem + a.vt_off);
   float* b0t = (float*)(w0t + a.vrows);
-  for (int k = tid; k < a.vrows; k += (int)blockDim.x) {
+  for (int k = tid; VM >= 2 && k < a.vrows; k += (int)blockDim.x) {
     f32x4 w = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -303,13 +312,13 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
     const int ob0 = (int)(item - ch * ngrp) * PW_OC;
     const int b = (int)(ch / chunks_per_b);
     const int p0 = (int)(ch - (long long)b * chunks_per_b) * CH + NPX * c;  // this lane's NPX pixels
-    const bool al = (a.P % NPX) == 0;  // one 4 NPX-byte access (all pixels or none); see fno_ld4
+    constexpr bool al = AL;  // P a multiple of NPX: one 4 NPX-byte access (all pixels or none); see fno_ld4
     const float* xb = a.x + (long long)b * a.Cin * a.P;
     f32x4 x0q[4];  // rows of x0 at this lane's pixels (virtual operands)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      x0q[i] = ((a.xmode == 2 || a.zmode == 2) && i < a.K0) ? fno_ldn<NPX>(a.x0 + ((long long)b * a.K0 + i) * a.P, p0, a.P, al)
-                                                             : (f32x4){0.f, 0.f, 0.f, 0.f};
+      x0q[i] = (VM >= 2 && i < a.K0) ? fno_ldn<NPX>(a.x0 + ((long long)b * a.K0 + i) * a.P, p0, a.P, al)
+                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       f32x4 acc[PW_OC][4];
 #pragma unroll
@@ -326,7 +335,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 8 * g + j;
-          xn[j] = pw_bop<NPX>(a, xb, k, p0, al, x0q, w0t, b0t);
+          xn[j] = pw_bop<NPX, VM>(a, xb, k, p0, al, x0q, w0t, b0t);
         }
         for (int q2 = 0; q2 < kq2; ++q2) {
           u32x4 bp[4][3];  // [tile][plane]
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const int k = 32 * (q2 + 1) + 8 * g + j;
-              xn[j] = pw_bop<NPX>(a, xb, k, p0, al, x0q, w0t, b0t);
+              xn[j] = pw_bop<NPX, VM>(a, xb, k, p0, al, x0q, w0t, b0t);
             }
           }
 #pragma unroll
@@ -362,7 +371,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 4 * r + g;
-        xn[r] = pw_bop<NPX>(a, xb, k, p0, al, x0q, w0t, b0t);
+        xn[r] = pw_bop<NPX, VM>(a, xb, k, p0, al, x0q, w0t, b0t);
       }
       for (int q = 0; q < a.kq; ++q) {
         f32x4 xv[4];
@@ -372,7 +381,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int k = 16 * (q + 1) + 4 * r + g;
-            xn[r] = pw_bop<NPX>(a, xb, k, p0, al, x0q, w0t, b0t);
+            xn[r] = pw_bop<NPX, VM>(a, xb, k, p0, al, x0q, w0t, b0t);
           }
         }
 #pragma unroll
@@ -398,7 +407,7 @@ __global__ void __launch_bounds__(64 * PW_WAVES, 2) pw_conv_kernel(PwArgs a) {
           const long long off = ((long long)b * a.CoutT + a.co0 + o) * a.P;  // this row
           f32x4 v = (f32x4){acc[j][0][rr], acc[j][1][rr], acc[j][2][rr], acc[j][3][rr]};
           if (a.bias) v += a.bias[a.co0 + o];
-          if (a.zmode == 2) {
+          if constexpr (VM == 3) {
             v *= pw_virtual<NPX>(w0t[a.co0 + o], b0t[a.co0 + o], x0q, true);
           } else if (a.zmul) {
             const f32x4 z = fno_ldn<NPX>(a.zmul + off, p0, a.P, al);
@@ -456,8 +465,8 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
     ppsci_set_error("pw_conv: invalid argument");
     return PPSCI_E_INVALID;
   }
-  if (xmode == 2 && zmode == 2 && (xv->x0 != zv->x0 || xv->W0 != zv->W0 || xv->b0 != zv->b0 || xv->K0 != zv->K0)) {
-    ppsci_set_error("pw_conv: two different virtual operands in one call");
+  if (xmode != 0 && zmode == 2) {
+    ppsci_set_error("pw_conv: a virtual zmul together with a virtual / GELU x operand has no kernel instance");
     return PPSCI_E_UNSUPPORTED;
   }
   PwArgs a;
@@ -511,18 +520,23 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
   const bool wide = resident == 1;
   // (XDL: a work item always takes 4 output blocks, so that one split of the B operand feeds 96 MFMAs)
   const int oc = (wide && !PPSCI_XDL) ? 2 : 4, waves = wide ? 8 : 4;
-  // pixels per lane (work item = 16 npx pixels): 4 (16-byte accesses) when that already gives every SIMD several waves;
-  // 2 or 1 for small problems -- a 16 x 64 x 64 FNO batch is 1024 items of 64 pixels, i.e. ONE wave per SIMD with nothing
-  // to cover its load -> split -> MFMA -> store chain (measured: 32 -> 32 channels 14 us at npx 4)
+  // pixels per lane (work item = 16 npx pixels): 4 (16-byte accesses) unless that leaves most CUs without a single wave.
+  // Measured on the 16 x 64 x 64 TFNO step (1024 items of 64 pixels = one wave per SIMD): forcing 2 or 1 pixels per lane
+  // for 2 / 4 waves per SIMD made the step SLOWER (0.844 ms at 4, 0.854 at 2, 0.890 at 1): the kernels are bound by
+  // their memory instructions per pixel, not by the latency of one wave's chain.
   const long long groups = (nob_slab + oc - 1) / oc;
-  const long long want = 4LL * 4 * PPSCI_NUM_CU;  // four waves per SIMD
+  const long long want = PPSCI_NUM_CU;
   int npx = g_pw_npx;
-  if (npx != 1 && npx != 2 && npx != 4 && (xmode == 2 || zmode == 2)) {
-    npx = 4;  // bound by the GELU evaluations per loaded element, not by latency (measured: 50 us at 4, 63 us at 1)
+  const int vm = zmode == 2 ? 3 : xmode;
+  if (vm != 0) {
+    npx = 4;  // (the operand-evaluating instances exist for 4 pixels per lane only)
   } else if (npx != 1 && npx != 2 && npx != 4) {
     npx = 4;
     while (npx > 1 && (long long)B * ((P + 16 * npx - 1) / (16 * npx)) * groups * nslab < want) npx >>= 1;
   }
+  // rows of P pixels start on 4 npx-byte boundaries: the aligned instances; otherwise element accesses, 4 pixels per lane
+  const bool aligned = (P % npx) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (!aligned) npx = 4;
   const long long nchunk = (long long)B * ((P + 16 * npx - 1) / (16 * npx));
   const long long nitem = nchunk * groups;  // per slab
   long long wg_slab = (nitem + waves - 1) / waves;
@@ -530,21 +544,32 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
   if (wg_slab > cap) wg_slab = cap;
   const long long grid = wg_slab * nslab;
   int se = 0;
-#define PW_LAUNCH(OC, WV, NPX)                                                                               \
-  do {                                                                                                       \
-    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<OC, WV, NPX>), (int)lds);                                         \
-    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<OC, WV, NPX>), PwArgs, (int)grid, 64 * WV, (int)lds, stream, a); \
+#define PW_LAUNCH(OC, WV, NPX, VM, AL)                                                                               \
+  do {                                                                                                               \
+    se = PPSCI_SET_MAX_LDS((pw_conv_kernel<OC, WV, NPX, VM, AL>), (int)lds);                                         \
+    if (se == 0) PPSCI_LAUNCH((pw_conv_kernel<OC, WV, NPX, VM, AL>), PwArgs, (int)grid, 64 * WV, (int)lds, stream, a); \
+  } while (0)
+#define PW_LAUNCH_ALL(OC, WV)                                \
+  do {                                                       \
+    if (!aligned) {                                          \
+      if (vm == 1) PW_LAUNCH(OC, WV, 4, 1, false);           \
+      else if (vm == 2) PW_LAUNCH(OC, WV, 4, 2, false);      \
+      else if (vm == 3) PW_LAUNCH(OC, WV, 4, 3, false);      \
+      else PW_LAUNCH(OC, WV, 4, 0, false);                   \
+    } else if (vm == 1) PW_LAUNCH(OC, WV, 4, 1, true);       \
+    else if (vm == 2) PW_LAUNCH(OC, WV, 4, 2, true);         \
+    else if (vm == 3) PW_LAUNCH(OC, WV, 4, 3, true);         \
+    else if (npx == 4) PW_LAUNCH(OC, WV, 4, 0, true);        \
+    else if (npx == 2) PW_LAUNCH(OC, WV, 2, 0, true);        \
+    else PW_LAUNCH(OC, WV, 1, 0, true);                      \
   } while (0)
   if (wide) {
     constexpr int OCW = PPSCI_XDL ? 4 : 2;
-    if (npx == 4) PW_LAUNCH(OCW, 8, 4);
-    else if (npx == 2) PW_LAUNCH(OCW, 8, 2);
-    else PW_LAUNCH(OCW, 8, 1);
+    PW_LAUNCH_ALL(OCW, 8);
   } else {
-    if (npx == 4) PW_LAUNCH(4, 4, 4);
-    else if (npx == 2) PW_LAUNCH(4, 4, 2);
-    else PW_LAUNCH(4, 4, 1);
+    PW_LAUNCH_ALL(4, 4);
   }
+#undef PW_LAUNCH_ALL
 #undef PW_LAUNCH
   if (se != 0) {
     ppsci_set_error("pw_conv: cannot raise dynamic LDS to %lld B", lds);
@@ -572,8 +597,9 @@ struct PwWArgs {
 
 // four pixels p .. p + 3 (< lim) of input-channel row i of the weight gradient's x operand
 // (w0, bk: row i of W0 and b0[i] of a virtual operand, loaded once per wave)
+template <int XM>
 __device__ __forceinline__ f32x4 pww_x(const PwWArgs& a, const float* xrow, int b, f32x4 w0, float bk, int p, int lim, bool al) {
-  if (a.xmode == 2) {
+  if constexpr (XM == 2) {
     f32x4 x0q[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -581,7 +607,7 @@ __device__ __forceinline__ f32x4 pww_x(const PwWArgs& a, const float* xrow, int 
     return pw_virtual(w0, bk, x0q, false);
   }
   f32x4 v = fno_ld4(xrow, p, lim, al);
-  if (a.xmode == 1) {
+  if constexpr (XM == 1) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) v[t] = fno_gelu(v[t]);
   }
@@ -592,7 +618,7 @@ __device__ __forceinline__ f32x4 pww_x(const PwWArgs& a, const float* xrow, int 
 // (a multiple of 16).  TB*TB accumulators per wave: every operand float4 feeds TB MFMA chains -- the kernel is bound by
 // the L2 traffic of its operands (each wave streams 2 * 16TB rows x cpix pixels), which per flop falls as 1 / TB.
 // TB = 2 for small layers (a 32 x 32 FNO layer is ONE tile), TB = 4 from 128 x 128 on.
-template <int TB>
+template <int TB, int XM, bool AL>
 __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int nibt = (a.nib + TB - 1) / TB, nobt = (a.nob + TB - 1) / TB;
@@ -617,7 +643,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
     xr[u] = a.x + ((long long)b * a.Ci + xi[u]) * a.P;
     w0r[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     b0r[u] = 0.f;
-    if (a.xmode == 2) {
+    if constexpr (XM == 2) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (q < a.K0) w0r[u][q] = a.W0[(long long)xi[u] * a.K0 + q];
@@ -635,7 +661,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
 #pragma unroll
   for (int u = 0; u < TB; ++u) bsum[u] = 0.f;
   const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
-  const bool al = (a.P & 3) == 0;  // see fno_ld4; the remainder loop zero-fills beyond pend
+  constexpr bool al = AL;  // P a multiple of 4 (and 16-byte aligned operands): see fno_ld4; the remainder loop zero-fills beyond pend
   int pbeg = p0;
   if constexpr (PPSCI_XDL) {
     // K = 32 pixels per step: lane (g, c) holds pixels p + 8g .. + 7 of its row for both operands (two float4 each),
@@ -645,8 +671,8 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
 #pragma unroll
       for (int u = 0; u < TB; ++u) {
         const f32x4 g0 = *(const f32x4*)&gr[u][pbeg + 8 * g] * mo[u], g1 = *(const f32x4*)&gr[u][pbeg + 8 * g + 4] * mo[u];
-        const f32x4 x0 = pww_x(a, xr[u], b, w0r[u], b0r[u], pbeg + 8 * g, pend, true) * mi[u],
-                    x1 = pww_x(a, xr[u], b, w0r[u], b0r[u], pbeg + 8 * g + 4, pend, true) * mi[u];
+        const f32x4 x0 = pww_x<XM>(a, xr[u], b, w0r[u], b0r[u], pbeg + 8 * g, pend, true) * mi[u],
+                    x1 = pww_x<XM>(a, xr[u], b, w0r[u], b0r[u], pbeg + 8 * g + 4, pend, true) * mi[u];
         bsum[u] += ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]));
         const ppsci_split4 a0 = ppsci_split(g0), a1 = ppsci_split(g1), b0 = ppsci_split(x0), b1 = ppsci_split(x1);
 #pragma unroll
@@ -669,7 +695,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
       gv[u] = fno_ld4(gr[u], p + 4 * g, pend, al) * mo[u];
-      xv[u] = pww_x(a, xr[u], b, w0r[u], b0r[u], p + 4 * g, pend, al) * mi[u];
+      xv[u] = pww_x<XM>(a, xr[u], b, w0r[u], b0r[u], p + 4 * g, pend, al) * mi[u];
     }
 #pragma unroll
     for (int u = 0; u < TB; ++u) {
@@ -744,13 +770,28 @@ static int pw_wgrad_run(int B, int Ci, int Co, int P, const float* x, const ppsc
   a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
   a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
+  const bool aligned = (P & 3) == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0 &&
+                       (xmode == 2 ? (reinterpret_cast<uintptr_t>(xv->x0) & 15) == 0 : (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+#define PWW_LAUNCH(TB)                                                                                          \
+  do {                                                                                                          \
+    if (aligned) {                                                                                              \
+      if (xmode == 2) PPSCI_LAUNCH((pw_wgrad_kernel<TB, 2, true>), PwWArgs, (int)grid, 64, 0, stream, a);       \
+      else if (xmode == 1) PPSCI_LAUNCH((pw_wgrad_kernel<TB, 1, true>), PwWArgs, (int)grid, 64, 0, stream, a);  \
+      else PPSCI_LAUNCH((pw_wgrad_kernel<TB, 0, true>), PwWArgs, (int)grid, 64, 0, stream, a);                  \
+    } else {                                                                                                    \
+      if (xmode == 2) PPSCI_LAUNCH((pw_wgrad_kernel<TB, 2, false>), PwWArgs, (int)grid, 64, 0, stream, a);      \
+      else if (xmode == 1) PPSCI_LAUNCH((pw_wgrad_kernel<TB, 1, false>), PwWArgs, (int)grid, 64, 0, stream, a); \
+      else PPSCI_LAUNCH((pw_wgrad_kernel<TB, 0, false>), PwWArgs, (int)grid, 64, 0, stream, a);                 \
+    }                                                                                                           \
+  } while (0)
   if (Ci >= 128 && Co >= 128) {
     const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 3) / 4) * ((a.nib + 3) / 4);
-    PPSCI_LAUNCH(pw_wgrad_kernel<4>, PwWArgs, (int)grid, 64, 0, stream, a);
+    PWW_LAUNCH(4);
   } else {
     const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
-    PPSCI_LAUNCH(pw_wgrad_kernel<2>, PwWArgs, (int)grid, 64, 0, stream, a);
+    PWW_LAUNCH(2);
   }
+#undef PWW_LAUNCH
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("pw_conv_wgrad: launch failed");
     return PPSCI_E_LAUNCH;
@@ -814,13 +855,14 @@ __device__ __forceinline__ void fno_block_sum_d2(double& u, double& v, double* r
 }
 
 // one workgroup (256 threads) per (b, c) row
+template <bool AL>
 __global__ void __launch_bounds__(256) gn_rowstats_kernel(GnArgs a) {
   __shared__ float red[4];
   const int row = blockIdx.x, c = row % a.C;
   const float* vr = a.v + (long long)row * a.P;
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  const bool al = (a.P & 3) == 0;
+  constexpr bool al = AL;
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
     f32x4 u = fno_ld4(vr, p, a.P, al) + sb;
     if (!al) {
@@ -842,6 +884,7 @@ __global__ void __launch_bounds__(256) gn_rowstats_kernel(GnArgs a) {
 // one workgroup per (b, c) row.  The statistics of sample b are finished HERE from the row sums (C pairs, in double, a
 // fixed-shape tree) -- by every workgroup of the sample in parallel instead of a one-workgroup kernel between the row
 // pass and this one (that kernel was a 5 us serial chain); the workgroup of channel 0 stores them for the backward pass.
+template <bool AL>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
   __shared__ double red[512];
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
@@ -864,7 +907,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
       a.stats[2 * b + 1] = rstd;
     }
   }
-  const bool al = (a.P & 3) == 0;
+  constexpr bool al = AL;
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   const float sc = a.norm ? rstd * a.gamma[c] : 1.f, sh = a.norm ? a.beta[c] : 0.f;
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
@@ -884,6 +927,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
 }
 
 // backward pass 1: gt = gout * GELU'(t); row sums of gt, gt * xh, xh
+template <bool AL>
 __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
   __shared__ float red[4];
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
@@ -891,7 +935,7 @@ __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   const float mean = a.norm ? a.stats[2 * b] : 0.f, rstd = a.norm ? a.stats[2 * b + 1] : 1.f;
   float r1 = 0.f, r2 = 0.f, r3 = 0.f;
-  const bool al = (a.P & 3) == 0;
+  constexpr bool al = AL;
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
     f32x4 g4 = fno_ld4(a.gout + base, p, a.P, al);  // zero beyond the row: such elements add nothing to r1, r2
     if (a.gout2) g4 += fno_ld4(a.gout2 + base, p, a.P, al);
@@ -928,12 +972,13 @@ __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
 //   dsbias[c] = sum_b rstd_b (gamma_c r1[b,c] - P m1_b - r3[b,c] m2_b)     (= sum over b and p of gv; norm == 0: sum_b r1)
 // -- m1_b, m2_b of every sample again from the row sums: 16 threads per sample, 16 samples at a time, all in a fixed order.
 // (Round 3 had a one-workgroup kernel between the passes for all of this: 9.9 us of serial double-precision loops.)
+template <bool AL>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnArgs a) {
   __shared__ double red[512];
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
   const long long base = (long long)row * a.P;
   const double n = (double)a.C * a.P;
-  const bool al = (a.P & 3) == 0;
+  constexpr bool al = AL;
   if (!a.norm) {
     for (int p = threadIdx.x * 4; p < a.P; p += 1024) fno_st4(a.gv + base, p, a.P, al, fno_ld4(a.gt + base, p, a.P, al));
   } else {
@@ -1030,8 +1075,16 @@ extern "C" int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float
   memset(&a, 0, sizeof(a));
   a.v = v, a.sbias = sbias, a.gamma = gamma, a.beta = beta, a.skip = skip, a.rows = rows, a.stats = stats, a.t = t, a.y = y;
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu, a.eps = eps;
-  if (norm) PPSCI_LAUNCH(gn_rowstats_kernel, GnArgs, B * C, 256, 0, stream, a);
-  PPSCI_LAUNCH(gn_apply_kernel, GnArgs, B * C, 256, 0, stream, a);
+  // (16-byte accesses when every row starts on a 16-byte boundary; element accesses otherwise)
+  const bool aligned = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(skip) |
+                                         reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (aligned) {
+    if (norm) PPSCI_LAUNCH(gn_rowstats_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
+    PPSCI_LAUNCH(gn_apply_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
+  } else {
+    if (norm) PPSCI_LAUNCH(gn_rowstats_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+    PPSCI_LAUNCH(gn_apply_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+  }
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("fno_tail_fwd: launch failed");
     return PPSCI_E_LAUNCH;
@@ -1053,8 +1106,16 @@ extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const
   a.v = v, a.sbias = sbias, a.gamma = gamma, a.t = (float*)t, a.gout = gout, a.gout2 = gout2, a.rows = rows, a.stats = stats;
   a.gt = gt, a.gv = gv, a.ggamma = ggamma, a.gbeta = gbeta, a.gsbias = gsbias;
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu;
-  PPSCI_LAUNCH(gn_bwd_rows_kernel, GnArgs, B * C, 256, 0, stream, a);
-  PPSCI_LAUNCH(gn_bwd_apply_kernel, GnArgs, B * C, 256, 0, stream, a);
+  const bool aligned = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gout) |
+                                         reinterpret_cast<uintptr_t>(gout2) | reinterpret_cast<uintptr_t>(gt) |
+                                         reinterpret_cast<uintptr_t>(gv)) & 15) == 0;
+  if (aligned) {
+    PPSCI_LAUNCH(gn_bwd_rows_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
+    PPSCI_LAUNCH(gn_bwd_apply_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
+  } else {
+    PPSCI_LAUNCH(gn_bwd_rows_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+    PPSCI_LAUNCH(gn_bwd_apply_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+  }
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("fno_tail_bwd: launch failed");
     return PPSCI_E_LAUNCH;
