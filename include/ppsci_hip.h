@@ -400,7 +400,9 @@ int ppsci_pw_conv(int B, int Cin, int Cout, int P, const float* x, const float* 
  *   mode 2  GELU(W0 x0 + b0), never stored    -- x0 [B, K0, P] with K0 <= 4 input channels (the lifting layer's input),
  *                                                W0 [C, K0], b0 [C] or NULL; as `zmul`: GELU'(W0 x0 + b0).
  * ppsci_pw_conv_v / ppsci_pw_conv_wgrad_v: ppsci_pw_conv / ppsci_pw_conv_wgrad with such an `x` (xv; NULL = mode 0;
- * `x` may be NULL in mode 2) and, for the convolution, such a `zmul` (zv: mode 0 or 2). */
+ * `x` may be NULL in mode 2) and, for the convolution, such a `zmul` (zv: mode 0 or 2).  ld_partials != 0: the row
+ * stride (floats) of BOTH partial arrays -- with partials_b = partials + Co*Ci and ld_partials = Co*Ci + Co one
+ * ppsci_reduce_rows call sums weight and bias gradients (they are neighbours in the reference's parameter order). */
 typedef struct {
   int32_t mode;
   int32_t K0;
@@ -412,7 +414,7 @@ int ppsci_pw_conv_v(int B, int Cin, int Cout, int P, const float* x, const ppsci
                     const float* bias, const float* zmul, const ppsci_pw_virtual* zv, int accumulate, float* out, float* act,
                     void* stream);
 int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv, const float* gy,
-                          float* partials, float* partials_b, void* stream);
+                          float* partials, float* partials_b, int64_t ld_partials, void* stream);
 /* Testing / tuning knob: pixels per lane of ppsci_pw_conv's work items (1, 2 or 4; 0 = chosen from the problem size: fewer
  * pixels per lane give small problems more waves). */
 void ppsci_set_pw_pixels_per_lane(int npx);

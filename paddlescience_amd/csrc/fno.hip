@@ -589,6 +589,7 @@ struct PwWArgs {
   float* part;      // [nchunk][Co*Ci]: per-chunk partial of gW (row-major [Co, Ci])
   float* part_b;    // [nchunk][Co] or null: per-chunk partial of gb
   int B, Ci, Co, P, nib, nob, cpix, chunks_per_b;
+  long long ldp, ldpb;  // row strides of part / part_b (floats)
   int xmode, K0;      // x as a function of a stored tensor (ppsci_pw_virtual)
   const float* x0;
   const float* W0;
@@ -706,7 +707,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
       bsum[u] += (gv[u][0] + gv[u][1]) + (gv[u][2] + gv[u][3]);
     }
   }
-  float* prow = a.part + (long long)ch * ((long long)a.Co * a.Ci);
+  float* prow = a.part + (long long)ch * a.ldp;
   // D[row = 4g + rr][col = c] = gW[o = 16ob + 4g + rr][i = 16ib + c]
 #pragma unroll
   for (int u = 0; u < TB; ++u)
@@ -726,7 +727,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
       bs += __shfl_xor(bs, 16, 64);
       bs += __shfl_xor(bs, 32, 64);
       const int o = 16 * (ob + u) + c;
-      if (g == 0 && o < a.Co) a.part_b[(long long)ch * a.Co + o] = bs;
+      if (g == 0 && o < a.Co) a.part_b[(long long)ch * a.ldpb + o] = bs;
     }
   }
 }
@@ -741,20 +742,21 @@ extern "C" int64_t ppsci_pw_conv_wgrad_chunks(int B, int P) {
 
 // part_w: [chunks][Co*Ci], part_b: [chunks][Co] (or null); sum each with ppsci_reduce_rows(part, chunks, cols, out)
 static int pw_wgrad_run(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv, const float* gy,
-                        float* partials, float* partials_b, void* stream);
+                        float* partials, float* partials_b, int64_t ld_partials, void* stream);
 
 extern "C" int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const float* gy, float* partials,
                                    float* partials_b, void* stream) {
-  return pw_wgrad_run(B, Ci, Co, P, x, nullptr, gy, partials, partials_b, stream);
+  return pw_wgrad_run(B, Ci, Co, P, x, nullptr, gy, partials, partials_b, 0, stream);
 }
 
 extern "C" int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv,
-                                     const float* gy, float* partials, float* partials_b, void* stream) {
-  return pw_wgrad_run(B, Ci, Co, P, x, xv, gy, partials, partials_b, stream);
+                                     const float* gy, float* partials, float* partials_b, int64_t ld_partials,
+                                     void* stream) {
+  return pw_wgrad_run(B, Ci, Co, P, x, xv, gy, partials, partials_b, ld_partials, stream);
 }
 
 static int pw_wgrad_run(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv, const float* gy,
-                        float* partials, float* partials_b, void* stream) {
+                        float* partials, float* partials_b, int64_t ld_partials, void* stream) {
   const int xmode = xv ? xv->mode : 0;
   if (B < 1 || Ci < 1 || Co < 1 || P < 1 || (!x && xmode != 2) || !gy || !partials ||
       pw_virtual_check(xv, "pw_conv_wgrad") != PPSCI_OK) {
@@ -766,6 +768,12 @@ static int pw_wgrad_run(int B, int Ci, int Co, int P, const float* x, const ppsc
   a.xmode = xmode;
   if (xmode == 2) a.x0 = xv->x0, a.W0 = xv->W0, a.b0 = xv->b0, a.K0 = xv->K0;
   a.x = x, a.gy = gy, a.part = partials, a.part_b = partials_b;
+  if (ld_partials != 0 && ld_partials < (int64_t)Co * Ci) {
+    ppsci_set_error("pw_conv_wgrad: ld_partials smaller than a row");
+    return PPSCI_E_INVALID;
+  }
+  a.ldp = ld_partials ? ld_partials : (long long)Co * Ci;
+  a.ldpb = ld_partials ? ld_partials : Co;
   a.B = B, a.Ci = Ci, a.Co = Co, a.P = P;
   a.nib = (Ci + 15) / 16, a.nob = (Co + 15) / 16;
   a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;

@@ -25,6 +25,18 @@
 
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
+struct SpecWArgs {
+  ppsci_spectral_desc d;
+  const float* x;
+  const float* g;
+  float* gwr;
+  float* gwi;
+  int c0;
+  long long total;
+  float wscale;  // see ppsci_spectral_conv2d_bwd_real
+  int w_full;    // > 0: g is rfftn(dL/dy): weight gradients get wscale * c(my), c = 1 on the DC / Nyquist columns, else 2
+};
+
 struct SpecArgs {
   ppsci_spectral_desc d;
   const float* x;   // [B, Cin, H, Wf, 2]   (Cin = c_in for fwd, c_out for bwd_x)
@@ -38,6 +50,8 @@ struct SpecArgs {
   int zero_fill;    // > 0: that many EXTRA workgroups (behind the mode workgroups) clear every position of `out` that
                     // no kept mode writes
   int nmode_wg;     // modes x batch tiles
+  int nw_wg;        // > 0: that many further workgroups compute the weight gradient `w` (the backward's second half:
+  SpecWArgs w;      // independent of the data gradient, same operands -- one launch instead of two)
   int w_lds;        // weights of the mode staged in LDS
 };
 
@@ -68,6 +82,39 @@ __device__ __forceinline__ float spec_w(const SpecArgs& a, int kk, int jj, int m
   const long long idx = ((long long)i * co + o) * ms + mode_off;
   if (kk < co) return jj < ci ? a.wr[idx] : -a.wi[idx];
   return jj < ci ? a.wi[idx] : a.wr[idx];
+}
+
+// gw[i,o,mode] = sum_b conj(x[b,i]) * g[b,o]:  gwr = sum xr*gr + xi*gi,  gwi = sum xr*gi - xi*gr
+
+__device__ __forceinline__ void spec_wgrad_body(const SpecWArgs& a, long long t) {
+  if (t >= a.total) return;
+  const int ms = a.d.modes_x * a.d.modes_y;
+  const int mode = (int)(t % ms);
+  const long long io = t / ms;
+  const int o = (int)(io % a.d.c_out), i = (int)(io / a.d.c_out);
+  const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
+  const long long plane = (long long)a.d.h * a.d.wf * 2;
+  const long long pix_x = ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
+  const long long pix_g = ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
+  float sr = 0.f, si = 0.f;
+  for (int b = 0; b < a.d.batch; ++b) {
+    const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix_x;
+    const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix_g;
+    const float xr = xp[0], xi = xp[1], gr = gp[0], gi = gp[1];
+    sr += xr * gr + xi * gi;
+    si += xr * gi - xi * gr;
+  }
+  if (a.w_full > 0) {
+    const float cm = a.wscale * ((my == 0 || 2 * my == a.w_full) ? 1.f : 2.f);
+    sr *= cm;
+    si *= cm;
+  }
+  a.gwr[t] = sr;
+  a.gwi[t] = si;
+}
+
+__global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
+  spec_wgrad_body(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 // ONE workgroup (4 waves) per (mode, 16-row batch tile): the mode's operands -- 16 x Cin complex inputs and the Ci x Co
@@ -101,6 +148,10 @@ __global__ void __launch_bounds__(256) spectral_mode_kernel(SpecArgs a) {
     // modes_x with the shift of r_dst below; columns my < modes_y.  Disjoint from the product stores: no ordering needed.
     const int shift = a.conj_t ? a.d.h - a.d.h / 2 : a.d.h / 2;
     const int nplane = a.d.batch * a.cout, per = a.d.h * a.d.wf;
+    if ((int)blockIdx.x >= a.nmode_wg + a.zero_fill) {
+      spec_wgrad_body(a.w, (long long)((int)blockIdx.x - a.nmode_wg - a.zero_fill) * 256 + tid);
+      return;
+    }
     for (int pl = (int)blockIdx.x - a.nmode_wg; pl < nplane; pl += a.zero_fill) {
       float* o = a.out + (long long)pl * per * 2;
       for (int e = tid; e < per; e += 256) {
@@ -164,47 +215,6 @@ __global__ void __launch_bounds__(256) spectral_mode_kernel(SpecArgs a) {
   }
 }
 
-// gw[i,o,mode] = sum_b conj(x[b,i]) * g[b,o]:  gwr = sum xr*gr + xi*gi,  gwi = sum xr*gi - xi*gr
-struct SpecWArgs {
-  ppsci_spectral_desc d;
-  const float* x;
-  const float* g;
-  float* gwr;
-  float* gwi;
-  int c0;
-  long long total;
-  float wscale;  // see ppsci_spectral_conv2d_bwd_real
-  int w_full;    // > 0: g is rfftn(dL/dy): weight gradients get wscale * c(my), c = 1 on the DC / Nyquist columns, else 2
-};
-
-__global__ void __launch_bounds__(256) spectral_wgrad_kernel(SpecWArgs a) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.total) return;
-  const int ms = a.d.modes_x * a.d.modes_y;
-  const int mode = (int)(t % ms);
-  const long long io = t / ms;
-  const int o = (int)(io % a.d.c_out), i = (int)(io / a.d.c_out);
-  const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
-  const long long plane = (long long)a.d.h * a.d.wf * 2;
-  const long long pix_x = ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
-  const long long pix_g = ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
-  float sr = 0.f, si = 0.f;
-  for (int b = 0; b < a.d.batch; ++b) {
-    const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix_x;
-    const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix_g;
-    const float xr = xp[0], xi = xp[1], gr = gp[0], gi = gp[1];
-    sr += xr * gr + xi * gi;
-    si += xr * gi - xi * gr;
-  }
-  if (a.w_full > 0) {
-    const float cm = a.wscale * ((my == 0 || 2 * my == a.w_full) ? 1.f : 2.f);
-    sr *= cm;
-    si *= cm;
-  }
-  a.gwr[t] = sr;
-  a.gwi[t] = si;
-}
-
 static int spec_check(const ppsci_spectral_desc* d, int* c0) {
   if (!d || d->batch < 1 || d->c_in < 1 || d->c_out < 1 || d->h < 2 || d->wf < 1 || d->modes_x < 1 || d->modes_y < 1 ||
       d->modes_x > d->h || d->modes_y > d->wf) {
@@ -216,7 +226,7 @@ static int spec_check(const ppsci_spectral_desc* d, int* c0) {
 }
 
 static int launch_contract(const ppsci_spectral_desc* d, const float* x, const float* wr, const float* wi, float* out,
-                           int conj_t, void* stream, float scale = 1.f, int zero_fill = 0) {
+                           int conj_t, void* stream, float scale = 1.f, int zero_fill = 0, const SpecWArgs* wg = nullptr) {
   SpecArgs a;
   memset(&a, 0, sizeof(a));
   int rc = spec_check(d, &a.c0);
@@ -244,7 +254,11 @@ static int launch_contract(const ppsci_spectral_desc* d, const float* x, const f
   }
   a.w_lds = lds_x + lds_w <= 64 * 1024 ? 1 : 0;
   const long long lds = lds_x + (a.w_lds ? lds_w : 0);
-  const int grid = a.nmode_wg + a.zero_fill;
+  if (wg) {
+    a.w = *wg;
+    a.nw_wg = (int)((wg->total + 255) / 256);
+  }
+  const int grid = a.nmode_wg + a.zero_fill + a.nw_wg;
   if (PPSCI_SET_MAX_LDS(spectral_mode_kernel, (int)lds) != 0) {
     ppsci_set_error("spectral_conv: cannot raise dynamic LDS to %lld B", lds);
     return PPSCI_E_LAUNCH;
@@ -327,13 +341,10 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
     ppsci_set_error("spectral_conv2d_bwd: null pointer");
     return PPSCI_E_INVALID;
   }
-  if (gx_ft) {
-    int rc = launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale, zero_fill);
-    if (rc != PPSCI_OK) return rc;
-  }
-  if (gw_re && gw_im) {
-    SpecWArgs a;
-    memset(&a, 0, sizeof(a));
+  SpecWArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool want_w = gw_re && gw_im;
+  if (want_w) {
     int rc = spec_check(d, &a.c0);
     if (rc != PPSCI_OK) return rc;
     a.d = *d;
@@ -344,6 +355,9 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
     a.total = (long long)d->c_in * d->c_out * d->modes_x * d->modes_y;
     a.wscale = wscale;
     a.w_full = w_full;
+  }
+  if (gx_ft) return launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale, zero_fill, want_w ? &a : nullptr);
+  if (want_w) {
     PPSCI_LAUNCH(spectral_wgrad_kernel, SpecWArgs, (int)((a.total + 255) / 256), 256, 0, stream, a);
     int e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) {

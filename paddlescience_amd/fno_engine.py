@@ -119,7 +119,7 @@ class FnoNative:
         self.gt = torch.empty((B, Ch, P), **f)
         self.gv = torch.empty((B, Ch, P), **f)
         self.chunks = max(int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P)), int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0)))
-        wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels))
+        wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels)) + cmax
         self.part_w = torch.empty(self.chunks * wmax, **f)
         self.part_b = torch.empty(self.chunks * cmax, **f)
         mx, my = m.fno_blocks.convs[0].n_modes
@@ -191,11 +191,21 @@ class FnoNative:
 
     # ------------------------------------------------------------------ backward
     def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param, xv=None) -> None:
-        L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
-                                              _p(self.part_w), _p(self.part_b) if b_param is not None else None,
-                                              _stream_ptr(gy)))
         chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))  # (P differs between the padded blocks and lifting / projection)
-        hp.reduce_rows(self.part_w, chunks, co * ci, w_param.grad.view(-1), False)
+        wg = w_param.grad.view(-1)
+        if b_param is not None and b_param.grad.data_ptr() == wg.data_ptr() + 4 * co * ci:
+            # weight and bias gradients are neighbours in the flat buffer: partial rows [Co*Ci | Co], ONE fixed-order sum
+            ld = co * ci + co
+            L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
+                                                  _p(self.part_w), C.c_void_p(self.part_w.data_ptr() + 4 * co * ci), ld,
+                                                  _stream_ptr(gy)))
+            both = torch.as_strided(wg, (ld,), (1,))
+            hp.reduce_rows(self.part_w, chunks, ld, both, False)
+            return
+        L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
+                                              _p(self.part_w), _p(self.part_b) if b_param is not None else None, 0,
+                                              _stream_ptr(gy)))
+        hp.reduce_rows(self.part_w, chunks, co * ci, wg, False)
         if b_param is not None:
             hp.reduce_rows(self.part_b, chunks, co, b_param.grad.view(-1), False)
 

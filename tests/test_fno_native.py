@@ -213,7 +213,7 @@ def test_pw_conv_operands_evaluated_on_load(dev, shape):
     for x, xv in ((a, None), (z, v1), (None, v2)):
         pw = torch.full((chunks * Co * Ch,), float("nan"), device=d)
         pb = torch.full((chunks * Co,), float("nan"), device=d)
-        L.check(lib.ppsci_pw_conv_wgrad_v(B, Ch, Co, P, p(x), C.byref(xv) if xv is not None else None, p(gy), p(pw), p(pb), None))
+        L.check(lib.ppsci_pw_conv_wgrad_v(B, Ch, Co, P, p(x), C.byref(xv) if xv is not None else None, p(gy), p(pw), p(pb), 0, None))
         gW, gb = torch.zeros(Co * Ch, device=d), torch.zeros(Co, device=d)
         hp.reduce_rows(pw, chunks, Co * Ch, gW, False)
         hp.reduce_rows(pb, chunks, Co, gb, False)
