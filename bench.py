@@ -548,8 +548,10 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
             "ms_per_step_hip_events": t_ev * 1e3,
             "roofline": step_hbm_roofline("tfno", t),
             "spectral_contract_kernel": {"kernel_ms": t_k * 1e3, "operand_TBps": ach,
-                                         "note": "84 modes x [16 x 64]x[64 x 64] real GEMM, 1.4 MB of operands, 11 MFLOP: "
-                                                 "launch/latency-bound at this size; 9.6 % of the step"},
+                                         "note": "84 modes x [16 x 64]x[64 x 64] real GEMM, 1.4 MB of operands, 11 MFLOP, one "
+                                                 "workgroup per mode with its operands staged in LDS; the same launch clears "
+                                                 "the 8.6 MB output spectrum around the kept modes (that, not the GEMM, is its "
+                                                 "duration)"},
             "native_forward_backward": eng.native is not None, "parity": parity}
 
 
