@@ -373,6 +373,25 @@ int ppsci_spectral_conv2d_fwd_scaled(const ppsci_spectral_desc* d, const float* 
 int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re,
                                           const float* w_im, const float* ghat_ft, float* gx_ft, float* gw_re, float* gw_im,
                                           float wscale, int w_full, float xscale, int zero_fill, void* stream);
+/* The transform pair on the KEPT modes only (csrc/spectral_conv.hip): the spectral convolution multiplies all but
+ * modes_x x modes_y of the H x (W/2+1) coefficients by zero, so rfftn / irfftn (fno_block.py:718-720, :791) reduce to two
+ * small dense DFTs per [H, W] plane, staged in LDS -- the plane is read / written once and the spectrum is
+ * [n, modes_x, modes_y, 2] floats (84 complex numbers instead of 8.6 MB per transform at the BASELINE shape).
+ *   ppsci_dft2_kept_fwd: X = rfftn(x) at the kept modes, unscaled;   ppsci_dft2_kept_inv: y = irfftn of (Z at the kept
+ *   modes, zero elsewhere), unscaled, Re of the DC / Nyquist columns only (as a library C2R does).
+ * rows: 0 = the rows FactorizedSpectralConv slices from the shifted input spectrum, 1 = the rows its second fftshift
+ * writes the products to (they differ by one for odd H).  A forward pass uses (fwd rows 0, inv rows 1), the backward pass
+ * (fwd rows 1 on dL/dy, inv rows 0).  ppsci_dft2_kept_supported: 1 when a plane and its tables fit LDS (up to ~ 120 x 120);
+ * otherwise use ppsci_fft2d_* with the full-spectrum entry points.
+ * ppsci_spectral_conv2d_fwd_kept / _bwd_kept: ppsci_spectral_conv2d_fwd_scaled / _bwd_real_scaled on such spectra. */
+int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y);
+int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y, int rows, const float* x, float* X, void* stream);
+int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y, void* stream);
+int ppsci_spectral_conv2d_fwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
+                                   float* out_k, float scale, void* stream);
+int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
+                                   const float* ghat_k, float* gx_k, float* gw_re, float* gw_im, float wscale, int w_full,
+                                   float xscale, void* stream);
 /* Batched 2-D real FFTs on hipFFT, on `stream`, unscaled (csrc/fft.hip): rfftn / irfftn of fno_block.py:718-720, :791.
  * r2c: [batch, H, W] -> [batch, H, W/2+1, 2]; c2r: the reverse, DESTROYING its input. */
 int ppsci_fft2d_r2c(int batch, int H, int W, const float* in, float* out, void* stream);

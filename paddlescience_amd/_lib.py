@@ -143,6 +143,12 @@ _SYMBOLS = {
     "ppsci_spectral_conv2d_bwd_real_scaled": (C.c_int, [C.POINTER(SpectralDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                                         C.c_float, C.c_int, C.c_void_p]),
+    "ppsci_dft2_kept_supported": (C.c_int, [C.c_int] * 4),
+    "ppsci_dft2_kept_fwd": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 3),
+    "ppsci_dft2_kept_inv": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 3),
+    "ppsci_spectral_conv2d_fwd_kept": (C.c_int, [C.POINTER(SpectralDesc)] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]),
+    "ppsci_spectral_conv2d_bwd_kept": (C.c_int, [C.POINTER(SpectralDesc)] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_float,
+                                                                                                 C.c_void_p]),
     "ppsci_fft2d_r2c": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_fft2d_c2r": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_pw_conv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

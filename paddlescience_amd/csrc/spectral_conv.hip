@@ -21,7 +21,14 @@
 #ifndef PPSCI_EMU
 #include <hip/hip_runtime.h>
 #endif
+#include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
@@ -35,6 +42,7 @@ struct SpecWArgs {
   long long total;
   float wscale;  // see ppsci_spectral_conv2d_bwd_real
   int w_full;    // > 0: g is rfftn(dL/dy): weight gradients get wscale * c(my), c = 1 on the DC / Nyquist columns, else 2
+  int compact;   // x / g hold the kept modes only: [B, C, modes_x, modes_y, 2] (ppsci_dft2_kept_*)
 };
 
 struct SpecArgs {
@@ -50,6 +58,7 @@ struct SpecArgs {
   int zero_fill;    // > 0: that many EXTRA workgroups (behind the mode workgroups) clear every position of `out` that
                     // no kept mode writes
   int nmode_wg;     // modes x batch tiles
+  int compact;      // x / out hold the kept modes only: [B, C, modes_x, modes_y, 2] (ppsci_dft2_kept_*): no rows to map
   int nw_wg;        // > 0: that many further workgroups compute the weight gradient `w` (the backward's second half:
   SpecWArgs w;      // independent of the data gradient, same operands -- one launch instead of two)
   int w_lds;        // weights of the mode staged in LDS
@@ -93,9 +102,9 @@ __device__ __forceinline__ void spec_wgrad_body(const SpecWArgs& a, long long t)
   const long long io = t / ms;
   const int o = (int)(io % a.d.c_out), i = (int)(io / a.d.c_out);
   const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
-  const long long plane = (long long)a.d.h * a.d.wf * 2;
-  const long long pix_x = ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
-  const long long pix_g = ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
+  const long long plane = a.compact ? (long long)ms * 2 : (long long)a.d.h * a.d.wf * 2;
+  const long long pix_x = a.compact ? (long long)mode * 2 : ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
+  const long long pix_g = a.compact ? (long long)mode * 2 : ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
   float sr = 0.f, si = 0.f;
   for (int b = 0; b < a.d.batch; ++b) {
     const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix_x;
@@ -168,8 +177,9 @@ __global__ void __launch_bounds__(256) spectral_mode_kernel(SpecArgs a) {
   const int mx = mode / a.d.modes_y, my = mode - mx * a.d.modes_y;
   const int r_src = a.conj_t ? spec_row_out(a.d, a.c0, mx) : spec_row_in(a.d, a.c0, mx);
   const int r_dst = a.conj_t ? spec_row_in(a.d, a.c0, mx) : spec_row_out(a.d, a.c0, mx);
-  const long long plane = (long long)a.d.h * a.d.wf * 2;
-  const long long pix = ((long long)r_src * a.d.wf + my) * 2, pix_dst = ((long long)r_dst * a.d.wf + my) * 2;
+  const long long plane = a.compact ? (long long)a.d.modes_x * a.d.modes_y * 2 : (long long)a.d.h * a.d.wf * 2;
+  const long long pix = a.compact ? (long long)mode * 2 : ((long long)r_src * a.d.wf + my) * 2;
+  const long long pix_dst = a.compact ? (long long)mode * 2 : ((long long)r_dst * a.d.wf + my) * 2;
   const int K = 2 * a.cin, ldx = K + 1, ci = a.d.c_in, co = a.d.c_out, ldw = co + 1;
   float* xs = smem;
   float* wrs = xs + 16 * ldx;
@@ -226,7 +236,8 @@ static int spec_check(const ppsci_spectral_desc* d, int* c0) {
 }
 
 static int launch_contract(const ppsci_spectral_desc* d, const float* x, const float* wr, const float* wi, float* out,
-                           int conj_t, void* stream, float scale = 1.f, int zero_fill = 0, const SpecWArgs* wg = nullptr) {
+                           int conj_t, void* stream, float scale = 1.f, int zero_fill = 0, const SpecWArgs* wg = nullptr,
+                           int compact = 0) {
   SpecArgs a;
   memset(&a, 0, sizeof(a));
   int rc = spec_check(d, &a.c0);
@@ -243,7 +254,8 @@ static int launch_contract(const ppsci_spectral_desc* d, const float* x, const f
   a.ntile_b = (d->batch + 15) / 16;
   a.nblk_n = (2 * a.cout + 15) / 16;
   a.nmode_wg = d->modes_x * d->modes_y * a.ntile_b;
-  if (zero_fill) {
+  a.compact = compact;
+  if (zero_fill && !compact) {
     const long long nplane = (long long)d->batch * a.cout;
     a.zero_fill = (int)(nplane < 4096 ? nplane : 4096);
   }
@@ -283,7 +295,7 @@ extern "C" int ppsci_spectral_conv2d_fwd(const ppsci_spectral_desc* d, const flo
 
 static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                         const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
-                        void* stream, float xscale = 1.f, int zero_fill = 0);
+                        void* stream, float xscale = 1.f, int zero_fill = 0, int compact = 0);
 
 // out_ft = scale * (x_ft . w) on the kept modes; `zero_fill` != 0: every other position of the output spectrum is cleared
 // by the same launch -- for callers whose inverse transform destroys its input (hipFFT C2R, ppsci_fft2d_c2r) or that hand
@@ -336,7 +348,7 @@ extern "C" int ppsci_spectral_conv2d_bwd_real(const ppsci_spectral_desc* d, cons
 
 static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const float* w_re, const float* w_im,
                         const float* gout_ft, float* gx_ft, float* gw_re, float* gw_im, float wscale, int w_full,
-                        void* stream, float xscale, int zero_fill) {
+                        void* stream, float xscale, int zero_fill, int compact) {
   if (!x_ft || !w_re || !w_im || !gout_ft) {
     ppsci_set_error("spectral_conv2d_bwd: null pointer");
     return PPSCI_E_INVALID;
@@ -355,8 +367,9 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
     a.total = (long long)d->c_in * d->c_out * d->modes_x * d->modes_y;
     a.wscale = wscale;
     a.w_full = w_full;
+    a.compact = compact;
   }
-  if (gx_ft) return launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale, zero_fill, want_w ? &a : nullptr);
+  if (gx_ft) return launch_contract(d, gout_ft, w_re, w_im, gx_ft, 1, stream, xscale, zero_fill, want_w ? &a : nullptr, compact);
   if (want_w) {
     PPSCI_LAUNCH(spectral_wgrad_kernel, SpecWArgs, (int)((a.total + 255) / 256), 256, 0, stream, a);
     int e = PPSCI_LAST_LAUNCH_ERROR();
@@ -367,3 +380,277 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
   }
   return PPSCI_OK;
 }
+
+// ------------------------------------------------------------------------------------------ kept modes only
+// The spectral convolution keeps modes_x x modes_y of the H x (W/2+1) coefficients (12 x 7 of 64 x 33 at the BASELINE
+// shape) and multiplies everything else by zero.  A library FFT computes -- and the inverse reads -- all of them: 8.6 MB of
+// spectrum per transform, plus the clearing of it.  These kernels evaluate the transform pair on the kept modes only, as two
+// small dense DFTs per [H, W] plane staged in LDS (row DFT onto the kept columns, then column DFT onto the kept rows; the
+// inverse the other way round):  ~160 kflop per plane, the plane is read / written once, the spectrum is 84 numbers.
+//   ppsci_dft2_kept_fwd : x [n, H, W] real        -> X [n, modes_x, modes_y] complex = rfftn(x) at the kept modes (unscaled)
+//   ppsci_dft2_kept_inv : Z [n, modes_x, modes_y] -> y [n, H, W] real = irfftn of the spectrum that is Z at the kept modes
+//                         and zero elsewhere (unscaled; like the library C2R: Re of the DC / Nyquist columns only)
+// `rows`: 0 = the rows the reference's slice takes from the shifted INPUT spectrum, 1 = the rows its second fftshift puts
+// the products to (spec_row_in / spec_row_out: the same for even H).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct DftArgs {
+  const float* src;
+  float* dst;
+  const float* tab;  // twiddles tw [W][my][2] | th [H][mx][2], computed once per shape on the host in double (a "plan")
+  int n, H, W, mx, my, c0, rows;
+};
+
+// LDS (floats): tw [W][my][2] | th [H][mx][2] | plane [H*W] (fwd) or Z [mx*my*2] (inv) | T [H][my][2] | fwd: partial sums
+__device__ __forceinline__ void dft_twiddles(const DftArgs& a, float* tw) {
+  const int nt = 2 * (a.W * a.my + a.H * a.mx);
+  for (int idx = threadIdx.x; idx < nt; idx += blockDim.x) tw[idx] = a.tab[idx];
+}
+
+__global__ void __launch_bounds__(256) dft2_kept_fwd_kernel(DftArgs a) {
+  PPSCI_DYN_SMEM(smem);
+  float* tw = smem;
+  float* th = tw + 2 * a.W * a.my;
+  float* pl = th + 2 * a.H * a.mx;
+  const int ldp = a.W + 1;  // (odd row stride: the MFMA's A operand reads 16 rows at one column)
+  float* T = pl + a.H * ldp;
+  dft_twiddles(a, tw);
+  const int tid = threadIdx.x, P = a.H * a.W;
+  for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
+    __syncthreads();  // (twiddles ready; the previous plane's T consumed)
+    const float* x = a.src + (long long)p * P;
+    for (int e = tid; e < P; e += 256) {
+      const int h = e / a.W;
+      pl[e + h] = x[e];  // = pl[h * ldp + w]
+    }
+    __syncthreads();
+    // rows: T[h][q] = sum_w x[h][w] e^{-2 pi i w q / W}
+    const f32x2* th2 = (const f32x2*)th;
+    f32x2* T2 = (f32x2*)T;
+    {
+      // [H x W] . [W x 2 my] on the fp32 MFMA (16 x 16 x 4): rows h, columns 2 q + {re, im}, k = w.  The column index of the
+      // D tile is the float index inside row h of T ([h][my][2]), so the result rows are stored as they come.
+      const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+      const int nrb = (a.H + 15) / 16, ncol = 2 * a.my, nnb = (ncol + 15) / 16;
+      for (int it = wave; it < nrb * nnb; it += 4) {
+        const int rb = it / nnb, nb = it - rb * nnb;
+        const int h = 16 * rb + c, col = 16 * nb + c;
+        const bool hok = h < a.H, cok = col < ncol;
+        const float* arow = pl + (hok ? h : 0) * ldp;
+        const float* bcol = tw + (cok ? col : 0);  // tw[w][my][2] = row w of 2 my floats: (cos, sin) pairs
+        const float bs = (col & 1) ? -1.f : 1.f;   // e^{-i phi} = cos - i sin
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w0 = 0; w0 < a.W; w0 += 4) {
+          const int w = w0 + g;
+          const bool wok = w < a.W;
+          const float av = (hok && wok) ? arow[w] : 0.f;
+          const float bv = (cok && wok) ? bs * bcol[w * ncol] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        if (cok) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int hh = 16 * rb + 4 * g + rr;
+            if (hh < a.H) T[hh * ncol + col] = acc[rr];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // columns: X[m][q] = sum_h T[h][q] e^{-2 pi i h k_m / H}; the h range in `parts` pieces (mx * my outputs are fewer than
+    // the workgroup's threads), combined in a fixed order through LDS
+    const int nm = a.mx * a.my;
+    const int parts = nm < 256 ? (256 / nm < a.H ? 256 / nm : a.H) : 1;
+    f32x2* part = (f32x2*)(T + 2 * a.H * a.my);  // [parts][nm], parts * nm <= 256 (or one part of nm)
+    for (int it = tid; it < parts * nm || (parts == 1 && it < nm); it += 256) {
+      const int pt = it / nm, idx = it - pt * nm;
+      const int m = idx / a.my, q = idx - m * a.my;
+      const int h0 = (int)((long long)a.H * pt / parts), h1 = (int)((long long)a.H * (pt + 1) / parts);
+      float re = 0.f, im = 0.f;
+#pragma unroll 4
+      for (int h = h0; h < h1; ++h) {
+        const f32x2 t = T2[h * a.my + q], e = th2[h * a.mx + m];
+        re += t[0] * e[0] + t[1] * e[1];
+        im += t[1] * e[0] - t[0] * e[1];
+      }
+      part[it] = (f32x2){re, im};
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nm; idx += 256) {
+      f32x2 acc = part[idx];
+      for (int pt = 1; pt < parts; ++pt) acc += part[pt * nm + idx];
+      *(f32x2*)(a.dst + ((long long)p * nm + idx) * 2) = acc;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
+  PPSCI_DYN_SMEM(smem);
+  float* tw = smem;
+  float* th = tw + 2 * a.W * a.my;
+  float* Z = th + 2 * a.H * a.mx;
+  float* T = Z + 2 * a.mx * a.my;
+  dft_twiddles(a, tw);
+  const int tid = threadIdx.x, P = a.H * a.W, nm = a.mx * a.my;
+  for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
+    __syncthreads();
+    const float* z = a.src + (long long)p * nm * 2;
+    for (int e = tid; e < 2 * nm; e += 256) Z[e] = z[e];
+    __syncthreads();
+    // columns: T[h][q] = sum_m Z[m][q] e^{+2 pi i h k_m / H}
+    const f32x2* th2 = (const f32x2*)th;
+    const f32x2* Z2 = (const f32x2*)Z;
+    f32x2* T2 = (f32x2*)T;
+    for (int idx = tid; idx < a.H * a.my; idx += 256) {
+      const int h = idx / a.my, q = idx - h * a.my;
+      float re = 0.f, im = 0.f;
+#pragma unroll 4
+      for (int m = 0; m < a.mx; ++m) {
+        const f32x2 z = Z2[m * a.my + q], e = th2[h * a.mx + m];
+        re += z[0] * e[0] - z[1] * e[1];
+        im += z[0] * e[1] + z[1] * e[0];
+      }
+      const float c = (q == 0 || 2 * q == a.W) ? 1.f : 2.f;  // the Hermitian weight of column q, folded in here
+      T2[idx] = (f32x2){c * re, c * im};
+    }
+    __syncthreads();
+    // rows: y[h][w] = sum_q c(q) Re(T[h][q] e^{+2 pi i w q / W}),  c = 1 on the DC / Nyquist column, else 2
+    //   = [H x 2 my] . [2 my x W] on the fp32 MFMA: k = 2 q + {re, im} (the float index inside a row of T), B = (cos, -sin)
+    float* y = a.dst + (long long)p * P;
+    {
+      const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+      const int nrb = (a.H + 15) / 16, nnb = (a.W + 15) / 16, ncol = 2 * a.my;
+      for (int it = wave; it < nrb * nnb; it += 4) {
+        const int rb = it / nnb, nb = it - rb * nnb;
+        const int h = 16 * rb + c, w = 16 * nb + c;
+        const bool hok = h < a.H, wok = w < a.W;
+        const float* arow = T + (hok ? h : 0) * ncol;
+        const float* brow = tw + (wok ? w : 0) * ncol;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < ncol; k0 += 4) {
+          const int k = k0 + g;
+          const bool kok = k < ncol;
+          const float av = (hok && kok) ? arow[k] : 0.f;
+          const float bv = (wok && kok) ? ((k & 1) ? -brow[k] : brow[k]) : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        if (wok) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int hh = 16 * rb + 4 * g + rr;
+            if (hh < a.H) y[(long long)hh * a.W + w] = acc[rr];
+          }
+        }
+      }
+    }
+  }
+}
+
+static long long dft_lds_bytes(int H, int W, int mx, int my, int inverse) {
+  const long long part = inverse ? 0 : 2LL * (mx * my > 256 ? mx * my : 256);
+  return 4LL * (2LL * W * my + 2LL * H * mx + (inverse ? 2LL * mx * my : (long long)H * (W + 1)) + 2LL * H * my + part);
+}
+
+// 1 when the kept-mode transforms take this shape (a plane and its tables fit the LDS of two workgroups per CU)
+extern "C" int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y) {
+  if (H < 2 || W < 2 || modes_x < 1 || modes_y < 1 || modes_x > H || modes_y > W / 2 + 1) return 0;
+  return dft_lds_bytes(H, W, modes_x, modes_y, 0) <= 64 * 1024 ? 1 : 0;
+}
+
+// Twiddle tables per (device, H, W, modes, rows): built on the host in double, uploaded at the first call (an eager one:
+// the engine captures HIP graphs from the second step on -- the same life cycle as a library FFT plan), kept for the process.
+static std::mutex g_dft_mutex;
+static std::map<std::tuple<int, int, int, int, int, int>, float*> g_dft_tabs;
+static const float* dft_table(int H, int W, int mx, int my, int rows) {
+  int dev = 0;
+#ifndef PPSCI_EMU
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+#endif
+  std::lock_guard<std::mutex> lock(g_dft_mutex);
+  const auto key = std::make_tuple(dev, H, W, mx, my, rows);
+  auto it = g_dft_tabs.find(key);
+  if (it != g_dft_tabs.end()) return it->second;
+  std::vector<float> t(2 * ((size_t)W * my + (size_t)H * mx));
+  const double two_pi = 6.283185307179586476925;
+  for (int w = 0; w < W; ++w)
+    for (int q = 0; q < my; ++q) {
+      const double ang = two_pi * (double)((long long)w * q % W) / (double)W;
+      t[2 * ((size_t)w * my + q)] = (float)cos(ang);
+      t[2 * ((size_t)w * my + q) + 1] = (float)sin(ang);
+    }
+  float* th = t.data() + 2 * (size_t)W * my;
+  const int c0 = (H - mx) / 2, sh = rows ? H / 2 : H - H / 2;  // spec_row_out / spec_row_in
+  for (int h = 0; h < H; ++h)
+    for (int m = 0; m < mx; ++m) {
+      const int k = (c0 + m + sh) % H;
+      const double ang = two_pi * (double)((long long)h * k % H) / (double)H;
+      th[2 * ((size_t)h * mx + m)] = (float)cos(ang);
+      th[2 * ((size_t)h * mx + m) + 1] = (float)sin(ang);
+    }
+  float* devp = nullptr;
+#ifdef PPSCI_EMU
+  devp = (float*)malloc(t.size() * sizeof(float));
+  if (devp) memcpy(devp, t.data(), t.size() * sizeof(float));
+#else
+  if (hipMalloc((void**)&devp, t.size() * sizeof(float)) != hipSuccess) return nullptr;
+  if (hipMemcpy(devp, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+#endif
+  g_dft_tabs[key] = devp;
+  return devp;
+}
+
+static int dft_run(int n, int H, int W, int mx, int my, int rows, const float* src, float* dst, int inverse, void* stream) {
+  if (n < 1 || !src || !dst || (rows != 0 && rows != 1) || !ppsci_dft2_kept_supported(H, W, mx, my)) {
+    ppsci_set_error("dft2_kept: invalid argument or unsupported shape (%d planes of %d x %d, modes %d x %d)", n, H, W, mx, my);
+    return PPSCI_E_INVALID;
+  }
+  const float* tab = dft_table(H, W, mx, my, rows);
+  if (!tab) {
+    ppsci_set_error("dft2_kept: cannot build the twiddle table");
+    return PPSCI_E_LAUNCH;
+  }
+  DftArgs a{src, dst, tab, n, H, W, mx, my, (H - mx) / 2, rows};
+  const long long lds = dft_lds_bytes(H, W, mx, my, inverse);
+  int grid = n < 8 * PPSCI_NUM_CU ? n : 8 * PPSCI_NUM_CU;
+  int se;
+  if (inverse) {
+    se = PPSCI_SET_MAX_LDS(dft2_kept_inv_kernel, (int)lds);
+    if (se == 0) PPSCI_LAUNCH(dft2_kept_inv_kernel, DftArgs, grid, 256, (int)lds, stream, a);
+  } else {
+    se = PPSCI_SET_MAX_LDS(dft2_kept_fwd_kernel, (int)lds);
+    if (se == 0) PPSCI_LAUNCH(dft2_kept_fwd_kernel, DftArgs, grid, 256, (int)lds, stream, a);
+  }
+  if (se != 0 || PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("dft2_kept: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y, int rows, const float* x, float* X,
+                                   void* stream) {
+  return dft_run(n, H, W, modes_x, modes_y, rows, x, X, 0, stream);
+}
+extern "C" int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
+                                   void* stream) {
+  return dft_run(n, H, W, modes_x, modes_y, rows, Z, y, 1, stream);
+}
+
+// The contraction and its adjoints on kept-mode spectra [B, C, modes_x, modes_y, 2] (no rows to map, nothing to clear)
+extern "C" int ppsci_spectral_conv2d_fwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re,
+                                              const float* w_im, float* out_k, float scale, void* stream) {
+  if (!d || !x_k || !w_re || !w_im || !out_k) {
+    ppsci_set_error("spectral_conv2d_fwd_kept: null pointer");
+    return PPSCI_E_INVALID;
+  }
+  return launch_contract(d, x_k, w_re, w_im, out_k, 0, stream, scale, 0, nullptr, 1);
+}
+extern "C" int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re,
+                                              const float* w_im, const float* ghat_k, float* gx_k, float* gw_re,
+                                              float* gw_im, float wscale, int w_full, float xscale, void* stream) {
+  if (!d || w_full < 1) {
+    ppsci_set_error("spectral_conv2d_bwd_kept: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  return spectral_bwd(d, x_k, w_re, w_im, ghat_k, gx_k, gw_re, gw_im, wscale, w_full, stream, xscale, 0, 1);
+}
+

@@ -20,6 +20,7 @@ it (arch/fno.py holds parameters, not operations); what it does not cover is ref
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -102,10 +103,15 @@ class FnoNative:
         self.t = [torch.empty((B, Ch, P), **f) for _ in range(nl)]              # pre-activations
         Wf = W // 2 + 1
         self.v = [torch.empty((B, Ch, P), **f) for _ in range(nl)]               # spectral outputs (irfftn results)
-        self.xft = [torch.empty((B, Ch, H, Wf, 2), **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
-        self.out_ft = torch.empty((B, Ch, H, Wf, 2), **f)  # cleared + kept modes written every time (C2R destroys it)
-        self.gx_ft = torch.empty((B, Ch, H, Wf, 2), **f)
-        self.ghat = torch.empty((B, Ch, H, Wf, 2), **f)
+        mx, my = m.fno_blocks.convs[0].n_modes
+        # the transforms on the kept modes only (two small DFTs per plane in LDS, spectra of mx x my numbers) when a plane
+        # fits LDS; hipFFT on the full spectrum otherwise.  PPSCI_FNO_FULL_FFT=1 forces the library path (tests, timing)
+        self.kept = bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my)) and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1"
+        sp = (B, Ch, mx, my, 2) if self.kept else (B, Ch, H, Wf, 2)
+        self.xft = [torch.empty(sp, **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
+        self.out_ft = torch.empty(sp, **f)  # (full spectrum: cleared + kept modes written every time, C2R destroys it)
+        self.gx_ft = torch.empty(sp, **f)
+        self.ghat = torch.empty(sp, **f)
         self.gsp = torch.empty((B, Ch, P), **f)
         self.rows = torch.empty(B * Ch * 4, **f)
         self.stats = [torch.empty(4 * B, **f) for _ in range(nl)]
@@ -122,7 +128,6 @@ class FnoNative:
         wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels)) + cmax
         self.part_w = torch.empty(self.chunks * wmax, **f)
         self.part_b = torch.empty(self.chunks * cmax, **f)
-        mx, my = m.fno_blocks.convs[0].n_modes
         self.desc = L.SpectralDesc()
         d = self.desc
         d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, Ch, Ch, H, Wf, mx, my
@@ -170,10 +175,17 @@ class FnoNative:
             if self.stab:  # fno_block.py:1199: x = tanh(x) in front of the spectral convolution (the skip sees x)
                 L.check(L.lib().ppsci_tanh_fwd(B * Ch * P, _p(xl), _p(self.xs[l]), st))
                 xl = self.xs[l]
-            L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
-            L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
-                                                             _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
-            L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.out_ft), _p(v), st))
+            if self.kept:
+                mx, my = self.desc.modes_x, self.desc.modes_y
+                L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 0, _p(xl), _p(xft), st))
+                L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(self.desc), _p(xft), _p(conv.weight_real),
+                                                               _p(conv.weight_imag), _p(self.out_ft), self.inv_n, st))
+                L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
+            else:
+                L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
+                L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
+                                                                 _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
+                L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.out_ft), _p(v), st))
             nrm = fb.norm[l] if fb.norm is not None else None
             last = l == nl - 1
             L.check(L.lib().ppsci_fno_tail_fwd(
@@ -250,11 +262,19 @@ class FnoNative:
             else:
                 hp.reduce_rows(self.gt.view(1, -1), 1, B * Ch * P, gnext.view(-1), False)
             # spectral branch: dL/dx_l += irfftn( rfftn(gv) . conj(w)^T ), weight gradients from x_ft and rfftn(gv)
-            L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
-            L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
-                C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat), _p(self.gx_ft),
-                _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, 1, st))
-            L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
+            if self.kept:  # (the adjoint reads dL/dy's spectrum at the OUTPUT rows and writes the input rows)
+                mx, my = self.desc.modes_x, self.desc.modes_y
+                L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 1, _p(self.gv), _p(self.ghat), st))
+                L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
+                    C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat),
+                    _p(self.gx_ft), _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, st))
+                L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 0, _p(self.gx_ft), _p(self.gsp), st))
+            else:
+                L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
+                L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
+                    C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat),
+                    _p(self.gx_ft), _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, 1, st))
+                L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.gx_ft), _p(self.gsp), st))
             if self.stab:  # gnext += gsp * (1 - tanh(x_l)^2)
                 L.check(L.lib().ppsci_tanh_bwd(B * Ch * P, _p(self.xs[l]), _p(self.gsp), _p(gnext), 1, st))
                 gx2 = None

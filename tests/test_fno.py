@@ -71,3 +71,44 @@ def test_spectral_conv_forward_and_gradients(B, ci, co, H, W, modes, dev):
     assert rel(gx.cpu().numpy(), gxr.numpy()) < 2e-6
     assert rel(gwr.cpu().numpy(), gwrr.numpy()) < 2e-6
     assert rel(gwi.cpu().numpy(), gwir.numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("n,H,W,modes", [(3, 16, 16, (8, 5)), (2, 9, 8, (4, 3)), (2, 11, 13, (6, 4)), (4, 64, 64, (12, 7)),
+                                         (2, 10, 12, (10, 7)), (1, 69, 69, (12, 7))])
+def test_transforms_on_the_kept_modes(n, H, W, modes, dev):
+    """ppsci_dft2_kept_fwd / _inv: rfftn at the rows / columns the spectral convolution keeps, and irfftn of a spectrum that
+    is zero everywhere else -- against torch.fft in fp64 with the reference's fftshift / slice bookkeeping (rows 0: the rows
+    taken from the shifted input spectrum; rows 1: where the second fftshift puts them; odd H: one apart).  A 10 x 12 case
+    keeps ALL columns (Nyquist included), 64 x 64 is the BASELINE shape."""
+    if dev == "emu" and H * W > 2000:
+        pytest.skip("too slow under the CPU emulator; runs on the GPU")
+    from paddlescience_amd.device import get_device
+
+    d = get_device()
+    mx, my = modes
+    lib = L.lib()
+    assert lib.ppsci_dft2_kept_supported(H, W, mx, my) == 1
+    rng = np.random.default_rng(3)
+    x = torch.as_tensor(rng.standard_normal((n, H, W)).astype(np.float32)).to(d)
+    start = H - mx
+    rows = slice(start // 2, -start // 2) if start else slice(None)
+    xf = torch.fft.rfftn(x.double().cpu(), dim=(-2, -1))
+    for which in (0, 1):
+        # the frequency rows behind shifted rows `rows`.  rows 0: shifted = fftshift(spectrum), i.e. shifted[s] = spectrum[
+        # fftshift(arange)[s]]; rows 1: spectrum = fftshift(shifted), i.e. shifted[s] lands at spectrum[ifftshift(arange)[s]]
+        idx = torch.arange(H)
+        src_rows = (torch.fft.fftshift(idx) if which == 0 else torch.fft.ifftshift(idx))[rows]
+        X = torch.full((n, mx, my, 2), float("nan"), device=d)
+        L.check(lib.ppsci_dft2_kept_fwd(n, H, W, mx, my, which, _p(x), _p(X), _stream_ptr(x)))
+        ref = xf[:, src_rows][:, :, :my]
+        got = torch.view_as_complex(X.double().cpu().contiguous())
+        assert rel(torch.view_as_real(got).numpy(), torch.view_as_real(ref).numpy()) < 2e-6, which
+        # inverse: the kept modes placed at those rows of a zero spectrum
+        Z = torch.as_tensor(rng.standard_normal((n, mx, my, 2)).astype(np.float32)).to(d)
+        full = torch.zeros((n, H, W // 2 + 1), dtype=torch.complex128)
+        full[:, src_rows, :my] = torch.view_as_complex(Z.double().cpu().contiguous())
+        yref = torch.fft.irfftn(full, s=(H, W), dim=(-2, -1), norm="forward")  # unscaled, as hipFFT C2R
+        y = torch.full((n, H, W), float("nan"), device=d)
+        L.check(lib.ppsci_dft2_kept_inv(n, H, W, mx, my, which, _p(Z), _p(y), _stream_ptr(y)))
+        assert rel(y.cpu().numpy(), yref.numpy()) < 2e-6, which
+
