@@ -359,7 +359,7 @@ def api_parity(name, inputs, outputs, hidden, make_eq, reduction, weight, tmp):
 
 def pinn_entry(label, solver, opt, cc, n, p_mat, S, steps, warmup, kernel_name, stem=None):
     def step():  # == the body of Solver.train()'s iteration for one constraint
-        if not solver._step_in_one_launch([cc.fused], [], 1.0):
+        if not solver._step_in_one_launch([cc.fused], 1.0):
             solver.engine.forward_backward([cc.fused])
             opt.step(solver.engine.grad)
 
@@ -535,11 +535,12 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
     conv = model.fno_blocks.convs[0]
     d = L.SpectralDesc()
     d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, 32, 32, H, W // 2 + 1, *conv.n_modes
-    x_ft = torch.randn(B, 32, H, W // 2 + 1, 2, device="cuda")
+    mx_, my_ = conv.n_modes
+    x_ft = torch.randn(B, 32, mx_, my_, 2, device="cuda")  # kept-mode spectra, as the step holds them
     o_ft = torch.zeros_like(x_ft)
     st = hp._stream_ptr(x_ft)
-    t_k = time_events(lambda: L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(
-        C.byref(d), hp._p(x_ft), hp._p(conv.weight_real), hp._p(conv.weight_imag), hp._p(o_ft), 1.0, 1, st)))
+    t_k = time_events(lambda: L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(
+        C.byref(d), hp._p(x_ft), hp._p(conv.weight_real), hp._p(conv.weight_imag), hp._p(o_ft), 1.0, st)))
     byts = 4.0 * (2 * 32 * 32 * 84 + 2 * 2 * B * 32 * 84)  # weights re+im, x_ft slice in, out slice out
     ach = byts / t_k / 1e12
     return {"config": "cfg4 TFNO-2D Darcy shape: 64x64 grid, batch 16, in 3, hidden 32, lifting 256, projection 64, "
@@ -549,9 +550,8 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
             "roofline": step_hbm_roofline("tfno", t),
             "spectral_contract_kernel": {"kernel_ms": t_k * 1e3, "operand_TBps": ach,
                                          "note": "84 modes x [16 x 64]x[64 x 64] real GEMM, 1.4 MB of operands, 11 MFLOP, one "
-                                                 "workgroup per mode with its operands staged in LDS; the same launch clears "
-                                                 "the 8.6 MB output spectrum around the kept modes (that, not the GEMM, is its "
-                                                 "duration)"},
+                                                 "workgroup per mode with its operands staged in LDS, on kept-mode spectra "
+                                                 "(ppsci_dft2_kept_*): launch / latency-bound at this size"},
             "native_forward_backward": eng.native is not None, "parity": parity}
 
 

@@ -53,3 +53,27 @@ def test_bench_refuses_a_launcher_world_that_differs_from_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_secondary_pinn_entry_runs_the_solver_step(tmp_path, monkeypatch):
+    """The secondary entries (cfg 1 / cfg 3) time `Solver`'s own iteration body through `bench.pinn_entry`; they only run
+    on a GPU, so a signature drift between bench.py and the Solver is caught here on the emulator at a tiny size."""
+    monkeypatch.setenv("PPSCI_BENCH_EMU", "1")
+    monkeypatch.setenv("PPSCI_BENCH_PURE_STEPS", "1")
+    import importlib
+
+    import numpy as np
+
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    sys.path.insert(0, ROOT)
+    bench = importlib.reload(importlib.import_module("bench"))
+    import ppsci
+
+    X = np.random.default_rng(0).uniform(0, 1, (48, 2)).astype(np.float32)
+    solver, opt, cc, _ = bench.api_pinn("t", ("x", "y"), ("u",), [20, 20, 20], ppsci.equation.Laplace(2), X, "mean", None,
+                                        str(tmp_path))
+    e = bench.pinn_entry("tiny", solver, opt, cc, 48, 1.0, 5, 1, 0, "k")
+    assert e["value"] > 0 and e["steps"] == 1
+

@@ -21,7 +21,7 @@ def laplace(tmp, hidden, n, one):
     e = bench.pinn_entry("", solver, opt, cc, n, 1, 5, 200, 20, "<>")
 
     def step():
-        if not solver._step_in_one_launch([cc.fused], [], 1.0):
+        if not solver._step_in_one_launch([cc.fused], 1.0):
             solver.engine.forward_backward([cc.fused])
             opt.step(solver.engine.grad)
 
