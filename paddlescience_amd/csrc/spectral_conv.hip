@@ -413,15 +413,27 @@ __global__ void __launch_bounds__(256) dft2_kept_fwd_kernel(DftArgs a) {
   float* pl = th + 2 * a.H * a.mx;
   const int ldp = a.W + 1;  // (odd row stride: the MFMA's A operand reads 16 rows at one column)
   float* T = pl + a.H * ldp;
-  dft_twiddles(a, tw);
   const int tid = threadIdx.x, P = a.H * a.W;
+  bool first = true;
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
-    __syncthreads();  // (twiddles ready; the previous plane's T consumed)
+    // the plane's loads (the first 16 per thread: all of a 64 x 64 plane) are requested BEFORE the twiddle table's, so
+    // that the two memory round trips of the first plane overlap
     const float* x = a.src + (long long)p * P;
-    for (int e = tid; e < P; e += 256) {
-      const int h = e / a.W;
-      pl[e + h] = x[e];  // = pl[h * ldp + w]
+    float xr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = tid + 256 * k;
+      xr[k] = e < P ? x[e] : 0.f;
     }
+    if (first) dft_twiddles(a, tw);
+    first = false;
+    __syncthreads();  // (the previous plane's T and partial sums consumed)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = tid + 256 * k;
+      if (e < P) pl[e + e / a.W] = xr[k];  // = pl[h * ldp + w]
+    }
+    for (int e = tid + 4096; e < P; e += 256) pl[e + e / a.W] = x[e];
     __syncthreads();
     // rows: T[h][q] = sum_w x[h][w] e^{-2 pi i w q / W}
     const f32x2* th2 = (const f32x2*)th;
@@ -489,12 +501,25 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
   float* th = tw + 2 * a.W * a.my;
   float* Z = th + 2 * a.H * a.mx;
   float* T = Z + 2 * a.mx * a.my;
-  dft_twiddles(a, tw);
   const int tid = threadIdx.x, P = a.H * a.W, nm = a.mx * a.my;
+  bool first = true;
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
-    __syncthreads();
     const float* z = a.src + (long long)p * nm * 2;
-    for (int e = tid; e < 2 * nm; e += 256) Z[e] = z[e];
+    float zr[2];  // (requested before the twiddle table, see the forward kernel)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      zr[k] = e < 2 * nm ? z[e] : 0.f;
+    }
+    if (first) dft_twiddles(a, tw);
+    first = false;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + 256 * k;
+      if (e < 2 * nm) Z[e] = zr[k];
+    }
+    for (int e = tid + 512; e < 2 * nm; e += 256) Z[e] = z[e];
     __syncthreads();
     // columns: T[h][q] = sum_m Z[m][q] e^{+2 pi i h k_m / H}
     const f32x2* th2 = (const f32x2*)th;
