@@ -236,3 +236,37 @@ def test_tfno_full_size_batch16_64x64(dev):
     for n, p in torch.nn.Module.named_parameters(model):
         assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 2e-5, n
 
+
+@pytest.mark.parametrize("padding,full_fft", [(0.078125, False), (0.078125, True), (0.1, False)])
+def test_tfno_64x64_with_the_yaml_domain_padding(dev, padding, full_fft, monkeypatch):
+    """The padding the reference's TFNO yaml names (0.078125: 64 -> 69 x 69 planes, odd: element accesses, the double
+    fftshift one row apart) and 0.1 (70 x 70: a multiple of 4 but not of 16) at the BASELINE plane size, batch 4, on the
+    kept-mode transforms and on the library FFT: output, loss and every gradient against the fp64 oracle."""
+    if dev != "gpu":
+        pytest.skip("full plane sizes run on the GPU only")
+    import ppsci
+    from oracle import ref_torch as R
+
+    monkeypatch.setenv("PPSCI_FNO_FULL_FFT", "1" if full_fft else "0")
+    torch.manual_seed(1)
+    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 12, 12, hidden_channels=32, in_channels=3, out_channels=1,
+                                 lifting_channels=256, projection_channels=64, n_layers=4, norm="group_norm",
+                                 domain_padding=padding)
+    x = torch.as_tensor(np.random.default_rng(2).standard_normal((4, 3, 64, 64)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(3).standard_normal((4, 1, 64, 64)).astype(np.float32)).cuda()
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.fno_forward(x.cpu().double(), P, 4, (12, 12), "group_norm", domain_padding=padding)
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    yh = nat.forward(x)
+    assert nat.kept == (not full_fft) and nat.hw == ((69, 69) if padding < 0.09 else (70, 70))
+    losses, gy = ppsci.loss.MSELoss("mean").value_and_grad(yh, y, "y")
+    assert K._rel(yh.cpu().numpy(), yo.detach().numpy()) < 2e-6
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    for n, p in torch.nn.Module.named_parameters(model):
+        assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 2e-5, n
+
