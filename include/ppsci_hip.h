@@ -387,6 +387,10 @@ int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* d, const fl
 int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y);
 int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y, int rows, const float* x, float* X, void* stream);
 int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y, void* stream);
+/* ppsci_dft2_kept_inv that also leaves the first pass of the block tail behind: rows_out[plane][4] gets the sums of
+ * y + sbias[plane % C] and of its square (ppsci_fno_tail_fwd_ex with have_rows = 1 then skips its statistics pass). */
+int ppsci_dft2_kept_inv_stats(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
+                              const float* sbias, int C, float* rows_out, void* stream);
 int ppsci_spectral_conv2d_fwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
                                    float* out_k, float scale, void* stream);
 int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
@@ -457,6 +461,20 @@ int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const
 int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
                        const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
                        float* gv, float* ggamma, float* gbeta, float* gsbias, void* stream);
+/* The block tail next to the kept-mode transforms: a workgroup of the apply kernels produces one whole [H, W] plane, so it
+ * can transform that plane from LDS instead of storing it for a transform launch to read back.
+ *   _fwd_ex: have_rows != 0 -- `rows` already holds the row sums (ppsci_dft2_kept_inv_stats): no statistics pass;
+ *            X_next != NULL -- also emits the kept modes (input rows) of y = the next block's input, [B*C, mx, my, 2].
+ *   _bwd_ex: ghat != NULL -- also emits the kept modes (OUTPUT rows) of gv = dL/dv, which only the spectral branch's
+ *            backward reads; gv may then be NULL (never stored).
+ * H * W == P and ppsci_dft2_kept_supported(H, W, modes_x, modes_y) are required when X_next / ghat is given. */
+int ppsci_fno_tail_fwd_ex(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                          const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
+                          float* y, int have_rows, int H, int W, int modes_x, int modes_y, float* X_next, void* stream);
+int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
+                          const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
+                          float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int modes_x, int modes_y,
+                          float* ghat, void* stream);
 
 /* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
  * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it

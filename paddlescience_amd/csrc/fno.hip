@@ -22,6 +22,7 @@
 //   map, the skip addition and GELU; backward with per-row sums, a tiny fixed-order finalisation and one apply pass.
 // All reductions have a fixed order (no float atomics): bit-reproducible.
 #include "taylor_tile.h"  // ppsci_split / PPSCI_XDL: fp32 GEMMs on the bf16 (XDL) matrix pipe
+#include "dft_kept.h"     // the apply kernels of the block tail can transform the plane they have just produced
 
 #ifndef PPSCI_EMU
 #include <hip/hip_runtime.h>
@@ -84,7 +85,6 @@ __device__ __forceinline__ void fno_st4(float* row, long long p, long long lim, 
   }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // N = 1, 2 or 4 neighbouring pixels (components N.. of the result are zero); al: P a multiple of N
 template <int N>
 __device__ __forceinline__ f32x4 fno_ldn(const float* row, long long p, long long lim, bool al) {
@@ -829,7 +829,15 @@ struct GnArgs {
   float* gsbias;
   int B, C, P, norm, gelu;
   float eps;
+  DftArgs d;           // DFT instances: the kept modes of the plane this workgroup produces (y forward, gv backward) -> d.dst
 };
+
+// puts four neighbouring values of the row into the LDS plane [H][W + 1] of the transform
+__device__ __forceinline__ void gn_to_plane(float* pl, int W, int p, int P, f32x4 v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (p + k < P) pl[p + k + (p + k) / W] = v[k];
+}
 
 __device__ __forceinline__ float fno_block_sum(float v, float* red) {
   // sum over the 256 threads of the workgroup, fixed order; result in every thread
@@ -892,9 +900,15 @@ __global__ void __launch_bounds__(256) gn_rowstats_kernel(GnArgs a) {
 // one workgroup per (b, c) row.  The statistics of sample b are finished HERE from the row sums (C pairs, in double, a
 // fixed-shape tree) -- by every workgroup of the sample in parallel instead of a one-workgroup kernel between the row
 // pass and this one (that kernel was a 5 us serial chain); the workgroup of channel 0 stores them for the backward pass.
-template <bool AL>
+template <bool AL, bool DFT>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
   __shared__ double red[512];
+  PPSCI_DYN_SMEM(smem);  // DFT: tw | th | plane | T | partial sums (dft_kept.h)
+  float* tw = smem;
+  float* th = tw + 2 * a.d.W * a.d.my;
+  float* pl = th + 2 * a.d.H * a.d.mx;
+  float* T = pl + a.d.H * (a.d.W + 1);
+  if constexpr (DFT) dft_twiddles(a.d, tw);  // (in flight during the statistics below)
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
   const long long base = (long long)row * a.P;
   float mean = 0.f, rstd = 1.f;
@@ -930,7 +944,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
         for (int k = 0; k < 4; ++k) y[k] = fno_gelu(u[k]);
       }
       fno_st4(a.y + base, p, a.P, al, y);
+      if constexpr (DFT) gn_to_plane(pl, a.d.W, p, a.P, y);
     }
+  }
+  if constexpr (DFT) {  // y is the next block's input: its kept modes now, from LDS, instead of a transform launch that reads it back
+    __syncthreads();
+    dft_fwd_stages(a.d, tw, th, pl, T, a.d.dst + (long long)row * a.d.mx * a.d.my * 2);
   }
 }
 
@@ -980,15 +999,25 @@ __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
 //   dsbias[c] = sum_b rstd_b (gamma_c r1[b,c] - P m1_b - r3[b,c] m2_b)     (= sum over b and p of gv; norm == 0: sum_b r1)
 // -- m1_b, m2_b of every sample again from the row sums: 16 threads per sample, 16 samples at a time, all in a fixed order.
 // (Round 3 had a one-workgroup kernel between the passes for all of this: 9.9 us of serial double-precision loops.)
-template <bool AL>
+template <bool AL, bool DFT>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnArgs a) {
   __shared__ double red[512];
+  PPSCI_DYN_SMEM(smem);  // DFT: tw | th | plane | T | partial sums (dft_kept.h)
+  float* tw = smem;
+  float* th = tw + 2 * a.d.W * a.d.my;
+  float* pl = th + 2 * a.d.H * a.d.mx;
+  float* T = pl + a.d.H * (a.d.W + 1);
+  if constexpr (DFT) dft_twiddles(a.d, tw);
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
   const long long base = (long long)row * a.P;
   const double n = (double)a.C * a.P;
   constexpr bool al = AL;
   if (!a.norm) {
-    for (int p = threadIdx.x * 4; p < a.P; p += 1024) fno_st4(a.gv + base, p, a.P, al, fno_ld4(a.gt + base, p, a.P, al));
+    for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
+      const f32x4 g4 = fno_ld4(a.gt + base, p, a.P, al);
+      if (a.gv) fno_st4(a.gv + base, p, a.P, al, g4);
+      if constexpr (DFT) gn_to_plane(pl, a.d.W, p, a.P, g4);
+    }
   } else {
     double s1 = 0.0, s2 = 0.0;
     for (int cc = threadIdx.x; cc < a.C; cc += 256) {
@@ -1003,8 +1032,14 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(GnArgs a) {
     for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
       const f32x4 g4 = fno_ld4(a.gt + base, p, a.P, al);
       const f32x4 xh = (fno_ld4(a.v + base, p, a.P, al) + sb - mean) * rstd;
-      fno_st4(a.gv + base, p, a.P, al, (g4 * gm - m1 - xh * m2) * rstd);
+      const f32x4 gv4 = (g4 * gm - m1 - xh * m2) * rstd;
+      if (a.gv) fno_st4(a.gv + base, p, a.P, al, gv4);
+      if constexpr (DFT) gn_to_plane(pl, a.d.W, p, a.P, gv4);
     }
+  }
+  if constexpr (DFT) {  // dL/dv only feeds the spectral branch's transform: its kept modes (output rows) straight from LDS
+    __syncthreads();
+    dft_fwd_stages(a.d, tw, th, pl, T, a.d.dst + (long long)row * a.d.mx * a.d.my * 2);
   }
   if (b != 0) return;
   // parameter gradients of channel c (uniform branch: the whole workgroup)
@@ -1072,26 +1107,82 @@ static int gn_check(int B, int C, int P) {
 }
 
 // rows: [B*C*4] floats of scratch; stats: [4*B] floats (mean, rstd per sample; the backward appends two more per sample)
+static int gn_dft_args(DftArgs* d, int P, int H, int W, int mx, int my, int rows, float* dst, long long* lds) {
+  if (H * W != P || !ppsci_dft2_kept_supported(H, W, mx, my)) {
+    ppsci_set_error("fno block tail: the kept-mode transform does not take %d x %d planes with %d x %d modes", H, W, mx, my);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  memset(d, 0, sizeof(*d));
+  d->tab = ppsci_dft_table(H, W, mx, my, rows);
+  if (!d->tab) {
+    ppsci_set_error("fno block tail: cannot build the twiddle table");
+    return PPSCI_E_LAUNCH;
+  }
+  d->dst = dst, d->H = H, d->W = W, d->mx = mx, d->my = my, d->c0 = (H - mx) / 2, d->rows = rows;
+  *lds = 4LL * dft_fwd_lds_floats(H, W, mx, my);
+  return PPSCI_OK;
+}
+
+static int fno_tail_fwd_run(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                            const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
+                            float* y, int have_rows, int H, int W, int mx, int my, float* X_next, void* stream);
+
 extern "C" int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
                                   const float* gamma, const float* beta, const float* skip, float* rows, float* stats,
                                   float* t, float* y, void* stream) {
-  if (gn_check(B, C, P) != PPSCI_OK || !v || !t || !rows || !stats || (norm && (!gamma || !beta))) {
+  return fno_tail_fwd_run(B, C, P, norm, gelu, eps, v, sbias, gamma, beta, skip, rows, stats, t, y, 0, 0, 0, 0, 0, nullptr, stream);
+}
+
+// ppsci_fno_tail_fwd with: have_rows != 0 -- `rows` already holds the row sums of v + sbias (ppsci_dft2_kept_inv_stats wrote
+// them): no statistics pass;  X_next != NULL -- the apply kernel also emits the kept modes (input rows) of y, the next
+// block's input ([B*C, modes_x, modes_y, 2]; H * W == P, ppsci_dft2_kept_supported): no transform launch reads y back.
+extern "C" int ppsci_fno_tail_fwd_ex(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                                     const float* gamma, const float* beta, const float* skip, float* rows, float* stats,
+                                     float* t, float* y, int have_rows, int H, int W, int modes_x, int modes_y, float* X_next,
+                                     void* stream) {
+  return fno_tail_fwd_run(B, C, P, norm, gelu, eps, v, sbias, gamma, beta, skip, rows, stats, t, y, have_rows, H, W, modes_x,
+                          modes_y, X_next, stream);
+}
+
+static int fno_tail_fwd_run(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
+                            const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
+                            float* y, int have_rows, int H, int W, int mx, int my, float* X_next, void* stream) {
+  if (gn_check(B, C, P) != PPSCI_OK || !v || !t || !rows || !stats || (norm && (!gamma || !beta)) || (X_next && !y)) {
     ppsci_set_error("fno_tail_fwd: invalid argument");
     return PPSCI_E_INVALID;
   }
   GnArgs a;
   memset(&a, 0, sizeof(a));
+  long long lds = 0;
+  if (X_next) {
+    int rc = gn_dft_args(&a.d, P, H, W, mx, my, 0, X_next, &lds);
+    if (rc != PPSCI_OK) return rc;
+  }
+  const DftArgs dsave = a.d;
   a.v = v, a.sbias = sbias, a.gamma = gamma, a.beta = beta, a.skip = skip, a.rows = rows, a.stats = stats, a.t = t, a.y = y;
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu, a.eps = eps;
+  a.d = dsave;
   // (16-byte accesses when every row starts on a 16-byte boundary; element accesses otherwise)
   const bool aligned = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(skip) |
                                          reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-  if (aligned) {
-    if (norm) PPSCI_LAUNCH(gn_rowstats_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
-    PPSCI_LAUNCH(gn_apply_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
-  } else {
-    if (norm) PPSCI_LAUNCH(gn_rowstats_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
-    PPSCI_LAUNCH(gn_apply_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+  const bool stats_pass = norm && !have_rows;
+  int se = 0;
+#define GN_FWD(AL)                                                                                       \
+  do {                                                                                                   \
+    if (stats_pass) PPSCI_LAUNCH(gn_rowstats_kernel<AL>, GnArgs, B * C, 256, 0, stream, a);              \
+    if (X_next) {                                                                                        \
+      se = PPSCI_SET_MAX_LDS((gn_apply_kernel<AL, true>), (int)lds);                                     \
+      if (se == 0) PPSCI_LAUNCH((gn_apply_kernel<AL, true>), GnArgs, B * C, 256, (int)lds, stream, a);   \
+    } else {                                                                                             \
+      PPSCI_LAUNCH((gn_apply_kernel<AL, false>), GnArgs, B * C, 256, 0, stream, a);                      \
+    }                                                                                                    \
+  } while (0)
+  if (aligned) GN_FWD(true);
+  else GN_FWD(false);
+#undef GN_FWD
+  if (se != 0) {
+    ppsci_set_error("fno_tail_fwd: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
   }
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("fno_tail_fwd: launch failed");
@@ -1101,28 +1192,68 @@ extern "C" int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float
 }
 
 // ggamma / gbeta / gsbias: [C] each (null to skip); gt: dL/dt (= gradient of the skip branch); gv: dL/dv
+static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
+                            const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
+                            float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int mx, int my, float* ghat,
+                            void* stream);
+
 extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias,
                                   const float* gamma, const float* t, const float* gout, const float* gout2, float* rows,
                                   float* stats, float* gt, float* gv, float* ggamma, float* gbeta, float* gsbias,
                                   void* stream) {
-  if (gn_check(B, C, P) != PPSCI_OK || !v || !gout || !rows || !stats || !gt || !gv || (gelu && !t) || (norm && !gamma)) {
+  return fno_tail_bwd_run(B, C, P, norm, gelu, v, sbias, gamma, t, gout, gout2, rows, stats, gt, gv, ggamma, gbeta, gsbias, 0, 0,
+                          0, 0, nullptr, stream);
+}
+
+// ppsci_fno_tail_bwd with ghat != NULL: the second pass also emits the kept modes (OUTPUT rows) of gv = dL/dv, which is what
+// the spectral branch's backward transforms first ([B*C, modes_x, modes_y, 2]); gv itself may then be NULL (never stored).
+extern "C" int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias,
+                                     const float* gamma, const float* t, const float* gout, const float* gout2, float* rows,
+                                     float* stats, float* gt, float* gv, float* ggamma, float* gbeta, float* gsbias, int H,
+                                     int W, int modes_x, int modes_y, float* ghat, void* stream) {
+  return fno_tail_bwd_run(B, C, P, norm, gelu, v, sbias, gamma, t, gout, gout2, rows, stats, gt, gv, ggamma, gbeta, gsbias, H, W,
+                          modes_x, modes_y, ghat, stream);
+}
+
+static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
+                            const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
+                            float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int mx, int my, float* ghat,
+                            void* stream) {
+  if (gn_check(B, C, P) != PPSCI_OK || !v || !gout || !rows || !stats || !gt || (!gv && !ghat) || (gelu && !t) ||
+      (norm && !gamma)) {
     ppsci_set_error("fno_tail_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
   GnArgs a;
   memset(&a, 0, sizeof(a));
+  long long lds = 0;
+  if (ghat) {
+    int rc = gn_dft_args(&a.d, P, H, W, mx, my, 1, ghat, &lds);
+    if (rc != PPSCI_OK) return rc;
+  }
   a.v = v, a.sbias = sbias, a.gamma = gamma, a.t = (float*)t, a.gout = gout, a.gout2 = gout2, a.rows = rows, a.stats = stats;
   a.gt = gt, a.gv = gv, a.ggamma = ggamma, a.gbeta = gbeta, a.gsbias = gsbias;
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu;
   const bool aligned = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gout) |
                                          reinterpret_cast<uintptr_t>(gout2) | reinterpret_cast<uintptr_t>(gt) |
                                          reinterpret_cast<uintptr_t>(gv)) & 15) == 0;
-  if (aligned) {
-    PPSCI_LAUNCH(gn_bwd_rows_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
-    PPSCI_LAUNCH(gn_bwd_apply_kernel<true>, GnArgs, B * C, 256, 0, stream, a);
-  } else {
-    PPSCI_LAUNCH(gn_bwd_rows_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
-    PPSCI_LAUNCH(gn_bwd_apply_kernel<false>, GnArgs, B * C, 256, 0, stream, a);
+  int se = 0;
+#define GN_BWD(AL)                                                                                           \
+  do {                                                                                                       \
+    PPSCI_LAUNCH(gn_bwd_rows_kernel<AL>, GnArgs, B * C, 256, 0, stream, a);                                  \
+    if (ghat) {                                                                                              \
+      se = PPSCI_SET_MAX_LDS((gn_bwd_apply_kernel<AL, true>), (int)lds);                                     \
+      if (se == 0) PPSCI_LAUNCH((gn_bwd_apply_kernel<AL, true>), GnArgs, B * C, 256, (int)lds, stream, a);   \
+    } else {                                                                                                 \
+      PPSCI_LAUNCH((gn_bwd_apply_kernel<AL, false>), GnArgs, B * C, 256, 0, stream, a);                      \
+    }                                                                                                        \
+  } while (0)
+  if (aligned) GN_BWD(true);
+  else GN_BWD(false);
+#undef GN_BWD
+  if (se != 0) {
+    ppsci_set_error("fno_tail_bwd: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
   }
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("fno_tail_bwd: launch failed");

@@ -392,19 +392,7 @@ static int spectral_bwd(const ppsci_spectral_desc* d, const float* x_ft, const f
 //                         and zero elsewhere (unscaled; like the library C2R: Re of the DC / Nyquist columns only)
 // `rows`: 0 = the rows the reference's slice takes from the shifted INPUT spectrum, 1 = the rows its second fftshift puts
 // the products to (spec_row_in / spec_row_out: the same for even H).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct DftArgs {
-  const float* src;
-  float* dst;
-  const float* tab;  // twiddles tw [W][my][2] | th [H][mx][2], computed once per shape on the host in double (a "plan")
-  int n, H, W, mx, my, c0, rows;
-};
-
-// LDS (floats): tw [W][my][2] | th [H][mx][2] | plane [H*W] (fwd) or Z [mx*my*2] (inv) | T [H][my][2] | fwd: partial sums
-__device__ __forceinline__ void dft_twiddles(const DftArgs& a, float* tw) {
-  const int nt = 2 * (a.W * a.my + a.H * a.mx);
-  for (int idx = threadIdx.x; idx < nt; idx += blockDim.x) tw[idx] = a.tab[idx];
-}
+#include "dft_kept.h"
 
 __global__ void __launch_bounds__(256) dft2_kept_fwd_kernel(DftArgs a) {
   PPSCI_DYN_SMEM(smem);
@@ -435,63 +423,7 @@ __global__ void __launch_bounds__(256) dft2_kept_fwd_kernel(DftArgs a) {
     }
     for (int e = tid + 4096; e < P; e += 256) pl[e + e / a.W] = x[e];
     __syncthreads();
-    // rows: T[h][q] = sum_w x[h][w] e^{-2 pi i w q / W}
-    const f32x2* th2 = (const f32x2*)th;
-    f32x2* T2 = (f32x2*)T;
-    {
-      // [H x W] . [W x 2 my] on the fp32 MFMA (16 x 16 x 4): rows h, columns 2 q + {re, im}, k = w.  The column index of the
-      // D tile is the float index inside row h of T ([h][my][2]), so the result rows are stored as they come.
-      const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-      const int nrb = (a.H + 15) / 16, ncol = 2 * a.my, nnb = (ncol + 15) / 16;
-      for (int it = wave; it < nrb * nnb; it += 4) {
-        const int rb = it / nnb, nb = it - rb * nnb;
-        const int h = 16 * rb + c, col = 16 * nb + c;
-        const bool hok = h < a.H, cok = col < ncol;
-        const float* arow = pl + (hok ? h : 0) * ldp;
-        const float* bcol = tw + (cok ? col : 0);  // tw[w][my][2] = row w of 2 my floats: (cos, sin) pairs
-        const float bs = (col & 1) ? -1.f : 1.f;   // e^{-i phi} = cos - i sin
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int w0 = 0; w0 < a.W; w0 += 4) {
-          const int w = w0 + g;
-          const bool wok = w < a.W;
-          const float av = (hok && wok) ? arow[w] : 0.f;
-          const float bv = (cok && wok) ? bs * bcol[w * ncol] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-        }
-        if (cok) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int hh = 16 * rb + 4 * g + rr;
-            if (hh < a.H) T[hh * ncol + col] = acc[rr];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // columns: X[m][q] = sum_h T[h][q] e^{-2 pi i h k_m / H}; the h range in `parts` pieces (mx * my outputs are fewer than
-    // the workgroup's threads), combined in a fixed order through LDS
-    const int nm = a.mx * a.my;
-    const int parts = nm < 256 ? (256 / nm < a.H ? 256 / nm : a.H) : 1;
-    f32x2* part = (f32x2*)(T + 2 * a.H * a.my);  // [parts][nm], parts * nm <= 256 (or one part of nm)
-    for (int it = tid; it < parts * nm || (parts == 1 && it < nm); it += 256) {
-      const int pt = it / nm, idx = it - pt * nm;
-      const int m = idx / a.my, q = idx - m * a.my;
-      const int h0 = (int)((long long)a.H * pt / parts), h1 = (int)((long long)a.H * (pt + 1) / parts);
-      float re = 0.f, im = 0.f;
-#pragma unroll 4
-      for (int h = h0; h < h1; ++h) {
-        const f32x2 t = T2[h * a.my + q], e = th2[h * a.mx + m];
-        re += t[0] * e[0] + t[1] * e[1];
-        im += t[1] * e[0] - t[0] * e[1];
-      }
-      part[it] = (f32x2){re, im};
-    }
-    __syncthreads();
-    for (int idx = tid; idx < nm; idx += 256) {
-      f32x2 acc = part[idx];
-      for (int pt = 1; pt < parts; ++pt) acc += part[pt * nm + idx];
-      *(f32x2*)(a.dst + ((long long)p * nm + idx) * 2) = acc;
-    }
+    dft_fwd_stages(a, tw, th, pl, T, a.dst + (long long)p * a.mx * a.my * 2);
   }
 }
 
@@ -501,6 +433,7 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
   float* th = tw + 2 * a.W * a.my;
   float* Z = th + 2 * a.H * a.mx;
   float* T = Z + 2 * a.mx * a.my;
+  float* sred = T + 2 * a.H * a.my;  // 512 floats: the row sums' tree
   const int tid = threadIdx.x, P = a.H * a.W, nm = a.mx * a.my;
   bool first = true;
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
@@ -541,6 +474,8 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
     // rows: y[h][w] = sum_q c(q) Re(T[h][q] e^{+2 pi i w q / W}),  c = 1 on the DC / Nyquist column, else 2
     //   = [H x 2 my] . [2 my x W] on the fp32 MFMA: k = 2 q + {re, im} (the float index inside a row of T), B = (cos, -sin)
     float* y = a.dst + (long long)p * P;
+    const float sb = (a.rows_out && a.sbias) ? a.sbias[p % a.C] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
     {
       const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
       const int nrb = (a.H + 15) / 16, nnb = (a.W + 15) / 16, ncol = 2 * a.my;
@@ -562,17 +497,39 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int hh = 16 * rb + 4 * g + rr;
-            if (hh < a.H) y[(long long)hh * a.W + w] = acc[rr];
+            if (hh < a.H) {
+              y[(long long)hh * a.W + w] = acc[rr];
+              const float u = acc[rr] + sb;
+              s1 += u;
+              s2 += u * u;
+            }
           }
         }
+      }
+    }
+    if (a.rows_out) {  // the block tail's first pass (gn_rowstats_kernel) for free: the plane is in this workgroup's registers
+      __syncthreads();
+      sred[tid] = s1;
+      sred[256 + tid] = s2;
+      __syncthreads();
+      for (int wd = 128; wd > 0; wd >>= 1) {
+        if (tid < wd) {
+          sred[tid] += sred[tid + wd];
+          sred[256 + tid] += sred[256 + tid + wd];
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        a.rows_out[(long long)p * 4 + 0] = sred[0];
+        a.rows_out[(long long)p * 4 + 1] = sred[256];
       }
     }
   }
 }
 
 static long long dft_lds_bytes(int H, int W, int mx, int my, int inverse) {
-  const long long part = inverse ? 0 : 2LL * (mx * my > 256 ? mx * my : 256);
-  return 4LL * (2LL * W * my + 2LL * H * mx + (inverse ? 2LL * mx * my : (long long)H * (W + 1)) + 2LL * H * my + part);
+  if (!inverse) return 4LL * dft_fwd_lds_floats(H, W, mx, my);
+  return 4LL * (2LL * W * my + 2LL * H * mx + 2LL * mx * my + 2LL * H * my + 512);
 }
 
 // 1 when the kept-mode transforms take this shape (a plane and its tables fit the LDS of two workgroups per CU)
@@ -585,7 +542,7 @@ extern "C" int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y)
 // the engine captures HIP graphs from the second step on -- the same life cycle as a library FFT plan), kept for the process.
 static std::mutex g_dft_mutex;
 static std::map<std::tuple<int, int, int, int, int, int>, float*> g_dft_tabs;
-static const float* dft_table(int H, int W, int mx, int my, int rows) {
+const float* ppsci_dft_table(int H, int W, int mx, int my, int rows) {
   int dev = 0;
 #ifndef PPSCI_EMU
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -623,17 +580,18 @@ static const float* dft_table(int H, int W, int mx, int my, int rows) {
   return devp;
 }
 
-static int dft_run(int n, int H, int W, int mx, int my, int rows, const float* src, float* dst, int inverse, void* stream) {
+static int dft_run(int n, int H, int W, int mx, int my, int rows, const float* src, float* dst, int inverse, void* stream,
+                   const float* sbias = nullptr, int C = 1, float* rows_out = nullptr) {
   if (n < 1 || !src || !dst || (rows != 0 && rows != 1) || !ppsci_dft2_kept_supported(H, W, mx, my)) {
     ppsci_set_error("dft2_kept: invalid argument or unsupported shape (%d planes of %d x %d, modes %d x %d)", n, H, W, mx, my);
     return PPSCI_E_INVALID;
   }
-  const float* tab = dft_table(H, W, mx, my, rows);
+  const float* tab = ppsci_dft_table(H, W, mx, my, rows);
   if (!tab) {
     ppsci_set_error("dft2_kept: cannot build the twiddle table");
     return PPSCI_E_LAUNCH;
   }
-  DftArgs a{src, dst, tab, n, H, W, mx, my, (H - mx) / 2, rows};
+  DftArgs a{src, dst, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, C > 0 ? C : 1};
   const long long lds = dft_lds_bytes(H, W, mx, my, inverse);
   int grid = n < 8 * PPSCI_NUM_CU ? n : 8 * PPSCI_NUM_CU;
   int se;
@@ -658,6 +616,17 @@ extern "C" int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y
 extern "C" int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
                                    void* stream) {
   return dft_run(n, H, W, modes_x, modes_y, rows, Z, y, 1, stream);
+}
+
+// ppsci_dft2_kept_inv + the first pass of the block tail that consumes y: rows_out[plane][4] gets sum(y + sbias[plane % C])
+// and the sum of its square (what gn_rowstats_kernel computes from a second read of y); ppsci_fno_tail_fwd_ex(have_rows = 1)
+extern "C" int ppsci_dft2_kept_inv_stats(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
+                                         const float* sbias, int C, float* rows_out, void* stream) {
+  if (!rows_out || C < 1) {
+    ppsci_set_error("dft2_kept_inv_stats: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  return dft_run(n, H, W, modes_x, modes_y, rows, Z, y, 1, stream, sbias, C, rows_out);
 }
 
 // The contraction and its adjoints on kept-mode spectra [B, C, modes_x, modes_y, 2] (no rows to map, nothing to clear)

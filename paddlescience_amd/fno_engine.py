@@ -107,6 +107,8 @@ class FnoNative:
         # the transforms on the kept modes only (two small DFTs per plane in LDS, spectra of mx x my numbers) when a plane
         # fits LDS; hipFFT on the full spectrum otherwise.  PPSCI_FNO_FULL_FFT=1 forces the library path (tests, timing)
         self.kept = bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my)) and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1"
+        # (the tanh stabilizer puts a pointwise function between a block's output and the next transform's input)
+        self.fuse_dft = self.kept and m.fno_blocks.stabilizer != "tanh"
         sp = (B, Ch, mx, my, 2) if self.kept else (B, Ch, H, Wf, 2)
         self.xft = [torch.empty(sp, **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
         self.out_ft = torch.empty(sp, **f)  # (full spectrum: cleared + kept modes written every time, C2R destroys it)
@@ -175,19 +177,33 @@ class FnoNative:
             if self.stab:  # fno_block.py:1199: x = tanh(x) in front of the spectral convolution (the skip sees x)
                 L.check(L.lib().ppsci_tanh_fwd(B * Ch * P, _p(xl), _p(self.xs[l]), st))
                 xl = self.xs[l]
+            nrm = fb.norm[l] if fb.norm is not None else None
+            last = l == nl - 1
             if self.kept:
+                # The tail's apply kernel of block l - 1 has already left the kept modes of x_l in xft[l] (its workgroups
+                # hold whole planes); the inverse transform leaves the row sums of the tail's statistics pass behind
                 mx, my = self.desc.modes_x, self.desc.modes_y
-                L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 0, _p(xl), _p(xft), st))
+                if not (self.fuse_dft and l > 0):
+                    L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 0, _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(self.desc), _p(xft), _p(conv.weight_real),
                                                                _p(conv.weight_imag), _p(self.out_ft), self.inv_n, st))
-                L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
+                if nrm is not None:
+                    L.check(L.lib().ppsci_dft2_kept_inv_stats(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), _p(conv.bias),
+                                                              Ch, _p(self.rows), st))
+                else:
+                    L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
+                L.check(L.lib().ppsci_fno_tail_fwd_ex(
+                    B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
+                    _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
+                    _p(sk), _p(self.rows), _p(self.stats[l]), _p(self.t[l]), None if last else _p(self.x[l + 1]),
+                    1 if nrm is not None else 0, H, W, mx, my,
+                    _p(self.xft[l + 1]) if (self.fuse_dft and not last) else None, st))
+                continue
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
                                                                  _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
                 L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.out_ft), _p(v), st))
-            nrm = fb.norm[l] if fb.norm is not None else None
-            last = l == nl - 1
             L.check(L.lib().ppsci_fno_tail_fwd(
                 B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
                 _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
@@ -250,11 +266,19 @@ class FnoNative:
             conv, skip = fb.convs[l], fb.fno_skips[l]
             nrm = fb.norm[l] if fb.norm is not None else None
             last = l == nl - 1
-            L.check(L.lib().ppsci_fno_tail_bwd(
-                B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
-                _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows), _p(self.stats[l]),
-                _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
-                _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
+            if self.kept:  # dL/dv only feeds the spectral branch: its kept modes come out of the tail's second pass, gv is not stored
+                L.check(L.lib().ppsci_fno_tail_bwd_ex(
+                    B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
+                    _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows),
+                    _p(self.stats[l]), _p(self.gt), None, _p(nrm.weight.grad) if nrm is not None else None,
+                    _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), H, W, self.desc.modes_x,
+                    self.desc.modes_y, _p(self.ghat), st))
+            else:
+                L.check(L.lib().ppsci_fno_tail_bwd(
+                    B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
+                    _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows),
+                    _p(self.stats[l]), _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
+                    _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
             # skip branch: s = Wskip x_l  (identity: the gradient passes straight through)
             if isinstance(skip, fno_arch.Conv1x1):
                 self._wgrad(B, Ch, Ch, P, self.x[l], self.gt, skip.weight, None)
@@ -264,7 +288,6 @@ class FnoNative:
             # spectral branch: dL/dx_l += irfftn( rfftn(gv) . conj(w)^T ), weight gradients from x_ft and rfftn(gv)
             if self.kept:  # (the adjoint reads dL/dy's spectrum at the OUTPUT rows and writes the input rows)
                 mx, my = self.desc.modes_x, self.desc.modes_y
-                L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 1, _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
                     C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat),
                     _p(self.gx_ft), _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, st))
