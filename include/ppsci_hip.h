@@ -466,7 +466,9 @@ int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, 
  *   _fwd_ex: have_rows != 0 -- `rows` already holds the row sums (ppsci_dft2_kept_inv_stats): no statistics pass;
  *            X_next != NULL -- also emits the kept modes (input rows) of y = the next block's input, [B*C, mx, my, 2].
  *   _bwd_ex: ghat != NULL -- also emits the kept modes (OUTPUT rows) of gv = dL/dv, which only the spectral branch's
- *            backward reads; gv may then be NULL (never stored).
+ *            backward reads; gv may then be NULL (never stored);
+ *            gout2_modes != NULL (gout2 NULL) -- the second addend of dL/dy as kept modes (input rows, unscaled): its
+ *            inverse transform is evaluated per plane in LDS by the first pass (no inverse launch, no plane in memory).
  * H * W == P and ppsci_dft2_kept_supported(H, W, modes_x, modes_y) are required when X_next / ghat is given. */
 int ppsci_fno_tail_fwd_ex(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
                           const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
@@ -474,7 +476,7 @@ int ppsci_fno_tail_fwd_ex(int B, int C, int P, int norm, int gelu, float eps, co
 int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
                           const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
                           float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int modes_x, int modes_y,
-                          float* ghat, void* stream);
+                          float* ghat, const float* gout2_modes, void* stream);
 
 /* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
  * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it

@@ -97,3 +97,59 @@ __device__ __forceinline__ void dft_fwd_stages(const DftArgs& a, const float* tw
     *(f32x2*)(dst + 2 * idx) = acc;
   }
 }
+
+// floats of LDS of the inverse stages: tw | th | Z [mx][my][2] | T [H][my][2]   (+ the caller's own output plane, if in LDS)
+__host__ __device__ inline long long dft_inv_lds_floats(int H, int W, int mx, int my) {
+  return 2LL * W * my + 2LL * H * mx + 2LL * mx * my + 2LL * H * my;
+}
+
+// Kept modes Z ([mx][my][2] in LDS, written and synchronised by the caller) -> the plane y[h * ldo + w] (global memory or
+// LDS).  256 threads, one barrier inside; the caller synchronises before it reads y from LDS.
+template <typename F>
+__device__ __forceinline__ void dft_inv_stages(const DftArgs& a, const float* tw, const float* th, const float* Z, float* T,
+                                               F&& emit) {
+  const int tid = threadIdx.x;
+  // columns: T[h][q] = sum_m Z[m][q] e^{+2 pi i h k_m / H}
+  const f32x2* th2 = (const f32x2*)th;
+  const f32x2* Z2 = (const f32x2*)Z;
+  f32x2* T2 = (f32x2*)T;
+  for (int idx = tid; idx < a.H * a.my; idx += 256) {
+    const int h = idx / a.my, q = idx - h * a.my;
+    float re = 0.f, im = 0.f;
+#pragma unroll 4
+    for (int m = 0; m < a.mx; ++m) {
+      const f32x2 z = Z2[m * a.my + q], e = th2[h * a.mx + m];
+      re += z[0] * e[0] - z[1] * e[1];
+      im += z[0] * e[1] + z[1] * e[0];
+    }
+    const float c = (q == 0 || 2 * q == a.W) ? 1.f : 2.f;  // the Hermitian weight of column q, folded in here
+    T2[idx] = (f32x2){c * re, c * im};
+  }
+  __syncthreads();
+  // rows: y[h][w] = sum_q c(q) Re(T[h][q] e^{+2 pi i w q / W}),  c = 1 on the DC / Nyquist column, else 2
+  //   = [H x 2 my] . [2 my x W] on the fp32 MFMA: k = 2 q + {re, im} (the float index inside a row of T), B = (cos, -sin)
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int nrb = (a.H + 15) / 16, nnb = (a.W + 15) / 16, ncol = 2 * a.my;
+  for (int it = wave; it < nrb * nnb; it += 4) {
+    const int rb = it / nnb, nb = it - rb * nnb;
+    const int h = 16 * rb + c, w = 16 * nb + c;
+    const bool hok = h < a.H, wok = w < a.W;
+    const float* arow = T + (hok ? h : 0) * ncol;
+    const float* brow = tw + (wok ? w : 0) * ncol;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < ncol; k0 += 4) {
+      const int k = k0 + g;
+      const bool kok = k < ncol;
+      const float av = (hok && kok) ? arow[k] : 0.f;
+      const float bv = (wok && kok) ? ((k & 1) ? -brow[k] : brow[k]) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (wok) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int hh = 16 * rb + 4 * g + rr;
+        if (hh < a.H) emit(hh, w, acc[rr]);
+      }
+    }
+  }
+}

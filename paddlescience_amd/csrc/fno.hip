@@ -830,6 +830,7 @@ struct GnArgs {
   int B, C, P, norm, gelu;
   float eps;
   DftArgs d;           // DFT instances: the kept modes of the plane this workgroup produces (y forward, gv backward) -> d.dst
+  DftArgs di;          // INV instance of the backward's first pass: the second gradient addend arrives as kept modes (di.src)
 };
 
 // puts four neighbouring values of the row into the LDS plane [H][W + 1] of the transform
@@ -954,11 +955,31 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GnArgs a) {
 }
 
 // backward pass 1: gt = gout * GELU'(t); row sums of gt, gt * xh, xh
-template <bool AL>
+template <bool AL, bool INV>
 __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
   __shared__ float red[4];
   const int row = blockIdx.x, c = row % a.C, b = row / a.C;
   const long long base = (long long)row * a.P;
+  // INV: the second addend of dL/dy is the inverse transform of this plane's kept modes (the spectral branch's gradient of
+  // the block behind): evaluated here into LDS instead of a transform launch that writes the plane for this kernel to read
+  PPSCI_DYN_SMEM(smem);  // tw | th | Z | T | plane [H][W]
+  float* pl2 = nullptr;
+  if constexpr (INV) {
+    float* tw = smem;
+    float* th = tw + 2 * a.di.W * a.di.my;
+    float* Z = th + 2 * a.di.H * a.di.mx;
+    float* T = Z + 2 * a.di.mx * a.di.my;
+    pl2 = T + 2 * a.di.H * a.di.my;
+    const int nm2 = 2 * a.di.mx * a.di.my;
+    const float* z = a.di.src + (long long)row * nm2;
+    for (int e = threadIdx.x; e < nm2; e += 256) Z[e] = z[e];
+    dft_twiddles(a.di, tw);
+    __syncthreads();
+    float* const out = pl2;
+    const int W_ = a.di.W;
+    dft_inv_stages(a.di, tw, th, Z, T, [&](int hh, int w, float val) { out[hh * W_ + w] = val; });
+    __syncthreads();
+  }
   const float sb = a.sbias ? a.sbias[c] : 0.f;
   const float mean = a.norm ? a.stats[2 * b] : 0.f, rstd = a.norm ? a.stats[2 * b + 1] : 1.f;
   float r1 = 0.f, r2 = 0.f, r3 = 0.f;
@@ -966,6 +987,11 @@ __global__ void __launch_bounds__(256) gn_bwd_rows_kernel(GnArgs a) {
   for (int p = threadIdx.x * 4; p < a.P; p += 1024) {
     f32x4 g4 = fno_ld4(a.gout + base, p, a.P, al);  // zero beyond the row: such elements add nothing to r1, r2
     if (a.gout2) g4 += fno_ld4(a.gout2 + base, p, a.P, al);
+    if constexpr (INV) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (p + k < a.P) g4[k] += pl2[p + k];
+    }
     if (a.gelu) {
       const f32x4 t4 = fno_ld4(a.t + base, p, a.P, al);
 #pragma unroll
@@ -1195,32 +1221,34 @@ static int fno_tail_fwd_run(int B, int C, int P, int norm, int gelu, float eps, 
 static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
                             const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
                             float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int mx, int my, float* ghat,
-                            void* stream);
+                            const float* gout2_modes, void* stream);
 
 extern "C" int ppsci_fno_tail_bwd(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias,
                                   const float* gamma, const float* t, const float* gout, const float* gout2, float* rows,
                                   float* stats, float* gt, float* gv, float* ggamma, float* gbeta, float* gsbias,
                                   void* stream) {
   return fno_tail_bwd_run(B, C, P, norm, gelu, v, sbias, gamma, t, gout, gout2, rows, stats, gt, gv, ggamma, gbeta, gsbias, 0, 0,
-                          0, 0, nullptr, stream);
+                          0, 0, nullptr, nullptr, stream);
 }
 
 // ppsci_fno_tail_bwd with ghat != NULL: the second pass also emits the kept modes (OUTPUT rows) of gv = dL/dv, which is what
 // the spectral branch's backward transforms first ([B*C, modes_x, modes_y, 2]); gv itself may then be NULL (never stored).
+// gout2_modes != NULL (then gout2 must be NULL): the second addend of dL/dy as kept modes (INPUT rows; unscaled, as
+// ppsci_dft2_kept_inv takes them) -- the first pass evaluates its inverse transform per plane in LDS.
 extern "C" int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias,
                                      const float* gamma, const float* t, const float* gout, const float* gout2, float* rows,
                                      float* stats, float* gt, float* gv, float* ggamma, float* gbeta, float* gsbias, int H,
-                                     int W, int modes_x, int modes_y, float* ghat, void* stream) {
+                                     int W, int modes_x, int modes_y, float* ghat, const float* gout2_modes, void* stream) {
   return fno_tail_bwd_run(B, C, P, norm, gelu, v, sbias, gamma, t, gout, gout2, rows, stats, gt, gv, ggamma, gbeta, gsbias, H, W,
-                          modes_x, modes_y, ghat, stream);
+                          modes_x, modes_y, ghat, gout2_modes, stream);
 }
 
 static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float* v, const float* sbias, const float* gamma,
                             const float* t, const float* gout, const float* gout2, float* rows, float* stats, float* gt,
                             float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int mx, int my, float* ghat,
-                            void* stream) {
+                            const float* gout2_modes, void* stream) {
   if (gn_check(B, C, P) != PPSCI_OK || !v || !gout || !rows || !stats || !gt || (!gv && !ghat) || (gelu && !t) ||
-      (norm && !gamma)) {
+      (norm && !gamma) || (gout2 && gout2_modes)) {
     ppsci_set_error("fno_tail_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -1231,16 +1259,31 @@ static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float
     int rc = gn_dft_args(&a.d, P, H, W, mx, my, 1, ghat, &lds);
     if (rc != PPSCI_OK) return rc;
   }
+  long long lds_i = 0;
+  if (gout2_modes) {
+    int rc = gn_dft_args(&a.di, P, H, W, mx, my, 0, nullptr, &lds_i);
+    if (rc != PPSCI_OK) return rc;
+    a.di.src = gout2_modes;
+    lds_i = 4LL * (dft_inv_lds_floats(H, W, mx, my) + (long long)H * W);
+  }
+  const DftArgs di_save = a.di;
   a.v = v, a.sbias = sbias, a.gamma = gamma, a.t = (float*)t, a.gout = gout, a.gout2 = gout2, a.rows = rows, a.stats = stats;
   a.gt = gt, a.gv = gv, a.ggamma = ggamma, a.gbeta = gbeta, a.gsbias = gsbias;
   a.B = B, a.C = C, a.P = P, a.norm = norm, a.gelu = gelu;
+  a.di = di_save;
   const bool aligned = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(gout) |
                                          reinterpret_cast<uintptr_t>(gout2) | reinterpret_cast<uintptr_t>(gt) |
                                          reinterpret_cast<uintptr_t>(gv)) & 15) == 0;
   int se = 0;
 #define GN_BWD(AL)                                                                                           \
   do {                                                                                                       \
-    PPSCI_LAUNCH(gn_bwd_rows_kernel<AL>, GnArgs, B * C, 256, 0, stream, a);                                  \
+    if (gout2_modes) {                                                                                       \
+      se = PPSCI_SET_MAX_LDS((gn_bwd_rows_kernel<AL, true>), (int)lds_i);                                    \
+      if (se == 0) PPSCI_LAUNCH((gn_bwd_rows_kernel<AL, true>), GnArgs, B * C, 256, (int)lds_i, stream, a);  \
+    } else {                                                                                                 \
+      PPSCI_LAUNCH((gn_bwd_rows_kernel<AL, false>), GnArgs, B * C, 256, 0, stream, a);                       \
+    }                                                                                                        \
+    if (se != 0) break;                                                                                      \
     if (ghat) {                                                                                              \
       se = PPSCI_SET_MAX_LDS((gn_bwd_apply_kernel<AL, true>), (int)lds);                                     \
       if (se == 0) PPSCI_LAUNCH((gn_bwd_apply_kernel<AL, true>), GnArgs, B * C, 256, (int)lds, stream, a);   \

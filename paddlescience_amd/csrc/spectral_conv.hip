@@ -454,59 +454,15 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
     }
     for (int e = tid + 512; e < 2 * nm; e += 256) Z[e] = z[e];
     __syncthreads();
-    // columns: T[h][q] = sum_m Z[m][q] e^{+2 pi i h k_m / H}
-    const f32x2* th2 = (const f32x2*)th;
-    const f32x2* Z2 = (const f32x2*)Z;
-    f32x2* T2 = (f32x2*)T;
-    for (int idx = tid; idx < a.H * a.my; idx += 256) {
-      const int h = idx / a.my, q = idx - h * a.my;
-      float re = 0.f, im = 0.f;
-#pragma unroll 4
-      for (int m = 0; m < a.mx; ++m) {
-        const f32x2 z = Z2[m * a.my + q], e = th2[h * a.mx + m];
-        re += z[0] * e[0] - z[1] * e[1];
-        im += z[0] * e[1] + z[1] * e[0];
-      }
-      const float c = (q == 0 || 2 * q == a.W) ? 1.f : 2.f;  // the Hermitian weight of column q, folded in here
-      T2[idx] = (f32x2){c * re, c * im};
-    }
-    __syncthreads();
-    // rows: y[h][w] = sum_q c(q) Re(T[h][q] e^{+2 pi i w q / W}),  c = 1 on the DC / Nyquist column, else 2
-    //   = [H x 2 my] . [2 my x W] on the fp32 MFMA: k = 2 q + {re, im} (the float index inside a row of T), B = (cos, -sin)
     float* y = a.dst + (long long)p * P;
     const float sb = (a.rows_out && a.sbias) ? a.sbias[p % a.C] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    {
-      const int lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
-      const int nrb = (a.H + 15) / 16, nnb = (a.W + 15) / 16, ncol = 2 * a.my;
-      for (int it = wave; it < nrb * nnb; it += 4) {
-        const int rb = it / nnb, nb = it - rb * nnb;
-        const int h = 16 * rb + c, w = 16 * nb + c;
-        const bool hok = h < a.H, wok = w < a.W;
-        const float* arow = T + (hok ? h : 0) * ncol;
-        const float* brow = tw + (wok ? w : 0) * ncol;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < ncol; k0 += 4) {
-          const int k = k0 + g;
-          const bool kok = k < ncol;
-          const float av = (hok && kok) ? arow[k] : 0.f;
-          const float bv = (wok && kok) ? ((k & 1) ? -brow[k] : brow[k]) : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-        }
-        if (wok) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int hh = 16 * rb + 4 * g + rr;
-            if (hh < a.H) {
-              y[(long long)hh * a.W + w] = acc[rr];
-              const float u = acc[rr] + sb;
-              s1 += u;
-              s2 += u * u;
-            }
-          }
-        }
-      }
-    }
+    dft_inv_stages(a, tw, th, Z, T, [&](int hh, int w, float val) {
+      y[(long long)hh * a.W + w] = val;
+      const float u = val + sb;
+      s1 += u;
+      s2 += u * u;
+    });
     if (a.rows_out) {  // the block tail's first pass (gn_rowstats_kernel) for free: the plane is in this workgroup's registers
       __syncthreads();
       sred[tid] = s1;

@@ -262,6 +262,7 @@ class FnoNative:
         else:
             _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
         gx2 = None  # a second addend of dL/d(block output): the spectral branch's share, added by the consumer on load
+        gx2_modes = None  # ... or its kept modes: the consumer evaluates the inverse transform itself (fuse_dft)
         for l in range(nl - 1, -1, -1):
             conv, skip = fb.convs[l], fb.fno_skips[l]
             nrm = fb.norm[l] if fb.norm is not None else None
@@ -272,7 +273,7 @@ class FnoNative:
                     _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows),
                     _p(self.stats[l]), _p(self.gt), None, _p(nrm.weight.grad) if nrm is not None else None,
                     _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), H, W, self.desc.modes_x,
-                    self.desc.modes_y, _p(self.ghat), st))
+                    self.desc.modes_y, _p(self.ghat), _p(gx2_modes), st))
             else:
                 L.check(L.lib().ppsci_fno_tail_bwd(
                     B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
@@ -291,6 +292,13 @@ class FnoNative:
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
                     C.byref(self.desc), _p(self.xft[l]), _p(conv.weight_real), _p(conv.weight_imag), _p(self.ghat),
                     _p(self.gx_ft), _p(conv.weight_real.grad), _p(conv.weight_imag.grad), self.inv_n, W, self.inv_n, st))
+                if self.fuse_dft and l > 0:
+                    # the tail of block l - 1 inverse-transforms these modes plane by plane in LDS; gx_ft is rewritten only
+                    # by that block's own spectral backward, which runs behind its tail
+                    gx2, gx2_modes = None, self.gx_ft
+                    gx, gnext = gnext, gx
+                    continue
+                gx2_modes = None
                 L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 0, _p(self.gx_ft), _p(self.gsp), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
