@@ -258,8 +258,9 @@ typedef struct ppsci_adam_args {
 int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
 int ppsci_taylor_step_kind(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
 /* test / tool knobs (process-global): the fused tile kernel on (default) or off; how a fused launch ends: -1 by grid
- * size (default), 0 the in-kernel reduction tree, 1 the reduction kernels behind the launch.  Both are read when a
- * launch is PLANNED (workspace_bytes, _plan). */
+ * size (default: 0 for small grids, 1 otherwise), 0 the in-kernel reduction tree, 1 two reduction kernels behind the
+ * launch, 2 the first level of the tree inside the launch and one kernel behind it (slower than 1, kept for tests).  Both are read when a launch is
+ * PLANNED (workspace_bytes, _plan). */
 void ppsci_set_fused_step(int on);
 void ppsci_set_step_tail(int mode);
 /* kind 2: residual programs made of loads, constants, +, -, *, negation and detach under MSE terms (every BASELINE PDE)

@@ -316,7 +316,7 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
 static int g_fused_step = 1, g_step_tail = -1, g_fast_vm = 1;
 extern "C" void ppsci_set_fast_program(int on) { g_fast_vm = on ? 1 : 0; }
 extern "C" void ppsci_set_fused_step(int on) { g_fused_step = on ? 1 : 0; }
-extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = mode < 0 ? -1 : (mode ? 1 : 0); }
+extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = (mode < 0 || mode > 2) ? -1 : mode; }
 // a tree over more rows than this is slower than the reduction kernels: every level is a ~10-20 us pass of ONE workgroup
 // over 16 rows of (L-1) * 16 KB, against ~12 us for the two kernels over all rows
 #define PPSCI_FUSED_TREE_MAX_GRID 48
@@ -490,7 +490,12 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
   if (a.t.fused) {
     a.f.xfrag = ws + y.frag;
     a.b.xfrag = (const u32x4*)(ws + y.frag) + (long long)(d->n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB);
+    // 0: the whole reduction tree inside the launch (small grids); 1: nothing inside, two kernels behind it (large grids);
+    // 2: the tree's first level inside the launch, one kernel behind it -- measured SLOWER than 1 at 512 workgroups
+    // (100 k points: 302 us against 270 us per step: the rows then have to be agent-scope write-through stores and the
+    // last workgroups of the groups add a serial pass over 16 x 49 KB each), kept as a tested knob
     a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 1 : 0);
+    if (a.t.external == 2 && grid <= PPSCI_STEP_FAN) a.t.external = 0;  // (one group: its sum IS the total)
   }
   {
     unsigned fast[EPI_FAST_WORDS];
@@ -628,6 +633,13 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
     x.beta2 = t.beta2;
     x.eps_t = t.eps_t;
     x.grad_scale = t.grad_scale;
+  }
+  if (t.external == 2) {
+    // the launch has left the sums of groups of PPSCI_STEP_FAN rows in the first rows of `tree`
+    const int nrows = (t.grid + PPSCI_STEP_FAN - 1) / PPSCI_STEP_FAN;
+    const long long off_s = t.per_tile, off_l = t.per_tile + ((t.psmall + 3) & ~3);
+    x.loss_rows = nullptr;  // (taken from the rows)
+    return ppsci_wgrad_reduce_chunks(a.b.d, a.b.q, nrows, t.tree, t.rowlen, off_s, off_l, t.grad, x, stream);
   }
   return ppsci_wgrad_reduce_ex(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, t.grad, x, stream);
 }

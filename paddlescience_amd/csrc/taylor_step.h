@@ -25,7 +25,10 @@ struct StepTail {
   float lr_t, beta1, beta2, eps_t, grad_scale;
   int fused;           // host side only: planned onto the fused tile kernel (taylor_fused.inc)
   int external;        // fused tile kernel: 1 = the launch stops at the workgroups' rows; the host issues the two reduction kernels
-                       // (+ loss sum, Adam) behind it -- a 512-row tree of 48 KB rows is slower than those (taylor_api.hip)
+                       // (+ loss sum, Adam) behind it -- a 512-row tree of 48 KB rows is slower than those (taylor_api.hip);
+                       // 2 = the launch runs the FIRST level of the tree (the last workgroup of every group of
+                       // PPSCI_STEP_FAN sums the group's rows into `tree`, hidden behind the workgroups still computing) and
+                       // the host issues ONE kernel behind it (sum of the level-1 rows, loss terms, Adam)
 };
 
 struct StepArgs {

@@ -157,6 +157,10 @@ __device__ __forceinline__ void ppsci_step_tail(const StepTail& t, const ppsci_m
     }
     float* dst = t.tree + (long long)(row0 + g) * t.rowlen;
     ppsci_step_reduce<false>(t, d, q, src, first, gsize, dst);
+    if (t.external == 2) {  // one level only: the kernel behind this launch sums the level-1 rows
+      if (tid == 0) t.counters[cnt0 + g] = 0u;  // (every member of the group has taken its ticket: ready for the next launch)
+      return;
+    }
     const float* base = t.tree + (long long)row0 * t.rowlen;
     src = StepSrc{base, base + off_s, base + off_l, t.rowlen, t.rowlen, t.rowlen};
     idx = g;

@@ -482,6 +482,8 @@ int ppsci_wgrad_reduce_ex(const ppsci_mlp_desc& d, const ppsci_derived& q, int n
                           void* stream);
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
                        const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream);
+int ppsci_wgrad_reduce_chunks(const ppsci_mlp_desc& d, const ppsci_derived& q, int nrows, const float* rows, long long rowlen,
+                              long long off_small, long long off_loss, float* row, const ppsci_wred_extras& x, void* stream);
 
 // per-activation entry points (one translation unit each, so they compile in parallel).
 // launch == 0: only plan (fills a.resident / a.iters and *grid_out); launch == 1: plan + launch.

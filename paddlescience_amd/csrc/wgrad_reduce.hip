@@ -16,6 +16,7 @@ struct WRedArgs {
   ppsci_derived q;
   int L, H, ntiles, nchunks, nb4;  // nb4 = workgroups per chunk (each covers 256 float4)
   long long per_tile;              // (L-1)*HP*HP floats
+  long long tmp_stride, small_stride, loss_stride;  // row strides of tmp / tmp_small / x.loss_rows (floats)
   ppsci_wred_extras x;             // stage 2: row (+)= / loss terms / Adam in the same launch (taylor_tile.h)
 };
 
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
     for (int k = 0; k < a.x.n_res; ++k) {
       float v = 0.f;
 #pragma unroll 4
-      for (int r = threadIdx.x; r < a.x.loss_nrows; r += 256) v += a.x.loss_rows[(long long)r * a.x.n_res + k];
+      for (int r = threadIdx.x; r < a.x.loss_nrows; r += 256) v += a.x.loss_rows[(long long)r * a.loss_stride + k];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // clamped index + select: the loads stay unconditional (no branch between them)
           const int cu = c + u < a.nchunks ? c + u : a.nchunks - 1;
-          const float t = a.tmp[(long long)cu * a.per_tile + j];
+          const float t = a.tmp[(long long)cu * a.tmp_stride + j];
           v4[u] += c + u < a.nchunks ? t : 0.f;
         }
       }
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int cu = c + u < a.nchunks ? c + u : a.nchunks - 1;
-        const float t = a.tmp_small[(long long)cu * a.psmall + ci];
+        const float t = a.tmp_small[(long long)cu * a.small_stride + ci];
         v4[u] += c + u < a.nchunks ? t : 0.f;
       }
     }
@@ -128,6 +129,36 @@ __global__ void __launch_bounds__(256) wgrad_reduce2_kernel(WRedArgs a) {
     a.x.v[idx] = vv;
     a.x.p[idx] = a.x.p[idx] - a.x.lr_t * (mm / (sqrtf(vv) + a.x.eps_t));
   }
+}
+
+// Stage 2 alone on rows that are chunk sums already (the first level of the in-kernel reduction tree of the fused tile
+// kernel, taylor_step_tail.h): `rows` [nrows][rowlen] = hidden-weight blocks | small tensors at off_small | loss terms at
+// off_loss.  Total, grad (+)= it, the loss terms and (x.p) the Adam update in ONE launch.
+int ppsci_wgrad_reduce_chunks(const ppsci_mlp_desc& d, const ppsci_derived& q, int nrows, const float* rows, long long rowlen,
+                              long long off_small, long long off_loss, float* row, const ppsci_wred_extras& x0, void* stream) {
+  WRedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x0;
+  a.x.loss_rows = x0.loss_out ? rows + off_loss : nullptr;
+  a.x.loss_nrows = nrows;
+  a.psmall = ppsci_small_params(d, q);
+  a.m = d.d_out;
+  a.d0 = q.d0;
+  a.tmp = (float*)rows;
+  a.tmp_small = (float*)rows + off_small;
+  a.row = row;
+  a.q = q;
+  a.L = d.n_hidden;
+  a.H = d.width;
+  a.nchunks = nrows;
+  a.per_tile = (long long)(d.n_hidden - 1) * q.HP * q.HP;
+  a.tmp_stride = a.small_stride = a.loss_stride = rowlen;
+  PPSCI_LAUNCH(wgrad_reduce2_kernel, WRedArgs, (q.P + 255) / 256 + (a.x.loss_rows != nullptr ? 1 : 0), 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("wgrad_reduce2: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
 }
 
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
@@ -159,6 +190,7 @@ int ppsci_wgrad_reduce_ex(const ppsci_mlp_desc& d, const ppsci_derived& q, int n
   a.nchunks = ntiles < PPSCI_WRED_CHUNKS ? ntiles : PPSCI_WRED_CHUNKS;
   if (a.nchunks < 1) a.nchunks = 1;
   a.per_tile = (long long)(d.n_hidden - 1) * q.HP * q.HP;
+  a.tmp_stride = a.per_tile, a.small_stride = a.psmall, a.loss_stride = x.n_res;
   a.nb4 = a.per_tile > 0 ? (int)((a.per_tile / 4 + 255) / 256) : 0;
   {
     PPSCI_LAUNCH(wgrad_reduce1_kernel, WRedArgs, a.nchunks * (a.nb4 + a.nbs), 256, 0, stream, a);

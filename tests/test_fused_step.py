@@ -50,9 +50,13 @@ def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints
 
 
 CASES = [
-    # (activation, hidden layers, width, constraints [(program, points)], max_grid, tail: 0 tree / 1 reduction kernels)
+    # (activation, hidden layers, width, constraints [(program, points)], max_grid,
+    #  tail: 0 tree / 1 two reduction kernels / 2 first tree level in the launch + one kernel)
     ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 0),                # BASELINE configs[1]'s net; a ragged last tile
     ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 1),
+    ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 2),
+    ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 2),
+    ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 0, 2),     # (the second constraint accumulates, then Adam)
     ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 0),                # several tiles per workgroup, a ragged last round
     ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 1),
     ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 0, 0),     # two constraints: the second accumulates, then Adam
@@ -112,7 +116,7 @@ def test_fused_step_is_deterministic(dev):
     lay = hp.NetLayout(2, 4, 64, 1, "tanh")
     flat = _weights(lay, 3)
     steps, n = (2, 200) if dev != "gpu" else (100, 20_000)
-    for tail in (0, 1):
+    for tail in (0, 1, 2):
         a = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
         b = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
         assert np.array_equal(a[0], b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))

@@ -3,6 +3,7 @@ stream; one JSON line per configuration):  python tools/fused_bench.py [points .
   sep_us          forward + epilogue + reverse + reductions + Adam as separate launches
   fused_tree_us   weight split + fused kernel ending in the reduction tree (gradient, loss, Adam in the launch)
   fused_ext_us    weight split + fused kernel + the two reduction kernels + loss sum + Adam
+  fused_hyb_us    weight split + fused kernel with the FIRST tree level inside + one reduction kernel (measured slower than fused_ext)
   main_us         the fused kernel alone (no weight split, no reduction)"""
 import json
 import os
@@ -24,7 +25,7 @@ def run(n, hidden=4, width=64, reps=30):
     X = np.random.default_rng(42).uniform([0, -1], [1, 1], (n, 2)).astype(np.float32)
     out = {"net": f"{hidden}x{width}", "points": n}
     grads = {}
-    for tag, one, tail in (("sep", False, -1), ("fused_tree", True, 0), ("fused_ext", True, 1)):
+    for tag, one, tail in (("sep", False, -1), ("fused_tree", True, 0), ("fused_ext", True, 1), ("fused_hyb", True, 2)):
         L.lib().ppsci_set_step_tail(tail)
         lay = hp.NetLayout(2, hidden, width, 1, "tanh")
         xs = [torch.tensor(X[:, j].copy(), device=dev) for j in range(2)]
@@ -44,6 +45,7 @@ def run(n, hidden=4, width=64, reps=30):
     L.lib().ppsci_set_step_tail(-1)
     out["grad_rel_tree_vs_sep"] = bench.rel(grads["fused_tree"], grads["sep"])
     out["grad_rel_ext_vs_sep"] = bench.rel(grads["fused_ext"], grads["sep"])
+    out["grad_rel_hyb_vs_sep"] = bench.rel(grads["fused_hyb"], grads["sep"])
     p_mat = 2 * width + (hidden - 1) * width * width + width
     out["main_tflops"] = round(6.0 * p_mat * 4 * n / (out["main_us"] * 1e-6) / 1e12, 1)
     return out
