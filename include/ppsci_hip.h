@@ -164,6 +164,15 @@ int ppsci_is_device_build(void);
  * of padded width > 32 (allocated on first use by ppsci_taylor_fwd / ppsci_taylor_bwd).  Call it before freeing
  * `params`; waits for the device. */
 void ppsci_release_fragments(const float* params);
+/* Up to 16 independent ppsci_reduce_rows in ONE launch (out[j] (+)= sum over rows of partials[r][j], fixed order per
+ * segment): the weight-gradient partials of all layers of an FNO backward are summed by one kernel at its end. */
+typedef struct {
+  const float* partials;
+  float* out;
+  int64_t rows, cols;
+  int32_t accumulate;
+} ppsci_reduce_seg;
+int ppsci_reduce_rows_multi(int nseg, const ppsci_reduce_seg* segs, void* stream);
 /* PPSCI_OK when the current HIP device is a gfx950 (the kernels' cross-workgroup reductions rely on its store / vmcnt
  * behaviour, and the code object holds no other ISA); PPSCI_E_UNSUPPORTED with the device's name otherwise.  The Python
  * host side calls it once when it loads the library on a machine with a GPU. */

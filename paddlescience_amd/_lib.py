@@ -46,6 +46,11 @@ class PwVirtual(C.Structure):
     _fields_ = [("mode", C.c_int32), ("K0", C.c_int32), ("x0", C.c_void_p), ("W0", C.c_void_p), ("b0", C.c_void_p)]
 
 
+class ReduceSeg(C.Structure):
+    """ppsci_reduce_seg: one row reduction of ppsci_reduce_rows_multi."""
+    _fields_ = [("partials", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("accumulate", C.c_int32)]
+
+
 class ModMlpDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_hidden", "width", "d_out", "activation")]
 
@@ -95,6 +100,7 @@ _SYMBOLS = {
     "ppsci_last_error": (C.c_char_p, []),
     "ppsci_is_device_build": (C.c_int, []),
     "ppsci_check_device": (C.c_int, []),
+    "ppsci_reduce_rows_multi": (C.c_int, [C.c_int, C.POINTER(ReduceSeg), C.c_void_p]),
     "ppsci_release_fragments": (None, [C.c_void_p]),
     "ppsci_set_max_grid": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),

@@ -52,6 +52,38 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(ReduceArgs a) {
   }
 }
 
+// Several independent row reductions in ONE launch (the weight-gradient partials of the layers of an FNO backward: eight
+// reductions of a few microseconds each, which are launch latency, not work): workgroup b belongs to the segment whose
+// [first, first + count) range holds it and does there exactly what reduce_rows_kernel does.
+#define RED_MAX_SEG 16
+struct ReduceMultiArgs {
+  ReduceArgs seg[RED_MAX_SEG];
+  int first[RED_MAX_SEG + 1];  // workgroup ranges of the segments
+  int nseg;
+};
+__global__ void __launch_bounds__(256) reduce_rows_multi_kernel(ReduceMultiArgs m) {
+  PPSCI_DYN_SMEM(red);
+  int s = 0;
+  while (s + 1 < m.nseg && (int)blockIdx.x >= m.first[s + 1]) ++s;
+  const ReduceArgs& a = m.seg[s];
+  const int wg = (int)blockIdx.x - m.first[s];
+  const int groups = a.groups, cw = 256 / groups;
+  const int tc = threadIdx.x % cw, rg = threadIdx.x / cw;
+  const long long j = (long long)wg * cw + tc;
+  float v = 0.f;
+  if (j < a.cols) {
+#pragma unroll 8
+    for (long long r = rg; r < a.rows; r += groups) v += a.partials[r * a.cols + j];
+  }
+  red[rg * cw + tc] = v;
+  __syncthreads();
+  if (rg == 0 && j < a.cols) {
+    float t = red[tc];
+    for (int k = 1; k < groups; ++k) t += red[k * cw + tc];
+    a.out[j] = a.accumulate ? a.out[j] + t : t;
+  }
+}
+
 // One row: a plain copy / accumulate of `cols` floats (gradient hand-over between stages), every thread busy, float4
 // where the pointers allow it.
 __global__ void __launch_bounds__(256) reduce_rows_one_kernel(ReduceArgs a) {
@@ -411,6 +443,38 @@ extern "C" int ppsci_reduce_rows(const float* partials, int64_t rows, int64_t co
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("reduce_rows: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+extern "C" int ppsci_reduce_rows_multi(int nseg, const ppsci_reduce_seg* segs, void* stream) {
+  if (nseg < 1 || nseg > RED_MAX_SEG || !segs) {
+    ppsci_set_error("reduce_rows_multi: 1 .. %d segments", RED_MAX_SEG);
+    return PPSCI_E_INVALID;
+  }
+  ReduceMultiArgs m;
+  memset(&m, 0, sizeof(m));
+  m.nseg = nseg;
+  int total = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const ppsci_reduce_seg& g = segs[s];
+    if (!g.partials || !g.out || g.rows < 1 || g.cols < 1) {
+      ppsci_set_error("reduce_rows_multi: invalid segment %d", s);
+      return PPSCI_E_INVALID;
+    }
+    ReduceArgs a{g.partials, g.out, g.rows, g.cols, g.accumulate, RED_GROUPS};
+    if (g.rows >= 128 && g.cols <= 2048) a.groups = 32;  // (as ppsci_reduce_rows)
+    else if (g.rows >= 128 && g.cols <= 32768) a.groups = 16;
+    const int cw = 256 / a.groups;
+    m.seg[s] = a;
+    m.first[s] = total;
+    total += (int)((g.cols + cw - 1) / cw);
+  }
+  m.first[nseg] = total;
+  PPSCI_LAUNCH(reduce_rows_multi_kernel, ReduceMultiArgs, total, 256, 256 * sizeof(float), stream, m);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("reduce_rows_multi: launch failed");
     return PPSCI_E_LAUNCH;
   }
   return PPSCI_OK;

@@ -126,10 +126,8 @@ class FnoNative:
         self.gb = torch.empty((B, cmax, P), **f)
         self.gt = torch.empty((B, Ch, P), **f)
         self.gv = torch.empty((B, Ch, P), **f)
-        self.chunks = max(int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P)), int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0)))
-        wmax = max(Ch * Ch, self.c_lift * max(Ch, m.in_channels), self.c_proj * max(Ch, m.out_channels)) + cmax
-        self.part_w = torch.empty(self.chunks * wmax, **f)
-        self.part_b = torch.empty(self.chunks * cmax, **f)
+        self._wbufs: List[torch.Tensor] = []  # per-chunk partials of the weight gradients, one buffer per _wgrad call of a pass
+        self._wcall, self._wsegs = 0, []
         self.desc = L.SpectralDesc()
         d = self.desc
         d.batch, d.c_in, d.c_out, d.h, d.wf, d.modes_x, d.modes_y = B, Ch, Ch, H, Wf, mx, my
@@ -218,24 +216,46 @@ class FnoNative:
         return self.y.view(B, m.out_channels, H0, W0)
 
     # ------------------------------------------------------------------ backward
+    def _partials(self, n: int) -> torch.Tensor:
+        """The next per-chunk partial buffer of this backward pass (every weight gradient keeps its own until the one
+        reduction launch at the end: self._flush_wgrads)."""
+        i = self._wcall
+        self._wcall += 1
+        if i == len(self._wbufs):
+            self._wbufs.append(torch.empty(n, dtype=torch.float32, device=self.y.device))
+        assert self._wbufs[i].numel() >= n
+        return self._wbufs[i]
+
     def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param, xv=None) -> None:
         chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))  # (P differs between the padded blocks and lifting / projection)
         wg = w_param.grad.view(-1)
         if b_param is not None and b_param.grad.data_ptr() == wg.data_ptr() + 4 * co * ci:
             # weight and bias gradients are neighbours in the flat buffer: partial rows [Co*Ci | Co], ONE fixed-order sum
             ld = co * ci + co
+            part = self._partials(chunks * ld)
             L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
-                                                  _p(self.part_w), C.c_void_p(self.part_w.data_ptr() + 4 * co * ci), ld,
-                                                  _stream_ptr(gy)))
-            both = torch.as_strided(wg, (ld,), (1,))
-            hp.reduce_rows(self.part_w, chunks, ld, both, False)
+                                                  _p(part), C.c_void_p(part.data_ptr() + 4 * co * ci), ld, _stream_ptr(gy)))
+            self._wsegs.append((part.data_ptr(), wg.data_ptr(), chunks, ld))
             return
+        part = self._partials(chunks * co * ci)
+        part_b = self._partials(chunks * co) if b_param is not None else None
         L.check(L.lib().ppsci_pw_conv_wgrad_v(B, ci, co, P, _p(x), C.byref(xv) if xv is not None else None, _p(gy),
-                                              _p(self.part_w), _p(self.part_b) if b_param is not None else None, 0,
-                                              _stream_ptr(gy)))
-        hp.reduce_rows(self.part_w, chunks, co * ci, wg, False)
+                                              _p(part), _p(part_b), 0, _stream_ptr(gy)))
+        self._wsegs.append((part.data_ptr(), wg.data_ptr(), chunks, co * ci))
         if b_param is not None:
-            hp.reduce_rows(self.part_b, chunks, co, b_param.grad.view(-1), False)
+            self._wsegs.append((part_b.data_ptr(), b_param.grad.view(-1).data_ptr(), chunks, co))
+
+    def _flush_wgrads(self) -> None:
+        """ONE launch sums the per-chunk partials of every weight gradient of the pass (ppsci_reduce_rows_multi; up to 16
+        segments per launch): eight reductions of ~5 us each were launch latency, not work."""
+        st = _stream_ptr(self.y)
+        for i0 in range(0, len(self._wsegs), 16):
+            batch = self._wsegs[i0:i0 + 16]
+            arr = (L.ReduceSeg * len(batch))()
+            for k, (src, dst, rows, cols) in enumerate(batch):
+                arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src, dst, rows, cols, 0
+            L.check(L.lib().ppsci_reduce_rows_multi(len(batch), arr, st))
+        self._wsegs = []
 
     def backward(self, gy: torch.Tensor) -> None:
         """gy = dL/dy [B, C_out, H, W]; writes dL/d(parameter) into every parameter's `.grad` (views of flat_grad)."""
@@ -246,6 +266,7 @@ class FnoNative:
         lift, proj, fb = m.lifting.fcs, m.projection.fcs, m.fno_blocks
         gy = gy.contiguous().view(B, m.out_channels, P0)
         st = _stream_ptr(self.y)
+        self._wcall, self._wsegs = 0, []
         # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
         self._wgrad(B, self.c_proj, m.out_channels, P0, self.z2, gy, proj[1].weight, proj[1].bias, xv=self.gelu_on_load)
         gz2 = self.ga.view(-1)[:B * self.c_proj * P0].view(B, self.c_proj, P0)
@@ -330,3 +351,4 @@ class FnoNative:
             self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
         else:
             self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)
+        self._flush_wgrads()
