@@ -188,10 +188,11 @@ class ModifiedExec(PirateExec):
         m, H, c0, lib = self.model, self.H, self.c0, L.lib()
         grad = grad.view(-1)
         nl = len(self.layers)
+        self._pcall, self._psegs, self._pullbacks = 0, [], []  # (reductions are summed at the end: PirateExec._flush_sums)
         L.check(lib.ppsci_pirate_out_bwd(self.S, self.m, self.n, self.NP, _p(Ubar_rows), _p(self.Ybar), _sp(self.Ybar)))
         ob, _ = m._offsets["last_fc.bias"]
         for o in range(self.m):
-            hp.reduce_rows(Ubar_rows[o * self.S].view(self.n, 1), self.n, 1, grad[ob + o:ob + o + 1], False)
+            self._sum_later(Ubar_rows[o * self.S], self.n, 1, grad[ob + o:ob + o + 1])
         ylast, flast = (self.layers[-1]["O"], H) if nl else (self.X0, c0)
         self._wgrad(ylast, self.Ybar, flast, self.m, "last_fc", params, grad)
         xb0 = self.XB0 if self.XB0 is not None else self.XB[1]  # adjoint of x0
@@ -220,4 +221,5 @@ class ModifiedExec(PirateExec):
             L.check(lib.ppsci_pirate_embed_bwd(C.byref(self.desc), self._in_ptrs, _p(self._t(params, "fourier_emb.kernel")),
                                                _p(xb0), _p(self.pB), _sp(self.pB)))
             ok, nk = m._offsets["fourier_emb.kernel"]
-            hp.reduce_rows(self.pB, self.echunks, nk, grad[ok:ok + nk], False)
+            self._sum_later(self.pB, self.echunks, nk, grad[ok:ok + nk])
+        self._flush_sums()

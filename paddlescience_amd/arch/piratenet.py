@@ -363,47 +363,72 @@ class PirateExec:
         self.achunks = int(lib.ppsci_pirate_act_chunks(self.NP))
         self.wchunks = int(lib.ppsci_pw_conv_wgrad_chunks(self.S, self.NP))
         self.echunks = int(lib.ppsci_pirate_embed_chunks(self.n))
-        self.pb = torch.zeros((self.achunks, self.H), **f32)
-        self.palpha = torch.zeros(self.H * self.achunks, **f32)
-        wmax = max(self.H, self.c0) * self.H
-        self.pw = torch.zeros((self.wchunks, wmax), **f32)
+        # Per-chunk partial sums: every producer of a backward pass keeps its OWN buffer until the end of the pass, where
+        # ppsci_reduce_rows_multi sums them all in two launches (27 reductions of ~6 us each were launch latency, not work)
+        self._pbufs: List[torch.Tensor] = []
+        self._pcall, self._psegs, self._pullbacks = 0, [], []
         self.pB = torch.zeros((self.echunks, max(1, self.model.d0 * self.model.half)), **f32)
-        self.gw_eff = torch.zeros(wmax, **f32) if self.model._rwf else None
         self.XB0 = blk(self.c0) if self.c0 != self.H else None  # adjoint of x0 when its width differs from the hidden one
         self._train_ready = True
 
+    def _pbuf(self, n: int) -> torch.Tensor:
+        i = self._pcall
+        self._pcall += 1
+        if i == len(self._pbufs):
+            self._pbufs.append(torch.zeros(n, dtype=torch.float32, device=self.ZB.device))
+        assert self._pbufs[i].numel() >= n
+        return self._pbufs[i]
+
+    def _sum_later(self, part: torch.Tensor, rows: int, cols: int, dst: torch.Tensor) -> None:
+        self._psegs.append((part.data_ptr(), dst.data_ptr(), rows, cols))
+
+    def _flush_sums(self) -> None:
+        st = _sp(self.ZB)
+        for i0 in range(0, len(self._psegs), 16):
+            batch = self._psegs[i0:i0 + 16]
+            arr = (L.ReduceSeg * len(batch))()
+            for k, (src, dst, rows, cols) in enumerate(batch):
+                arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src, dst, rows, cols, 0
+            L.check(L.lib().ppsci_reduce_rows_multi(len(batch), arr, st))
+        self._psegs = []
+        for args in self._pullbacks:  # the trainable tensors behind the summed kernel-layout gradients
+            hp.linear_pullback(*args)
+        self._pullbacks = []
+
     def _wgrad(self, x, zbar, fin, fout, name, params, grad):
-        """d loss / d W[i, o] = sum_{s,p} x[s,i,p] zbar[s,o,p] -> the layer's trainable tensors in `grad`."""
+        """d loss / d W[i, o] = sum_{s,p} x[s,i,p] zbar[s,o,p] -> the layer's trainable tensors in `grad` (summed at the
+        end of the pass: _flush_sums)."""
         m = self.model
-        # (conv roles swapped: "x" = zbar with Ci = fout, "gy" = x with Co = fin, so the partial blocks are [fin, fout])
-        L.check(L.lib().ppsci_pw_conv_wgrad(self.S, fout, fin, self.NP, _p(zbar), _p(x), _p(self.pw), None, _sp(self.pw)))
         cols = fin * fout
+        pw = self._pbuf(self.wchunks * cols)
+        # (conv roles swapped: "x" = zbar with Ci = fout, "gy" = x with Co = fin, so the partial blocks are [fin, fout])
+        L.check(L.lib().ppsci_pw_conv_wgrad(self.S, fout, fin, self.NP, _p(zbar), _p(x), _p(pw), None, _sp(pw)))
         if m._rwf:
-            gw = self.gw_eff[:cols]
-            hp.reduce_rows(self.pw.view(-1)[: self.wchunks * cols].view(self.wchunks, cols), self.wchunks, cols, gw, False)
+            gw = self._pbuf(cols)
+            self._sum_later(pw, self.wchunks, cols, gw)
             ov, nv = m._offsets[name + ".weight_v"]
             og, ng = m._offsets[name + ".weight_g"]
-            hp.linear_pullback(L.LINEAR_RWF, fin, fout, params[ov:ov + nv], params[og:og + ng], gw, None, grad[ov:ov + nv],
-                               grad[og:og + ng], None)
+            self._pullbacks.append((L.LINEAR_RWF, fin, fout, params[ov:ov + nv], params[og:og + ng], gw, None,
+                                    grad[ov:ov + nv], grad[og:og + ng], None))
         else:
             ow, nw = m._offsets[name + ".weight"]
-            hp.reduce_rows(self.pw.view(-1)[: self.wchunks * cols].view(self.wchunks, cols), self.wchunks, cols,
-                           grad[ow:ow + nw], False)
+            self._sum_later(pw, self.wchunks, cols, grad[ow:ow + nw])
 
     def _act_bwd(self, mode, z, bias_name, obar, params, grad, U=None, V=None, x=None, alpha_name=None, xbar=None):
         m = self.model
         alpha = self._t(params, alpha_name) if alpha_name else None
+        pb = self._pbuf(self.achunks * self.H)
+        palpha = self._pbuf(self.H * self.achunks) if mode == L.PIRATE_RES else None
         L.check(L.lib().ppsci_pirate_act_bwd(mode, self.act, self.H, self.n, self.NP, self.n1, self.n2, _p(z),
                                              _p(self._t(params, bias_name)), _p(U), _p(V), _p(x), _p(alpha), _p(obar), _p(self.ZB),
                                              _p(self.UB) if mode == L.PIRATE_GATE else None,
-                                             _p(self.VB) if mode == L.PIRATE_GATE else None, _p(xbar), _p(self.pb),
-                                             _p(self.palpha) if mode == L.PIRATE_RES else None, _sp(self.ZB)))
+                                             _p(self.VB) if mode == L.PIRATE_GATE else None, _p(xbar), _p(pb),
+                                             _p(palpha), _sp(self.ZB)))
         ob, nb_ = m._offsets[bias_name]
-        hp.reduce_rows(self.pb, self.achunks, self.H, grad[ob:ob + nb_], False)
+        self._sum_later(pb, self.achunks, self.H, grad[ob:ob + nb_])
         if alpha_name:
             oa, na = m._offsets[alpha_name]
-            rows = self.H * self.achunks
-            hp.reduce_rows(self.palpha.view(rows, 1), rows, 1, grad[oa:oa + na], False)
+            self._sum_later(palpha, self.H * self.achunks, 1, grad[oa:oa + na])
 
     def backward(self, params: torch.Tensor, Ubar_rows: torch.Tensor, grad: torch.Tensor) -> None:
         """`grad`: flat [n_params] slice of the gradient buffer, fully overwritten."""
@@ -411,11 +436,12 @@ class PirateExec:
             self._alloc_train()
         m, H, lib = self.model, self.H, L.lib()
         grad = grad.view(-1)
+        self._pcall, self._psegs, self._pullbacks = 0, [], []
         # last_fc
         L.check(lib.ppsci_pirate_out_bwd(self.S, self.m, self.n, self.NP, _p(Ubar_rows), _p(self.Ybar), _sp(self.Ybar)))
         ob, nb_ = m._offsets["last_fc.bias"]
         for o in range(self.m):  # bias gradient = sum over points of the value-stream adjoint
-            hp.reduce_rows(Ubar_rows[o * self.S].view(self.n, 1), self.n, 1, grad[ob + o:ob + o + 1], False)
+            self._sum_later(Ubar_rows[o * self.S], self.n, 1, grad[ob + o:ob + o + 1])
         xlast = self.blocks[-1]["X"] if self.blocks else self.X0
         self._wgrad(xlast, self.Ybar, H, self.m, "last_fc", params, grad)
         cur = 0
@@ -449,4 +475,5 @@ class PirateExec:
         L.check(lib.ppsci_pirate_embed_bwd(C.byref(self.desc), self._in_ptrs, _p(self._t(params, "fourier_emb.kernel")),
                                            _p(self.XB[cur]), _p(self.pB), _sp(self.pB)))
         ok, nk = m._offsets["fourier_emb.kernel"]
-        hp.reduce_rows(self.pB, self.echunks, nk, grad[ok:ok + nk], False)
+        self._sum_later(self.pB, self.echunks, nk, grad[ok:ok + nk])
+        self._flush_sums()

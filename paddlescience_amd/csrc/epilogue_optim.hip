@@ -464,7 +464,8 @@ extern "C" int ppsci_reduce_rows_multi(int nseg, const ppsci_reduce_seg* segs, v
       return PPSCI_E_INVALID;
     }
     ReduceArgs a{g.partials, g.out, g.rows, g.cols, g.accumulate, RED_GROUPS};
-    if (g.rows >= 128 && g.cols <= 2048) a.groups = 32;  // (as ppsci_reduce_rows)
+    if (g.cols <= 8 && g.rows >= 512) a.groups = 256;  // few columns, many rows: a whole workgroup per column
+    else if (g.rows >= 128 && g.cols <= 2048) a.groups = 32;  // (as ppsci_reduce_rows)
     else if (g.rows >= 128 && g.cols <= 32768) a.groups = 16;
     const int cw = 256 / a.groups;
     m.seg[s] = a;
