@@ -341,6 +341,22 @@ int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const 
                              float* b_out, void* stream);
 int ppsci_linear_pullback(int kind, int fin, int fout, const float* v, const float* g, const float* gW,
                           const float* gb, float* gv, float* gg, float* gb_out, void* stream);
+/* Up to 16 layers in ONE launch: back == 0 ppsci_linear_materialize, back != 0 ppsci_linear_pullback of every job
+ * (a PirateNet has 11 re-parametrised layers: their launches were latency, not work). */
+typedef struct {
+  int32_t kind, fin, fout;
+  const float* v;
+  const float* g;
+  const float* b;
+  float* W;
+  float* b_out;
+  const float* gW;
+  const float* gb;
+  float* gv;
+  float* gg;
+  float* gb_out;
+} ppsci_linear_job;
+int ppsci_linear_multi(int n, const ppsci_linear_job* jobs, int back, void* stream);
 /* Per-layer widths (MLP(hidden_size=(h1, h2, ...)), mlp.py:199-201): the Taylor kernels run the padded width max(h_l); a
  * layer's trainable [fin_src, fout_src] matrix (+ bias) is the top-left block of its zero-filled [fin_dst, fout_dst] slice of
  * the kernel parameter buffer (ppsci_linear_pad, before the forward sweep), and only that block of the kernel-layout gradient

@@ -51,6 +51,12 @@ class ReduceSeg(C.Structure):
     _fields_ = [("partials", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("accumulate", C.c_int32)]
 
 
+class LinearJob(C.Structure):
+    """ppsci_linear_job: one layer of ppsci_linear_multi."""
+    _fields_ = [("kind", C.c_int32), ("fin", C.c_int32), ("fout", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "v", "g", "b", "W", "b_out", "gW", "gb", "gv", "gg", "gb_out")]
+
+
 class ModMlpDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_hidden", "width", "d_out", "activation")]
 
@@ -100,6 +106,7 @@ _SYMBOLS = {
     "ppsci_last_error": (C.c_char_p, []),
     "ppsci_is_device_build": (C.c_int, []),
     "ppsci_check_device": (C.c_int, []),
+    "ppsci_linear_multi": (C.c_int, [C.c_int, C.POINTER(LinearJob), C.c_int, C.c_void_p]),
     "ppsci_reduce_rows_multi": (C.c_int, [C.c_int, C.POINTER(ReduceSeg), C.c_void_p]),
     "ppsci_release_fragments": (None, [C.c_void_p]),
     "ppsci_set_max_grid": (None, [C.c_int]),

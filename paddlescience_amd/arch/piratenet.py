@@ -306,10 +306,12 @@ class PirateExec:
         m = self.model
         if not m._rwf:
             return
+        jobs = []
         for name in m.linear_names():
             fin, fout = m._byname[name + ".weight_v"].shape
-            hp.linear_materialize(L.LINEAR_RWF, fin, fout, self._t(params, name + ".weight_v"), self._t(params, name + ".weight_g"),
-                                  None, self.weff[name], None)
+            jobs.append((L.LINEAR_RWF, fin, fout, self._t(params, name + ".weight_v"), self._t(params, name + ".weight_g"),
+                         None, self.weff[name], None))
+        hp.linear_multi(jobs, False, params)  # every factored layer in one launch (16 per launch)
 
     def _dense(self, x, W, fin, fout, out, accumulate=False):
         # out[s, o, p] = sum_i W[i, o] x[s, i, p]: nn.Linear weight [in, out] used as the transposed conv weight
@@ -391,8 +393,8 @@ class PirateExec:
                 arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src, dst, rows, cols, 0
             L.check(L.lib().ppsci_reduce_rows_multi(len(batch), arr, st))
         self._psegs = []
-        for args in self._pullbacks:  # the trainable tensors behind the summed kernel-layout gradients
-            hp.linear_pullback(*args)
+        if self._pullbacks:  # the trainable tensors behind the summed kernel-layout gradients, 16 layers per launch
+            hp.linear_multi(self._pullbacks, True, self.ZB)
         self._pullbacks = []
 
     def _wgrad(self, x, zbar, fin, fout, name, params, grad):

@@ -10,6 +10,7 @@
 // materialize: trainable tensors -> the layer's slice of the kernel parameter buffer (before the forward sweep);
 // pullback   : gradient of that slice -> gradients of the trainable tensors (after the reverse sweep).
 #include "ppsci_common.h"
+#include <string.h>
 
 #ifndef PPSCI_EMU
 #include <hip/hip_runtime.h>
@@ -48,10 +49,9 @@ __device__ __forceinline__ float rp_colsum(float v, float* red, int tc, int rg) 
   return s;
 }
 
-__global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) {
-  __shared__ float red[RP_COLS * RP_RG];
+__device__ __forceinline__ void linear_materialize_body(const ReparamArgs& a, int wg, float* red) {
   const int tc = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
-  const int j = blockIdx.x * RP_COLS + tc;
+  const int j = wg * RP_COLS + tc;
   const bool live = j < a.fout;
   if (a.kind == PPSCI_LINEAR_BROADCAST) {
     if (live && rg == 0) a.W[j] = a.v[0];
@@ -89,10 +89,14 @@ __global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) 
   if (live && rg == 0 && a.b_out && a.b) a.b_out[j] = a.b[j];
 }
 
-__global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
+__global__ void __launch_bounds__(256) linear_materialize_kernel(ReparamArgs a) {
   __shared__ float red[RP_COLS * RP_RG];
+  linear_materialize_body(a, (int)blockIdx.x, red);
+}
+
+__device__ __forceinline__ void linear_pullback_body(const ReparamArgs& a, int wg, float* red) {
   const int tc = threadIdx.x % RP_COLS, rg = threadIdx.x / RP_COLS;
-  const int j = blockIdx.x * RP_COLS + tc;
+  const int j = wg * RP_COLS + tc;
   if (a.kind == PPSCI_LINEAR_FOURIER) {
     const int half = a.fout / 2;
     if (j >= half) return;
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
     return;
   }
   if (a.kind == PPSCI_LINEAR_BROADCAST) {  // one thread: a fixed-order sum of at most 256 values
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (wg != 0 || threadIdx.x != 0) return;
     float sum = 0.f;
     for (int k = 0; k < a.fout; ++k) sum += a.gW[k];
     a.gv[0] = sum;
@@ -142,6 +146,28 @@ __global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
   if (live && rg == 0 && a.gb_out && a.gb) a.gb_out[j] = a.gb[j];
 }
 
+__global__ void __launch_bounds__(256) linear_pullback_kernel(ReparamArgs a) {
+  __shared__ float red[RP_COLS * RP_RG];
+  linear_pullback_body(a, (int)blockIdx.x, red);
+}
+
+// Up to RP_MAX_JOBS layers in ONE launch (a PirateNet has 11 re-parametrised layers: 12 launches of 6 - 9 us each per
+// direction were launch latency): workgroup b works on the job whose [first, first + count) range holds it.
+#define RP_MAX_JOBS 16
+struct ReparamMulti {
+  ReparamArgs job[RP_MAX_JOBS];
+  int first[RP_MAX_JOBS + 1];
+  int n, back;
+};
+__global__ void __launch_bounds__(256) linear_multi_kernel(ReparamMulti m) {
+  __shared__ float red[RP_COLS * RP_RG];
+  int s = 0;
+  while (s + 1 < m.n && (int)blockIdx.x >= m.first[s + 1]) ++s;
+  const int wg = (int)blockIdx.x - m.first[s];
+  if (m.back) linear_pullback_body(m.job[s], wg, red);
+  else linear_materialize_body(m.job[s], wg, red);
+}
+
 static bool reparam_kind_ok(int kind) { return kind >= PPSCI_LINEAR_PLAIN && kind <= PPSCI_LINEAR_BROADCAST; }
 
 extern "C" int ppsci_linear_materialize(int kind, int fin, int fout, const float* v, const float* g, const float* b,
@@ -178,6 +204,40 @@ extern "C" int ppsci_linear_pullback(int kind, int fin, int fout, const float* v
   int err = PPSCI_LAST_LAUNCH_ERROR();
   if (err != 0) {
     ppsci_set_error("linear_pullback: launch failed (hip error %d)", err);
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
+// n <= 16 layers per launch; `back` == 0: materialize (v, g, b -> W, b_out), 1: pullback (v, g, gW, gb -> gv, gg, gb_out)
+extern "C" int ppsci_linear_multi(int n, const ppsci_linear_job* jobs, int back, void* stream) {
+  if (n < 1 || n > RP_MAX_JOBS || !jobs) {
+    ppsci_set_error("linear_multi: 1 .. %d jobs", RP_MAX_JOBS);
+    return PPSCI_E_INVALID;
+  }
+  ReparamMulti m;
+  memset(&m, 0, sizeof(m));
+  m.n = n, m.back = back ? 1 : 0;
+  int total = 0;
+  for (int s = 0; s < n; ++s) {
+    const ppsci_linear_job& j = jobs[s];
+    const bool needs_g = j.kind == PPSCI_LINEAR_WEIGHT_NORM || j.kind == PPSCI_LINEAR_RWF;
+    const bool ok = back ? (j.gW && j.gv && (!needs_g || (j.v && j.g && j.gg))) : (j.v && j.W && (!needs_g || j.g));
+    if (!reparam_kind_ok(j.kind) || j.fin < 1 || j.fout < 1 || !ok || (j.kind == PPSCI_LINEAR_FOURIER && (j.fout & 1))) {
+      ppsci_set_error("linear_multi: invalid job %d", s);
+      return PPSCI_E_INVALID;
+    }
+    ReparamArgs a{};
+    a.kind = j.kind, a.fin = j.fin, a.fout = j.fout, a.v = j.v, a.g = j.g, a.b = j.b, a.W = j.W, a.b_out = j.b_out;
+    a.gW = j.gW, a.gb = j.gb, a.gv = j.gv, a.gg = j.gg, a.gb_out = j.gb_out;
+    m.job[s] = a;
+    m.first[s] = total;
+    total += (j.fout + RP_COLS - 1) / RP_COLS;
+  }
+  m.first[n] = total;
+  PPSCI_LAUNCH(linear_multi_kernel, ReparamMulti, total, 256, 0, stream, m);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("linear_multi: launch failed");
     return PPSCI_E_LAUNCH;
   }
   return PPSCI_OK;

@@ -276,6 +276,25 @@ def linear_materialize(kind: int, fin: int, fout: int, v: torch.Tensor, g: Optio
     L.check(L.lib().ppsci_linear_materialize(kind, fin, fout, _p(v), _p(g), _p(b), _p(W), _p(b_out), _stream_ptr(W)))
 
 
+def linear_multi(jobs, back: bool, like: torch.Tensor) -> None:
+    """ppsci_linear_multi: the materialize (back = False) or pullback (True) of several layers, 16 per launch.  jobs: the
+    argument tuples of linear_materialize (kind, fin, fout, v, g, b, W, b_out) / linear_pullback (kind, fin, fout, v, g, gW,
+    gb, gv, gg, gb_out)."""
+    _require_device(like)
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    for i0 in range(0, len(jobs), 16):
+        batch = jobs[i0:i0 + 16]
+        arr = (L.LinearJob * len(batch))()
+        for k, j in enumerate(batch):
+            _chk_f32(*[t for t in j[3:] if t is not None])
+            arr[k].kind, arr[k].fin, arr[k].fout = j[0], j[1], j[2]
+            if back:
+                arr[k].v, arr[k].g, arr[k].gW, arr[k].gb, arr[k].gv, arr[k].gg, arr[k].gb_out = [ptr(t) for t in j[3:10]]
+            else:
+                arr[k].v, arr[k].g, arr[k].b, arr[k].W, arr[k].b_out = [ptr(t) for t in j[3:8]]
+        L.check(L.lib().ppsci_linear_multi(len(batch), arr, 1 if back else 0, _stream_ptr(like)))
+
+
 def linear_pad(src_dims, dst_dims, v: torch.Tensor, b: torch.Tensor, W: torch.Tensor, b_out: torch.Tensor) -> None:
     """ppsci_linear_pad: trainable [fin_s, fout_s] block (+ bias) -> zero-filled kernel-layout [fin_d, fout_d] slice."""
     _require_device(W)
