@@ -309,12 +309,15 @@ class MLP(Arch, metaclass=_MLPMeta):
     def materialize(self) -> torch.Tensor:
         """Fill `kernel_params` from the trainable tensors; call before every forward sweep."""
         t = self._byname
+        jobs = []
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
             if kind == L.LINEAR_PADDED:
                 hp.linear_pad(fin, fout, t[v].reshape(-1), t[b], self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn])
                 continue
-            hp.linear_materialize(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, t[b] if b else None,
-                                  self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn] if bn else None)
+            jobs.append((kind, fin, fout, t[v].reshape(-1), t[g] if g else None, t[b] if b else None,
+                         self.kernel_params[wo:wo + wn], self.kernel_params[bo:bo + bn] if bn else None))
+        if jobs:
+            hp.linear_multi(jobs, False, self.kernel_params)  # all re-parametrised layers in one launch (16 per launch)
         return self.kernel_params
 
     def pull_back(self, grad_kernel: torch.Tensor) -> torch.Tensor:
@@ -322,13 +325,16 @@ class MLP(Arch, metaclass=_MLPMeta):
         if not self.reparam:
             return grad_kernel
         t, gt = self._byname, self._gviews
+        jobs = []
         for kind, fin, fout, v, g, b, (wo, wn, _), (bo, bn, _) in self._records:
             if kind == L.LINEAR_PADDED:
                 hp.linear_unpad(fin, fout, grad_kernel[wo:wo + wn], grad_kernel[bo:bo + bn], gt[v].reshape(-1), gt[b])
                 continue
-            hp.linear_pullback(kind, fin, fout, t[v].reshape(-1), t[g] if g else None, grad_kernel[wo:wo + wn],
-                               grad_kernel[bo:bo + bn] if bn else None, gt[v].reshape(-1), gt[g] if g else None,
-                               gt[b] if b else None)
+            jobs.append((kind, fin, fout, t[v].reshape(-1), t[g] if g else None, grad_kernel[wo:wo + wn],
+                         grad_kernel[bo:bo + bn] if bn else None, gt[v].reshape(-1), gt[g] if g else None,
+                         gt[b] if b else None))
+        if jobs:
+            hp.linear_multi(jobs, True, grad_kernel)
         return self._grad_train
 
     # ---- parameters
