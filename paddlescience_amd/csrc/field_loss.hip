@@ -51,8 +51,7 @@ __global__ void __launch_bounds__(256) field_sums_kernel(FieldArgs a) {
   const float* x = a.x + r * P;
   const float* y = a.y + r * P;
   float sd = 0.f, sy = 0.f;
-  for (long long p = threadIdx.x; p < P; p += 256) {
-    const int i = (int)(p / a.W), j = (int)(p - (long long)i * a.W);
+  for (int p = threadIdx.x; p < (int)P; p += 256) {
     const float yv = y[p], e = x[p] - yv;
     if (a.order == 2) {  // p = 1: sums of magnitudes
       sd += fabsf(e);
@@ -62,6 +61,7 @@ __global__ void __launch_bounds__(256) field_sums_kernel(FieldArgs a) {
     sd += e * e;
     sy += yv * yv;
     if (a.order == 1) {
+      const int i = p / a.W, j = p - i * a.W;  // (only the H1 terms need the position)
       const float dxx = fl_dapply(x + j, a.W, i, a.H, a.ihx, a.fix_x), dxy = fl_dapply(y + j, a.W, i, a.H, a.ihx, a.fix_x);
       const float dyx = fl_dapply(x + (long long)i * a.W, 1, j, a.W, a.ihy, a.fix_y);
       const float dyy = fl_dapply(y + (long long)i * a.W, 1, j, a.W, a.ihy, a.fix_y);
