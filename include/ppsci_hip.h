@@ -276,6 +276,15 @@ void ppsci_set_step_tail(int mode);
  * run pre-decoded (csrc/epilogue_vm.h epi_point_fast) instead of through the opcode interpreter; 0 forces the interpreter
  * (tests compare the two). */
 void ppsci_set_fast_program(int on);
+/* kind 2: a pre-decoded program that IS one of the compile-time tables of csrc/epi_static_programs.h (the residuals of
+ * the reference's equation classes -- AllenCahn, Laplace, Poisson, NavierStokes -- and value constraints, generated by
+ * tools/gen_static_programs.py from the same lowering the API path uses) is evaluated as straight-line code by every wave
+ * of the fused tile kernel instead of by the VM on one wave (csrc/epi_static.h); 0 keeps every program on the VM (tests
+ * compare the two).  Read when a launch is PLANNED.  _plan_static: 0 or the table's id (and its name).
+ * _predecode: the pre-decoded form of a program (256 dwords: steps | loads + constants | terms | constant values; returns
+ * the number of steps, -1 when the program needs the interpreter) -- what the tables are matched against. */
+void ppsci_set_static_program(int on);
+int ppsci_epilogue_predecode(const ppsci_epilogue_desc* e, uint32_t* out256, int* n_loads);
 /* The same with the argument block prepared once: a training loop launches the same constraint thousands of times
  * with the same buffers, and at 20-40 us of device time per step the per-call planning (occupancy / attribute queries,
  * argument checks) of ppsci_taylor_step would dominate.  _plan: NULL on error / unsupported (ppsci_last_error);
@@ -293,6 +302,7 @@ int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogu
  * the fragments are those of the last _run); kind 1: the whole launch without Adam. */
 int ppsci_taylor_step_run_main(ppsci_step_plan* plan, void* stream);
 void ppsci_taylor_step_plan_free(ppsci_step_plan* plan);
+int ppsci_taylor_step_plan_static(const ppsci_step_plan* plan, const char** name);
 int ppsci_taylor_step(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, float* params, int64_t n_points,
                       const float* const* inputs_host, const float* const* aux_host, float* U, float* Ubar,
                       float* residual_out, void* stash, void* workspace, int64_t workspace_bytes, float* loss_terms,

@@ -135,6 +135,9 @@ _SYMBOLS = {
     "ppsci_set_fused_step": (None, [C.c_int]),
     "ppsci_set_step_tail": (None, [C.c_int]),
     "ppsci_set_fast_program": (None, [C.c_int]),
+    "ppsci_set_static_program": (None, [C.c_int]),
+    "ppsci_epilogue_predecode": (C.c_int, [C.POINTER(EpilogueDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "ppsci_taylor_step_plan_static": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),
     "ppsci_taylor_step_plan": (C.c_void_p, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_void_p, C.c_int64,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

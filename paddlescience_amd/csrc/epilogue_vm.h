@@ -37,6 +37,8 @@ struct EpiArgs {
   const unsigned* fast;
   int nfast;
   int nfast_loads;  // entries of the load table: the program's loads AND constants, in program order
+  int static_id;    // > 0: the program IS table `static_id` of epi_static_programs.h (epi_static.h): evaluated as compile-time
+                    // straight-line code by every wave; `fast` still holds the tables (constants, scales)
 };
 
 // ---- pre-decoded programs for epi_point_fast.  One 32-bit word per arithmetic step (loads and constants are not steps):

@@ -2,6 +2,7 @@
 // checks, derived sizes, and dispatch to the per-activation translation units.
 #include "taylor_tile.h"
 #include "taylor_step.h"
+#include "epi_static.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -313,8 +314,16 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
 // ------------------------------------------------------------------------------------ one-launch step
 // process-global knobs of the one-launch step (tests / tools): the fused tile kernel on or off; how a fused launch ends
 // (-1: by grid size, 0: the in-kernel reduction tree, 1: the host issues the reduction kernels behind the launch)
-static int g_fused_step = 1, g_step_tail = -1, g_fast_vm = 1;
+static int g_fused_step = 1, g_step_tail = -1, g_fast_vm = 1, g_static_prog = 1;
 extern "C" void ppsci_set_fast_program(int on) { g_fast_vm = on ? 1 : 0; }
+extern "C" void ppsci_set_static_program(int on) { g_static_prog = on ? 1 : 0; }
+extern "C" int ppsci_epilogue_predecode(const ppsci_epilogue_desc* e, uint32_t* out256, int* n_loads) {
+  int nl = 0;
+  if (!e || !out256) return -1;
+  const int n = epi_fast_encode(*e, out256, &nl);
+  if (n_loads) *n_loads = nl;
+  return n;
+}
 extern "C" void ppsci_set_fused_step(int on) { g_fused_step = on ? 1 : 0; }
 extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = (mode < 0 || mode > 2) ? -1 : mode; }
 // a tree over more rows than this is slower than the reduction kernels: every level is a ~10-20 us pass of ONE workgroup
@@ -325,13 +334,15 @@ static int run_step_act(StepArgs& a, void* stream, int launch, int* grid) {
   if (a.f.d.fourier_half > 0) return PPSCI_E_UNSUPPORTED;
   if (launch == 2 ? a.t.fused != 0 : g_fused_step != 0) {
     int rc = PPSCI_E_UNSUPPORTED;
+    const bool st = a.e.static_id > 0;  // the residual program is a compile-time table: the kernels without the VM
     switch (a.f.d.activation) {
-      case PPSCI_ACT_TANH: rc = ppsci_fused_run_tanh(a, stream, launch, grid); break;
-      case PPSCI_ACT_SILU: rc = ppsci_fused_run_silu(a, stream, launch, grid); break;
-      case PPSCI_ACT_SIN: rc = ppsci_fused_run_sin(a, stream, launch, grid); break;
+      case PPSCI_ACT_TANH: rc = st ? ppsci_fused_static_run_tanh(a, stream, launch, grid) : ppsci_fused_run_tanh(a, stream, launch, grid); break;
+      case PPSCI_ACT_SILU: rc = st ? ppsci_fused_static_run_silu(a, stream, launch, grid) : ppsci_fused_run_silu(a, stream, launch, grid); break;
+      case PPSCI_ACT_SIN: rc = st ? ppsci_fused_static_run_sin(a, stream, launch, grid) : ppsci_fused_run_sin(a, stream, launch, grid); break;
       default: break;
     }
     if (rc != PPSCI_E_UNSUPPORTED || launch == 2) return rc;
+    a.e.static_id = 0;  // (no fused tile kernel for this net: the one-launch kernel of padded width 32 runs the VM)
   }
   a.t.fused = 0;
   switch (a.f.d.activation) {
@@ -394,6 +405,14 @@ static int fill_step(StepArgs& a, const ppsci_mlp_desc* d, const ppsci_epilogue_
   epi_fill_loads(a.e);
   a.e.N = n_points;
   a.e.ntiles = a.f.ntiles;
+  // a program that IS one of the compile-time tables (epi_static.h) selects the fused tile kernels built without the VM:
+  // known before the launch is planned (grid, LDS and occupancy are those of the kernel that will run)
+  if (g_fast_vm && g_static_prog) {
+    unsigned fast[EPI_FAST_WORDS];
+    int nl = 0;
+    const int nfast = epi_fast_encode(a.e.e, fast, &nl);
+    if (nfast >= 0) a.e.static_id = epi_static_match(a.e.e, fast, nfast, nl, d->n1, d->n2, d->d_out);
+  }
   return PPSCI_OK;
 }
 
@@ -547,6 +566,14 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
 }
 
 extern "C" void ppsci_taylor_step_plan_free(ppsci_step_plan* plan) { delete plan; }
+
+// 0: the plan's residual program runs on the epilogue VM; > 0: it is compile-time table `id` of csrc/epi_static_programs.h
+// (`name`, when given, receives the table's name)
+extern "C" int ppsci_taylor_step_plan_static(const ppsci_step_plan* plan, const char** name) {
+  const int id = plan ? plan->a.e.static_id : 0;
+  if (name) *name = epi_static_name(id);
+  return id;
+}
 
 extern "C" int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogue_desc* e) {
   if (!plan || !e || e->n_res != plan->a.e.e.n_res) {

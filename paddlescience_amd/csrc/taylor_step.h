@@ -49,3 +49,7 @@ int ppsci_step_run_sin(StepArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fused_run_tanh(StepArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fused_run_silu(StepArgs& a, void* stream, int launch, int* grid_out);
 int ppsci_fused_run_sin(StepArgs& a, void* stream, int launch, int* grid_out);
+// the same kernels for plans whose residual program is a compile-time table (a.e.static_id > 0; taylor_fused_static_<act>.hip)
+int ppsci_fused_static_run_tanh(StepArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fused_static_run_silu(StepArgs& a, void* stream, int launch, int* grid_out);
+int ppsci_fused_static_run_sin(StepArgs& a, void* stream, int launch, int* grid_out);

@@ -482,6 +482,10 @@ int ppsci_wgrad_reduce_ex(const ppsci_mlp_desc& d, const ppsci_derived& q, int n
                           void* stream);
 int ppsci_wgrad_reduce(const ppsci_mlp_desc& d, const ppsci_derived& q, int ntiles, const float* wpart, float* tmp,
                        const float* small_rows, int nsmall_rows, float* tmp_small, float* row, void* stream);
+// one launch: the sums, grad (+)=, the loss terms, Adam and the fragments of the updated hidden matrices (`frag`: the step
+// workspace's fragment buffer or null) -- the tail of a fused-tile step (wgrad_reduce.hip wgrad_tail_kernel)
+int ppsci_wgrad_tail(const ppsci_mlp_desc& d, const ppsci_derived& q, int nrows, const float* rows_w, const float* rows_s,
+                     float* row, const ppsci_wred_extras& x, void* frag, void* stream);
 int ppsci_wgrad_reduce_chunks(const ppsci_mlp_desc& d, const ppsci_derived& q, int nrows, const float* rows, long long rowlen,
                               long long off_small, long long off_loss, float* row, const ppsci_wred_extras& x, void* stream);
 

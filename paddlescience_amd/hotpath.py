@@ -219,6 +219,12 @@ class StepPlan:
                                     adam["eps"], adam.get("grad_scale", 1.0), adam["t"]))
         L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev)))
 
+    @property
+    def static_program(self) -> str:
+        """Name of the compile-time table (csrc/epi_static_programs.h) this plan's residual program runs as; "" = the VM."""
+        nm = C.c_char_p()
+        return (nm.value or b"").decode() if L.lib().ppsci_taylor_step_plan_static(self.handle, C.byref(nm)) > 0 else ""
+
     def run_main(self) -> None:
         """Measurement: the main kernel of the step alone (ppsci_taylor_step_run_main)."""
         L.check(L.lib().ppsci_taylor_step_run_main(self.handle, _stream_ptr(self._dev)))

@@ -27,6 +27,7 @@ def run(n, hidden=4, width=64, reps=30):
     grads = {}
     for tag, one, tail in (("sep", False, -1), ("fused_tree", True, 0), ("fused_ext", True, 1), ("fused_hyb", True, 2)):
         L.lib().ppsci_set_step_tail(tail)
+        L.lib().ppsci_set_static_program(0 if os.environ.get("PPSCI_STATIC_PROGRAM", "1") == "0" else 1)  # A/B: the VM
         lay = hp.NetLayout(2, hidden, width, 1, "tanh")
         xs = [torch.tensor(X[:, j].copy(), device=dev) for j in range(2)]
         cst = FusedConstraint("EQ", lay, hp.StreamSpec([[0.0, 1.0], [1.0, 0.0]], 1), bench.allen_cahn_program(n), xs, [],
@@ -41,6 +42,7 @@ def run(n, hidden=4, width=64, reps=30):
         out[tag + "_us"] = round(bench.time_events(lambda: eng.train_step([cst], 1e-3), reps) * 1e6, 2)
         if one:
             assert cst._step_kind == hp.STEP_FUSED_TILE
+            out["static_program"] = cst._step_plan.static_program
             out["main_us"] = round(bench.time_events(cst._step_plan.run_main, reps) * 1e6, 2)
     L.lib().ppsci_set_step_tail(-1)
     out["grad_rel_tree_vs_sep"] = bench.rel(grads["fused_tree"], grads["sep"])
