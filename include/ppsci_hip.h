@@ -268,8 +268,9 @@ int64_t ppsci_taylor_step_workspace_bytes(const ppsci_mlp_desc* d, const ppsci_e
 int ppsci_taylor_step_kind(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points);
 /* test / tool knobs (process-global): the fused tile kernel on (default) or off; how a fused launch ends: -1 by grid
  * size (default: 0 for small grids, 1 otherwise), 0 the in-kernel reduction tree, 1 two reduction kernels behind the
- * launch, 2 the first level of the tree inside the launch and one kernel behind it (slower than 1, kept for tests).  Both are read when a launch is
- * PLANNED (workspace_bytes, _plan). */
+ * launch, 2 the first level of the tree inside the launch and one kernel behind it (slower than 1, kept for tests), 3 (the
+ * default for large grids) ONE kernel behind the launch: sums, grad (+)=, loss terms, Adam and the bf16 fragments of the updated
+ * hidden matrices for the next step.  Both are read when a launch is PLANNED (workspace_bytes, _plan). */
 void ppsci_set_fused_step(int on);
 void ppsci_set_step_tail(int mode);
 /* kind 2: residual programs made of loads, constants, +, -, *, negation and detach under MSE terms (every BASELINE PDE)
@@ -296,6 +297,17 @@ ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, const ppsci_epi
                                         float* U, float* Ubar, float* residual_out, void* stash, void* workspace,
                                         int64_t workspace_bytes, float* loss_terms, float* grad);
 int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream);
+/* _run with flags.  PPSCI_STEP_KEEP_FRAGMENTS (kind 2): the caller vouches that NOTHING has written the parameters since this
+ * plan's previous _run returned; when that run's tail kernel left the bf16 fragments of the updated hidden matrices behind
+ * (step tail mode 3, the default for large grids) the weight-split launch in front of the tile kernel is skipped -- a step is
+ * then two launches.  Without the flag (or after any other writer) the fragments are split again: always safe. */
+#define PPSCI_STEP_KEEP_FRAGMENTS 1
+int ppsci_taylor_step_run_ex(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream, int flags);
+/* Data parallelism (fused_allreduce_gradients between backward and optimizer.step, ppsci/solver/train.py:168-175): after
+ * _run without Adam and the caller's SUM all-reduce of `grad`, ONE launch applies Adam to the parameters from the finished
+ * gradient and (kind 2) leaves the fragments of the updated hidden matrices behind, as the tail kernel of a single-rank
+ * step does -- the next _run_ex may keep them. */
+int ppsci_taylor_step_plan_apply(ppsci_step_plan* plan, const ppsci_adam_args* adam, void* stream);
 int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const ppsci_epilogue_desc* e);
 /* measurement (bench.py's roofline entry): the MAIN kernel of the planned step alone -- kind 2: the fused tile kernel
  * without the weight-split launch in front of it and without any reduction (the workgroups' rows stay in the workspace;

@@ -26,6 +26,7 @@ EMBED_NONE, EMBED_PERIOD, EMBED_STREAMS = 0, 1, 2
  OP_DETACH, OP_ASIN, OP_ACOS, OP_ATAN, OP_ATAN2, OP_ASINH, OP_ACOSH, OP_ATANH, OP_ERF, OP_LGAMMA, OP_CEIL, OP_FLOOR,
  OP_LD_PARAM, OP_COUNT) = range(38)
 MAX_EPARAM = 8
+STEP_KEEP_FRAGMENTS = 1  # ppsci_taylor_step_run_ex flag (include/ppsci_hip.h)
 
 
 class MlpDesc(C.Structure):
@@ -135,6 +136,8 @@ _SYMBOLS = {
     "ppsci_set_fused_step": (None, [C.c_int]),
     "ppsci_set_step_tail": (None, [C.c_int]),
     "ppsci_set_fast_program": (None, [C.c_int]),
+    "ppsci_taylor_step_run_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(AdamArgs), C.c_void_p, C.c_int]),
+    "ppsci_taylor_step_plan_apply": (C.c_int, [C.c_void_p, C.POINTER(AdamArgs), C.c_void_p]),
     "ppsci_set_static_program": (None, [C.c_int]),
     "ppsci_epilogue_predecode": (C.c_int, [C.POINTER(EpilogueDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "ppsci_taylor_step_plan_static": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p)]),

@@ -48,6 +48,24 @@ __device__ __forceinline__ unsigned ppsci_cvt_pk_bf16(float a, float b) {
   typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2_));
 }
+// x minus the low / high bf16 of the packed pair h, as ONE instruction: v_dot2c_f32_bf16  x += h . (-1, 0)  resp.  h . (0, -1)
+// (the products are exact, and so is the sum: h is x rounded to 8 significand bits) -- instead of unpacking the bf16 into a
+// float (a shift or a mask) and subtracting: 7 instead of 9 VALU instructions per pair of values in ppsci_split.
+// The constant operands are kept out of the optimiser's sight (SGPRs): hipcc folds the packed pair (-1, 0) into the inline
+// operand "-1.0", which the hardware reads as something else -- 65 456 of 65 536 results wrong on MI355X with literal
+// constants, 0 with register operands (tools/microbench/dot2_test.hip).
+__device__ __forceinline__ float ppsci_bf16_sub_lo(unsigned h, float x) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  unsigned k = 0x0000bf80u;  // (lo, hi) = (-1, 0)
+  asm volatile("" : "+s"(k));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, h), __builtin_bit_cast(bf16x2_, k), x, false);
+}
+__device__ __forceinline__ float ppsci_bf16_sub_hi(unsigned h, float x) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  unsigned k = 0xbf800000u;  // (lo, hi) = (0, -1)
+  asm volatile("" : "+s"(k));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_, h), __builtin_bit_cast(bf16x2_, k), x, false);
+}
 // v_mfma_f32_16x16x32_bf16: lane (g = l>>4, c = l&15) supplies A[i = c][k = 8g + j] and B[k = 8g + j][n = c], j = 0..7
 // (here as two 4-bf16 halves: j = 0..3 from *_lo, 4..7 from *_hi); C/D as the fp32 16x16 MFMAs (row 4g + r, col c)
 __device__ __forceinline__ f32x4 ppsci_xdl32(u32x2 a_lo, u32x2 a_hi, u32x2 b_lo, u32x2 b_hi, f32x4 c) {

@@ -491,7 +491,10 @@ static long long dft_lds_bytes(int H, int W, int mx, int my, int inverse) {
 // 1 when the kept-mode transforms take this shape (a plane and its tables fit the LDS of two workgroups per CU)
 extern "C" int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y) {
   if (H < 2 || W < 2 || modes_x < 1 || modes_y < 1 || modes_x > H || modes_y > W / 2 + 1) return 0;
-  return dft_lds_bytes(H, W, modes_x, modes_y, 0) <= 64 * 1024 ? 1 : 0;
+  // the largest consumer: the stand-alone forward stages, or the inverse stages next to a plane in the block tail's fused
+  // kernels (csrc/fno.hip gn_apply / gn_bwd_apply with the transform inside), each + the 4 KB of static LDS those hold
+  const long long fwd = dft_lds_bytes(H, W, modes_x, modes_y, 0), inv = dft_lds_bytes(H, W, modes_x, modes_y, 1) + 4LL * H * (W + 1);
+  return (fwd > inv ? fwd : inv) + 4096 <= 64 * 1024 ? 1 : 0;
 }
 
 // Twiddle tables per (device, H, W, modes, rows): built on the host in double, uploaded at the first call (an eager one:

@@ -325,7 +325,7 @@ extern "C" int ppsci_epilogue_predecode(const ppsci_epilogue_desc* e, uint32_t* 
   return n;
 }
 extern "C" void ppsci_set_fused_step(int on) { g_fused_step = on ? 1 : 0; }
-extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = (mode < 0 || mode > 2) ? -1 : mode; }
+extern "C" void ppsci_set_step_tail(int mode) { g_step_tail = (mode < 0 || mode > 3) ? -1 : mode; }
 // a tree over more rows than this is slower than the reduction kernels: every level is a ~10-20 us pass of ONE workgroup
 // over 16 rows of (L-1) * 16 KB, against ~12 us for the two kernels over all rows
 #define PPSCI_FUSED_TREE_MAX_GRID 48
@@ -407,7 +407,11 @@ static int fill_step(StepArgs& a, const ppsci_mlp_desc* d, const ppsci_epilogue_
   a.e.ntiles = a.f.ntiles;
   // a program that IS one of the compile-time tables (epi_static.h) selects the fused tile kernels built without the VM:
   // known before the launch is planned (grid, LDS and occupancy are those of the kernel that will run)
-  if (g_fast_vm && g_static_prog) {
+  // (those kernels are also the ones written for RAW inputs -- no period embedding, no caller-supplied input streams: the
+  // layer-0 code of the general case, with its descriptor look-ups per tile, is not in them)
+  bool raw = true;
+  for (int j = 0; j < d->d_raw; ++j) raw = raw && d->embed[j] == PPSCI_EMBED_NONE;
+  if (g_fast_vm && g_static_prog && raw) {
     unsigned fast[EPI_FAST_WORDS];
     int nl = 0;
     const int nfast = epi_fast_encode(a.e.e, fast, &nl);
@@ -427,6 +431,7 @@ struct ppsci_step_plan {
   StepArgs a;
   StepLayout y;
   float* ws;
+  bool frag_fresh;  // fused tile kernel: the fragments in the workspace are those of the parameters as this plan's last run left them
 };
 
 extern "C" int ppsci_taylor_step_kind(const ppsci_mlp_desc* d, const ppsci_epilogue_desc* e, int64_t n_points) {
@@ -506,6 +511,7 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
   float* ws = (float*)workspace;
   plan->y = y;
   plan->ws = ws;
+  plan->frag_fresh = false;
   if (a.t.fused) {
     a.f.xfrag = ws + y.frag;
     a.b.xfrag = (const u32x4*)(ws + y.frag) + (long long)(d->n_hidden - 1) * PPSCI_GFRAG_PER_LAYER(a.f.q.NB);
@@ -513,8 +519,12 @@ extern "C" ppsci_step_plan* ppsci_taylor_step_plan(const ppsci_mlp_desc* d, cons
     // 2: the tree's first level inside the launch, one kernel behind it -- measured SLOWER than 1 at 512 workgroups
     // (100 k points: 302 us against 270 us per step: the rows then have to be agent-scope write-through stores and the
     // last workgroups of the groups add a serial pass over 16 x 49 KB each), kept as a tested knob
-    a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 1 : 0);
+    // 3 (the default for large grids): as 1 with ONE kernel behind the launch, which also leaves the bf16 fragments of the
+    // updated hidden matrices behind (no weight-split launch in front of the next step)
+    a.t.external = g_step_tail >= 0 ? g_step_tail : (grid > PPSCI_FUSED_TREE_MAX_GRID ? 3 : 0);
     if (a.t.external == 2 && grid <= PPSCI_STEP_FAN) a.t.external = 0;  // (one group: its sum IS the total)
+    a.t.one_tail = a.t.external == 3 ? 1 : 0;
+    if (a.t.one_tail) a.t.external = 1;  // (what the kernel sees: the launch stops at the workgroups' rows)
   }
   {
     unsigned fast[EPI_FAST_WORDS];
@@ -585,6 +595,10 @@ extern "C" int ppsci_taylor_step_plan_set_scales(ppsci_step_plan* plan, const pp
 }
 
 extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream) {
+  return ppsci_taylor_step_run_ex(plan, accumulate, adam, stream, 0);
+}
+
+extern "C" int ppsci_taylor_step_run_ex(ppsci_step_plan* plan, int accumulate, const ppsci_adam_args* adam, void* stream, int flags) {
   if (!plan) {
     ppsci_set_error("taylor_step_run: invalid argument");
     return PPSCI_E_INVALID;
@@ -615,7 +629,11 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
   StepArgs& a = plan->a;
   const StepLayout& y = plan->y;
   float* ws = plan->ws;
-  {
+  // PPSCI_STEP_KEEP_FRAGMENTS: the caller vouches that nothing has written the parameters since this plan's last run; if
+  // that run left current fragments behind (its tail kernel writes them next to the Adam update) the weight split is skipped
+  const bool keep = (flags & PPSCI_STEP_KEEP_FRAGMENTS) && plan->frag_fresh;
+  plan->frag_fresh = false;
+  if (!keep) {
     const int L = a.f.d.n_hidden, NB = a.f.q.NB;
     const int total = 2 * (L - 1) * NB * (NB / 2) * 64;
     struct PArgs {
@@ -641,7 +659,7 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
   if (t.external) t.do_adam = 0;
   int rc = run_step_act(a, stream, 2, &grid);
   t.do_adam = do_adam;
-  if (rc != PPSCI_OK || !t.external) return rc;
+  if (rc != PPSCI_OK || !t.external) return rc;  // (Adam inside the launch: the fragments are stale from here on)
   // two launches: chunk sums of the workgroups' rows, then -- one thread per parameter -- the total, grad (+)= it, the Adam
   // update; the loss terms by one more workgroup of the second launch
   ppsci_wred_extras x;
@@ -661,6 +679,11 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
     x.eps_t = t.eps_t;
     x.grad_scale = t.grad_scale;
   }
+  if (t.one_tail) {
+    rc = ppsci_wgrad_tail(a.b.d, a.b.q, t.grid, t.rows_w, t.rows_s, t.grad, x, ws + y.frag, stream);
+    plan->frag_fresh = rc == PPSCI_OK;  // (with or without Adam: the fragments are those of the parameters as they are now)
+    return rc;
+  }
   if (t.external == 2) {
     // the launch has left the sums of groups of PPSCI_STEP_FAN rows in the first rows of `tree`
     const int nrows = (t.grid + PPSCI_STEP_FAN - 1) / PPSCI_STEP_FAN;
@@ -668,7 +691,39 @@ extern "C" int ppsci_taylor_step_run(ppsci_step_plan* plan, int accumulate, cons
     x.loss_rows = nullptr;  // (taken from the rows)
     return ppsci_wgrad_reduce_chunks(a.b.d, a.b.q, nrows, t.tree, t.rowlen, off_s, off_l, t.grad, x, stream);
   }
-  return ppsci_wgrad_reduce_ex(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, t.grad, x, stream);
+  rc = ppsci_wgrad_reduce_ex(a.b.d, a.b.q, t.grid, t.rows_w, ws + y.red_tmp, t.rows_s, t.grid, ws + y.red_small, t.grad, x, stream);
+  plan->frag_fresh = rc == PPSCI_OK && !adam;  // (no Adam here: the parameters are what the fragments were split from)
+  return rc;
+}
+
+// Data parallelism (one SUM all-reduce of the flat gradient between the step's sums and the optimizer,
+// /root/reference/ppsci/solver/train.py:168-175): the Adam update from the FINISHED gradient `grad` of the plan -- and, for
+// the fused tile kernel, the bf16 fragments of the updated hidden matrices -- in one launch, so that a data-parallel step is
+// tile kernel + tail kernel (sums) + all-reduce + this, with no weight-split launch in front of the next step.
+extern "C" int ppsci_taylor_step_plan_apply(ppsci_step_plan* plan, const ppsci_adam_args* adam, void* stream) {
+  if (!plan || !adam || !adam->m || !adam->v || adam->step_t < 1) {
+    ppsci_set_error("taylor_step_plan_apply: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  StepArgs& a = plan->a;
+  StepTail& t = a.t;
+  const double b1t = pow((double)adam->beta1, (double)adam->step_t), b2t = pow((double)adam->beta2, (double)adam->step_t);
+  const double c2 = sqrt(1.0 - b2t);  // == ppsci_adam_step
+  ppsci_wred_extras x;
+  memset(&x, 0, sizeof(x));
+  x.accumulate = 1;  // no rows: the "sum" is the gradient as it stands
+  x.p = t.p;
+  x.m = adam->m;
+  x.v = adam->v;
+  x.lr_t = (float)(adam->lr * c2 / (1.0 - b1t));
+  x.beta1 = adam->beta1;
+  x.beta2 = adam->beta2;
+  x.eps_t = (float)(adam->eps * c2);
+  x.grad_scale = adam->grad_scale;
+  plan->frag_fresh = false;
+  const int rc = ppsci_wgrad_tail(a.b.d, a.b.q, 0, t.rows_w, t.rows_s, t.grad, x, t.fused ? plan->ws + plan->y.frag : nullptr, stream);
+  plan->frag_fresh = rc == PPSCI_OK && t.fused;
+  return rc;
 }
 
 // measurement: the main kernel of the planned step alone (kind 2: the fused tile kernel without the weight split in front

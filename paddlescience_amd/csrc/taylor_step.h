@@ -24,6 +24,8 @@ struct StepTail {
   int accumulate, do_adam;
   float lr_t, beta1, beta2, eps_t, grad_scale;
   int fused;           // host side only: planned onto the fused tile kernel (taylor_fused.inc)
+  int one_tail;        // host side only (with external == 1): ONE kernel behind the launch -- sums, grad (+)=, loss terms, Adam and the
+                       // fragments of the updated hidden matrices (wgrad_reduce.hip wgrad_tail_kernel) -- instead of two
   int external;        // fused tile kernel: 1 = the launch stops at the workgroups' rows; the host issues the two reduction kernels
                        // (+ loss sum, Adam) behind it -- a 512-row tree of 48 KB rows is slower than those (taylor_api.hip);
                        // 2 = the launch runs the FIRST level of the tree (the last workgroup of every group of

@@ -289,11 +289,11 @@ __device__ __forceinline__ ppsci_split4 ppsci_split(f32x4 x) {
   for (int i = 0; i < 2; ++i) {
     float a = x[2 * i], b = x[2 * i + 1];
     const unsigned h = ppsci_cvt_pk_bf16(a, b);
-    a -= ppsci_bf16lo_f32(h);
-    b -= ppsci_bf16hi_f32(h);
+    a = ppsci_bf16_sub_lo(h, a);  // a - (a as bf16): exact; one v_dot2c_f32_bf16 each (ppsci_common.h)
+    b = ppsci_bf16_sub_hi(h, b);
     const unsigned m = ppsci_cvt_pk_bf16(a, b);
-    a -= ppsci_bf16lo_f32(m);
-    b -= ppsci_bf16hi_f32(m);
+    a = ppsci_bf16_sub_lo(m, a);
+    b = ppsci_bf16_sub_hi(m, b);
     o.p[0][i] = h;
     o.p[1][i] = m;
     o.p[2][i] = ppsci_cvt_pk_bf16(a, b);

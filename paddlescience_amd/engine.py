@@ -420,6 +420,20 @@ class Engine:
         scale = (1.0 / self.world) if (self.dp_reduce == "mean" and self.world > 1) else 1.0
         hp.adam_step(self.params, self.grad, self.m, self.v, lr, self.t, self.beta1, self.beta2, self.eps, scale)
 
+    def apply_adam_fused(self, constraints: Sequence[FusedConstraint], adam: dict) -> bool:
+        """Data parallelism with the fused tile kernel (one constraint, padded width 64): forward_backward() was tile kernel +
+        tail kernel (sums); behind the all-reduce -- enqueued on the launch stream, no host synchronisation -- ONE launch
+        applies Adam from the finished gradient and leaves the bf16 fragments of the updated matrices for the next step
+        (ppsci_taylor_step_plan_apply): the per-GPU step is the single-rank step + the collective.  False: nothing done (the
+        caller runs its optimizer)."""
+        c0 = constraints[0] if len(constraints) == 1 else None
+        if (self.world > 1 and c0 is not None and isinstance(c0, FusedConstraint) and self.one_launch_ready(constraints)
+                and c0._step_kind == hp.STEP_FUSED_TILE and getattr(c0, "_step_plan", None) is not None
+                and c0._step_plan.key == (self.params.data_ptr(), self.grad.data_ptr())):
+            c0._step_plan.apply_adam(adam)
+            return True
+        return False
+
     def train_step(self, constraints: Sequence[FusedConstraint], lr: float) -> None:
         if self.world == 1 and self.one_launch_ready(constraints):
             self.t += 1
@@ -427,4 +441,9 @@ class Engine:
                                                           eps=self.eps, grad_scale=1.0, t=self.t))
         self.forward_backward(constraints)
         self.allreduce()
+        scale = (1.0 / self.world) if (self.dp_reduce == "mean" and self.world > 1) else 1.0
+        if self.apply_adam_fused(constraints, dict(m=self.m, v=self.v, lr=lr, beta1=self.beta1, beta2=self.beta2, eps=self.eps,
+                                                   grad_scale=scale, t=self.t + 1)):
+            self.t += 1
+            return
         self.optimizer_step(lr)

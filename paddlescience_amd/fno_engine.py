@@ -66,8 +66,35 @@ class FnoNative:
             raise NotImplementedError(f"native FNO path: {why}")
         self.m = model
         self.shape = None
+        # One buffer set per input shape (batch, H, W), kept alive: training, evaluation and prediction share this executor
+        # (arch/fno.py), the reference's TFNO config trains at 16 x 16 and evaluates at 32 x 32 with eval_during_train, a ragged
+        # last eval batch changes the batch size -- and the operator engine REPLAYS a captured HIP graph of the training step
+        # that holds the training buffers' addresses.  Handing those back to the caching allocator when another shape comes by
+        # would leave the graph writing through stale pointers.  At most `max_sets` sets are kept (least recently used out);
+        # dropping one bumps `generation`, which is part of the engine's graph key, so no captured step outlives its buffers.
+        self._sets = {}
+        self.max_sets = 8
+        self.generation = 0
 
     # ------------------------------------------------------------------ buffers
+    def _switch(self, B: int, H: int, W: int) -> None:
+        """Make the buffer set of input shape (B, H, W) the current one (allocating it on first use); the previous set stays
+        alive under its own key."""
+        keep = ("m", "shape", "_sets", "max_sets", "generation")
+        if self.shape is not None:
+            self._sets[self.shape] = {k: v for k, v in self.__dict__.items() if k not in keep}
+        for k in [k for k in self.__dict__ if k not in keep]:
+            del self.__dict__[k]
+        key = (B, H, W)
+        if key in self._sets:
+            self.__dict__.update(self._sets.pop(key))  # (re-inserted when it is switched away from: most recently used last)
+            self.shape = key
+            return
+        while len(self._sets) >= self.max_sets:
+            self._sets.pop(next(iter(self._sets)))
+            self.generation += 1
+        self._alloc(B, H, W)
+
     def _alloc(self, B: int, H: int, W: int) -> None:
         m = self.m
         dev = m.flat_params.device
@@ -145,7 +172,7 @@ class FnoNative:
         m = self.m
         B, _, H0, W0 = x.shape
         if self.shape != (B, H0, W0):
-            self._alloc(B, H0, W0)
+            self._switch(B, H0, W0)
         P, P0, Ch, nl = self.P, self.P0, m.hidden_channels, m.n_layers
         H, W = self.hw
         self.x_in = x.contiguous().view(B, m.in_channels, P0)

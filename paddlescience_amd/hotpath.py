@@ -193,7 +193,9 @@ class StepPlan:
         ip = L.ptr_array([t.data_ptr() for t in inputs])
         ap = L.ptr_array([t.data_ptr() for t in aux]) if aux else None
         self._free = L.lib().ppsci_taylor_step_plan_free
-        self._run = L.lib().ppsci_taylor_step_run
+        self._run = L.lib().ppsci_taylor_step_run_ex
+        self._params = params
+        self._frag_token = None  # (global parameter-write count, torch version of `params`) right after this plan's last run
         self.handle = L.lib().ppsci_taylor_step_plan(C.byref(desc), C.byref(edesc), _p(params), n, ip, ap, _p(U), _p(Ubar),
                                                      _p(resid), _p(stash), _p(workspace), workspace.numel() * 4,
                                                      _p(loss_terms), _p(grad))
@@ -217,7 +219,24 @@ class StepPlan:
         if adam is not None:
             aa = C.byref(L.AdamArgs(adam["m"].data_ptr(), adam["v"].data_ptr(), adam["lr"], adam["beta1"], adam["beta2"],
                                     adam["eps"], adam.get("grad_scale", 1.0), adam["t"]))
-        L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev)))
+        # The tail kernel of a fused-tile step leaves the bf16 fragments of the updated hidden matrices behind; the next run
+        # skips the weight-split launch when NOTHING has written the parameters in between: no kernel of this module
+        # (param_writes counts adam_step / optim_step / the re-parametrisation kernels / other plans' fused Adam) and no torch
+        # operation (the tensor's version counter).  Anything else makes the library split again.
+        keep = self._frag_token is not None and self._frag_token == (_PARAM_WRITES[0], self._params._version)
+        L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev), L.STEP_KEEP_FRAGMENTS if keep else 0))
+        if adam is not None:
+            note_param_write()
+        self._frag_token = (_PARAM_WRITES[0], self._params._version)
+
+    def apply_adam(self, adam: dict) -> None:
+        """Data parallelism: Adam from the finished (all-reduced) gradient of the plan + the fragments of the updated hidden
+        matrices, one launch (ppsci_taylor_step_plan_apply)."""
+        aa = L.AdamArgs(adam["m"].data_ptr(), adam["v"].data_ptr(), adam["lr"], adam["beta1"], adam["beta2"], adam["eps"],
+                        adam.get("grad_scale", 1.0), adam["t"])
+        L.check(L.lib().ppsci_taylor_step_plan_apply(self.handle, C.byref(aa), _stream_ptr(self._dev)))
+        note_param_write()
+        self._frag_token = (_PARAM_WRITES[0], self._params._version)
 
     @property
     def static_program(self) -> str:
@@ -235,6 +254,15 @@ class StepPlan:
             self._free(h)
 
 
+_PARAM_WRITES = [0]
+
+
+def note_param_write() -> None:
+    """Called by everything in this module that lets a kernel write a parameter buffer (torch operations are seen through
+    the tensors' version counters): StepPlan.run compares the count to decide whether its weight fragments are current."""
+    _PARAM_WRITES[0] += 1
+
+
 def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor, accumulate: bool) -> None:
     _require_device(out)
     _chk_f32(partials, out)
@@ -245,6 +273,7 @@ def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
     _require_device(params)
     _chk_f32(params, grad, m, v)
+    note_param_write()
     L.check(L.lib().ppsci_adam_step(params.numel(), _p(params), _p(grad), _p(m), _p(v), lr, beta1, beta2, eps,
                                     step_t, grad_scale, _stream_ptr(params)))
 
@@ -258,6 +287,7 @@ def optim_step(kind: int, params: torch.Tensor, grad: torch.Tensor, states: Sequ
     """ppsci_optim_step: hyper = [lr, grad_scale, l2, a, b, c, d] (include/ppsci_hip.h)."""
     _require_device(params)
     _chk_f32(params, grad, *[t for t in states if t is not None])
+    note_param_write()
     st = list(states) + [None] * (3 - len(states))
     hy = (C.c_float * 7)(*[float(v) for v in list(hyper) + [0.0] * (7 - len(hyper))])
     L.check(L.lib().ppsci_optim_step(kind, params.numel(), _p(params), _p(grad), _p(st[0]), _p(st[1]), _p(st[2]), hy,
@@ -279,6 +309,7 @@ def linear_materialize(kind: int, fin: int, fout: int, v: torch.Tensor, g: Optio
     """ppsci_linear_materialize: trainable tensors of one layer -> its slice of the kernel parameter buffer."""
     _require_device(W)
     _chk_f32(*[t for t in (v, g, b, W, b_out) if t is not None])
+    note_param_write()
     L.check(L.lib().ppsci_linear_materialize(kind, fin, fout, _p(v), _p(g), _p(b), _p(W), _p(b_out), _stream_ptr(W)))
 
 
@@ -287,6 +318,8 @@ def linear_multi(jobs, back: bool, like: torch.Tensor) -> None:
     argument tuples of linear_materialize (kind, fin, fout, v, g, b, W, b_out) / linear_pullback (kind, fin, fout, v, g, gW,
     gb, gv, gg, gb_out)."""
     _require_device(like)
+    if not back:
+        note_param_write()
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
     for i0 in range(0, len(jobs), 16):
         batch = jobs[i0:i0 + 16]
@@ -305,6 +338,7 @@ def linear_pad(src_dims, dst_dims, v: torch.Tensor, b: torch.Tensor, W: torch.Te
     """ppsci_linear_pad: trainable [fin_s, fout_s] block (+ bias) -> zero-filled kernel-layout [fin_d, fout_d] slice."""
     _require_device(W)
     _chk_f32(v, b, W, b_out)
+    note_param_write()
     L.check(L.lib().ppsci_linear_pad(src_dims[0], src_dims[1], dst_dims[0], dst_dims[1], _p(v), _p(b), _p(W), _p(b_out),
                                      _stream_ptr(W)))
 

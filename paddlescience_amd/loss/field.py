@@ -60,6 +60,31 @@ class FieldLossPlan:
         return loss, gx
 
 
+class _FieldLossFn(torch.autograd.Function):
+    """The scalar loss as a differentiable function of the field `x` (value and adjoint by the kernels): what lets a loss
+    object be used inside arbitrary Python on the network output -- weighted sums of several losses, a non-identity output
+    expression, a FunctionalLoss -- when the operator engine differentiates that Python with torch (operator_engine.py)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, y, coef):
+        loss, gx = plan.value_and_grad(x.detach(), y.detach(), coef)
+        ctx.save_for_backward(gx)
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return None, g * gx, None, None
+
+
+def scalar_loss(plan: FieldLossPlan, x: torch.Tensor, y: torch.Tensor, coef: float) -> torch.Tensor:
+    """plan's loss of (x, y) as a fresh 0-d tensor (never a view of the plan's cached buffer: a caller may keep it across
+    batches); differentiable w.r.t. x when x requires a gradient."""
+    if x.requires_grad:
+        return _FieldLossFn.apply(plan, x, y, float(coef))
+    return plan.value(x, y, coef)[0].reshape(()).clone()
+
+
 def reduce_coef(shape: Sequence[int], reduce_dims: Optional[Sequence[int]], reductions: Sequence[str]) -> Optional[float]:
     """The reference reduces the [B, C] matrix of row terms over `reduce_dims` with sum / mean and squeezes the result;
     when that leaves ONE number, it is coef * (sum of all row terms): the coefficient, else None (not a scalar loss)."""

@@ -24,8 +24,9 @@ class _RowLoss:
     order = 0
 
     def __init__(self, d, L, reduce_dims, reductions, fix=(False, False)):
-        if d != 2:
-            raise NotImplementedError(f"{type(self).__name__}(d={d}): the field-loss kernels cover 2-D fields (the FNO path is 2-D)")
+        if d != 2:  # (the reference's constructor default is d = 1, metric.py:88: its examples pass d = 2)
+            raise NotImplementedError(f"{type(self).__name__}(d={d}): the field-loss kernels cover 2-D fields (the FNO path is 2-D); "
+                                      "pass d=2")
         self.d = d
         self.L = [float(L)] * d if isinstance(L, (int, float)) else [float(v) for v in L]
         self.reduce_dims = [reduce_dims] if isinstance(reduce_dims, int) else (None if reduce_dims is None else list(reduce_dims))
@@ -63,11 +64,11 @@ class _RowLoss:
     rel_mode, abs_mode = field.REL, field.ABS
 
     def rel(self, x, y, h=None):
-        return self._plan(self.rel_mode, self._spacing(x, h)).value(x, y, self._coef(x))[0].reshape(())
+        return field.scalar_loss(self._plan(self.rel_mode, self._spacing(x, h)), x, y, self._coef(x))
 
     def abs(self, x, y, h=None):
         sp = self._spacing(x, h)
-        return self._plan(self.abs_mode, sp, self._abs_const(sp)).value(x, y, self._coef(x))[0].reshape(())
+        return field.scalar_loss(self._plan(self.abs_mode, sp, self._abs_const(sp)), x, y, self._coef(x))
 
     def rel_and_grad(self, x, y, h=None, scale: float = 1.0):
         loss, gx = self._plan(self.rel_mode, self._spacing(x, h)).value_and_grad(x, y, self._coef(x) * scale)

@@ -139,7 +139,8 @@ class OperatorEngine:
         # An FNO step is ~200 kernels of ~10 us (FFTs, the spectral contraction, 1x1 convolutions, norms, their
         # backward): launch-bound from Python/autograd, so forward + loss + backward is captured once per batch shape
         # into a HIP graph and replayed (engine.StepGraph; PPSCI_HIP_GRAPH=0 or a failed capture -> eager).
-        key = tuple((id(c), c.version) for c in constraints)
+        # (the executor's generation: a captured step must not outlive the activation buffers it was captured on)
+        key = tuple((id(c), c.version) for c in constraints) + (self.native.generation,)
         self._step_graph.run(key, lambda: self._forward_backward_eager(constraints))
 
     def allreduce(self):

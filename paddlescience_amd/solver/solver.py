@@ -346,7 +346,7 @@ class Solver:
                         if iter_id % self.update_freq == 0 or iter_id == self.iters_per_epoch:
                             self.optimizer.step(self._acc_grad, gscale / self.update_freq)
                             self._acc_count = 0
-                    else:
+                    elif not self._adam_behind_allreduce(eng_csts, gscale):
                         self.optimizer.step(self._train_grad(), gscale)
                 self.optimizer.clear_grad()
                 if self.lr_scheduler is not None and not getattr(self.lr_scheduler, "by_epoch", False):
@@ -446,6 +446,21 @@ class Solver:
         opt.t += 1
         self.engine.step_one_launch(eng_csts, dict(m=opt.m, v=opt.v, lr=opt.get_lr(), beta1=opt.beta1, beta2=opt.beta2,
                                                    eps=opt.epsilon, grad_scale=gscale, t=opt.t))
+        return True
+
+    def _adam_behind_allreduce(self, eng_csts, gscale: float) -> bool:
+        """Data parallelism, fused tile kernel (one constraint of padded width 64, plain Adam): the optimizer step and the next
+        step's weight fragments in ONE launch behind the all-reduce (engine.apply_adam_fused) instead of the optimizer's own
+        kernel + a weight-split launch.  False: nothing was done."""
+        opt = self.optimizer
+        if (self.world_size == 1 or self._reparam or type(opt).__name__ != "_AdamState" or opt.grad_clip is not None or opt.l2 != 0.0
+                or opt.eq_store is not None or not hasattr(self.engine, "apply_adam_fused")
+                or opt.model.flat_params.data_ptr() != self.engine.params.data_ptr()):
+            return False
+        if not self.engine.apply_adam_fused(eng_csts, dict(m=opt.m, v=opt.v, lr=opt.get_lr(), beta1=opt.beta1, beta2=opt.beta2,
+                                                           eps=opt.epsilon, grad_scale=gscale, t=opt.t + 1)):
+            return False
+        opt.t += 1
         return True
 
     def _train_grad(self) -> torch.Tensor:

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_solver(outdir, world_batch, reduction, steps, pirate=False, ragged=False):
+def build_solver(outdir, world_batch, reduction, steps, pirate=False, ragged=False, width=16):
     import ppsci
     from oracle import taylor_np as T
     from tests.common import set_model_weights
@@ -25,8 +25,8 @@ def build_solver(outdir, world_batch, reduction, steps, pirate=False, ragged=Fal
                 if n_.endswith("alpha"):
                     v_.fill_(0.4)
     else:
-        model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
-        set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
+        model = ppsci.arch.MLP(("t", "x"), ("u",), 2, width, "tanh")
+        set_model_weights(model, T.make_net(2, [width, width], 1, seed=7, bias_scale=0.05))
     N = world_batch
     X = np.random.default_rng(3).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
     lab = np.random.default_rng(4).standard_normal((N, 1)).astype(np.float32) * 0.1
@@ -122,6 +122,8 @@ def main():
         return main_viv(outdir)
     if reduction == "periodic":
         return main_periodic(outdir)
+    if reduction == "iterable":
+        return main_iterable(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -132,7 +134,12 @@ def main():
         dist.init_process_group("gloo")
     pirate = reduction == "pirate"
     ragged = reduction.startswith("ragged_")
-    if ragged:
+    if reduction == "fused64":
+        # padded width 64: the fused tile kernel; under data parallelism its step is tile kernel + tail kernel -> all-reduce ->
+        # Adam + fragments in one launch (engine.Engine.train_step, ppsci_taylor_step_plan_apply); four steps, so that the
+        # fragments the apply kernel left behind are used (the weight split is skipped from the second step on)
+        solver, model = build_solver(outdir, 64, "mean", 4, width=64)
+    elif ragged:
         solver, model = build_solver(outdir, 67, reduction[len("ragged_"):], 2, ragged=True)
     else:
         solver, model = build_solver(outdir, 64, "mean" if pirate else reduction, 2, pirate=pirate)
@@ -142,6 +149,32 @@ def main():
     if not dist.is_initialized() or dist.get_rank() == 0:
         np.savez(os.path.join(outdir, f"result_w{world}.npz"), params=model.flat_params.numpy(), pred=pred["u"],
                  loss=np.asarray(solver.last_losses["loss"]))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_iterable(outdir):
+    """data/__init__.py:62-66 of the reference: an IterableDataset under world_size > 1 is refused -- in a REAL two-rank
+    process group."""
+    import ppsci.data as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+
+    class FakeDS:
+        is_iterable = True
+
+    msg = ""
+    try:
+        D.build_dataloader(FakeDS(), {})
+    except ValueError as e:
+        msg = str(e)
+    ok_ext = D.build_dataloader(FakeDS(), {"shard_in_engine": True}) is not None  # (this framework's SPINN extension)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    with open(os.path.join(outdir, f"iterable_w{world}_r{rank}.json"), "w") as f:
+        json.dump({"world": dist.get_world_size() if dist.is_initialized() else 1, "message": msg, "extension": ok_ext}, f)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -251,6 +251,19 @@ inline unsigned ppsci_cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: rou
   };
   return (rne(a) & 0xffffu) | (rne(b) << 16);
 }
+// v_dot2c_f32_bf16 with the constant operands (-1, 0) / (0, -1): x minus the low / high bf16 of h (exact in fp32)
+inline float ppsci_bf16_sub_lo(unsigned h, float x) {
+  const unsigned v = h << 16;
+  float f;
+  std::memcpy(&f, &v, 4);
+  return x - f;
+}
+inline float ppsci_bf16_sub_hi(unsigned h, float x) {
+  const unsigned v = h & 0xffff0000u;
+  float f;
+  std::memcpy(&f, &v, 4);
+  return x - f;
+}
 inline float emu_bf16_at(const unsigned* w, int j) {  // j-th bf16 of a packed array
   const unsigned v = (j & 1) ? (w[j >> 1] & 0xffff0000u) : (w[j >> 1] << 16);
   float f;

@@ -46,6 +46,14 @@ def test_bench_gpus8_as_the_driver_launches_it():
     assert s["points_per_rank"] * 8 == s["points_total"]
     assert s["allreduce_ms"] is not None and s["allreduce_ms"] > 0 and s["allreduce_bytes"] == 4 * 66819
     assert r["value"] > 0 and s["value"] > 0
+    # the strong-scaling numbers also sit in `config` (the part of the line every consumer keeps), next to the communicator
+    c = r["config"]
+    assert c["strong_points_per_s"] == s["value"] and c["strong_ms_per_step"] == s["ms_per_step"]
+    assert c["strong_points_per_rank"] * 8 == 1_000_000 or "EMULATOR" in r["data"]
+    assert c["strong_allreduce_ms"] == s["allreduce_ms"] and c["strong_allreduce_bytes"] == 4 * 66819
+    assert c["comm_world_size"] == 8 and c["comm_backend"] == "gloo"
+    # the primary step under data parallelism: the fused tile kernel stays, Adam + fragments in one launch behind the all-reduce
+    assert "all-reduce" in c["dp_step"] and "Adam + fragments" in c["dp_step"]
 
 
 def test_bench_refuses_a_launcher_world_that_differs_from_gpus():

@@ -97,8 +97,10 @@ def test_two_ranks_reproduce_single_rank_periodic_constraint_and_eval_gather(tmp
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5)
 
 
-def test_iterable_dataset_refuses_world_size_gt_1():
-    """data/__init__.py:62-66."""
+def test_iterable_dataset_refuses_world_size_gt_1(tmp_path):
+    """data/__init__.py:62-66: refused in a real two-rank process group (every rank), accepted on one rank."""
+    import json
+
     import ppsci.data as D
 
     class FakeDS:
@@ -108,6 +110,26 @@ def test_iterable_dataset_refuses_world_size_gt_1():
 
     assert not dist.is_initialized()
     assert D.build_dataloader(FakeDS(), {}) is not None
+    d = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29537", worker, d, "iterable"], check=True, env=env, cwd=ROOT, timeout=300,
+                   stdout=subprocess.DEVNULL)
+    for rank in (0, 1):
+        r = json.load(open(os.path.join(d, f"iterable_w2_r{rank}.json")))
+        assert r["world"] == 2 and r["message"] == "world_size(2) should be 1 when using IterableDataset." and r["extension"]
+
+
+def test_two_ranks_reproduce_single_rank_fused_tile_kernel(tmp_path):
+    """Padded width 64: under data parallelism the step keeps the fused tile kernel -- tile kernel + tail kernel (sums) ->
+    ONE all-reduce of the flat gradient -> Adam and the next step's weight fragments in one launch
+    (ppsci_taylor_step_plan_apply) -- and reproduces the single-rank run (whose Adam sits in the tail kernel)."""
+    d = str(tmp_path)
+    one = _run(d, 1, "fused64")
+    two = _run(d, 2, "fused64")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5, atol=1e-6)
 
 
 def test_batch_sampler_rank_strided_shards():

@@ -118,3 +118,65 @@ def test_solver_trains_fno_like_oracle_adam(dev, tmp_path):
     assert np.isfinite(metric) and "MSE.y" in group["V"]
     pred = solver.predict({"x": x}, batch_size=2, return_numpy=True)
     assert pred["y"].shape == (4, 1, 8, 8)
+
+
+def test_training_survives_evaluation_at_another_shape(dev, tmp_path):
+    """FNONet.forward (train, eval, predict) is ONE executor and the training step is a replayed HIP graph that holds the
+    executor's buffer addresses (the reference's TFNO config trains at 16 x 16 and evaluates at 32 x 32 with
+    eval_during_train; a ragged last eval batch changes the batch size): evaluating at another shape between training
+    steps must leave those buffers alone -- the parameters after train / eval-elsewhere / train are bit for bit those of
+    the same steps without the evaluation."""
+    import ppsci
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((4, 3, 8, 8)).astype(np.float32)
+    y = rng.standard_normal((4, 1, 8, 8)).astype(np.float32)
+    x_big = rng.standard_normal((3, 3, 16, 16)).astype(np.float32)   # another resolution AND another batch size
+
+    def run(evaluate_between):
+        model = _model("group_norm", seed=5)
+        cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": x}, "label": {"y": y}}, "batch_size": 4,
+               "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+        cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), name="Sup")
+        opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+        solver = ppsci.solver.Solver(model, {"Sup": cst}, str(tmp_path), opt, epochs=4, iters_per_epoch=1, log_freq=10)
+        solver.train()  # (the second step captures the graph, the later ones replay it)
+        if evaluate_between:
+            for _ in range(3):
+                out = model({"x": x_big})["y"]
+                assert out.shape == (3, 1, 16, 16) and torch.isfinite(out).all()
+                # (what the caching allocator would hand the freed training buffers to)
+                junk = [torch.full((4, 8, 64), float("nan"), device=model.flat_params.device) for _ in range(16)]
+                del junk
+            assert len(model.native()._sets) == 1 and model.native().shape == (3, 16, 16)
+        solver.epochs = 8
+        solver.train()
+        return model.flat_params.detach().cpu().numpy().copy()
+
+    a, b = run(False), run(True)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+def test_field_losses_combine_under_autograd(dev):
+    """LpLoss / H1Loss values are differentiable functions of the field (loss/field.py scalar_loss): a user function that
+    combines them (FunctionalLoss: l2 + h1, weights, a non-identity output expression) trains -- the operator engine
+    differentiates that Python w.r.t. the network output with torch."""
+    import ppsci
+    from paddlescience_amd.loss.lp_h1 import H1Loss, LpLoss
+
+    model = _model(None, seed=2)
+    d = model.flat_params.device
+    rng = np.random.default_rng(1)
+    xt = torch.as_tensor(rng.standard_normal((2, 1, 8, 8)).astype(np.float32)).to(d).requires_grad_(True)
+    yt = torch.as_tensor(rng.standard_normal((2, 1, 8, 8)).astype(np.float32)).to(d)
+    l2, h1 = LpLoss(d=2, p=2), H1Loss(d=2)
+    total = 0.7 * l2.rel(xt, yt) + 0.3 * h1.rel(xt, yt)
+    (g,) = torch.autograd.grad(total, xt)
+    _, g2 = l2.rel_and_grad(xt.detach(), yt, scale=0.7)
+    _, g1 = h1.rel_and_grad(xt.detach(), yt, scale=0.3)
+    assert rel(g.cpu().numpy(), (g2 + g1).cpu().numpy()) < 1e-6
+    # values handed out earlier are not overwritten by later calls on the same plan
+    v1 = l2.rel(xt.detach(), yt)
+    keep = float(v1)
+    l2.rel(2.0 * xt.detach(), yt)
+    assert float(v1) == keep

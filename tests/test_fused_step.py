@@ -18,11 +18,12 @@ from tests.test_one_launch import _constraint, _program, _weights
 dev = make_dev_fixture()
 
 
-def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints=4, fast_program=1):
+def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints=4, fast_program=1, static_program=1):
     lib = L.lib()
     lib.ppsci_set_max_grid(max_grid)
     lib.ppsci_set_step_tail(tail)
     lib.ppsci_set_fast_program(fast_program)
+    lib.ppsci_set_static_program(static_program)
     try:
         params = torch.tensor(flat, device=d)
         eng = Engine(lay, params)
@@ -47,14 +48,18 @@ def _run(d, lay, specs, flat, fused, steps, max_grid=0, tail=-1, max_constraints
         lib.ppsci_set_max_grid(0)
         lib.ppsci_set_step_tail(-1)
         lib.ppsci_set_fast_program(1)
+        lib.ppsci_set_static_program(1)
 
 
 CASES = [
     # (activation, hidden layers, width, constraints [(program, points)], max_grid,
-    #  tail: 0 tree / 1 two reduction kernels / 2 first tree level in the launch + one kernel)
+    #  tail: 0 tree / 1 two reduction kernels / 2 first tree level in the launch + one kernel / 3 one tail kernel)
     ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 0),                # BASELINE configs[1]'s net; a ragged last tile
     ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 1),
     ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 2),
+    ("tanh", 4, 64, [("allen_cahn", 1000)], 0, 3),                # ONE kernel behind the launch (+ the next step's fragments)
+    ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 3, 3),     # (two constraints: two plans, the second one's Adam)
+    ("silu", 2, 40, [("allen_cahn", 500)], 0, 3),
     ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 2),
     ("tanh", 3, 50, [("laplace", 900), ("value", 90)], 0, 2),     # (the second constraint accumulates, then Adam)
     ("tanh", 4, 64, [("allen_cahn", 2100)], 5, 0),                # several tiles per workgroup, a ragged last round
@@ -76,7 +81,7 @@ def test_fused_step_matches_separate_launches(dev, act, depth, width, specs, max
     flat = _weights(lay, 7)
     steps = 3
     if dev != "gpu":  # the emulator runs a few hundred points per second
-        if (max_grid, tail) in ((5, 1), (5, 2), (3, 1)) or (len(specs) == 2 and tail == 2):
+        if (max_grid, tail) in ((5, 1), (5, 2), (3, 1)) or (len(specs) == 2 and tail == 2) or (act == "silu" and tail == 3):
             pytest.skip("emulator: this kernel instance and tail mode are covered by the neighbouring cases; runs on the GPU")
         specs = [(k, max(40, n // 6 + 3)) for k, n in specs]
         steps = 2
@@ -105,8 +110,9 @@ def test_predecoded_program_equals_the_interpreter(dev, kind):
     lay = hp.NetLayout(2, 3, 64, 1, "tanh")
     flat = _weights(lay, 13)
     n = 90 if dev != "gpu" else 3000
-    a = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=1)
-    b = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=0)
+    # (compile-time tables off: they run in another instantiation of the kernel, tests/test_static_programs.py)
+    a = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=1, static_program=0)
+    b = _run(d, lay, [(kind, n)], flat, True, 2, fast_program=0, static_program=0)
     assert np.array_equal(a[0], b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
     assert all(np.array_equal(x[0], y[0]) for x, y in zip(a[2], b[2])) and np.array_equal(a[3][0], b[3][0])
     assert np.array_equal(a[5][0], b[5][0]) and np.abs(a[1][0]).max() > 0
@@ -118,11 +124,51 @@ def test_fused_step_is_deterministic(dev):
     lay = hp.NetLayout(2, 4, 64, 1, "tanh")
     flat = _weights(lay, 3)
     steps, n = (2, 200) if dev != "gpu" else (100, 20_000)
-    for tail in (0, 1, 2):
+    for tail in (0, 1, 2, 3):
         a = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
         b = _run(d, lay, [("allen_cahn", n)], flat, True, steps, tail=tail)
         assert np.array_equal(a[0], b[0]) and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
         assert np.isfinite(a[0]).all()
+
+
+def test_tail_kernel_fragments_follow_every_parameter_write(dev):
+    """Step tail 3: the kernel behind the tile kernel leaves the bf16 fragments of the UPDATED hidden matrices behind and the
+    next step skips the weight split -- unless something wrote the parameters in between (a torch operation, another
+    kernel of the package).  The results must be those of a run that splits the weights in front of every step."""
+    d = device.get_device()
+    lay = hp.NetLayout(2, 4, 64, 1, "tanh")
+    flat = _weights(lay, 11)
+    n = 150 if dev != "gpu" else 20_000
+
+    def run(force_split, meddle):
+        L.lib().ppsci_set_step_tail(3)
+        try:
+            params = torch.tensor(flat, device=d)
+            eng = Engine(lay, params)
+            c = _constraint(d, "allen_cahn", lay, n, 100)
+            kept = []
+            for step in range(5):
+                if force_split:
+                    hp.note_param_write()
+                if meddle and step == 2:
+                    params.mul_(1.001)  # a torch write: the version counter moves
+                if meddle and step == 3:    # a kernel write: the package's own Adam on the same buffer
+                    hp.adam_step(params, eng.grad, eng.m, eng.v, 1e-3, 7)
+                plan = getattr(c, "_step_plan", None)
+                kept.append(plan is not None and plan._frag_token == (hp._PARAM_WRITES[0], params._version))
+                eng.train_step([c], 1e-2)
+            return params.detach().cpu().numpy(), kept
+        finally:
+            L.lib().ppsci_set_step_tail(-1)
+
+    p_keep, kept = run(False, False)
+    p_split, never = run(True, False)
+    assert kept == [False, True, True, True, True] and not any(never)
+    assert np.array_equal(p_keep, p_split) and rel(p_keep, flat) > 1e-4
+    p_keep2, kept2 = run(False, True)
+    p_split2, _ = run(True, True)
+    assert kept2 == [False, True, False, False, True]
+    assert np.array_equal(p_keep2, p_split2) and not np.array_equal(p_keep2, p_keep)
 
 
 def test_fused_step_workspace_is_checked(dev):

@@ -4,8 +4,8 @@ The fused tile kernel evaluates a residual program that IS one of the generated 
 wave; any other program runs on the epilogue VM.  Checked here:
   * the committed header is what the generator produces from the package's own lowering (so the tables cannot drift from
     what `ppsci.equation.*` lowers to), and the generator's Python port of the pre-decoder equals the C one;
-  * static vs VM vs opcode interpreter: the same gradients, loss terms, residuals and dL/dU (bit for bit: same operations
-    in the same order);
+  * static vs VM vs opcode interpreter: the same gradients, loss terms, residuals and dL/dU (same operations in the same
+    order: bit for bit on the emulator; on the GPU up to the compiler's choice of which product of a sum it fuses);
   * the API path (Solver-style constraint on `ppsci.equation.AllenCahn`) lands on its table; a program that is in no table
     lands on the VM and still agrees with the separate launches.
 Reference: /root/reference/ppsci/equation/pde/allen_cahn.py:56-64, laplace.py:40-55, navier_stokes.py:96-160, loss/mse.py:82-105."""
@@ -89,12 +89,18 @@ def test_static_program_equals_the_vm_and_the_interpreter(dev, kind, table, act,
     b = _run(d, lay, kind, n, flat, 2, static=0)
     c = _run(d, lay, kind, n, flat, 2, static=0, fast=0)
     assert a["name"] == table and b["name"] == "" and c["name"] == ""
+    # the VM and the interpreter are one kernel binary: bit-identical.  The compile-time program is another instantiation of
+    # the kernel: the same operations in the same order, but hipcc is free to pick WHICH product of `w0 h0 + w1 h1` it fuses
+    # into the add (observed on MI355X: U differs in the last bit at a few points, everything else is bit-identical); the
+    # emulator build does not contract at all, so there the three agree bit for bit.
+    same = np.array_equal if dev != "gpu" else (lambda x, y: rel(x, y) < 5e-7)
+    assert np.array_equal(b["p"], c["p"]) and all(np.array_equal(x, y) for x, y in zip(b["g"], c["g"]))
     for o in (b, c):
-        assert np.array_equal(a["p"], o["p"])
+        assert same(a["p"], o["p"])
         for k in ("g", "l"):
-            assert all(np.array_equal(x, y) for x, y in zip(a[k], o[k])), k
+            assert all(same(x, y) for x, y in zip(a[k], o[k])), k
         for k in ("r", "U", "Ub"):
-            assert np.array_equal(a[k], o[k]), k
+            assert same(a[k], o[k]), k
     assert np.abs(a["g"][0]).max() > 0 and np.isfinite(a["p"]).all()
     # ... and the separate launches (pinned to the reference by the golden tests) up to the summation order
     a1 = _run(d, lay, kind, n, flat, 1, static=1)
@@ -141,4 +147,4 @@ def test_api_constraint_on_allen_cahn_lands_on_its_table(dev):
     g1, name1 = grads(1)
     g0, name0 = grads(0)
     assert name1 == "allen_cahn" and name0 == ""
-    assert np.array_equal(g1, g0) and np.abs(g1).max() > 0
+    assert (np.array_equal(g1, g0) if dev != "gpu" else rel(g1, g0) < 5e-7) and np.abs(g1).max() > 0
