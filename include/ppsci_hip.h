@@ -158,6 +158,10 @@ void ppsci_set_wide_min_nb(int nb);
  * net allows it (padded width <= 64, fragments and accumulators fit LDS); 0 forces the per-tile streaming path that
  * wider / deeper nets use, so that both are covered by the same tests. */
 void ppsci_set_bwd_accum(int on);
+/* padded width 129..256, <= 4 streams: 1 (default) the layer-by-layer XDL reverse kernel (csrc/taylor_bwd_lw.inc: one launch per
+ * hidden-to-hidden matrix, its gradient accumulated in registers, the adjoint handed on through the workspace); 0 the
+ * round-2 fp32-MFMA kernel that streams per-tile gradient blocks (A/B measurements, tests).  Read when a launch is planned. */
+void ppsci_set_bwd_layerwise(int on);
 /* 1 if this build runs on a GPU (gfx950), 0 for the CPU SIMT emulator used only by tests/. */
 int ppsci_is_device_build(void);
 /* Frees the pre-split weight-fragment buffers the library keeps per parameter buffer for the feature-split kernels
@@ -637,6 +641,21 @@ int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float* Fx, const 
 int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_desc* d);
 int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
                          const float* gadj, float* scratch, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream);
+
+/* ---- data-parallel collectives on RCCL (csrc/comm.hip): the fused gradient all-reduce of solver/train.py:168-171 and
+ * the evaluation gather of utils/misc.py, on the ONE flat gradient buffer -- so that a host without torch.distributed can
+ * drive data parallelism through this library: ppsci_taylor_step_run_ex (no Adam) -> ppsci_allreduce_sum on `grad` ->
+ * ppsci_taylor_step_plan_apply.  librccl is resolved lazily at ppsci_comm_init (the copy already loaded into the process is
+ * preferred: torch carries its own); one communicator per process = per GPU.  ppsci_comm_unique_id: 128 bytes, produced by
+ * rank 0 and shipped to the others by any host channel.  The Python host keeps torch.distributed (the same RCCL) by default
+ * and uses these with PPSCI_NATIVE_ALLREDUCE=1.  Exercised on one GPU with world = 1 (tests/test_comm.py); world > 1 has not
+ * run on hardware (1-GPU leases). */
+int ppsci_comm_unique_id(void* out128);
+int ppsci_comm_init(int rank, int world, const void* id128); /* collective; current HIP device = this rank's GPU */
+int ppsci_comm_world_size(void);                              /* 0 before ppsci_comm_init */
+int ppsci_allreduce_sum(float* buf, int64_t n, void* stream); /* in place, ordered on `stream` */
+int ppsci_allgather(const float* send, float* recv, int64_t n, void* stream); /* recv: [world][n] */
+int ppsci_comm_destroy(void);
 
 #ifdef __cplusplus
 }

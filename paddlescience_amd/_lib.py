@@ -113,6 +113,13 @@ _SYMBOLS = {
     "ppsci_set_max_grid": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),
     "ppsci_set_bwd_accum": (None, [C.c_int]),
+    "ppsci_set_bwd_layerwise": (None, [C.c_int]),
+    "ppsci_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ppsci_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "ppsci_comm_world_size": (C.c_int, []),
+    "ppsci_allreduce_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "ppsci_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "ppsci_comm_destroy": (C.c_int, []),
     "ppsci_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
     "ppsci_stash_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),
     "ppsci_bwd_partial_rows": (C.c_int64, [C.POINTER(MlpDesc), C.c_int64]),

@@ -208,6 +208,9 @@ extern "C" int ppsci_get_max_grid(void) { return g_max_grid; }
 static int g_wide_min_nb = 8;
 extern "C" void ppsci_set_wide_min_nb(int nb) { g_wide_min_nb = nb; }
 extern "C" int ppsci_get_wide_min_nb(void) { return g_wide_min_nb; }
+static int g_bwd_lw = 1;
+extern "C" void ppsci_set_bwd_layerwise(int on) { g_bwd_lw = on ? 1 : 0; }
+extern "C" int ppsci_get_bwd_layerwise(void) { return g_bwd_lw; }
 static int g_bwd_accum = 1;
 extern "C" void ppsci_set_bwd_accum(int on) { g_bwd_accum = on; }
 extern "C" int ppsci_get_bwd_accum(void) { return g_bwd_accum; }

@@ -157,6 +157,7 @@ __device__ __forceinline__ unsigned ppsci_readlane(unsigned v, int lane) {
 extern "C" int ppsci_get_max_grid(void);
 extern "C" int ppsci_get_wide_min_nb(void);
 extern "C" int ppsci_get_bwd_accum(void);
+extern "C" int ppsci_get_bwd_layerwise(void);
 
 #ifndef PPSCI_FWD_WAVES
 #define PPSCI_FWD_WAVES 8   // waves (16-point tiles in flight) per forward workgroup (8 measured 7% faster than 4)

@@ -243,6 +243,12 @@ extern "C" int64_t ppsci_bwd_partial_rows(const ppsci_mlp_desc* d, int64_t n_poi
 
 static long long bwd_per_tile_floats(const BwdArgs& a) { return (long long)(a.d.n_hidden - 1) * a.q.HP * a.q.HP; }
 
+// layer-by-layer kernel of padded width 256 (taylor_bwd_lw.inc): the adjoint handed from launch to launch, [ntiles][S][NB][64] float4
+static long long bwd_hbuf_floats(const BwdArgs& a) {
+  const int S = 1 + a.d.n1 + a.d.n2 + a.d.n3 + a.d.n4;
+  return a.lw ? (long long)a.ntiles * S * a.q.NB * 64 * 4 : 0;
+}
+
 // slots of per-tile (or, accumulating kernels, per-workgroup) hidden-weight gradient blocks in the workspace
 static long long bwd_wpart_slots(const BwdArgs& a, int grid) { return a.accum ? grid : (long long)a.ntiles + 1; }
 
@@ -260,8 +266,8 @@ extern "C" int64_t ppsci_bwd_workspace_bytes(const ppsci_mlp_desc* d, int64_t n_
   // hidden-weight blocks per tile (+ the spare slot) or per workgroup | chunk sums | per-workgroup small-parameter
   // rows | their chunk sums
   const long long fl = (slots + chunks) * bwd_per_tile_floats(a) +
-                       ((long long)grid + PPSCI_WRED_CHUNKS) * ppsci_small_params(a.d, a.q);
-  return fl * 4 + 16;
+                       ((long long)grid + PPSCI_WRED_CHUNKS) * ppsci_small_params(a.d, a.q) + bwd_hbuf_floats(a);
+  return fl * 4 + 16 + (a.lw ? 16 : 0);
 }
 
 extern "C" int ppsci_taylor_fwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
@@ -301,6 +307,10 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   float* tmp = wpart + slots * bwd_per_tile_floats(a);
   float* small_rows = tmp + chunks * bwd_per_tile_floats(a);
   float* small_tmp = small_rows + (long long)grid * psmall;  // [PPSCI_WRED_CHUNKS][psmall]
+  if (a.lw) {  // (16-byte aligned: float4 accesses)
+    float* hb = small_tmp + (long long)PPSCI_WRED_CHUNKS * psmall;
+    a.hbuf = (f32x4*)(((uintptr_t)hb + 15) & ~(uintptr_t)15);
+  }
   a.partials = small_rows;
   a.wpart = (f32x4*)workspace;
   int rc = run_bwd_act(a, stream, 1, &grid);

@@ -453,6 +453,10 @@ struct BwdArgs {
   int accum;     // 1: hidden-weight gradient blocks accumulated per WORKGROUP (wpart has one slot per workgroup)
   int xdl_split; // 1: planned onto the register-accumulating feature-split kernel (always one slot per workgroup)
   const void* xfrag;  // feature-split XDL kernels: pre-split hidden-weight fragments (ppsci_presplit)
+  // layer-by-layer kernel of padded width 256 (taylor_bwd_lw.inc): one launch per hidden-to-hidden matrix
+  int lw;        // 1: planned onto it (the workspace holds `hbuf`)
+  int layer;     // the matrix W_layer of this launch
+  f32x4* hbuf;   // [ntiles][S][NB][64]: hbar of the layer below, handed from launch to launch
 };
 
 // Parameters that are NOT hidden-to-hidden matrices, in the compact order the reverse kernels flush their LDS

@@ -295,6 +295,33 @@ def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
         cur.wait_stream(st)
 
 
+_NATIVE_COMM = None
+
+
+def native_comm_ready() -> bool:
+    """PPSCI_NATIVE_ALLREDUCE=1 on a multi-rank GPU job: create (once) the RCCL communicator of the C ABI (csrc/comm.hip) -- rank
+    0's 128-byte id travels over the existing torch.distributed group -- and use ppsci_allreduce_sum for the gradient all-reduce.
+    Default (unset / 0): torch.distributed.all_reduce, which is the same RCCL underneath."""
+    global _NATIVE_COMM
+    if _NATIVE_COMM is None:
+        dist = torch.distributed
+        if (os.environ.get("PPSCI_NATIVE_ALLREDUCE", "0") != "1" or not dist.is_initialized() or dist.get_world_size() < 2
+                or not torch.cuda.is_available() or L.is_emulated()):
+            _NATIVE_COMM = False
+        else:
+            import ctypes as C
+
+            lib = L.lib()
+            buf = C.create_string_buffer(128)
+            if dist.get_rank() == 0:
+                L.check(lib.ppsci_comm_unique_id(buf))
+            box = [buf.raw if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            L.check(lib.ppsci_comm_init(dist.get_rank(), dist.get_world_size(), C.c_char_p(box[0])))
+            _NATIVE_COMM = True
+    return _NATIVE_COMM
+
+
 def _release_fragments(ptr: int) -> None:
     try:
         L.lib().ppsci_release_fragments(ptr)
@@ -413,7 +440,10 @@ class Engine:
         # ONE collective per step: the flat fp32 gradient, SUM, in place, through torch.distributed (backend "nccl" is RCCL
         # over xGMI on ROCm; "gloo" in the CPU tests).  Matches fused_allreduce_gradients (/root/reference/ppsci/solver/train.py:168-171).
         if self.world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            if native_comm_ready():  # PPSCI_NATIVE_ALLREDUCE=1: the C ABI's RCCL communicator (csrc/comm.hip)
+                L.check(L.lib().ppsci_allreduce_sum(hp._p(self.grad), self.grad.numel(), hp._stream_ptr(self.grad)))
+            else:
+                torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
 
     def optimizer_step(self, lr: float) -> None:
         self.t += 1

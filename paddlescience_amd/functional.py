@@ -57,4 +57,24 @@ maximum = _binary("max", torch.maximum, np.maximum)
 minimum = _binary("min", torch.minimum, np.minimum)
 pow = _binary("pow", torch.pow, np.power)  # noqa: A001
 atan2 = _binary("atan2", torch.atan2, np.arctan2)
-__all__ = sorted(list(_TORCH) + ["maximum", "minimum", "pow", "atan2"])
+
+
+def where(cond, x, y):
+    """paddle.where(cond, x, y) per point.  Traced: `cond` is the 0 / 1 indicator a comparison of traced values yields
+    (graph.Sym._compare), and the result is  y + cond (x - y)  in the residual program -- both branches are evaluated at every
+    point (a branch that is not finite where it is NOT selected would poison the result: the reference's where does not have
+    that restriction), the adjoint reaches x with weight cond and y with 1 - cond, the condition itself has derivative zero."""
+    if isinstance(cond, Sym) or isinstance(x, Sym) or isinstance(y, Sym):
+        if isinstance(cond, (bool, np.bool_)):
+            return _lift(x) if cond else _lift(y)
+        if not isinstance(cond, Sym):
+            raise TypeError("where(): the condition is an array of values of ONE batch; a traced expression needs a traced condition "
+                            "(compare traced values: d['bc'] == 1)")
+        x, y = _lift(x), _lift(y)
+        return y + cond * (x - y)
+    if any(isinstance(v, torch.Tensor) for v in (cond, x, y)):
+        return torch.where(torch.as_tensor(cond, dtype=torch.bool), torch.as_tensor(x), torch.as_tensor(y))
+    return np.where(cond, x, y)
+
+
+__all__ = sorted(list(_TORCH) + ["maximum", "minimum", "pow", "atan2", "where"])

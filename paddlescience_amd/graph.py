@@ -138,6 +138,23 @@ class Sym:
         return float(self._scalar("item"))
 
     def _compare(self, o, f, what):
+        if _TRACE.values is None and isinstance(o, (Sym, int, float, np.floating, np.integer)):
+            # No fixed batch to look at: the comparison itself is traced, as the 0 / 1 valued per-point indicator the reference's
+            # bool tensor stands for in `paddle.where(cond, a, b)` (functional.where; examples/chip_heat/chip_heat.py:217-232) --
+            # built from the VM's heaviside (x > 0 ? 1 : 0) and abs, derivative zero.  bool() of it still raises (see _scalar).
+            d = self - _lift(o)
+            one = Sym.const(1.0)
+            if what == "gt":
+                return apply("heaviside", d)
+            if what == "lt":
+                return apply("heaviside", -d)
+            if what == "ge":
+                return one - apply("heaviside", -d)
+            if what == "le":
+                return one - apply("heaviside", d)
+            if what == "eq":
+                return one - apply("heaviside", apply("abs", d))
+            return apply("heaviside", apply("abs", d))  # ne
         if isinstance(o, Sym):
             o = concrete_values(o, what)
         elif not isinstance(o, (int, float, np.floating, np.integer)):
@@ -159,6 +176,10 @@ class Sym:
         return self._compare(o, np.equal, "eq")
 
     def __ne__(self, o):
+        if isinstance(o, Sym):
+            return self is not o
+        if _TRACE.values is None and isinstance(o, (int, float, np.floating, np.integer)):
+            return self._compare(o, np.not_equal, "ne")
         r = self.__eq__(o)
         return r if r is NotImplemented else (not r if isinstance(r, bool) else ~r)
 
@@ -484,16 +505,22 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         if len(vs) == 1:
             need(vs[0], k)
         elif k == 2:
-            a, b = n.dirs
+            a, b = sorted(n.dirs)  # (a + b and b + a are ONE direction: one key)
             mixed.add((a, b))
             need(a, 2), need(b, 2), need((a, b), 2)
         elif k == 4 and len(vs) == 2 and n.dirs.count(vs[0]) == 2:
             a, b = vs  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
             mixed4.add((a, b))
             need(a, 4), need(b, 4), need((a, b), 4), need((a, b, -1.0), 4)
+        elif k == 3 and len(vs) == 2:
+            # u_aab (a twice, b once) = (D3_{a+b} - D3_{a-b} - 2 D3_b) / 6: D3_{a+-b} = u_aaa +- 3 u_aab + 3 u_abb +- u_bbb
+            # (the shear forces of examples/biharmonic2d/biharmonic2d.py:325-336: d/dx (u_xx + u_yy))
+            a, b = (vs[0], vs[1]) if n.dirs.count(vs[0]) == 2 else (vs[1], vs[0])
+            lo, hi = sorted((a, b))  # (D3 along b - a is minus D3 along a - b: one stream serves u_aab and u_abb)
+            need(b, 3), need((lo, hi), 3), need((lo, hi, -1.0), 3)
         else:
             raise NotImplementedError(
-                f"mixed derivative {n!r}: beyond pure derivatives the fused HIP kernels carry u_ab and u_aabb")
+                f"mixed derivative {n!r}: beyond pure derivatives the fused HIP kernels carry u_ab, u_aab and u_aabb")
     in_keys: List[str] = []  # union of the members' inputs: the constraint's input arrays
     for mm in model_list:
         in_keys += [k for k in net_raw_vars(mm) if k not in in_keys]
@@ -612,12 +639,21 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 if len(vs) == 1:
                     val[id(n)] = prog.ld_u(c * S + base + dir_index[vs[0]])
                 elif len(n.dirs) == 2:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
-                    a, b = n.dirs
+                    a, b = sorted(n.dirs)
                     sab = prog.ld_u(c * S + base + dir_index[(a, b)])
                     sa = prog.ld_u(c * S + base + dir_index[a])
                     sb = prog.ld_u(c * S + base + dir_index[b])
                     t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, sab, sa), sb)
                     val[id(n)] = prog.op(L.OP_MUL, prog.const(0.5), t)
+                elif len(n.dirs) == 3:  # u_aab = (D3_{a+b} - D3_{a-b} - 2 D3_b) / 6
+                    a, b = (vs[0], vs[1]) if n.dirs.count(vs[0]) == 2 else (vs[1], vs[0])
+                    lo, hi = sorted((a, b))
+                    sp_ = prog.ld_u(c * S + base + dir_index[(lo, hi)])
+                    sm_ = prog.ld_u(c * S + base + dir_index[(lo, hi, -1.0)])  # D3 along lo - hi = +- D3 along a - b
+                    sb = prog.ld_u(c * S + base + dir_index[b])
+                    t = prog.op(L.OP_SUB if a == lo else L.OP_ADD, sp_, sm_)
+                    t = prog.op(L.OP_SUB, t, prog.op(L.OP_MUL, prog.const(2.0), sb))
+                    val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 6.0), t)
                 else:  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
                     a, b = vs
                     sp_ = prog.ld_u(c * S + base + dir_index[(a, b)])

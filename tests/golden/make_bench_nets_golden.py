@@ -32,6 +32,11 @@ CASES = {
                             points=lambda n: np.random.default_rng(42).uniform([0, -1], [1, 1], (n, 2)).astype(np.float32)),
     # BASELINE configs[2]: LDC NavierStokes 5x128, 1 M points uniform(-0.05, 0.05), nu = 0.01, rho = 1,
     # weights 1e-4, MSE-sum
+    # configs[1] at the shape of the reference's OWN yaml (examples/allen_cahn/conf/allen_cahn.yaml:38-42): 4 x 256 tanh with the
+    # period embedding x -> (cos(pi x), sin(pi x)) (periods: {x: [2.0, false]}, arch/mlp.py:95-114): the width-256 kernels
+    "allen_cahn_4x256_period": dict(eq="allen_cahn", inputs=("t", "x"), outputs=("u",), hidden=[256] * 4, reduction="mean",
+                                    periods={"x": [2.0, False]}, d_in=3,
+                                    points=lambda n: np.random.default_rng(42).uniform([0, -1], [1, 1], (n, 2)).astype(np.float32)),
     "ns2d_5x128": dict(eq="navier_stokes", inputs=("x", "y"), outputs=("u", "v", "p"), hidden=[128] * 5, reduction="sum",
                        weight=1e-4,
                        points=lambda n: np.random.default_rng(42).uniform(-0.05, 0.05, (n, 2)).astype(np.float32)),
@@ -62,8 +67,8 @@ def main():
     clear = mods["ad"].clear
     out = {}
     for name, c in CASES.items():
-        model = MLP(c["inputs"], c["outputs"], None, tuple(c["hidden"]), "tanh")
-        flat = bench_weights(len(c["inputs"]), c["hidden"], len(c["outputs"]))
+        model = MLP(c["inputs"], c["outputs"], None, tuple(c["hidden"]), "tanh", periods=c.get("periods"))
+        flat = bench_weights(c.get("d_in", len(c["inputs"])), c["hidden"], len(c["outputs"]))
         lin = [p for p in model.parameters() if p.dim() > 0]
         off = 0
         with torch.no_grad():

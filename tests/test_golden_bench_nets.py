@@ -1,5 +1,6 @@
 """Parity of the EXACT networks bench.py times (BASELINE configs[0..2]: Laplace2D 3x20, Allen-Cahn 4x64 without
-periods, LDC NavierStokes 5x128) on the first 2 048 points of their bench batches, against
+periods, LDC NavierStokes 5x128; and Allen-Cahn at the reference yaml's own shape, 4x256 with the period embedding of x:
+examples/allen_cahn/conf/allen_cahn.yaml:38-42) on the first 2 048 points of their bench batches, against
 tests/golden/bench_nets.npz -- produced by executing the REFERENCE's own hot-path code in float64 under the
 torch-backed paddle shim (tests/golden/make_bench_nets_golden.py).
 
@@ -28,7 +29,7 @@ def _keys(name):
 
 
 def _flat(name, c):
-    flat = bench_weights(len(c["inputs"]), c["hidden"], len(c["outputs"]))
+    flat = bench_weights(c.get("d_in", len(c["inputs"])), c["hidden"], len(c["outputs"]))
     cs = GOLD[f"{name}/param_checksum"]
     assert float(flat.astype(np.float64).sum()) == cs[0] and float(np.abs(flat.astype(np.float64)).sum()) == cs[1]
     return flat
@@ -43,7 +44,9 @@ def _equation(c):
 def test_oracle_reproduces_reference_run_on_bench_nets(name):
     c = CASES[name]
     flat = _flat(name, c).astype(np.float64)
-    net = T.make_net(len(c["inputs"]), c["hidden"], len(c["outputs"]))
+    # (periods: {key: [period, trainable]} of the reference -> the oracle's {input index: omega = 2 pi / period in fp32})
+    per = {c["inputs"].index(k): float(np.float32(2 * np.pi / float(p))) for k, (p, _) in (c.get("periods") or {}).items()}
+    net = T.make_net(len(c["inputs"]), c["hidden"], len(c["outputs"]), periods=per)
     off = 0
     for i in range(len(net.weights)):
         n = net.weights[i].size
@@ -77,7 +80,7 @@ def test_hip_path_matches_reference_run_on_bench_nets(name, dev, tmp_path):
     keys = _keys(name)
     n = GOLD[f"{name}/X"].shape[0] if dev == "gpu" else 48
     X = GOLD[f"{name}/X"][:n]
-    model = ppsci.arch.MLP(c["inputs"], c["outputs"], len(c["hidden"]), c["hidden"][0], "tanh")
+    model = ppsci.arch.MLP(c["inputs"], c["outputs"], len(c["hidden"]), c["hidden"][0], "tanh", periods=c.get("periods"))
     model.flat_params.copy_(torch.tensor(_flat(name, c)).to(model.flat_params.device))
     eq = _equation(c)
     inp = {k: X[:, j:j + 1] for j, k in enumerate(c["inputs"])}

@@ -283,6 +283,53 @@ def test_bwd_wide_nets(hidden, dout, dirs, n2, N, knob):
             off += n
 
 
+@pytest.mark.parametrize("hidden,dout,dirs,n2,act,N", [
+    ([256, 256, 256, 256], 1, [[0, 1], [1, 0]], 1, "tanh", 70),   # the reference allen_cahn.yaml's width, S = 4: three launches
+    ([200, 200], 2, [[0, 1], [1, 0]], 1, "silu", 37),               # one hidden matrix: the single launch is top AND bottom
+    ([256, 256, 256], 1, [[1, 0]], 1, "sin", 21),                   # S = 3: the odd stream's K = 16 step
+])
+def test_bwd_layerwise_width_256(hidden, dout, dirs, n2, act, N):
+    """Padded width 256: the layer-by-layer XDL reverse kernel (csrc/taylor_bwd_lw.inc: one launch per hidden matrix, the adjoint
+    handed on through the workspace) against the fp64 oracle and against the round-2 fp32-MFMA kernel it replaces; several
+    tiles per workgroup (max_grid 2)."""
+    from paddlescience_amd import _lib
+    from paddlescience_amd import hotpath as hp
+
+    dirs = np.asarray(dirs, dtype=np.float64).reshape(-1, 2)
+    net = T.make_net(2, hidden, dout, activation=act, bias_scale=0.1)
+    rng = np.random.default_rng(29)
+    X = rng.uniform(-1, 1, (N, 2)).astype(np.float32).astype(np.float64)
+    S = 1 + dirs.shape[0] + n2
+    Ubar = rng.standard_normal((dout, S, N)).astype(np.float32).astype(np.float64)
+    lib = _lib.lib()
+    lib.ppsci_set_max_grid(2)
+    try:
+        desc = _run_fwd(net, X, dirs, n2, stash=True)[0]
+        lib.ppsci_set_bwd_layerwise(1)
+        ws_lw = hp.bwd_workspace_bytes(desc, N)
+        got = _run_bwd(net, X, dirs, n2, Ubar)
+        lib.ppsci_set_bwd_layerwise(0)
+        ws_old = hp.bwd_workspace_bytes(desc, N)
+        old = _run_bwd(net, X, dirs, n2, Ubar)
+    finally:
+        lib.ppsci_set_bwd_layerwise(1)
+        lib.ppsci_set_max_grid(0)
+    assert ws_lw != ws_old  # (the two kernels lay their workspace out differently: really two code paths)
+    net32 = net.astype(np.float32).astype(np.float64)
+    _, cache = T.taylor_forward(net32, X, dirs, n2, keep=True)
+    gW, gb = T.taylor_backward(net32, cache, Ubar)
+    ref = T.flat_grads(gW, gb)
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) < 1e-5 and _rel(old, ref) < 1e-5, (_rel(got, ref), _rel(old, ref))
+    off = 0
+    for w, b in zip(gW, gb):
+        for t in (w, b):
+            n = t.size
+            if np.linalg.norm(t) > 0:
+                assert _rel(got[off:off + n], t.ravel()) < 3e-5
+            off += n
+
+
 def test_resident_multi_block_multi_iteration():
     from paddlescience_amd import _lib
 
