@@ -75,12 +75,40 @@ class FnoNative:
         self._sets = {}
         self.max_sets = 8
         self.generation = 0
+        # A TFNO step is ~57 kernels of 5-17 us, most of them a dependent chain -- but not all: a block's skip convolution does
+        # not depend on its spectral branch (forward), and no weight gradient is needed before the end of the backward pass.
+        # PPSCI_FNO_SIDE_STREAM=1 puts those launches onto a second HIP stream, forked from and joined back into the launch stream
+        # (inside the engine's captured graph: parallel branches).  Measured on MI355X (round 5, batch 16, 64 x 64): 0.766 ms
+        # per step against 0.677 ms in one stream -- the ~15 extra fork / join edges of the replayed graph cost more than the
+        # overlapped 5-12 us kernels give back -- so it is OFF by default (kept as a tested knob).
+        self.use_side = os.environ.get("PPSCI_FNO_SIDE_STREAM", "0") == "1" and model.flat_params.is_cuda
+        self._side = None
+
+    # ------------------------------------------------------------------ second stream
+    def _fork(self):
+        """Context manager: launches inside go to the side stream, ordered behind everything issued so far on the launch stream."""
+        import contextlib
+
+        if not self.use_side:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def _join(self) -> None:
+        """The launch stream waits for the side stream's work."""
+        if self.use_side and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     # ------------------------------------------------------------------ buffers
     def _switch(self, B: int, H: int, W: int) -> None:
+        keep = ("m", "shape", "_sets", "max_sets", "generation", "use_side", "_side")
+        return self._switch_(B, H, W, keep)
+
+    def _switch_(self, B: int, H: int, W: int, keep) -> None:
         """Make the buffer set of input shape (B, H, W) the current one (allocating it on first use); the previous set stays
         alive under its own key."""
-        keep = ("m", "shape", "_sets", "max_sets", "generation")
         if self.shape is not None:
             self._sets[self.shape] = {k: v for k, v in self.__dict__.items() if k not in keep}
         for k in [k for k in self.__dict__ if k not in keep]:
@@ -151,7 +179,9 @@ class FnoNative:
         cmax = max(Ch, self.c_lift, self.c_proj)
         self.ga = torch.empty((B, cmax, P), **f)
         self.gb = torch.empty((B, cmax, P), **f)
-        self.gt = torch.empty((B, Ch, P), **f)
+        # (one per block: the weight gradients that read them run on the side stream, next to the following blocks' tails)
+        self.gts = [torch.empty((B, Ch, P), **f) for _ in range(nl)]
+        self.gz2 = torch.empty((B, self.c_proj, P0), **f)
         self.gv = torch.empty((B, Ch, P), **f)
         self._wbufs: List[torch.Tensor] = []  # per-chunk partials of the weight gradients, one buffer per _wgrad call of a pass
         self._wcall, self._wsegs = 0, []
@@ -194,7 +224,8 @@ class FnoNative:
             conv = fb.convs[l]
             skip = fb.fno_skips[l]
             if isinstance(skip, fno_arch.Conv1x1):
-                _pw_conv(B, Ch, Ch, P, xl, skip.weight, self.s)
+                with self._fork():  # next to the spectral branch; the tail below joins
+                    _pw_conv(B, Ch, Ch, P, xl, skip.weight, self.s)
                 sk = self.s
             else:
                 sk = xl
@@ -217,6 +248,7 @@ class FnoNative:
                                                               Ch, _p(self.rows), st))
                 else:
                     L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
+                self._join()
                 L.check(L.lib().ppsci_fno_tail_fwd_ex(
                     B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
                     _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
@@ -229,6 +261,7 @@ class FnoNative:
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
                                                                  _p(conv.weight_imag), _p(self.out_ft), self.inv_n, 1, st))
                 L.check(L.lib().ppsci_fft2d_c2r(B * Ch, H, W, _p(self.out_ft), _p(v), st))
+            self._join()
             L.check(L.lib().ppsci_fno_tail_fwd(
                 B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
                 _p(conv.bias), _p(nrm.weight) if nrm is not None else None, _p(nrm.bias) if nrm is not None else None,
@@ -254,6 +287,12 @@ class FnoNative:
         return self._wbufs[i]
 
     def _wgrad(self, B, ci, co, P, x, gy, w_param, b_param, xv=None) -> None:
+        """Weight (+ bias) gradient of a 1x1 convolution: on the side stream -- its operands are complete on the launch stream
+        at this point and are not rewritten before backward() joins (per-block `gts`, an own `gz2`) -- next to the chain."""
+        with self._fork():
+            self._wgrad_(B, ci, co, P, x, gy, w_param, b_param, xv)
+
+    def _wgrad_(self, B, ci, co, P, x, gy, w_param, b_param, xv=None) -> None:
         chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P))  # (P differs between the padded blocks and lifting / projection)
         wg = w_param.grad.view(-1)
         if b_param is not None and b_param.grad.data_ptr() == wg.data_ptr() + 4 * co * ci:
@@ -296,13 +335,13 @@ class FnoNative:
         self._wcall, self._wsegs = 0, []
         # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
         self._wgrad(B, self.c_proj, m.out_channels, P0, self.z2, gy, proj[1].weight, proj[1].bias, xv=self.gelu_on_load)
-        gz2 = self.ga.view(-1)[:B * self.c_proj * P0].view(B, self.c_proj, P0)
+        gz2 = self.gz2
         _pw_conv(B, m.out_channels, self.c_proj, P0, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
         self._wgrad(B, Ch, self.c_proj, P0, self.xo, gz2, proj[0].weight, proj[0].bias)
         gx = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)  # dL/d(block output), ping-pongs with `gnext`
         gnext = self.ga.view(-1)[:B * Ch * P].view(B, Ch, P)
         if self.padded:  # the gradient of unpad is pad: zeros outside the window
-            gxu = self.xou  # (free: the forward value was consumed by the weight gradient above)
+            gxu = self.x0u  # (free during the backward pass; NOT xou: the weight gradient above still reads it on the side stream)
             _pw_conv(B, self.c_proj, Ch, P0, gz2, proj[0].weight, gxu, transpose=True)
             self._pad(gxu, self.gpad, False)
             gx = self.gpad
@@ -313,27 +352,28 @@ class FnoNative:
         gx2_modes = None  # ... or its kept modes: the consumer evaluates the inverse transform itself (fuse_dft)
         for l in range(nl - 1, -1, -1):
             conv, skip = fb.convs[l], fb.fno_skips[l]
+            gt = self.gts[l]
             nrm = fb.norm[l] if fb.norm is not None else None
             last = l == nl - 1
             if self.kept:  # dL/dv only feeds the spectral branch: its kept modes come out of the tail's second pass, gv is not stored
                 L.check(L.lib().ppsci_fno_tail_bwd_ex(
                     B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
                     _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows),
-                    _p(self.stats[l]), _p(self.gt), None, _p(nrm.weight.grad) if nrm is not None else None,
+                    _p(self.stats[l]), _p(gt), None, _p(nrm.weight.grad) if nrm is not None else None,
                     _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), H, W, self.desc.modes_x,
                     self.desc.modes_y, _p(self.ghat), _p(gx2_modes), st))
             else:
                 L.check(L.lib().ppsci_fno_tail_bwd(
                     B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, _p(self.v[l]), _p(conv.bias),
                     _p(nrm.weight) if nrm is not None else None, _p(self.t[l]), _p(gx), _p(gx2), _p(self.rows),
-                    _p(self.stats[l]), _p(self.gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
+                    _p(self.stats[l]), _p(gt), _p(self.gv), _p(nrm.weight.grad) if nrm is not None else None,
                     _p(nrm.bias.grad) if nrm is not None else None, _p(conv.bias.grad), st))
             # skip branch: s = Wskip x_l  (identity: the gradient passes straight through)
             if isinstance(skip, fno_arch.Conv1x1):
-                self._wgrad(B, Ch, Ch, P, self.x[l], self.gt, skip.weight, None)
-                _pw_conv(B, Ch, Ch, P, self.gt, skip.weight, gnext, transpose=True)
+                self._wgrad(B, Ch, Ch, P, self.x[l], gt, skip.weight, None)
+                _pw_conv(B, Ch, Ch, P, gt, skip.weight, gnext, transpose=True)
             else:
-                hp.reduce_rows(self.gt.view(1, -1), 1, B * Ch * P, gnext.view(-1), False)
+                hp.reduce_rows(gt.view(1, -1), 1, B * Ch * P, gnext.view(-1), False)
             # spectral branch: dL/dx_l += irfftn( rfftn(gv) . conj(w)^T ), weight gradients from x_ft and rfftn(gv)
             if self.kept:  # (the adjoint reads dL/dy's spectrum at the OUTPUT rows and writes the input rows)
                 mx, my = self.desc.modes_x, self.desc.modes_y
@@ -378,4 +418,5 @@ class FnoNative:
             self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
         else:
             self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)
+        self._join()  # every weight gradient's partial rows are complete
         self._flush_wgrads()
