@@ -21,8 +21,9 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 BARE = re.compile(r"\b(v_pk_mul_f32|v_pk_add_f32)\b.*\bop_sel:\[(0,1|1,0)\]\s*(//|$)")
 
 
-def scan(lib: str):
-    """[(kernel, instruction)] of the flagged instructions in every gfx950 code object bundled in `lib`."""
+def scan(lib: str, only: str = ""):
+    """[(kernel, instruction)] of the flagged instructions in every gfx950 code object bundled in `lib` (with `only`: in the
+    code objects that define a symbol containing that string -- the others are not disassembled)."""
     hits = []
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, "lib.so")
@@ -32,6 +33,10 @@ def scan(lib: str):
         if not objs:
             raise RuntimeError(f"{lib}: no gfx950 code object found")
         for f in objs:
+            if only:
+                syms = subprocess.run([OBJDUMP, "-t", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout
+                if only not in syms:
+                    continue
             out = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout
             kernel = "?"
             for line in out.splitlines():
