@@ -16,6 +16,7 @@ computes numerically (ad.py:73-75).
 from __future__ import annotations
 
 import contextlib
+import zlib
 import math
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -122,7 +123,7 @@ class Sym:
         v = concrete_values(self, what)
         if v.size != 1:
             raise TypeError(f"{what} of a traced expression with {v.size} values: only one-element values convert to Python scalars")
-        _TRACE.concretized.append(f"{what}({self!r})")
+        _TRACE.concretized.append(f"{what}({self!r}) = {float(v.reshape(-1)[0])!r}")
         return v.reshape(-1)[0]
 
     def __bool__(self):
@@ -160,7 +161,10 @@ class Sym:
         elif not isinstance(o, (int, float, np.floating, np.integer)):
             return NotImplemented
         v = f(concrete_values(self, what), np.float32(o))
-        _TRACE.concretized.append(f"{what}({self!r})")
+        # (the ANSWER is part of the record: ranks of a data-parallel job see different shards and must not silently compile
+        # different programs, solver.Solver._check_trace_decisions)
+        ans = repr(bool(v.reshape(-1)[0])) if v.size == 1 else f"{int(v.sum())} of {v.size} true, crc {zlib.crc32(np.packbits(v).tobytes()):08x}"
+        _TRACE.concretized.append(f"{what}({self!r}) = {ans}")
         return v if v.size != 1 else bool(v.reshape(-1)[0])
 
     def __lt__(self, o): return self._compare(o, np.less, "lt")

@@ -256,6 +256,7 @@ class Solver:
             raise NotImplementedError(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e})") from e
         if cc.specialised_to:
             logger.info(f"constraint {name}: traced for the values of its (fixed) batch: {', '.join(cc.specialised_to)}")
+        self._check_trace_decisions(name, cc)
         if first is not None:
             inp, lab, w = first
             cc.bind(inp, lab, self._shard_weights(name, cst, lab, w))
@@ -429,6 +430,31 @@ class Solver:
     def _materialize(self) -> None:
         if self._reparam:
             self.model.materialize()
+
+    def _check_trace_decisions(self, name: str, cc) -> None:
+        """Python control flow on the values of a fixed batch is followed at trace time (graph.batch_values).  Under data
+        parallelism every rank traces on ITS shard: the ranks must end up with the SAME program (residual program, loss terms,
+        derivative streams), otherwise they would train different programs against one all-reduced gradient without anybody
+        noticing (the reference evaluates the user's function on each rank's tensors every step, utils/expression.py:96-102, so
+        there a rank-dependent branch is at least visible in the loss).  A collective: every rank calls it for every
+        constraint, in the same order."""
+        import zlib
+
+        dist = torch.distributed
+        if self.world_size <= 1 or not dist.is_available() or not dist.is_initialized():
+            return
+        mine = (zlib.crc32(bytes(cc.fused.edesc)), repr(cc.fused.streams), list(cc.specialised_to))
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        if any(e[:2] != everyone[0][:2] for e in everyone):
+            odd = next(r for r, e in enumerate(everyone) if e[:2] != everyone[0][:2])
+            msg = (f"constraint {name}: the expressions branch on values of the batch and ranks 0 and {odd} took different "
+                   f"branches (rank 0 asked {everyone[0][2]}; rank {odd} asked {everyone[odd][2]}): their programs differ")
+            if os.environ.get("PPSCI_RANK_SPECIFIC_TRACES", "0") == "1":
+                logger.warning(msg + " -- accepted (PPSCI_RANK_SPECIFIC_TRACES=1): every rank trains its own program")
+            else:
+                raise RuntimeError(msg + "; make the condition independent of the shard, or set PPSCI_RANK_SPECIFIC_TRACES=1 "
+                                         "to train rank-specific programs")
 
     def _step_in_one_launch(self, eng_csts, gscale: float) -> bool:
         """The whole iteration (train.py:82-184) as one launch per constraint, the optimizer step inside the last one,

@@ -124,6 +124,8 @@ def main():
         return main_periodic(outdir)
     if reduction == "iterable":
         return main_iterable(outdir)
+    if reduction == "branch":
+        return main_branch(outdir)
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -175,6 +177,42 @@ def main_iterable(outdir):
     rank = dist.get_rank() if dist.is_initialized() else 0
     with open(os.path.join(outdir, f"iterable_w{world}_r{rank}.json"), "w") as f:
         json.dump({"world": dist.get_world_size() if dist.is_initialized() else 1, "message": msg, "extension": ok_ext}, f)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_branch(outdir):
+    """Python control flow on the values of a fixed batch, under two ranks whose shards give DIFFERENT answers: refused on every
+    rank (solver.Solver._check_trace_decisions); a condition every shard answers alike is accepted."""
+    import ppsci
+    from paddlescience_amd import device
+    from tests.emu import build_emu
+
+    build_emu.inject()
+    device.set_device("cpu")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    N = 32
+    X = np.random.default_rng(3).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    X[0, 1], X[1, 1] = 0.5, -0.5  # row 0 goes to rank 0, row 1 to rank 1 (rank-strided shards)
+    out = {}
+    for tag, cond in (("shard_dependent", lambda d: float(d["x"][0]) > 0.0), ("shard_independent", lambda d: float(d["t"][0]) >= 0.0)):
+        model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
+        cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"t": X[:, :1], "x": X[:, 1:]}, "label": {"v": np.zeros((N, 1), np.float32)}},
+               "batch_size": N // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+        cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"),
+                                                    {"v": lambda d, cond=cond: d["u"] * (2.0 if cond(d) else 1.0)}, name="EQ")
+        opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+        try:
+            ppsci.solver.Solver(model, {"EQ": cst}, os.path.join(outdir, tag), opt, epochs=1, iters_per_epoch=1).train()
+            out[tag] = "trained"
+        except RuntimeError as e:
+            out[tag] = str(e)
+    with open(os.path.join(outdir, f"branch_w{world}_r{rank}.json"), "w") as f:
+        json.dump(out, f)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -729,7 +729,7 @@ def test_eager_fallback_for_expressions_the_tracer_cannot_lower(tmp_path):
                          name="BC")
     solver = _solver(tmp_path, model, {"EQ": pde, "BC": bc})
     cc = solver._compiled["BC"]
-    assert cc.specialised_to == ["float(x[0:1])", "lt(x[1:2])"] and not solver._compiled["EQ"].specialised_to
+    assert cc.specialised_to == ["float(x[0:1]) = 0.0", "lt(x[1:2]) = True"] and not solver._compiled["EQ"].specialised_to
     assert cc._row_slices == {"u0": 0, "u__x": 1, "u__x__x": 2, "u__x__x__x": 3}
     p0 = model.flat_params.clone()
     solver.train()  # one Adam step

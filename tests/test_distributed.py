@@ -121,6 +121,23 @@ def test_iterable_dataset_refuses_world_size_gt_1(tmp_path):
         assert r["world"] == 2 and r["message"] == "world_size(2) should be 1 when using IterableDataset." and r["extension"]
 
 
+def test_ranks_must_agree_on_trace_time_branches(tmp_path):
+    """graph.batch_values follows Python control flow on the values of a fixed batch; two ranks whose shards answer differently
+    are refused on both ranks with the two answers in the message, a shard-independent condition trains."""
+    import json
+
+    d = str(tmp_path)
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29541", worker, d, "branch"], check=True, env=env, cwd=ROOT, timeout=600, stdout=subprocess.DEVNULL)
+    for rank in (0, 1):
+        r = json.load(open(os.path.join(d, f"branch_w2_r{rank}.json")))
+        assert r["shard_independent"] == "trained"
+        assert "ranks 0 and 1 took different branches" in r["shard_dependent"] and "float(x[0:1]) = 0.5" in r["shard_dependent"] \
+            and "float(x[0:1]) = -0.5" in r["shard_dependent"]
+
+
 def test_two_ranks_reproduce_single_rank_fused_tile_kernel(tmp_path):
     """Padded width 64: under data parallelism the step keeps the fused tile kernel -- tile kernel + tail kernel (sums) ->
     ONE all-reduce of the flat gradient -> Adam and the next step's weight fragments in one launch
