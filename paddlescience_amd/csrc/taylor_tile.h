@@ -169,6 +169,31 @@ __device__ __forceinline__ void ppsci_act_from_stash(float v, float& s, float& d
   }
 }
 
+// sigma(z) and the first three derivatives for the four features a lane holds, from what the stash holds.  tanh nets: plain
+// float4 arithmetic, so that the packed fp32 instructions the compiler selects pair feature r with r + 1 of ONE quantity.
+// The per-feature scalar form let the SLP vectoriser pair two DIFFERENT quantities of one feature -- (second, third derivative)
+// x a splat of the first -- as  v_pk_mul_f32 d, a, b op_sel:[0,1]  (low result = a.lo * b.HI): on MI355X, with two workgroups
+// on a CU, the low result of that one instruction came out as a.lo * 0 in lanes 48..63 in about 1 of 500 workgroups
+// (run-to-run differences of 1e-3 in one feature of the top layer's zbar; tools/det_probe7.py).
+// tests/test_isa_lint.py keeps that instruction form out of the library.
+template <int ACT>
+__device__ __forceinline__ void ppsci_act_from_stash4(const f32x4 v, f32x4& s, f32x4& d1, f32x4& d2, f32x4& d3) {
+  if constexpr (ACT == PPSCI_ACT_TANH) {
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, two = {2.f, 2.f, 2.f, 2.f}, six = {6.f, 6.f, 6.f, 6.f};
+    s = v;
+    d1 = one - s * s;
+    d2 = -two * s * d1;
+    d3 = d1 * (six * s * s - two);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sv, a, b, c;
+      ppsci_act_from_stash<ACT>(v[r], sv, a, b, c);
+      s[r] = sv, d1[r] = a, d2[r] = b, d3[r] = c;
+    }
+  }
+}
+
 // Derivatives 1..5 of the activation for the third / fourth-order Taylor streams (Faa di Bruno needs sigma^(4) in the
 // forward sweep and sigma^(5) in the reverse one).  `v` is what the stash holds: tanh(z) for tanh nets when
 // FROM_STASH, z otherwise.  tanh: polynomials in s; sigmoid family: polynomials in g1 = g(1-g); gelu: Hermite-type
