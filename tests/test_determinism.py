@@ -150,3 +150,61 @@ def test_tfno_step(tmp_path):
         eng.forward_backward([cst])
         g.append(model.flat_grad.detach().cpu().numpy().tobytes())
     assert len(set(g)) == 1, f"{len(set(g))} different gradients in {RUNS} calls"
+
+
+def test_piratenet_layer_by_layer(tmp_path):
+    """PirateNet 3 x 256 (period + Fourier embedding, random weight factorisation, gates): the layer-by-layer path's GEMM,
+    activation and weight-gradient kernels, 8 192 points."""
+    import sympy as sp
+
+    import paddlescience_amd as ppsci
+    from paddlescience_amd import device
+
+    device.set_device(None)
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device")
+    np.random.seed(3)
+    model = ppsci.arch.PirateNet(("t", "x"), ("u",), 3, 256, "tanh", periods={"x": (2.0, False)},
+                                 fourier={"dim": 256, "scale": 2.0}, random_weight={"mean": 1.0, "std": 0.1})
+    n = 8192
+    X = np.random.default_rng(1).uniform([0, -1], [1, 1], (n, 2)).astype(np.float32)
+    t, x = sp.symbols("t x")
+    u = sp.Function("u")(t, x)
+    eqs = {"allen_cahn": u.diff(t) - 0.0001 * u.diff(x, 2) + 5 * u**3 - 5 * u}
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": {"t": X[:, :1], "x": X[:, 1:]},
+                       "label": {"allen_cahn": np.zeros((n, 1), np.float32)}}}
+    c = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), eqs, name="EQ")
+    solver = ppsci.solver.Solver(model, {"EQ": c}, str(tmp_path), ppsci.optimizer.Adam(1e-3)(model), epochs=1, iters_per_epoch=1)
+    g = _gradients(solver, solver._compiled["EQ"], 8)
+    assert np.abs(np.frombuffer(g[0], np.float32)).max() > 0 and len(set(g)) == 1, f"{len(set(g))} different gradients"
+
+
+def test_spinn_helmholtz(tmp_path):
+    """BASELINE configs[4]: SPINN 128^3, three ModifiedMLP branches (csrc/spinn.hip)."""
+    import paddlescience_amd as ppsci
+    from paddlescience_amd import device
+
+    device.set_device(None)
+    if not torch.cuda.is_available():
+        pytest.skip("needs the device")
+    nc = 128
+    np.random.seed(111)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), 32, 4, 64, "tanh")
+    eq = ppsci.equation.Helmholtz(3, 1.0)
+    eq.model = model
+    rng = np.random.default_rng(42)
+    xs = [rng.uniform(-1, 1, (nc, 1)).astype(np.float32) for _ in range(3)]
+    uc = rng.standard_normal((nc, nc, nc, 1)).astype(np.float32)
+    data = {"x": xs[0], "y": xs[1], "z": xs[2], "uc": uc}
+    lab = {"helmholtz": uc}
+    pde = ppsci.constraint.SupervisedConstraint(
+        {"dataset": {"name": "ContinuousNamedArrayDataset", "input": lambda: data, "label": lambda d: lab}},
+        output_expr=eq.equations, loss=ppsci.loss.MSELoss("mean"), name="PDE")
+    solver = ppsci.solver.Solver(model, {"PDE": pde}, str(tmp_path), ppsci.optimizer.Adam(1e-3)(model), epochs=1, iters_per_epoch=1)
+    cc = solver._compiled["PDE"]
+    cc.bind(data, lab)
+    g = []
+    for _ in range(8):
+        solver.engine.forward_backward([cc])
+        g.append(solver.engine.grad.detach().cpu().numpy().tobytes())
+    assert np.abs(np.frombuffer(g[0], np.float32)).max() > 0 and len(set(g)) == 1, f"{len(set(g))} different gradients"
