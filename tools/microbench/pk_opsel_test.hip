@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(256, 2) probe_loads(const float* __restrict__ 
   if (FORM == 1) e0 = a0 * b0, e1 = a1 * b0;
   if (FORM == 2) e0 = __builtin_fmaf(a0, b1, 1.0f), e1 = __builtin_fmaf(a1, b1, 1.0f);
   if (FORM == 3) e0 = a1 * b0, e1 = a1 * b1;
+  if (FORM == 4 || FORM == 5) e0 = a0 * b1, e1 = a1 * b1;
   unsigned nbad = 0, idx = (blockIdx.x * 2654435761u + tid * 40503u) & mask;
   float sink = 0.f;
   for (int r = 0; r < rounds; ++r) {
@@ -115,6 +116,31 @@ __global__ void __launch_bounds__(256, 2) probe_loads(const float* __restrict__ 
       if (FORM == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o) : "v"(A), "v"(B));
       if (FORM == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0]" : "=v"(o) : "v"(A), "v"(B));
       if (FORM == 3) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(o) : "v"(A), "v"(B));
+      if (FORM == 4 || FORM == 5) {
+        // the kernel's pair: X is src0 of the first multiply and the DESTINATION of the second (write after read, back to back)
+        u64 X = A, d1;
+        float y0, y1;
+        if (FORM == 4)
+          asm volatile("v_mul_f32 %2, -2.0, %5\n\t"
+                       "v_fma_f32 %3, %5, %6, -2.0\n\t"
+                       "v_pk_mul_f32 %1, %0, %4 op_sel_hi:[1,0]\n\t"
+                       "v_pk_mul_f32 %0, %[Y], %4 op_sel:[0,1]"
+                       : "+v"(X), "=&v"(d1), "=&v"(y0), "=&v"(y1)
+                       : "v"(B), "v"(a1), "v"(b0), [Y] "v"(A));
+        else
+          asm volatile("v_mul_f32 %2, -2.0, %5\n\t"
+                       "v_fma_f32 %3, %5, %6, -2.0\n\t"
+                       "v_pk_mul_f32 %1, %0, %4 op_sel_hi:[1,0]\n\t"
+                       "s_nop 4\n\t"
+                       "v_pk_mul_f32 %0, %[Y], %4 op_sel:[0,1]"
+                       : "+v"(X), "=&v"(d1), "=&v"(y0), "=&v"(y1)
+                       : "v"(B), "v"(a1), "v"(b0), [Y] "v"(A));
+        o = X;
+        if (__builtin_bit_cast(unsigned, lo32(d1)) != __builtin_bit_cast(unsigned, a0 * b0) ||
+            __builtin_bit_cast(unsigned, hi32(d1)) != __builtin_bit_cast(unsigned, a1 * b0))
+          ++nbad;
+        sink += y0 + y1;
+      }
       if (__builtin_bit_cast(unsigned, lo32(o)) != __builtin_bit_cast(unsigned, e0) ||
           __builtin_bit_cast(unsigned, hi32(o)) != __builtin_bit_cast(unsigned, e1))
         ++nbad;
@@ -181,5 +207,7 @@ int main() {
   run_loads<1>("loads in flight: v_pk_mul op_sel_hi:[1,0]", din, dfar, mask, dbad);
   run_loads<2>("loads in flight: v_pk_fma op_sel:[0,1,0]", din, dfar, mask, dbad);
   run_loads<3>("loads in flight: v_pk_mul op_sel:[1,0]", din, dfar, mask, dbad);
+  run_loads<4>("pair: 2nd pk_mul writes the 1st's src0", din, dfar, mask, dbad);
+  run_loads<5>("the same with s_nop 4 between them", din, dfar, mask, dbad);
   return 0;
 }
