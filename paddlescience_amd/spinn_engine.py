@@ -110,7 +110,9 @@ class SpinnConstraint:
         total_global = gshape[0] * gshape[1] * gshape[2]
         self.desc.scale = float(self.scale_fn(total_global)) * rep
 
-    def forward(self, train: bool):
+    def forward(self, train: bool, reduce_loss: bool = True):
+        """reduce_loss=False: the per-workgroup loss rows stay in `lpart`; the caller sums them (SpinnEngine: together with the
+        gradient rows, one launch)."""
         m, lib = self.model, L.lib()
         vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
         L.check(lib.ppsci_modmlp_fwd_batch(C.byref(m.spec.desc), 3, vp([m.branch(b) for b in range(3)]),
@@ -118,7 +120,8 @@ class SpinnConstraint:
                                            vp(self.stash) if train else None, _stream_ptr(self.x[0])))
         L.check(lib.ppsci_spinn_grid_fwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.label), None,
                                          _p(self.gadj) if train else None, _p(self.lpart), _stream_ptr(self.label)))
-        hp.reduce_rows(self.lpart, self.lrows, 1, self.loss_term, False)
+        if reduce_loss:
+            hp.reduce_rows(self.lpart, self.lrows, 1, self.loss_term, False)
 
     def backward(self):
         m, lib = self.model, L.lib()
@@ -149,17 +152,32 @@ class SpinnEngine:
         P = self.model.branch_params
         if self.multi_stream and len(constraints) > 1 and self.grad.is_cuda:
             # the PDE grid and the six boundary faces are independent until their gradients are summed
-            run_on_streams(self._streams, [(lambda c=c: (c.forward(True), c.backward())) for c in constraints])
+            run_on_streams(self._streams, [(lambda c=c: (c.forward(True, False), c.backward())) for c in constraints])
         else:
             for c in constraints:
-                c.forward(True)
+                c.forward(True, False)
                 c.backward()
-        for i, c in enumerate(constraints):
+        # ONE launch (ppsci_reduce_rows_multi) sums every constraint's loss rows and the FIRST constraint's gradient rows -- segments
+        # with different destinations; the other constraints' gradient rows are added behind it, one launch each, in order (they
+        # share a destination).  Helmholtz3D's single PDE constraint: two launches (this one + Adam) instead of three.
+        segs = [(c.lpart, c.loss_term, c.lrows, 1) for c in constraints]
+        c0 = constraints[0]
+        if c0.gjoint:
+            segs.append((c0.gpart_all, self.grad[:3 * P], c0.gpart_all.shape[0], 3 * P))
+        else:
+            segs += [(c0.gpart[b], self.grad[b * P:(b + 1) * P], c0.gpart[b].shape[0], P) for b in range(3)]
+        for i0 in range(0, len(segs), 16):
+            batch = segs[i0:i0 + 16]
+            arr = (L.ReduceSeg * len(batch))()
+            for k, (src, dst, rows, cols) in enumerate(batch):
+                arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src.data_ptr(), dst.data_ptr(), rows, cols, 0
+            L.check(L.lib().ppsci_reduce_rows_multi(len(batch), arr, _stream_ptr(self.grad)))
+        for c in constraints[1:]:
             if c.gjoint:
-                hp.reduce_rows(c.gpart_all, c.gpart_all.shape[0], 3 * P, self.grad[:3 * P], i > 0)
+                hp.reduce_rows(c.gpart_all, c.gpart_all.shape[0], 3 * P, self.grad[:3 * P], True)
                 continue
             for b in range(3):
-                hp.reduce_rows(c.gpart[b], c.gpart[b].shape[0], P, self.grad[b * P:(b + 1) * P], i > 0)
+                hp.reduce_rows(c.gpart[b], c.gpart[b].shape[0], P, self.grad[b * P:(b + 1) * P], True)
 
     def forward_backward(self, constraints: Sequence[SpinnConstraint]):
         # A step is ~12 launches per constraint of a few microseconds each (seven constraints in the reference's
