@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-RUNS = 12
+RUNS = int(__import__("os").environ.get("PPSCI_DET_RUNS", "12"))
 
 
 def _pinn(tmp, inputs, outputs, hidden, act, eq, n, reduction="mean", weight=None, periods=None, seed=0):
