@@ -179,9 +179,16 @@ class FnoNative:
         cmax = max(Ch, self.c_lift, self.c_proj)
         self.ga = torch.empty((B, cmax, P), **f)
         self.gb = torch.empty((B, cmax, P), **f)
-        # (one per block: the weight gradients that read them run on the side stream, next to the following blocks' tails)
-        self.gts = [torch.empty((B, Ch, P), **f) for _ in range(nl)]
-        self.gz2 = torch.empty((B, self.c_proj, P0), **f)
+        if self.use_side or os.environ.get("PPSCI_FNO_OWN_BUFFERS", "0") == "1":  # (the second knob: A/B of the working set alone)
+            # one per block: the weight gradients that read them run on the side stream, next to the following blocks' tails
+            self.gts = [torch.empty((B, Ch, P), **f) for _ in range(nl)]
+            self.gz2 = torch.empty((B, self.c_proj, P0), **f)
+        else:
+            # one stream: every reader of a block's gradient has been enqueued before the next block overwrites it -- ONE buffer
+            # for all blocks, and the projection's hidden gradient in `ga` (the working set stays where round 4 had it)
+            gt = torch.empty((B, Ch, P), **f)
+            self.gts = [gt] * nl
+            self.gz2 = self.ga.view(-1)[:B * self.c_proj * P0].view(B, self.c_proj, P0)
         self.gv = torch.empty((B, Ch, P), **f)
         self._wbufs: List[torch.Tensor] = []  # per-chunk partials of the weight gradients, one buffer per _wgrad call of a pass
         self._wcall, self._wsegs = 0, []
