@@ -1307,6 +1307,148 @@ static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float
 
 
 // ------------------------------------------------------------------------------------------ DomainPadding
+// ------------------------------------------------------------------------------------------ lifting MLP, first layer, backward
+// The lifting MLP of FNONet (/root/reference/ppsci/arch/fno_block.py MLP(in -> lifting_channels -> hidden), tfnonet.py:95-110):
+//   a1 = GELU(z1),  z1 = W0 x0 + b0  (K0 <= 4 input channels, C1 = 256 lifting channels),   x_lift = W1 a1 + b1.
+// Its first layer's weight gradient needs  gz1[c][p] = GELU'(z1[c][p]) * sum_k W1[k][c] gx[k][p]  -- a [B, 256, P] tensor,
+// 8 x a block tensor (67 MB at batch 16, 64 x 64), which up to round 5 one launch wrote (ppsci_pw_conv_v, transpose, virtual
+// GELU') and the next read back (ppsci_pw_conv_wgrad_v): 37 + 30 us of a 0.65 ms TFNO step.  This kernel forms gz1 in
+// registers and reduces it against the K0 input channels at once:
+//   part[chunk][c * K0 + i] = sum_{p in chunk} gz1[c][p] x0[i][p],     part_b[chunk][c] = sum_{p in chunk} gz1[c][p]
+// with the chunks (256 pixels of one sample) and the row layout of ppsci_pw_conv_wgrad, so the same fixed-order row
+// reduction finishes it.  One workgroup of 16 waves per chunk and 256 channels; the gradient tile gx[:, chunk] is staged in LDS.
+#define LIFT0_CHMAX 64
+struct Lift0Args {
+  const float *x0, *W0, *b0, *W1, *gx;
+  float *part, *part_b;
+  long long ldp, ldpb;
+  int B, K0, C1, Ch, P, cpix, chunks_per_b;
+};
+__global__ void __launch_bounds__(1024) lift0_wgrad_kernel(Lift0Args a) {
+  // wave w of the 16: channels [16 w, 16 w + 16) of this workgroup's 256; the hidden gradient's first factor
+  //   G[c][p] = sum_k W1[k][c] gx[k][p]   as 16 x 16 tiles on the fp32 MFMA (K = 4 per instruction: A[i = c16][k = g] = W1[4 s + g][c],
+  //   B[k = g][n = c16] = gx[4 s + g][p]; D: lane (g, c16) holds channels 4 g + r of pixel c16),
+  // then per element GELU'(z1), the products with the K0 inputs, sums over the chunk's pixels per lane and, at the end, over the 16
+  // lanes of a group (fixed butterfly).  (A first version did the contraction on the VALU with one thread per channel and the tile
+  // read as LDS broadcasts: 58 us, LDS- and VALU-bound; the launches it replaces took 37 + 30 us.)
+  PPSCI_DYN_SMEM(smem);
+  const int LD = a.cpix + 16;                     // row stride of the k-major tile: groups g and g + 1 fall on the other 16 banks
+  float* gxs = smem;                              // [Ch][LD]
+  float* xs = gxs + a.Ch * LD;                    // [4][cpix]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
+  const int ncb = (a.C1 + 255) / 256;            // (channel blocks of 256; grid = chunks x ncb)
+  const int chunk = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - chunk * ncb;
+  const int b = chunk / a.chunks_per_b, p0 = (chunk - b * a.chunks_per_b) * a.cpix;
+  const int cp = a.P - p0 < a.cpix ? a.P - p0 : a.cpix;
+  const int cbase = cb * 256 + wave * 16;
+  const int ca = cbase + c16;                     // the channel whose W1 column this lane feeds into A
+  float af[LIFT0_CHMAX / 4];
+#pragma unroll
+  for (int s = 0; s < LIFT0_CHMAX / 4; ++s) af[s] = (ca < a.C1 && 4 * s + g < a.Ch) ? a.W1[(long long)(4 * s + g) * a.C1 + ca] : 0.f;
+  float w0[4][4], b0v[4];                         // of the four channels this lane holds in D
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = cbase + 4 * g + r;
+    b0v[r] = (c < a.C1 && a.b0 != nullptr) ? a.b0[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w0[r][i] = (c < a.C1 && i < a.K0) ? a.W0[(long long)c * a.K0 + i] : 0.f;
+  }
+  for (int idx = tid; idx < a.Ch * cp; idx += 1024) {
+    const int k = idx / cp, p = idx - k * cp;
+    gxs[k * LD + p] = a.gx[((long long)b * a.Ch + k) * a.P + p0 + p];
+  }
+  for (int idx = tid; idx < 4 * cp; idx += 1024) {
+    const int i = idx / cp, p = idx - i * cp;
+    xs[i * a.cpix + p] = i < a.K0 ? a.x0[((long long)b * a.K0 + i) * a.P + p0 + p] : 0.f;
+  }
+  __syncthreads();
+  float ab[4] = {0.f, 0.f, 0.f, 0.f}, aw[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aw[r][i] = 0.f;
+  const int nsteps = a.Ch / 4;
+  for (int pt = 0; pt * 16 < cp; ++pt) {
+    const int px = pt * 16 + c16;
+    const bool valid = px < cp;
+    const int pxs = valid ? px : 0;
+    f32x4 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < LIFT0_CHMAX / 4; ++s)
+      if (s < nsteps) {
+        const float bv = valid ? gxs[(4 * s + g) * LD + pxs] : 0.f;
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv, D, 0, 0, 0);
+      }
+    float xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = valid ? xs[i * a.cpix + pxs] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = b0v[r] + w0[r][0] * xv[0] + w0[r][1] * xv[1] + w0[r][2] * xv[2] + w0[r][3] * xv[3];
+      const float gz = valid ? D[r] * fno_gelu_grad(z) : 0.f;
+      ab[r] += gz;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aw[r][i] += gz * xv[i];
+    }
+  }
+  // sums over the 16 pixel lanes of each group (every lane of the group ends with the total)
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ab[r] += __shfl_xor(ab[r], m, 64);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aw[r][i] += __shfl_xor(aw[r][i], m, 64);
+    }
+  }
+  if (c16 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cbase + 4 * g + r;
+      if (c < a.C1) {
+        for (int i = 0; i < a.K0; ++i) a.part[(long long)chunk * a.ldp + (long long)c * a.K0 + i] = aw[r][i];
+        if (a.part_b != nullptr) a.part_b[(long long)chunk * a.ldpb + c] = ab[r];
+      }
+    }
+  }
+}
+
+extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0,
+                                     const float* W1, const float* gx, float* partials, float* partials_b, int64_t ld_partials,
+                                     void* stream) {
+  if (B < 1 || K0 < 1 || C1 < 1 || Ch < 1 || P < 1 || !x0 || !W0 || !W1 || !gx || !partials) {
+    ppsci_set_error("fno_lift0_wgrad: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  if (K0 > 4 || Ch > LIFT0_CHMAX || (Ch & 3) != 0) {
+    ppsci_set_error("fno_lift0_wgrad: built for <= 4 input channels and a hidden width that is a multiple of 4, <= %d (K0 = %d, Ch = %d)",
+                    LIFT0_CHMAX, K0, Ch);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  if (ld_partials != 0 && ld_partials < (int64_t)C1 * K0) {
+    ppsci_set_error("fno_lift0_wgrad: ld_partials smaller than a row");
+    return PPSCI_E_INVALID;
+  }
+  Lift0Args a;
+  a.x0 = x0, a.W0 = W0, a.b0 = b0, a.W1 = W1, a.gx = gx, a.part = partials, a.part_b = partials_b;
+  a.ldp = ld_partials ? ld_partials : (long long)C1 * K0;
+  a.ldpb = ld_partials ? ld_partials : C1;
+  a.B = B, a.K0 = K0, a.C1 = C1, a.Ch = Ch, a.P = P;
+  a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
+  a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
+  const int lds = (Ch * (a.cpix + 16) + 4 * a.cpix) * 4;
+  if (PPSCI_SET_MAX_LDS(lift0_wgrad_kernel, lds) != 0) {
+    ppsci_set_error("fno_lift0_wgrad: cannot raise dynamic LDS to %d B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  PPSCI_LAUNCH(lift0_wgrad_kernel, Lift0Args, B * a.chunks_per_b * ((C1 + 255) / 256), 1024, lds, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("fno_lift0_wgrad: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
 // fno_block.DomainPadding (/root/reference/ppsci/arch/fno_block.py:19-140): zero rows / columns around every [H, W] plane
 // between the lifting layer and the FNO blocks, removed again in front of the projection.  unpad == 0: dst [n, hp, wp] =
 // src [n, h, w] placed at (oh, ow), zero elsewhere; unpad == 1: dst [n, h, w] = src [n, hp, wp] window at (oh, ow).

@@ -318,6 +318,27 @@ class FnoNative:
         if b_param is not None:
             self._wsegs.append((part_b.data_ptr(), b_param.grad.view(-1).data_ptr(), chunks, co))
 
+    def _lift0_fused(self, B, Ch, P0, gx, lift) -> bool:
+        """Lifting MLP backward with the hidden tensor virtual: the second layer's weight gradient as before, the first layer's by
+        ppsci_fno_lift0_wgrad -- GELU'(W0 x + b0) * (W1^T gx) is formed in registers and reduced against the input channels at
+        once (was: 67 MB written by one launch and read back by the next at batch 16, 64 x 64).  False: shape outside the kernel's
+        envelope or PPSCI_FNO_LIFT0_FUSED=0 -- the caller takes the two-launch path."""
+        m = self.m
+        K0, C1 = m.in_channels, self.c_lift
+        w0, b0 = lift[0].weight, lift[0].bias
+        if (os.environ.get("PPSCI_FNO_LIFT0_FUSED", "1") == "0" or K0 > 4 or Ch > 64 or Ch % 4 != 0 or b0 is None
+                or b0.grad.data_ptr() != w0.grad.view(-1).data_ptr() + 4 * C1 * K0):
+            return False
+        self._wgrad(B, C1, Ch, P0, None, gx, lift[1].weight, lift[1].bias, xv=self.a1_virtual)
+        with self._fork():
+            chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0))
+            ld = C1 * K0 + C1
+            part = self._partials(chunks * ld)
+            L.check(L.lib().ppsci_fno_lift0_wgrad(B, K0, C1, Ch, P0, _p(self.x_in), _p(w0), _p(b0), _p(lift[1].weight), _p(gx),
+                                                  _p(part), C.c_void_p(part.data_ptr() + 4 * C1 * K0), ld, _stream_ptr(gx)))
+            self._wsegs.append((part.data_ptr(), w0.grad.view(-1).data_ptr(), chunks, ld))
+        return True
+
     def _flush_wgrads(self) -> None:
         """ONE launch sums the per-chunk partials of every weight gradient of the pass (ppsci_reduce_rows_multi; up to 16
         segments per launch): eight reductions of ~5 us each were launch latency, not work."""
@@ -416,13 +437,16 @@ class FnoNative:
         if self.c_lift:
             gz1 = self.gb if gx.data_ptr() != self.gb.data_ptr() else self.ga
             gz1 = gz1.view(-1)[:B * self.c_lift * P0].view(B, self.c_lift, P0)
-            if self.lift_virtual:
+            if self.lift_virtual and self._lift0_fused(B, Ch, P0, gx, lift):
+                pass  # (both weight gradients done: the first layer's without its hidden gradient in memory)
+            elif self.lift_virtual:
                 self._wgrad(B, self.c_lift, Ch, P0, None, gx, lift[1].weight, lift[1].bias, xv=self.a1_virtual)
                 _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, transpose=True, zv=self.a1_virtual)
+                self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
             else:
                 self._wgrad(B, self.c_lift, Ch, P0, self.a1, gx, lift[1].weight, lift[1].bias)
                 _pw_conv(B, Ch, self.c_lift, P0, gx, lift[1].weight, gz1, zmul=self.z1, transpose=True)
-            self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
+                self._wgrad(B, m.in_channels, self.c_lift, P0, self.x_in, gz1, lift[0].weight, lift[0].bias)
         else:
             self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)
         self._join()  # every weight gradient's partial rows are complete
