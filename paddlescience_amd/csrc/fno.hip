@@ -1318,13 +1318,16 @@ static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float
 // with the chunks (256 pixels of one sample) and the row layout of ppsci_pw_conv_wgrad, so the same fixed-order row
 // reduction finishes it.  One workgroup of 16 waves per chunk and 256 channels; the gradient tile gx[:, chunk] is staged in LDS.
 #define LIFT0_CHMAX 64
+#define LIFT0_WAVES 16  // waves (blocks of 16 channels) per workgroup (8 -- two workgroups per CU -- measured slower: 34.0 against 31.6 us;
+                        // the kernel is bound by the GELU' arithmetic, ~40 VALU instructions per element, as the launch it replaces was)
 struct Lift0Args {
   const float *x0, *W0, *b0, *W1, *gx;
   float *part, *part_b;
   long long ldp, ldpb;
   int B, K0, C1, Ch, P, cpix, chunks_per_b;
 };
-__global__ void __launch_bounds__(1024) lift0_wgrad_kernel(Lift0Args a) {
+template <int NS>  // K = 4 steps of the contraction: hidden width <= 4 NS
+__global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args a) {
   // wave w of the 16: channels [16 w, 16 w + 16) of this workgroup's 256; the hidden gradient's first factor
   //   G[c][p] = sum_k W1[k][c] gx[k][p]   as 16 x 16 tiles on the fp32 MFMA (K = 4 per instruction: A[i = c16][k = g] = W1[4 s + g][c],
   //   B[k = g][n = c16] = gx[4 s + g][p]; D: lane (g, c16) holds channels 4 g + r of pixel c16),
@@ -1333,18 +1336,19 @@ __global__ void __launch_bounds__(1024) lift0_wgrad_kernel(Lift0Args a) {
   // read as LDS broadcasts: 58 us, LDS- and VALU-bound; the launches it replaces took 37 + 30 us.)
   PPSCI_DYN_SMEM(smem);
   const int LD = a.cpix + 16;                     // row stride of the k-major tile: groups g and g + 1 fall on the other 16 banks
-  float* gxs = smem;                              // [Ch][LD]
-  float* xs = gxs + a.Ch * LD;                    // [4][cpix]
+  float* gxs = smem;                              // [4 NS][LD], rows >= Ch zero
+  float* xs = gxs + 4 * NS * LD;                  // [4][cpix]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
-  const int ncb = (a.C1 + 255) / 256;            // (channel blocks of 256; grid = chunks x ncb)
+  constexpr int CB = 16 * LIFT0_WAVES;          // channels per workgroup (grid = chunks x channel blocks)
+  const int ncb = (a.C1 + CB - 1) / CB;
   const int chunk = (int)blockIdx.x / ncb, cb = (int)blockIdx.x - chunk * ncb;
   const int b = chunk / a.chunks_per_b, p0 = (chunk - b * a.chunks_per_b) * a.cpix;
   const int cp = a.P - p0 < a.cpix ? a.P - p0 : a.cpix;
-  const int cbase = cb * 256 + wave * 16;
+  const int cbase = cb * CB + wave * 16;
   const int ca = cbase + c16;                     // the channel whose W1 column this lane feeds into A
-  float af[LIFT0_CHMAX / 4];
+  float af[NS];
 #pragma unroll
-  for (int s = 0; s < LIFT0_CHMAX / 4; ++s) af[s] = (ca < a.C1 && 4 * s + g < a.Ch) ? a.W1[(long long)(4 * s + g) * a.C1 + ca] : 0.f;
+  for (int s = 0; s < NS; ++s) af[s] = (ca < a.C1 && 4 * s + g < a.Ch) ? a.W1[(long long)(4 * s + g) * a.C1 + ca] : 0.f;
   float w0[4][4], b0v[4];                         // of the four channels this lane holds in D
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1353,13 +1357,13 @@ __global__ void __launch_bounds__(1024) lift0_wgrad_kernel(Lift0Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[r][i] = (c < a.C1 && i < a.K0) ? a.W0[(long long)c * a.K0 + i] : 0.f;
   }
-  for (int idx = tid; idx < a.Ch * cp; idx += 1024) {
-    const int k = idx / cp, p = idx - k * cp;
-    gxs[k * LD + p] = a.gx[((long long)b * a.Ch + k) * a.P + p0 + p];
+  for (int idx = tid; idx < 4 * NS * a.cpix; idx += 64 * LIFT0_WAVES) {  // (cpix is a power of two or the whole plane: see the launcher)
+    const int k = idx / a.cpix, p = idx - k * a.cpix;
+    gxs[k * LD + p] = (k < a.Ch && p < cp) ? a.gx[((long long)b * a.Ch + k) * a.P + p0 + p] : 0.f;
   }
-  for (int idx = tid; idx < 4 * cp; idx += 1024) {
-    const int i = idx / cp, p = idx - i * cp;
-    xs[i * a.cpix + p] = i < a.K0 ? a.x0[((long long)b * a.K0 + i) * a.P + p0 + p] : 0.f;
+  for (int idx = tid; idx < 4 * a.cpix; idx += 64 * LIFT0_WAVES) {
+    const int i = idx / a.cpix, p = idx - i * a.cpix;
+    xs[i * a.cpix + p] = (i < a.K0 && p < cp) ? a.x0[((long long)b * a.K0 + i) * a.P + p0 + p] : 0.f;
   }
   __syncthreads();
   float ab[4] = {0.f, 0.f, 0.f, 0.f}, aw[4][4];
@@ -1367,41 +1371,63 @@ __global__ void __launch_bounds__(1024) lift0_wgrad_kernel(Lift0Args a) {
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aw[r][i] = 0.f;
-  const int nsteps = a.Ch / 4;
-  for (int pt = 0; pt * 16 < cp; ++pt) {
-    const int px = pt * 16 + c16;
-    const bool valid = px < cp;
-    const int pxs = valid ? px : 0;
-    f32x4 D = {0.f, 0.f, 0.f, 0.f};
+  // Two pixel tiles per iteration: their B operands are requested first (2 x Ch / 4 independent LDS reads), then two independent
+  // MFMA chains run interleaved, then the pointwise part of both.  (Columns of pixels beyond the chunk take row 0 of the tile and
+  // are dropped at `gz`.  A software pipeline -- the next tile's MFMAs in front of this tile's pointwise part -- measured slower:
+  // 34.6 against 31.9 us.)
+  for (int pt = 0; pt * 16 < cp; pt += 2) {
+    const int px0 = pt * 16 + c16, px1 = px0 + 16;
+    const bool v0 = px0 < cp, v1 = px1 < cp;
+    const int q0 = v0 ? px0 : 0, q1 = v1 ? px1 : 0;
+    float bv0[NS], bv1[NS];
 #pragma unroll
-    for (int s = 0; s < LIFT0_CHMAX / 4; ++s)
-      if (s < nsteps) {
-        const float bv = valid ? gxs[(4 * s + g) * LD + pxs] : 0.f;
-        D = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv, D, 0, 0, 0);
+    for (int s = 0; s < NS; ++s)
+    {
+      bv0[s] = gxs[(4 * s + g) * LD + q0];  // (rows Ch .. 4 NS - 1 of the tile are zeros, and so are their A values)
+      bv1[s] = gxs[(4 * s + g) * LD + q1];
+    }
+    float xv0[4], xv1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv0[i] = xs[i * a.cpix + q0], xv1[i] = xs[i * a.cpix + q1];
+    f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+    {
+      D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv0[s], D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv1[s], D1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z0 = b0v[r] + w0[r][0] * xv0[0] + w0[r][1] * xv0[1] + w0[r][2] * xv0[2] + w0[r][3] * xv0[3];
+      const float z1 = b0v[r] + w0[r][0] * xv1[0] + w0[r][1] * xv1[1] + w0[r][2] * xv1[2] + w0[r][3] * xv1[3];
+      const float gz0 = v0 ? D0[r] * fno_gelu_grad(z0) : 0.f;
+      const float gz1 = v1 ? D1[r] * fno_gelu_grad(z1) : 0.f;
+      ab[r] += gz0;
+      ab[r] += gz1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        aw[r][i] += gz0 * xv0[i];
+        aw[r][i] += gz1 * xv1[i];
       }
-    float xv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xv[i] = valid ? xs[i * a.cpix + pxs] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float z = b0v[r] + w0[r][0] * xv[0] + w0[r][1] * xv[1] + w0[r][2] * xv[2] + w0[r][3] * xv[3];
-      const float gz = valid ? D[r] * fno_gelu_grad(z) : 0.f;
-      ab[r] += gz;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) aw[r][i] += gz * xv[i];
     }
   }
-  // sums over the 16 pixel lanes of each group (every lane of the group ends with the total)
+  // sums over the 16 pixel lanes of each group: DPP row shifts (the total lands in the group's last lane; 80 ds_bpermute through
+  // the LDS crossbar -- shared by the 16 waves -- took their place before)
+#define LIFT0_ROWSUM(v)                                                                                                   \
+  do {                                                                                                                    \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   \
+  } while (0)
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
+  for (int r = 0; r < 4; ++r) {
+    LIFT0_ROWSUM(ab[r]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ab[r] += __shfl_xor(ab[r], m, 64);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) aw[r][i] += __shfl_xor(aw[r][i], m, 64);
-    }
+    for (int i = 0; i < 4; ++i) LIFT0_ROWSUM(aw[r][i]);
   }
-  if (c16 == 0) {
+#undef LIFT0_ROWSUM
+  if (c16 == 15) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = cbase + 4 * g + r;
@@ -1436,12 +1462,21 @@ extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const
   a.B = B, a.K0 = K0, a.C1 = C1, a.Ch = Ch, a.P = P;
   a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
-  const int lds = (Ch * (a.cpix + 16) + 4 * a.cpix) * 4;
-  if (PPSCI_SET_MAX_LDS(lift0_wgrad_kernel, lds) != 0) {
-    ppsci_set_error("fno_lift0_wgrad: cannot raise dynamic LDS to %d B", lds);
-    return PPSCI_E_LAUNCH;
+  const int lds = ((Ch <= 32 ? 32 : 64) * (a.cpix + 16) + 4 * a.cpix) * 4;
+  const int grid = B * a.chunks_per_b * ((C1 + 16 * LIFT0_WAVES - 1) / (16 * LIFT0_WAVES));
+  if (Ch <= 32) {
+    if (PPSCI_SET_MAX_LDS(lift0_wgrad_kernel<8>, lds) != 0) {
+      ppsci_set_error("fno_lift0_wgrad: cannot raise dynamic LDS to %d B", lds);
+      return PPSCI_E_LAUNCH;
+    }
+    PPSCI_LAUNCH(lift0_wgrad_kernel<8>, Lift0Args, grid, 64 * LIFT0_WAVES, lds, stream, a);
+  } else {
+    if (PPSCI_SET_MAX_LDS(lift0_wgrad_kernel<16>, lds) != 0) {
+      ppsci_set_error("fno_lift0_wgrad: cannot raise dynamic LDS to %d B", lds);
+      return PPSCI_E_LAUNCH;
+    }
+    PPSCI_LAUNCH(lift0_wgrad_kernel<16>, Lift0Args, grid, 64 * LIFT0_WAVES, lds, stream, a);
   }
-  PPSCI_LAUNCH(lift0_wgrad_kernel, Lift0Args, B * a.chunks_per_b * ((C1 + 255) / 256), 1024, lds, stream, a);
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
     ppsci_set_error("fno_lift0_wgrad: launch failed");
     return PPSCI_E_LAUNCH;
