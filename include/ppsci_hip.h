@@ -490,6 +490,11 @@ int ppsci_pw_conv_v(int B, int Cin, int Cout, int P, const float* x, const ppsci
                     void* stream);
 int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const ppsci_pw_virtual* xv, const float* gy,
                           float* partials, float* partials_b, int64_t ld_partials, void* stream);
+/* Gradient of the projection MLP's hidden pre-activation when its last convolution has m <= 4 output channels:
+ * out[b][c][p] = GELU'(z2[b][c][p]) * sum_j W2[j][c] gy[b][j][p]  (z2, out [B, C, P]; W2 [m, C]; gy [B, m, P]) -- elementwise, streamed;
+ * P a multiple of 4 and 16-byte aligned buffers, otherwise PPSCI_E_UNSUPPORTED (the caller keeps ppsci_pw_conv with transpose and
+ * the GELU' epilogue).  Reference: the backward of /root/reference/ppsci/arch/fno_block.py MLP (projection) under paddle autograd. */
+int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const float* z2, const float* W2, const float* gy, float* out, void* stream);
 /* Weight + bias gradient of the FIRST convolution of the lifting MLP (x0 [B, K0, P] -> C1 channels -> GELU -> W1 [Ch, C1] -> the
  * blocks' input) from gx = dL/d(lifting output) [B, Ch, P], without the hidden gradient GELU'(W0 x0 + b0) * (W1^T gx) in memory:
  * partial rows in the layout of ppsci_pw_conv_wgrad (ppsci_pw_conv_wgrad_chunks(B, P) rows; row = [C1 * K0] weights, then -- at

@@ -1307,6 +1307,54 @@ static int fno_tail_bwd_run(int B, int C, int P, int norm, int gelu, const float
 
 
 // ------------------------------------------------------------------------------------------ DomainPadding
+// ------------------------------------------------------------------------------------------ projection MLP, hidden gradient
+// The projection MLP ends in a convolution to out_channels = 1 (Darcy; <= 4 here): the gradient of its hidden pre-activation,
+//   gz2[c][p] = GELU'(z2[c][p]) * sum_j W2[j][c] gy[j][p],
+// is an elementwise product with a rank-m factor, not a GEMM.  ppsci_pw_conv (transpose, GELU' epilogue) spent 31 us on it -- a
+// K = 1 contraction through the MFMA tiles -- for 17 MB read + 17 MB written; this kernel streams it.
+struct ProjGArgs {
+  const float *z2, *W2, *gy;
+  float* out;
+  int B, C, m, P;
+};
+__global__ void __launch_bounds__(256) proj_hidden_grad_kernel(ProjGArgs a) {
+  const long long q4 = (long long)a.P / 4, total = (long long)a.B * a.C * q4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long row = idx / q4;  // b * C + c
+    const int p = (int)(idx - row * q4) * 4;
+    const int b = (int)(row / a.C), c = (int)(row - (long long)b * a.C);
+    const f32x4 z = *(const f32x4*)&a.z2[row * a.P + p];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.m; ++j) g += *(const f32x4*)&a.gy[((long long)b * a.m + j) * a.P + p] * a.W2[(long long)j * a.C + c];
+    f32x4 o;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = g[t] * fno_gelu_grad(z[t]);
+    *(f32x4*)&a.out[row * a.P + p] = o;
+  }
+}
+
+extern "C" int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const float* z2, const float* W2, const float* gy, float* out,
+                                          void* stream) {
+  if (B < 1 || C < 1 || m < 1 || P < 1 || !z2 || !W2 || !gy || !out) {
+    ppsci_set_error("fno_proj_hidden_grad: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  if (m > 4 || (P & 3) != 0 || ((reinterpret_cast<uintptr_t>(z2) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) {
+    ppsci_set_error("fno_proj_hidden_grad: built for <= 4 output channels and 16-byte aligned rows (m = %d, P = %d)", m, P);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  ProjGArgs a{z2, W2, gy, out, B, C, m, P};
+  const long long total = (long long)B * C * (P / 4);
+  long long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  PPSCI_LAUNCH(proj_hidden_grad_kernel, ProjGArgs, (int)grid, 256, 0, stream, a);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("fno_proj_hidden_grad: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ lifting MLP, first layer, backward
 // The lifting MLP of FNONet (/root/reference/ppsci/arch/fno_block.py MLP(in -> lifting_channels -> hidden), tfnonet.py:95-110):
 //   a1 = GELU(z1),  z1 = W0 x0 + b0  (K0 <= 4 input channels, C1 = 256 lifting channels),   x_lift = W1 a1 + b1.

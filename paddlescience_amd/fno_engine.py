@@ -364,7 +364,13 @@ class FnoNative:
         # projection: y = W2 gelu(z2) + b2, z2 = W1 x_out + b1
         self._wgrad(B, self.c_proj, m.out_channels, P0, self.z2, gy, proj[1].weight, proj[1].bias, xv=self.gelu_on_load)
         gz2 = self.gz2
-        _pw_conv(B, m.out_channels, self.c_proj, P0, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
+        if (m.out_channels <= 4 and P0 % 4 == 0 and os.environ.get("PPSCI_FNO_PROJ_STREAMED", "1") != "0"
+                and (gy.data_ptr() | gz2.data_ptr() | self.z2.data_ptr()) % 16 == 0):
+            # <= 4 output channels: the hidden gradient is GELU'(z2) times a rank-m factor -- streamed (fno.hip), not a K = m GEMM
+            L.check(L.lib().ppsci_fno_proj_hidden_grad(B, self.c_proj, m.out_channels, P0, _p(self.z2), _p(proj[1].weight), _p(gy),
+                                                       _p(gz2), st))
+        else:
+            _pw_conv(B, m.out_channels, self.c_proj, P0, gy, proj[1].weight, gz2, zmul=self.z2, transpose=True)
         self._wgrad(B, Ch, self.c_proj, P0, self.xo, gz2, proj[0].weight, proj[0].bias)
         gx = self.gb.view(-1)[:B * Ch * P].view(B, Ch, P)  # dL/d(block output), ping-pongs with `gnext`
         gnext = self.ga.view(-1)[:B * Ch * P].view(B, Ch, P)
