@@ -1371,7 +1371,8 @@ extern "C" int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const floa
 struct Lift0Args {
   const float *x0, *W0, *b0, *W1, *gx;
   float *part, *part_b;
-  long long ldp, ldpb;
+  float* part1;   // or null: [chunks][ld1] rows of the SECOND layer's gradient, [Ch * C1] weights then [Ch] biases
+  long long ldp, ldpb, ld1;
   int B, K0, C1, Ch, P, cpix, chunks_per_b;
 };
 template <int NS>  // K = 4 steps of the contraction: hidden width <= 4 NS
@@ -1383,9 +1384,10 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
   // lanes of a group (fixed butterfly).  (A first version did the contraction on the VALU with one thread per channel and the tile
   // read as LDS broadcasts: 58 us, LDS- and VALU-bound; the launches it replaces took 37 + 30 us.)
   PPSCI_DYN_SMEM(smem);
-  const int LD = a.cpix + 16;                     // row stride of the k-major tile: groups g and g + 1 fall on the other 16 banks
+  const int LD = a.cpix + 17;                     // row stride of the k-major tile (odd: rows k, k + 1 start one bank apart)
   float* gxs = smem;                              // [4 NS][LD], rows >= Ch zero
   float* xs = gxs + 4 * NS * LD;                  // [4][cpix]
+  float* a1s = xs + 4 * a.cpix;                   // [waves][2 tiles][16 channels][17]: GELU(z1) of a tile, wave-private
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c16 = lane & 15;
   constexpr int CB = 16 * LIFT0_WAVES;          // channels per workgroup (grid = chunks x channel blocks)
   const int ncb = (a.C1 + CB - 1) / CB;
@@ -1405,8 +1407,8 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[r][i] = (c < a.C1 && i < a.K0) ? a.W0[(long long)c * a.K0 + i] : 0.f;
   }
-  for (int idx = tid; idx < 4 * NS * a.cpix; idx += 64 * LIFT0_WAVES) {  // (cpix is a power of two or the whole plane: see the launcher)
-    const int k = idx / a.cpix, p = idx - k * a.cpix;
+  for (int idx = tid; idx < 4 * NS * LD; idx += 64 * LIFT0_WAVES) {  // (the rows' padding as well: the second contraction reads a
+    const int k = idx / LD, p = idx - k * LD;                             //  whole 16-pixel tile behind the chunk's last pixel)
     gxs[k * LD + p] = (k < a.Ch && p < cp) ? a.gx[((long long)b * a.Ch + k) * a.P + p0 + p] : 0.f;
   }
   for (int idx = tid; idx < 4 * a.cpix; idx += 64 * LIFT0_WAVES) {
@@ -1419,6 +1421,15 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) aw[r][i] = 0.f;
+  // second layer's weight gradient (a.part1): O[c][k] = sum_p GELU(z1[c][p]) gx[k][p] for the wave's 16 channels, NS / 4 blocks
+  // of 16 k; on the MFMA with A[i = c][kk = pixel] (from the wave's scratch, transposed on the way) and B[kk = pixel][n = k]
+  constexpr int KB = NS / 4;
+  const bool second = a.part1 != nullptr;
+  f32x4 O[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) O[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* const sc0 = a1s + (wave * 2 + 0) * (16 * 17);
+  float* const sc1 = a1s + (wave * 2 + 1) * (16 * 17);
   // Two pixel tiles per iteration: their B operands are requested first (2 x Ch / 4 independent LDS reads), then two independent
   // MFMA chains run interleaved, then the pointwise part of both.  (Columns of pixels beyond the chunk take row 0 of the tile and
   // are dropped at `gz`.  A software pipeline -- the next tile's MFMAs in front of this tile's pointwise part -- measured slower:
@@ -1448,8 +1459,15 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
     for (int r = 0; r < 4; ++r) {
       const float z0 = b0v[r] + w0[r][0] * xv0[0] + w0[r][1] * xv0[1] + w0[r][2] * xv0[2] + w0[r][3] * xv0[3];
       const float z1 = b0v[r] + w0[r][0] * xv1[0] + w0[r][1] * xv1[1] + w0[r][2] * xv1[2] + w0[r][3] * xv1[3];
-      const float gz0 = v0 ? D0[r] * fno_gelu_grad(z0) : 0.f;
-      const float gz1 = v1 ? D1[r] * fno_gelu_grad(z1) : 0.f;
+      float c0, s0, c1, s1;
+      fno_gelu_parts(z0, c0, s0);
+      fno_gelu_parts(z1, c1, s1);
+      const float gz0 = v0 ? D0[r] * (c0 + z0 * 0.3989422804014327f * s0) : 0.f;  // (fno_gelu_grad)
+      const float gz1 = v1 ? D1[r] * (c1 + z1 * 0.3989422804014327f * s1) : 0.f;
+      if (second) {  // GELU(z1) of the two tiles, [channel][pixel] in the wave's scratch
+        sc0[(4 * g + r) * 17 + c16] = v0 ? z0 * c0 : 0.f;
+        sc1[(4 * g + r) * 17 + c16] = v1 ? z1 * c1 : 0.f;
+      }
       ab[r] += gz0;
       ab[r] += gz1;
 #pragma unroll
@@ -1457,6 +1475,21 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
         aw[r][i] += gz0 * xv0[i];
         aw[r][i] += gz1 * xv1[i];
       }
+    }
+    if (second) {
+      ppsci_wave_sync();  // the scratch is complete (written and read by this wave only)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {  // K = 4 pixels per step, both tiles
+        const float a0 = sc0[c16 * 17 + 4 * st + g], a1v = sc1[c16 * 17 + 4 * st + g];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const float b0 = gxs[(16 * kb + c16) * LD + pt * 16 + 4 * st + g];
+          const float b1 = gxs[(16 * kb + c16) * LD + pt * 16 + 16 + 4 * st + g];  // (the row's padding / zeros beyond the chunk)
+          O[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, O[kb], 0, 0, 0);
+          O[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, b1, O[kb], 0, 0, 0);
+        }
+      }
+      ppsci_wave_sync();  // (the next iteration rewrites the scratch)
     }
   }
   // sums over the 16 pixel lanes of each group: DPP row shifts (the total lands in the group's last lane; 80 ds_bpermute through
@@ -1485,11 +1518,28 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
       }
     }
   }
+  if (second) {
+    // O: lane (g, c16) holds channels cbase + 4 g + r (rows), k = 16 kb + c16 (column); weight layout [Ch][C1]
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int k = 16 * kb + c16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cbase + 4 * g + r;
+        if (k < a.Ch && c < a.C1) a.part1[(long long)chunk * a.ld1 + (long long)k * a.C1 + c] = O[kb][r];
+      }
+    }
+    if (cb == 0 && tid < a.Ch) {  // the second layer's bias gradient: sum of gx over the chunk's pixels (in pixel order)
+      float sb = 0.f;
+      for (int p = 0; p < cp; ++p) sb += gxs[tid * LD + p];
+      a.part1[(long long)chunk * a.ld1 + (long long)a.Ch * a.C1 + tid] = sb;
+    }
+  }
 }
 
 extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0,
                                      const float* W1, const float* gx, float* partials, float* partials_b, int64_t ld_partials,
-                                     void* stream) {
+                                     float* partials1, int64_t ld_partials1, void* stream) {
   if (B < 1 || K0 < 1 || C1 < 1 || Ch < 1 || P < 1 || !x0 || !W0 || !W1 || !gx || !partials) {
     ppsci_set_error("fno_lift0_wgrad: invalid argument");
     return PPSCI_E_INVALID;
@@ -1503,14 +1553,19 @@ extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const
     ppsci_set_error("fno_lift0_wgrad: ld_partials smaller than a row");
     return PPSCI_E_INVALID;
   }
+  if (partials1 != nullptr && (Ch > 32 || ld_partials1 < (int64_t)Ch * C1 + Ch)) {
+    ppsci_set_error("fno_lift0_wgrad: the second layer's gradient is built for a hidden width <= 32 and rows of Ch * C1 + Ch floats");
+    return PPSCI_E_UNSUPPORTED;
+  }
   Lift0Args a;
   a.x0 = x0, a.W0 = W0, a.b0 = b0, a.W1 = W1, a.gx = gx, a.part = partials, a.part_b = partials_b;
+  a.part1 = partials1, a.ld1 = ld_partials1;
   a.ldp = ld_partials ? ld_partials : (long long)C1 * K0;
   a.ldpb = ld_partials ? ld_partials : C1;
   a.B = B, a.K0 = K0, a.C1 = C1, a.Ch = Ch, a.P = P;
   a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
-  const int lds = ((Ch <= 32 ? 32 : 64) * (a.cpix + 16) + 4 * a.cpix) * 4;
+  const int lds = ((Ch <= 32 ? 32 : 64) * (a.cpix + 17) + 4 * a.cpix + LIFT0_WAVES * 2 * 16 * 17) * 4;
   const int grid = B * a.chunks_per_b * ((C1 + 16 * LIFT0_WAVES - 1) / (16 * LIFT0_WAVES));
   if (Ch <= 32) {
     if (PPSCI_SET_MAX_LDS(lift0_wgrad_kernel<8>, lds) != 0) {

@@ -329,14 +329,24 @@ class FnoNative:
         if (os.environ.get("PPSCI_FNO_LIFT0_FUSED", "1") == "0" or K0 > 4 or Ch > 64 or Ch % 4 != 0 or b0 is None
                 or b0.grad.data_ptr() != w0.grad.view(-1).data_ptr() + 4 * C1 * K0):
             return False
-        self._wgrad(B, C1, Ch, P0, None, gx, lift[1].weight, lift[1].bias, xv=self.a1_virtual)
+        w1, b1 = lift[1].weight, lift[1].bias
+        # the second layer's gradient from the same pass (GELU(z1) is at hand there) when its weight and bias gradients are neighbours
+        both = (Ch <= 32 and b1 is not None and b1.grad.data_ptr() == w1.grad.view(-1).data_ptr() + 4 * Ch * C1
+                and os.environ.get("PPSCI_FNO_LIFT1_FUSED", "1") != "0")
+        if not both:
+            self._wgrad(B, C1, Ch, P0, None, gx, w1, b1, xv=self.a1_virtual)
         with self._fork():
             chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0))
             ld = C1 * K0 + C1
             part = self._partials(chunks * ld)
-            L.check(L.lib().ppsci_fno_lift0_wgrad(B, K0, C1, Ch, P0, _p(self.x_in), _p(w0), _p(b0), _p(lift[1].weight), _p(gx),
-                                                  _p(part), C.c_void_p(part.data_ptr() + 4 * C1 * K0), ld, _stream_ptr(gx)))
+            ld1 = Ch * C1 + Ch
+            part1 = self._partials(chunks * ld1) if both else None
+            L.check(L.lib().ppsci_fno_lift0_wgrad(B, K0, C1, Ch, P0, _p(self.x_in), _p(w0), _p(b0), _p(w1), _p(gx),
+                                                  _p(part), C.c_void_p(part.data_ptr() + 4 * C1 * K0), ld,
+                                                  _p(part1) if both else None, ld1 if both else 0, _stream_ptr(gx)))
             self._wsegs.append((part.data_ptr(), w0.grad.view(-1).data_ptr(), chunks, ld))
+            if both:
+                self._wsegs.append((part1.data_ptr(), w1.grad.view(-1).data_ptr(), chunks, ld1))
         return True
 
     def _flush_wgrads(self) -> None:

@@ -10,6 +10,7 @@ if dev == "emu":
 def run(flag):
     os.environ["PPSCI_FNO_LIFT0_FUSED"] = flag
     os.environ["PPSCI_FNO_PROJ_STREAMED"] = flag
+    os.environ["PPSCI_FNO_LIFT1_FUSED"] = flag
     torch.manual_seed(0)
     model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, hidden_channels=8, in_channels=3, out_channels=1, lifting_channels=24,
                                  projection_channels=16, n_layers=2, norm="group_norm")
