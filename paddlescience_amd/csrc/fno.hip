@@ -619,9 +619,13 @@ __device__ __forceinline__ f32x4 pww_x(const PwWArgs& a, const float* xrow, int 
 // (a multiple of 16).  TB*TB accumulators per wave: every operand float4 feeds TB MFMA chains -- the kernel is bound by
 // the L2 traffic of its operands (each wave streams 2 * 16TB rows x cpix pixels), which per flop falls as 1 / TB.
 // TB = 2 for small layers (a 32 x 32 FNO layer is ONE tile), TB = 4 from 128 x 128 on.
-template <int TB, int XM, bool AL>
-__global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
+// WV = 4 (small layers, 256-pixel chunks): four waves per work item, a quarter of the chunk's pixels each, summed in wave order
+// through LDS -- an FNO batch of 16 x 4 096 pixels is only 256 chunks, a quarter of the chip's SIMDs at one wave per chunk
+// (10.7 us per 32 x 32 weight gradient), and smaller chunks would multiply the partial rows the reduction has to read.
+template <int TB, int XM, bool AL, int WV = 1>
+__global__ void __launch_bounds__(64 * WV, 2) pw_wgrad_kernel(PwWArgs a) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int wv = WV > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int nibt = (a.nib + TB - 1) / TB, nobt = (a.nob + TB - 1) / TB;
   int id = blockIdx.x;
   const int ib = TB * (id % nibt);
@@ -629,7 +633,8 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
   const int ob = TB * (id % nobt);
   const int ch = id / nobt;
   const int b = ch / a.chunks_per_b;
-  const int p0 = (ch - b * a.chunks_per_b) * a.cpix;
+  const int pc0 = (ch - b * a.chunks_per_b) * a.cpix;        // the chunk
+  const int p0 = pc0 + wv * (a.cpix / WV);                    // this wave's share of it
   const float* gr[TB];
   const float* xr[TB];
   int xi[TB];
@@ -661,7 +666,7 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
   float bsum[TB];
 #pragma unroll
   for (int u = 0; u < TB; ++u) bsum[u] = 0.f;
-  const int pend = p0 + a.cpix < a.P ? p0 + a.cpix : a.P;
+  const int pend = p0 + a.cpix / WV < a.P ? p0 + a.cpix / WV : a.P;
   constexpr bool al = AL;  // P a multiple of 4 (and 16-byte aligned operands): see fno_ld4; the remainder loop zero-fills beyond pend
   int pbeg = p0;
   if constexpr (PPSCI_XDL) {
@@ -706,6 +711,31 @@ __global__ void __launch_bounds__(64, 2) pw_wgrad_kernel(PwWArgs a) {
         for (int r = 0; r < 4; ++r) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[u][r], xv[v][r], acc[u][v], 0, 0, 0);
       bsum[u] += (gv[u][0] + gv[u][1]) + (gv[u][2] + gv[u][3]);
     }
+  }
+  if constexpr (WV > 1) {  // waves 1 .. WV-1 hand their sums to wave 0, which adds them in wave order
+    __shared__ float red[WV - 1][TB * TB * 4 + TB][64];
+    if (wv > 0) {
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+#pragma unroll
+        for (int v = 0; v < TB; ++v)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) red[wv - 1][(u * TB + v) * 4 + rr][lane] = acc[u][v][rr];
+        red[wv - 1][TB * TB * 4 + u][lane] = bsum[u];
+      }
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int w = 0; w < WV - 1; ++w)
+#pragma unroll
+      for (int u = 0; u < TB; ++u) {
+#pragma unroll
+        for (int v = 0; v < TB; ++v)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) acc[u][v][rr] += red[w][(u * TB + v) * 4 + rr][lane];
+        bsum[u] += red[w][TB * TB * 4 + u][lane];
+      }
   }
   float* prow = a.part + (long long)ch * a.ldp;
   // D[row = 4g + rr][col = c] = gW[o = 16ob + 4g + rr][i = 16ib + c]
@@ -797,7 +827,12 @@ static int pw_wgrad_run(int B, int Ci, int Co, int P, const float* x, const ppsc
     PWW_LAUNCH(4);
   } else {
     const long long grid = (long long)B * a.chunks_per_b * ((a.nob + 1) / 2) * ((a.nib + 1) / 2);
-    PWW_LAUNCH(2);
+    if (a.cpix == PW_WGRAD_CPIX && aligned && grid < 4096) {  // few work items: four waves each (see the kernel)
+      if (xmode == 2) PPSCI_LAUNCH((pw_wgrad_kernel<2, 2, true, 4>), PwWArgs, (int)grid, 256, 0, stream, a);
+      else if (xmode == 1) PPSCI_LAUNCH((pw_wgrad_kernel<2, 1, true, 4>), PwWArgs, (int)grid, 256, 0, stream, a);
+      else PPSCI_LAUNCH((pw_wgrad_kernel<2, 0, true, 4>), PwWArgs, (int)grid, 256, 0, stream, a);
+    } else
+      PWW_LAUNCH(2);
   }
 #undef PWW_LAUNCH
   if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
