@@ -520,19 +520,20 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
   const bool wide = resident == 1;
   // (XDL: a work item always takes 4 output blocks, so that one split of the B operand feeds 96 MFMAs)
   const int oc = (wide && !PPSCI_XDL) ? 2 : 4, waves = wide ? 8 : 4;
-  // pixels per lane (work item = 16 npx pixels): 4 (16-byte accesses) unless that leaves most CUs without a single wave.
-  // Measured on the 16 x 64 x 64 TFNO step (1024 items of 64 pixels = one wave per SIMD): forcing 2 or 1 pixels per lane
-  // for 2 / 4 waves per SIMD made the step SLOWER (0.844 ms at 4, 0.854 at 2, 0.890 at 1): the kernels are bound by
-  // their memory instructions per pixel, not by the latency of one wave's chain.
+  // pixels per lane (work item = 16 npx pixels): 4 (16-byte accesses) unless that leaves fewer than two waves per SIMD.
+  // Measured on the 16 x 64 x 64 TFNO step (1024 items of 64 pixels at 4 per lane): round 4, step 0.844 ms at 4, 0.854 at 2,
+  // 0.890 at 1; end of round 5, with the rest of the step shorter: 0.576 ms at 4, 0.562 at 2, 0.588 at 1 -- two waves per SIMD
+  // now pay for the eight-byte accesses.
   const long long groups = (nob_slab + oc - 1) / oc;
-  const long long want = PPSCI_NUM_CU;
+  const long long want = 8LL * PPSCI_NUM_CU;
   int npx = g_pw_npx;
   const int vm = zmode == 2 ? 3 : xmode;
   if (vm != 0) {
     npx = 4;  // (the operand-evaluating instances exist for 4 pixels per lane only)
   } else if (npx != 1 && npx != 2 && npx != 4) {
     npx = 4;
-    while (npx > 1 && (long long)B * ((P + 16 * npx - 1) / (16 * npx)) * groups * nslab < want) npx >>= 1;
+    while (npx > 2 && (long long)B * ((P + 16 * npx - 1) / (16 * npx)) * groups * nslab < want) npx >>= 1;
+    while (npx > 1 && (long long)B * ((P + 16 * npx - 1) / (16 * npx)) * groups * nslab < PPSCI_NUM_CU) npx >>= 1;
   }
   // rows of P pixels start on 4 npx-byte boundaries: the aligned instances; otherwise element accesses, 4 pixels per lane
   const bool aligned = (P % npx) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
