@@ -1,3 +1,6 @@
+"""FNO lifting / projection backward: the round-5 kernels (ppsci_fno_lift0_wgrad with both lifting gradients, ppsci_fno_proj_hidden_grad)
+against the launches they replace (PPSCI_FNO_LIFT0_FUSED / _LIFT1_FUSED / _PROJ_STREAMED = 0), every parameter gradient of a small TFNO.
+    python tools/lift0_check.py            (CPU emulator)        DEV=gpu python tools/lift0_check.py   (MI355X, 16 x 64 x 64)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
