@@ -496,7 +496,7 @@ int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const pp
  * the GELU' epilogue).  Reference: the backward of /root/reference/ppsci/arch/fno_block.py MLP (projection) under paddle autograd. */
 int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const float* z2, const float* W2, const float* gy, float* out, void* stream);
 /* Weight + bias gradient of the FIRST convolution of the lifting MLP (x0 [B, K0, P] -> C1 channels -> GELU -> W1 [Ch, C1] -> the
- * blocks' input) from gx = dL/d(lifting output) [B, Ch, P], without the hidden gradient GELU'(W0 x0 + b0) * (W1^T gx) in memory:
+ * blocks' input) from gx (+ gx2 when not NULL) = dL/d(lifting output) [B, Ch, P], without the hidden gradient GELU'(W0 x0 + b0) * (W1^T gx) in memory:
  * partial rows in the layout of ppsci_pw_conv_wgrad (ppsci_pw_conv_wgrad_chunks(B, P) rows; row = [C1 * K0] weights, then -- at
  * partials_b -- [C1] biases; ld_partials as there), summed by ppsci_reduce_rows.  K0 <= 4, Ch a multiple of 4, <= 64; otherwise
  * PPSCI_E_UNSUPPORTED (the caller keeps ppsci_pw_conv_v + ppsci_pw_conv_wgrad_v).  partials1 (or NULL; Ch <= 32): the SECOND
@@ -504,8 +504,8 @@ int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const float* z2, cons
  * sum_p GELU(W0 x0 + b0)[c][p] gx[k][p] and sum_p gx[k][p] (instead of ppsci_pw_conv_wgrad_v with the virtual operand).  Reference: the backward of
  * /root/reference/ppsci/arch/fno_block.py MLP (lifting) under paddle autograd. */
 int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0, const float* W1,
-                          const float* gx, float* partials, float* partials_b, int64_t ld_partials, float* partials1,
-                          int64_t ld_partials1, void* stream);
+                          const float* gx, const float* gx2, float* partials, float* partials_b, int64_t ld_partials,
+                          float* partials1, int64_t ld_partials1, void* stream);
 /* Testing / tuning knob: pixels per lane of ppsci_pw_conv's work items (1, 2 or 4; 0 = chosen from the problem size: fewer
  * pixels per lane give small problems more waves). */
 void ppsci_set_pw_pixels_per_lane(int npx);

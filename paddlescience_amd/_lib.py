@@ -186,7 +186,7 @@ _SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.POINTER(PwVirtual), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_fno_proj_hidden_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_fno_lift0_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "ppsci_pw_conv_wgrad_v": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(PwVirtual), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ppsci_set_pw_pixels_per_lane": (None, [C.c_int]),

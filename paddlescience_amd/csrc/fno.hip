@@ -1406,6 +1406,7 @@ extern "C" int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const floa
                         // the kernel is bound by the GELU' arithmetic, ~40 VALU instructions per element, as the launch it replaces was)
 struct Lift0Args {
   const float *x0, *W0, *b0, *W1, *gx;
+  const float* gx2;  // or null: a second addend of gx (the spectral branch's share of the first block's input gradient)
   float *part, *part_b;
   float* part1;   // or null: [chunks][ld1] rows of the SECOND layer's gradient, [Ch * C1] weights then [Ch] biases
   long long ldp, ldpb, ld1;
@@ -1445,7 +1446,13 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
   }
   for (int idx = tid; idx < 4 * NS * LD; idx += 64 * LIFT0_WAVES) {  // (the rows' padding as well: the second contraction reads a
     const int k = idx / LD, p = idx - k * LD;                             //  whole 16-pixel tile behind the chunk's last pixel)
-    gxs[k * LD + p] = (k < a.Ch && p < cp) ? a.gx[((long long)b * a.Ch + k) * a.P + p0 + p] : 0.f;
+    float v = 0.f;
+    if (k < a.Ch && p < cp) {
+      const long long off = ((long long)b * a.Ch + k) * a.P + p0 + p;
+      v = a.gx[off];
+      if (a.gx2 != nullptr) v += a.gx2[off];
+    }
+    gxs[k * LD + p] = v;
   }
   for (int idx = tid; idx < 4 * a.cpix; idx += 64 * LIFT0_WAVES) {
     const int i = idx / a.cpix, p = idx - i * a.cpix;
@@ -1574,8 +1581,8 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
 }
 
 extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0,
-                                     const float* W1, const float* gx, float* partials, float* partials_b, int64_t ld_partials,
-                                     float* partials1, int64_t ld_partials1, void* stream) {
+                                     const float* W1, const float* gx, const float* gx2, float* partials, float* partials_b,
+                                     int64_t ld_partials, float* partials1, int64_t ld_partials1, void* stream) {
   if (B < 1 || K0 < 1 || C1 < 1 || Ch < 1 || P < 1 || !x0 || !W0 || !W1 || !gx || !partials) {
     ppsci_set_error("fno_lift0_wgrad: invalid argument");
     return PPSCI_E_INVALID;
@@ -1594,7 +1601,7 @@ extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const
     return PPSCI_E_UNSUPPORTED;
   }
   Lift0Args a;
-  a.x0 = x0, a.W0 = W0, a.b0 = b0, a.W1 = W1, a.gx = gx, a.part = partials, a.part_b = partials_b;
+  a.x0 = x0, a.W0 = W0, a.b0 = b0, a.W1 = W1, a.gx = gx, a.gx2 = gx2, a.part = partials, a.part_b = partials_b;
   a.part1 = partials1, a.ld1 = ld_partials1;
   a.ldp = ld_partials ? ld_partials : (long long)C1 * K0;
   a.ldpb = ld_partials ? ld_partials : C1;

@@ -318,7 +318,21 @@ class FnoNative:
         if b_param is not None:
             self._wsegs.append((part_b.data_ptr(), b_param.grad.view(-1).data_ptr(), chunks, co))
 
-    def _lift0_fused(self, B, Ch, P0, gx, lift) -> bool:
+    def _lift_fused_both(self, Ch) -> bool:
+        m = self.m
+        lift = m.lifting.fcs
+        w0, b0, w1, b1 = lift[0].weight, lift[0].bias, lift[1].weight, lift[1].bias
+        K0, C1 = m.in_channels, self.c_lift
+        return (self.lift_virtual and os.environ.get("PPSCI_FNO_LIFT0_FUSED", "1") != "0" and K0 <= 4 and Ch <= 32 and Ch % 4 == 0
+                and b0 is not None and b1 is not None and os.environ.get("PPSCI_FNO_LIFT1_FUSED", "1") != "0"
+                and b0.grad.data_ptr() == w0.grad.view(-1).data_ptr() + 4 * C1 * K0
+                and b1.grad.data_ptr() == w1.grad.view(-1).data_ptr() + 4 * Ch * C1)
+
+    def _lift_takes_addend(self, Ch) -> bool:
+        """The lifting kernel is the ONLY consumer of dL/dx_0 (both lifting gradients from it, no padding in between)."""
+        return bool(self.c_lift) and not self.padded and self._lift_fused_both(Ch)
+
+    def _lift0_fused(self, B, Ch, P0, gx, lift, gx_add=None) -> bool:
         """Lifting MLP backward with the hidden tensor virtual: the second layer's weight gradient as before, the first layer's by
         ppsci_fno_lift0_wgrad -- GELU'(W0 x + b0) * (W1^T gx) is formed in registers and reduced against the input channels at
         once (was: 67 MB written by one launch and read back by the next at batch 16, 64 x 64).  False: shape outside the kernel's
@@ -341,7 +355,8 @@ class FnoNative:
             part = self._partials(chunks * ld)
             ld1 = Ch * C1 + Ch
             part1 = self._partials(chunks * ld1) if both else None
-            L.check(L.lib().ppsci_fno_lift0_wgrad(B, K0, C1, Ch, P0, _p(self.x_in), _p(w0), _p(b0), _p(w1), _p(gx),
+            assert gx_add is None or both
+            L.check(L.lib().ppsci_fno_lift0_wgrad(B, K0, C1, Ch, P0, _p(self.x_in), _p(w0), _p(b0), _p(w1), _p(gx), _p(gx_add),
                                                   _p(part), C.c_void_p(part.data_ptr() + 4 * C1 * K0), ld,
                                                   _p(part1) if both else None, ld1 if both else 0, _stream_ptr(gx)))
             self._wsegs.append((part.data_ptr(), w0.grad.view(-1).data_ptr(), chunks, ld))
@@ -393,6 +408,7 @@ class FnoNative:
         else:
             _pw_conv(B, self.c_proj, Ch, P, gz2, proj[0].weight, gx, transpose=True)
         gx2 = None  # a second addend of dL/d(block output): the spectral branch's share, added by the consumer on load
+        gx_add = None  # ... of dL/dx_0, for the lifting kernel
         gx2_modes = None  # ... or its kept modes: the consumer evaluates the inverse transform itself (fuse_dft)
         for l in range(nl - 1, -1, -1):
             conv, skip = fb.convs[l], fb.fno_skips[l]
@@ -443,6 +459,8 @@ class FnoNative:
                 gx2 = None
             elif l > 0:
                 gx2 = self.gsp  # dL/dx_l = gnext + gsp: the next block tail adds them on load (gsp is rewritten after it)
+            elif self._lift_takes_addend(Ch):
+                gx_add = self.gsp  # the lifting kernel adds it while it stages dL/dx_0 (one launch and 25 MB of traffic less)
             else:
                 hp.reduce_rows(self.gsp.view(1, -1), 1, B * Ch * P, gnext.view(-1), True)  # gnext += gsp
             gx, gnext = gnext, gx
@@ -453,7 +471,7 @@ class FnoNative:
         if self.c_lift:
             gz1 = self.gb if gx.data_ptr() != self.gb.data_ptr() else self.ga
             gz1 = gz1.view(-1)[:B * self.c_lift * P0].view(B, self.c_lift, P0)
-            if self.lift_virtual and self._lift0_fused(B, Ch, P0, gx, lift):
+            if self.lift_virtual and self._lift0_fused(B, Ch, P0, gx, lift, gx_add):
                 pass  # (both weight gradients done: the first layer's without its hidden gradient in memory)
             elif self.lift_virtual:
                 self._wgrad(B, self.c_lift, Ch, P0, None, gx, lift[1].weight, lift[1].bias, xv=self.a1_virtual)
