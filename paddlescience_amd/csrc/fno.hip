@@ -529,7 +529,10 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
   int npx = g_pw_npx;
   const int vm = zmode == 2 ? 3 : xmode;
   if (vm != 0) {
-    npx = 4;  // (the operand-evaluating instances exist for 4 pixels per lane only)
+    // the operand-evaluating instances: 4 pixels per lane; x = GELU(W0 x0 + b0) (mode 2: bound by the GELU arithmetic, whose
+    // latencies a second wave hides) also 2 when 4 leave one wave per SIMD: lifting forward 31.2 -> 27.3 us (mode 1 got slower)
+    npx = 4;
+    if (vm == 2 && g_pw_npx != 4 && (long long)B * ((P + 63) / 64) * groups * nslab < want) npx = 2;
   } else if (npx != 1 && npx != 2 && npx != 4) {
     npx = 4;
     while (npx > 2 && (long long)B * ((P + 16 * npx - 1) / (16 * npx)) * groups * nslab < want) npx >>= 1;
@@ -557,7 +560,8 @@ static int pw_conv_run(int B, int Cin, int Cout, int P, const float* x, const pp
       else if (vm == 2) PW_LAUNCH(OC, WV, 4, 2, false);      \
       else if (vm == 3) PW_LAUNCH(OC, WV, 4, 3, false);      \
       else PW_LAUNCH(OC, WV, 4, 0, false);                   \
-    } else if (vm == 1) PW_LAUNCH(OC, WV, 4, 1, true);       \
+    } else if (vm == 2 && npx == 2) PW_LAUNCH(OC, WV, 2, 2, true); \
+    else if (vm == 1) PW_LAUNCH(OC, WV, 4, 1, true);         \
     else if (vm == 2) PW_LAUNCH(OC, WV, 4, 2, true);         \
     else if (vm == 3) PW_LAUNCH(OC, WV, 4, 3, true);         \
     else if (npx == 4) PW_LAUNCH(OC, WV, 4, 0, true);        \
