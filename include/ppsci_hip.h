@@ -240,6 +240,12 @@ int ppsci_causal_weights(int64_t n_points, int n_chunks, float tol, const float*
 int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
                      const float* const* inputs_host, const float* Ubar, const void* stash,
                      void* workspace, float* grad_partials, void* stream);
+/* ppsci_taylor_bwd with the size of `workspace` stated (workspace_bytes < 0: unchecked, as above).  The kernel choice for
+ * padded width 129..256 (ppsci_set_bwd_layerwise) decides the workspace layout; this form runs the kernel the buffer was
+ * sized for when the knob has changed since, and returns PPSCI_E_INVALID when the buffer fits neither. */
+int ppsci_taylor_bwd_ws(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                        const float* const* inputs_host, const float* Ubar, const void* stash,
+                        void* workspace, int64_t workspace_bytes, float* grad_partials, void* stream);
 
 /* Adam hyper-parameters of ppsci_taylor_step (the same quantities as ppsci_adam_step's arguments). */
 typedef struct ppsci_adam_args {

@@ -19,6 +19,7 @@ import torch
 
 from .. import _lib as L
 from ..device import get_device
+from ..utils import initializer
 from ..graph import Sym
 from ..hotpath import _p, _stream_ptr
 from . import activation as act_mod
@@ -107,9 +108,8 @@ class SPINN(Arch):
                 self._names.append(f"branch_nets.{b}.{name}")
                 v = self.flat_params[off:off + n].view(*shp)
                 self._views.append(v)
-                if len(shp) == 2:  # glorot normal (initializer.py:475-498), numpy global RNG
-                    std = math.sqrt(2.0 / (shp[0] + shp[1]))
-                    v.copy_(torch.from_numpy(np.random.normal(0.0, std, size=shp).astype(np.float32)))
+                if len(shp) == 2:  # SPINN._init_weights (spinn.py:107-111): glorot_normal_ weights, zero biases
+                    initializer.glorot_normal_(v)
                 off += n
 
     def branch(self, b: int) -> torch.Tensor:

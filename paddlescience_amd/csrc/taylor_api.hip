@@ -285,9 +285,9 @@ extern "C" int ppsci_taylor_fwd(const ppsci_mlp_desc* d, const float* params, in
   return run_fwd_act(a, stream, 1, nullptr);
 }
 
-extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
-                                const float* const* inputs_host, const float* Ubar, const void* stash,
-                                void* workspace, float* grad_partials, void* stream) {
+static int taylor_bwd_impl(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                           const float* const* inputs_host, const float* Ubar, const void* stash,
+                           void* workspace, float* grad_partials, void* stream) {
   BwdArgs a;
   if (!params || !inputs_host || !Ubar || !stash || !workspace || !grad_partials || n_points <= 0 ||
       fill_bwd(a, d, n_points) != PPSCI_OK) {
@@ -319,6 +319,39 @@ extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, in
   // rows of W0 / biases / W_last, written in the canonical parameter layout
   return ppsci_wgrad_reduce(a.d, a.q, a.accum ? (int)slots : a.ntiles, wpart, tmp, small_rows, grid, small_tmp, grad_partials,
                             stream);
+}
+
+extern "C" int ppsci_taylor_bwd(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                                const float* const* inputs_host, const float* Ubar, const void* stash,
+                                void* workspace, float* grad_partials, void* stream) {
+  return taylor_bwd_impl(d, params, n_points, inputs_host, Ubar, stash, workspace, grad_partials, stream);
+}
+
+// The checked form: the kernel choice of padded width 129..256 (ppsci_set_bwd_layerwise) is read when the workspace is SIZED
+// and again at LAUNCH; a workspace sized under one setting and run under the other would be overrun (the layer-by-layer
+// kernel keeps its hand-over buffer there, the fp32-MFMA kernel its per-tile gradient blocks).  With the size known the
+// launch runs the kernel the buffer was sized for, or refuses.
+extern "C" int ppsci_taylor_bwd_ws(const ppsci_mlp_desc* d, const float* params, int64_t n_points,
+                                   const float* const* inputs_host, const float* Ubar, const void* stash,
+                                   void* workspace, int64_t workspace_bytes, float* grad_partials, void* stream) {
+  if (workspace_bytes < 0 || n_points <= 0 || !d)
+    return taylor_bwd_impl(d, params, n_points, inputs_host, Ubar, stash, workspace, grad_partials, stream);
+  const int knob = ppsci_get_bwd_layerwise();
+  int64_t need = ppsci_bwd_workspace_bytes(d, n_points);
+  if (need > 0 && need <= workspace_bytes)
+    return taylor_bwd_impl(d, params, n_points, inputs_host, Ubar, stash, workspace, grad_partials, stream);
+  ppsci_set_bwd_layerwise(!knob);
+  const int64_t other = ppsci_bwd_workspace_bytes(d, n_points);
+  int rc;
+  if (other > 0 && other <= workspace_bytes) {
+    rc = taylor_bwd_impl(d, params, n_points, inputs_host, Ubar, stash, workspace, grad_partials, stream);
+  } else {
+    ppsci_set_error("taylor_bwd: workspace of %lld bytes, %lld needed (ppsci_bwd_workspace_bytes)", (long long)workspace_bytes,
+                    (long long)need);
+    rc = PPSCI_E_INVALID;
+  }
+  ppsci_set_bwd_layerwise(knob);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------ one-launch step

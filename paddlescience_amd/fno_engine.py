@@ -111,6 +111,7 @@ class FnoNative:
         alive under its own key."""
         if self.shape is not None:
             self._sets[self.shape] = {k: v for k, v in self.__dict__.items() if k not in keep}
+        self.shape = None  # no current set until the new one is complete: a failed allocation leaves the executor usable
         for k in [k for k in self.__dict__ if k not in keep]:
             del self.__dict__[k]
         key = (B, H, W)

@@ -61,9 +61,12 @@ atan2 = _binary("atan2", torch.atan2, np.arctan2)
 
 def where(cond, x, y):
     """paddle.where(cond, x, y) per point.  Traced: `cond` is the 0 / 1 indicator a comparison of traced values yields
-    (graph.Sym._compare), and the result is  y + cond (x - y)  in the residual program -- both branches are evaluated at every
+    (graph.Sym._compare; with or without a fixed batch behind the trace, and for `symA == symB`), and the result is  y + cond (x - y)  in the residual program -- both branches are evaluated at every
     point (a branch that is not finite where it is NOT selected would poison the result: the reference's where does not have
     that restriction), the adjoint reaches x with weight cond and y with 1 - cond, the condition itself has derivative zero."""
+    ind = getattr(cond, "indicator", None)
+    if callable(ind):  # a comparison made during a trace (of a fixed batch's values, or of two traced values): its traced form
+        cond = ind()
     if isinstance(cond, Sym) or isinstance(x, Sym) or isinstance(y, Sym):
         if isinstance(cond, (bool, np.bool_)):
             return _lift(x) if cond else _lift(y)

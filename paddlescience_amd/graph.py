@@ -138,34 +138,46 @@ class Sym:
     def item(self):
         return float(self._scalar("item"))
 
+    def _indicator(self, o, what):
+        """The comparison as a traced per-point 0 / 1 value (what the reference's bool tensor stands for in
+        `paddle.where(cond, a, b)`; examples/chip_heat/chip_heat.py:217-232): built from the VM's heaviside (x > 0 ? 1 : 0)
+        and abs, derivative zero."""
+        d = self - _lift(o)
+        one = Sym.const(1.0)
+        if what == "gt":
+            return apply("heaviside", d)
+        if what == "lt":
+            return apply("heaviside", -d)
+        if what == "ge":
+            return one - apply("heaviside", -d)
+        if what == "le":
+            return one - apply("heaviside", d)
+        if what == "eq":
+            return one - apply("heaviside", apply("abs", d))
+        return apply("heaviside", apply("abs", d))  # ne
+
     def _compare(self, o, f, what):
-        if _TRACE.values is None and isinstance(o, (Sym, int, float, np.floating, np.integer)):
-            # No fixed batch to look at: the comparison itself is traced, as the 0 / 1 valued per-point indicator the reference's
-            # bool tensor stands for in `paddle.where(cond, a, b)` (functional.where; examples/chip_heat/chip_heat.py:217-232) --
-            # built from the VM's heaviside (x > 0 ? 1 : 0) and abs, derivative zero.  bool() of it still raises (see _scalar).
-            d = self - _lift(o)
-            one = Sym.const(1.0)
-            if what == "gt":
-                return apply("heaviside", d)
-            if what == "lt":
-                return apply("heaviside", -d)
-            if what == "ge":
-                return one - apply("heaviside", -d)
-            if what == "le":
-                return one - apply("heaviside", d)
-            if what == "eq":
-                return one - apply("heaviside", apply("abs", d))
-            return apply("heaviside", apply("abs", d))  # ne
-        if isinstance(o, Sym):
-            o = concrete_values(o, what)
-        elif not isinstance(o, (int, float, np.floating, np.integer)):
+        if not isinstance(o, (Sym, int, float, np.floating, np.integer)):
             return NotImplemented
-        v = f(concrete_values(self, what), np.float32(o))
+        if _TRACE.values is None:
+            # No fixed batch to look at: the comparison itself is traced.  bool() of it still raises (see _scalar).
+            return self._indicator(o, what)
+        try:
+            ov = concrete_values(o, what) if isinstance(o, Sym) else np.float32(o)
+            v = f(concrete_values(self, what), ov)
+        except TypeError:
+            # a fixed batch, but the compared values depend on the network: no answer at trace time, a traced indicator
+            return self._indicator(o, what)
         # (the ANSWER is part of the record: ranks of a data-parallel job see different shards and must not silently compile
         # different programs, solver.Solver._check_trace_decisions)
-        ans = repr(bool(v.reshape(-1)[0])) if v.size == 1 else f"{int(v.sum())} of {v.size} true, crc {zlib.crc32(np.packbits(v).tobytes()):08x}"
-        _TRACE.concretized.append(f"{what}({self!r}) = {ans}")
-        return v if v.size != 1 else bool(v.reshape(-1)[0])
+        if v.size == 1:
+            ans = bool(v.reshape(-1)[0])
+            _TRACE.concretized.append(f"{what}({self!r}) = {ans!r}")
+            return ans
+        # One answer per point of the fixed batch.  As a Python value it is the bool array the reference's tensor holds (its
+        # use -- indexing, any(), all() -- specialises the trace to this batch, so it is recorded when it is LOOKED at);
+        # handed to functional.where it is the traced indicator, which holds for any batch and specialises nothing.
+        return _BatchMask(v, self, o, what)
 
     def __lt__(self, o): return self._compare(o, np.less, "lt")
     def __le__(self, o): return self._compare(o, np.less_equal, "le")
@@ -173,19 +185,17 @@ class Sym:
     def __ge__(self, o): return self._compare(o, np.greater_equal, "ge")
 
     def __eq__(self, o):
-        # two traced values: identity (nodes are hash-consed: the same structure IS the same object); a number: the comparison
-        # of the reference's tensors, on the batch the trace is specialised to
+        # two traced values: as a Python truth value, identity (nodes are hash-consed: the same structure IS the same object --
+        # what `in` / dict lookups of this module rely on); as the condition of functional.where, the per-point comparison.
+        # A number: the comparison of the reference's tensors, on the batch the trace is specialised to
         if isinstance(o, Sym):
-            return self is o
+            return _IdentityAnswer(self is o, self, o, "eq")
         return self._compare(o, np.equal, "eq")
 
     def __ne__(self, o):
         if isinstance(o, Sym):
-            return self is not o
-        if _TRACE.values is None and isinstance(o, (int, float, np.floating, np.integer)):
-            return self._compare(o, np.not_equal, "ne")
-        r = self.__eq__(o)
-        return r if r is NotImplemented else (not r if isinstance(r, bool) else ~r)
+            return _IdentityAnswer(self is not o, self, o, "ne")
+        return self._compare(o, np.not_equal, "ne")
 
     __hash__ = object.__hash__
 
@@ -219,6 +229,83 @@ class Sym:
 # reference takes on every step, and the trace stays a per-point program for the kernels.  Values that depend on the
 # network (they change as it trains) still raise.  `_TRACE.concretized` records what was asked, so that the caller can
 # refuse to reuse such a trace for a batch with other values.
+class _IdentityAnswer:
+    """`symA == symB` / `symA != symB`: truthy by node identity; `.indicator()` is the traced per-point comparison."""
+    __slots__ = ("_ans", "_a", "_b", "_what")
+
+    def __init__(self, ans: bool, a: "Sym", b: "Sym", what: str):
+        self._ans, self._a, self._b, self._what = bool(ans), a, b, what
+
+    def __bool__(self):
+        return self._ans
+
+    def __eq__(self, other):
+        return self._ans == bool(other)
+
+    def __hash__(self):
+        return hash(self._ans)
+
+    def __repr__(self):
+        return repr(self._ans)
+
+    def indicator(self) -> "Sym":
+        return self._a._indicator(self._b, self._what)
+
+
+class _BatchMask(np.ndarray):
+    """The per-point answers of a comparison on the fixed batch of a static constraint (a bool array), which also
+    remembers the comparison: `functional.where` takes the traced indicator instead of the values."""
+
+    def __new__(cls, values: np.ndarray, a: "Sym", b, what: str):
+        obj = np.asarray(values, dtype=bool).view(cls)
+        obj._cmp = (a, b, what)
+        obj._noted = False
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._cmp = getattr(obj, "_cmp", None)
+        self._noted = getattr(obj, "_noted", True)
+
+    def _note(self):
+        if not self._noted and self._cmp is not None:
+            a, _, what = self._cmp
+            v = np.asarray(self)
+            _TRACE.concretized.append(f"{what}({a!r}) = {int(v.sum())} of {v.size} true, crc {zlib.crc32(np.packbits(v).tobytes()):08x}")
+            self._noted = True
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        for x in inputs:
+            if isinstance(x, _BatchMask):
+                x._note()
+        inputs = tuple(np.asarray(x) if isinstance(x, _BatchMask) else x for x in inputs)
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        self._note()
+        strip = lambda x: np.asarray(x) if isinstance(x, _BatchMask) else x  # noqa: E731
+        return func(*[strip(a) for a in args], **{k: strip(v) for k, v in kwargs.items()})
+
+    def __getitem__(self, key):
+        self._note()
+        return np.asarray(self)[key]
+
+    def __bool__(self):
+        self._note()
+        return bool(np.asarray(self))
+
+    def __iter__(self):
+        self._note()
+        return iter(np.asarray(self))
+
+    def tolist(self):
+        self._note()
+        return np.asarray(self).tolist()
+
+    def indicator(self) -> "Sym":
+        a, b, what = self._cmp
+        return a._indicator(b, what)
+
+
 class _TraceState:
     values: Optional[Dict[str, np.ndarray]] = None
     concretized: List[str] = []

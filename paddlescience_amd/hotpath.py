@@ -160,8 +160,9 @@ def taylor_bwd(desc: L.MlpDesc, params: torch.Tensor, inputs: Sequence[torch.Ten
     _require_device(params)
     _chk_f32(params, Ubar, grad_partials, *inputs)
     ptrs = L.ptr_array([t.data_ptr() for t in inputs])
-    L.check(L.lib().ppsci_taylor_bwd(C.byref(desc), _p(params), n, ptrs, _p(Ubar), _p(stash), _p(workspace),
-                                     _p(grad_partials), _stream_ptr(params)))
+    # (the checked form: the workspace was sized under the kernel-choice knobs of THAT moment, csrc/taylor_api.hip)
+    L.check(L.lib().ppsci_taylor_bwd_ws(C.byref(desc), _p(params), n, ptrs, _p(Ubar), _p(stash), _p(workspace),
+                                        workspace.numel() * workspace.element_size(), _p(grad_partials), _stream_ptr(params)))
 
 
 def taylor_step_workspace_bytes(desc: L.MlpDesc, edesc: L.EpilogueDesc, n: int) -> int:
@@ -223,11 +224,16 @@ class StepPlan:
         # skips the weight-split launch when NOTHING has written the parameters in between: no kernel of this module
         # (param_writes counts adam_step / optim_step / the re-parametrisation kernels / other plans' fused Adam) and no torch
         # operation (the tensor's version counter).  Anything else makes the library split again.
-        keep = self._frag_token is not None and self._frag_token == (_PARAM_WRITES[0], self._params._version)
+        # Never while a HIP graph is being captured: a captured sequence is replayed after optimizer steps this host code
+        # does not see, so the split launch must be part of every captured step.
+        capturing = self._params.is_cuda and torch.cuda.is_current_stream_capturing()
+        keep = (not capturing and self._frag_token is not None
+                and self._frag_token == (_PARAM_WRITES[0], self._params._version))
         L.check(self._run(self.handle, 1 if accumulate else 0, aa, _stream_ptr(self._dev), L.STEP_KEEP_FRAGMENTS if keep else 0))
         if adam is not None:
             note_param_write()
-        self._frag_token = (_PARAM_WRITES[0], self._params._version)
+        # a captured launch has not run: whatever replays it later leaves no trace here, so the next eager run splits again
+        self._frag_token = None if capturing else (_PARAM_WRITES[0], self._params._version)
 
     def apply_adam(self, adam: dict) -> None:
         """Data parallelism: Adam from the finished (all-reduced) gradient of the plan + the fragments of the updated hidden
@@ -236,7 +242,8 @@ class StepPlan:
                         adam.get("grad_scale", 1.0), adam["t"])
         L.check(L.lib().ppsci_taylor_step_plan_apply(self.handle, C.byref(aa), _stream_ptr(self._dev)))
         note_param_write()
-        self._frag_token = (_PARAM_WRITES[0], self._params._version)
+        capturing = self._params.is_cuda and torch.cuda.is_current_stream_capturing()
+        self._frag_token = None if capturing else (_PARAM_WRITES[0], self._params._version)
 
     @property
     def static_program(self) -> str:

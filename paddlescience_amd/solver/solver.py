@@ -6,8 +6,8 @@ What differs by design: every constraint is compiled ONCE into (Taylor-mode stre
 program) and a training iteration is a fixed sequence of kernel launches (engine.Engine); loss values
 are only read back (one device->host sync) every `log_freq` iterations, whereas the reference syncs on
 `.item()` for every loss term of every iteration (expression.py:122, train.py:145).
-Not supported (raise): AMP, loss aggregators other than Sum, to_static,
-visualizers."""
+Visualizers (`visualizer=`, `visualize()`) evaluate their expressions through `predict` and hand the arrays to
+`ppsci.visualize`'s writers.  Not supported (raise): AMP, to_static, loss aggregators other than Sum / GradNorm / NTK."""
 from __future__ import annotations
 
 import datetime
@@ -86,8 +86,6 @@ class Solver:
         if loss_aggregator is not None and not (isinstance(loss_aggregator, mtl.Sum)
                                                 or getattr(loss_aggregator, "per_loss_grad", False)):
             raise NotImplementedError("loss aggregators on the fused path: Sum, GradNorm, NTK")
-        if visualizer:
-            raise NotImplementedError("visualizers are out of scope of the hot path")
         self.cfg = cfg
         self.model = model
         self.constraint = constraint
@@ -252,7 +250,9 @@ class Solver:
         except (NotImplementedError, TypeError) as e:
             # the expressions are not a per-point program (arithmetic on row windows, tensor methods that reduce over the
             # batch, control flow on values that change every step, a derivative set beyond the instantiated stream sets
-            # ...): refused with the reason -- there is no op-by-op fallback
+            # ...): refused with the reason -- there is no op-by-op fallback.  The other ranks are waiting in the collective
+            # of _check_trace_decisions: take part in it (it raises there as well), then raise the reason of this rank
+            self._check_trace_decisions(name, None, f"{type(e).__name__}: {e}")
             raise NotImplementedError(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e})") from e
         if cc.specialised_to:
             logger.info(f"constraint {name}: traced for the values of its (fixed) batch: {', '.join(cc.specialised_to)}")
@@ -380,6 +380,8 @@ class Solver:
                     save_load.save_checkpoint(self.model, self.optimizer, self.best_metric, None, self.output_dir,
                                               "best_model", self.equation, aggregator=self.loss_aggregator)
                 logger.info(f"[Eval][Epoch {epoch_id}][best metric: {self.best_metric['metric']}]")
+                if self.visualizer is not None:  # "visualize after evaluation" (solver.py:602-604)
+                    self.visualize(epoch_id)
             if self.save_freq > 0 and epoch_id % self.save_freq == 0:
                 save_load.save_checkpoint(self.model, self.optimizer, {"metric": cur_metric, "epoch": epoch_id}, None,
                                           self.output_dir, f"epoch_{epoch_id}", self.equation, aggregator=self.loss_aggregator)
@@ -431,7 +433,7 @@ class Solver:
         if self._reparam:
             self.model.materialize()
 
-    def _check_trace_decisions(self, name: str, cc) -> None:
+    def _check_trace_decisions(self, name: str, cc, failure: Optional[str] = None) -> None:
         """Python control flow on the values of a fixed batch is followed at trace time (graph.batch_values).  Under data
         parallelism every rank traces on ITS shard: the ranks must end up with the SAME program (residual program, loss terms,
         derivative streams), otherwise they would train different programs against one all-reduced gradient without anybody
@@ -443,9 +445,18 @@ class Solver:
         dist = torch.distributed
         if self.world_size <= 1 or not dist.is_available() or not dist.is_initialized():
             return
-        mine = (zlib.crc32(bytes(cc.fused.edesc)), repr(cc.fused.streams), list(cc.specialised_to))
+        if cc is None:  # this rank's trace raised: say so to everybody instead of leaving them in the collective
+            mine = (None, None, [], failure or "trace failed")
+        else:
+            mine = (zlib.crc32(bytes(cc.fused.edesc)), repr(cc.fused.streams), list(cc.specialised_to), None)
         everyone = [None] * dist.get_world_size()
         dist.all_gather_object(everyone, mine)
+        failed = [(r, e[3]) for r, e in enumerate(everyone) if e[3] is not None]
+        if failed:
+            if cc is None:
+                return  # the caller raises this rank's own reason
+            raise NotImplementedError(f"constraint {name}: not lowerable on rank {failed[0][0]} ({failed[0][1]}); its shard takes "
+                                      "a path through the expressions that this rank's shard does not")
         if any(e[:2] != everyone[0][:2] for e in everyone):
             odd = next(r for r, e in enumerate(everyone) if e[:2] != everyone[0][:2])
             msg = (f"constraint {name}: the expressions branch on values of the batch and ranks 0 and {odd} took different "
@@ -718,8 +729,31 @@ class Solver:
             return {k: v.detach().cpu().numpy() for k, v in pred.items()}
         return pred
 
-    def visualize(self, epoch_id: int = 0):
-        raise NotImplementedError("visualizers are out of scope of the hot path")
+    def visualize(self, epoch_id: Optional[int] = None):
+        """solver.py:713-727 + visu.py:32-101: every visualizer's expressions on its own points (the compiled forward of
+        `predict`, in chunks of the visualizer's batch size), written by rank 0 under `<output_dir>/visual[/epoch_<n>]/`."""
+        if not self.visualizer:
+            raise ValueError("Solver.visualize needs at least one visualizer")
+        for vis in self.visualizer.values():
+            inputs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                      for k, v in vis.input_dict.items()}
+            # visu.py:50-58 slices every column by the batch window of the FIRST one, so a column of another length (the "sdf"
+            # that sample_initial_interior leaves in ldc2d_unsteady_Re10.py's hand-collated points) never reaches the model
+            n = len(next(iter(inputs.values())))
+            pred = self.predict({k: v for k, v in inputs.items() if len(v) == n}, vis.output_expr, batch_size=vis.batch_size,
+                                return_numpy=True)
+            if self.rank == 0:
+                visual_dir = os.path.join(self.output_dir, "visual")
+                if epoch_id:
+                    visual_dir = os.path.join(visual_dir, f"epoch_{epoch_id}")
+                os.makedirs(visual_dir, exist_ok=True)
+                data = {k: np.asarray(v, dtype=np.float32) for k, v in inputs.items()}
+                data.update({k: np.asarray(v, dtype=np.float32) for k, v in pred.items()})
+                vis.save(os.path.join(visual_dir, vis.prefix), data)
+        if isinstance(epoch_id, int):
+            logger.info(f"[Visualize][Epoch {epoch_id}] Finish visualization")
+        else:
+            logger.info("[Visualize] Finish visualization")
 
     def export(self, *args, **kwargs):
         raise NotImplementedError("inference export (paddle.inference / ONNX) is out of scope")

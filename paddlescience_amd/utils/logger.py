@@ -23,8 +23,22 @@ def _rank() -> int:
     return int(os.environ.get("RANK", "0"))
 
 
-def init_logger(name: str = "ppsci", log_file: Optional[str] = None, log_level: int = logging.INFO) -> None:
+def _level(log_level) -> int:
+    """logger.py:84-85: a level may be given by name in any case ("info", "DEBUG", "message")."""
+    if isinstance(log_level, str):
+        name = log_level.upper()
+        if name == "MESSAGE":
+            return MESSAGE
+        lvl = getattr(logging, name, None)
+        if not isinstance(lvl, int):
+            raise ValueError(f"unknown log level {log_level!r}")
+        return lvl
+    return int(log_level)
+
+
+def init_logger(name: str = "ppsci", log_file: Optional[str] = None, log_level=logging.INFO) -> None:
     global _logger
+    log_level = _level(log_level)
     _logger = logging.getLogger(name)
     _logger.handlers.clear()
     _logger.setLevel(log_level if _rank() == 0 else logging.ERROR)
@@ -46,7 +60,7 @@ def _get() -> logging.Logger:
 
 
 def set_log_level(level):
-    _get().setLevel(level)
+    _get().setLevel(_level(level))
 
 
 def debug(msg, *args):

@@ -261,3 +261,33 @@ def test_third_order_mixed_derivative_values(tmp_path):
             assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5, (k, np.linalg.norm(a - b) / np.linalg.norm(b))
     finally:
         _lib._inject_for_tests(None)
+
+
+def test_where_on_a_static_batch_and_on_two_traced_values():
+    """with the values of a FIXED batch behind the trace (what the Solver gives a full, unshuffled constraint)
+    `d["bc"] == 1` is a bool array for Python -- and must still be a traced condition for `functional.where`; and
+    `where(symA == symB, ...)` compares per point instead of silently taking the `y` branch (identity of the two nodes)."""
+    import paddlescience_amd.functional as Fn
+
+    m = _mlp(("x", "bc"), ("u",))
+    bc = np.array([0, 1, 1, 2, 0, 1], np.float32).reshape(-1, 1)
+    batch = {"x": np.linspace(0, 1, 6, dtype=np.float32).reshape(-1, 1), "bc": bc}
+    exprs = {"sel": lambda d: Fn.where(d["bc"] == 1, jacobian(d["u"], d["x"]), d["u"]),
+             "same": lambda d: Fn.where(d["x"] == d["bc"], d["u"], d["x"])}
+    free = cp.trace_exprs(m, ("x", "bc"), exprs, (), None, [])
+    fixed = cp.trace_exprs(m, ("x", "bc"), exprs, (), batch, [])
+    for k in exprs:
+        assert repr(fixed[k]) == repr(free[k]), k  # the same per-point program with or without the batch behind it
+        assert "heaviside" in repr(fixed[k])
+    # ... and nothing was specialised to the batch by handing the mask to where()
+    with graph.batch_values(batch) as tr:
+        d = {"x": graph.Sym.input("x"), "bc": graph.Sym.input("bc")}
+        mask = d["bc"] == 1
+        Fn.where(mask, d["x"], d["bc"])
+        assert tr.concretized == []
+        assert mask.tolist() == [[False], [True], [True], [False], [False], [True]] or list(np.asarray(mask).ravel()) == [False, True, True, False, False, True]
+        assert tr.concretized  # LOOKING at the values does specialise the trace (and is recorded for the rank check)
+    # truthiness of sym == sym stays node identity (hash-consing, `in` on lists of nodes)
+    a = graph.Sym.input("x")
+    assert (a == a) and not (a == graph.Sym.input("bc")) and (a != graph.Sym.input("bc"))
+    assert a in [graph.Sym.input("bc"), a]
