@@ -123,6 +123,8 @@ typedef struct ppsci_residual {
   int32_t area;    /* aux index of the "area" array (mse.py:92-93), or -1       */
   float scale;
   int32_t kind;    /* PPSCI_LOSS_*: how a point's difference d = v - label enters the sum */
+  int32_t scale_param; /* 0: none; k + 1: `scale` is multiplied by the DEVICE value eq_params[PPSCI_MAX_EPARAM + k]
+                          (ppsci_epilogue_params; the adjoint of a batch reduction, see PPSCI_LOSS_LINEAR) */
 } ppsci_residual;
 /* per-point term, W = weight * area (1 when absent):
  *   MSE      scale * W * d^2          MSELoss            loss/mse.py:82-105
@@ -133,6 +135,11 @@ typedef struct ppsci_residual {
 #define PPSCI_LOSS_ABS 1
 #define PPSCI_LOSS_SQRTABS 2
 #define PPSCI_LOSS_ABSREL 3
+/*   LINEAR   scale * W * d            a plain (weighted) batch sum: how `tensor.mean()` / `.sum()` inside a user expression
+ *            (utils/expression.py:96-102 runs arbitrary tensor code) is evaluated -- the sum of a first pass lands in a slot of
+ *            the second pass's eq_params -- and how its adjoint reaches the points: a third pass seeds the summand with
+ *            scale * eq_params[PPSCI_MAX_EPARAM + k] (`scale_param`).  ppsci_epilogue_params only (not the one-launch steps). */
+#define PPSCI_LOSS_LINEAR 4
 
 typedef struct ppsci_epilogue_desc {
   int32_t n_instr;
@@ -210,7 +217,8 @@ int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* 
                    float* loss_partials, void* stream);
 
 /* ppsci_epilogue for programs that read learnable equation parameters (PPSCI_OP_LD_PARAM; e.g. the damping and
- * stiffness exponents of equation/pde/viv.py:41-62): eq_params: [PPSCI_MAX_EPARAM] current values (broadcast over
+ * stiffness exponents of equation/pde/viv.py:41-62): eq_params: [PPSCI_MAX_EPARAM] current values (+ a second block of
+ * PPSCI_MAX_EPARAM term multipliers when a residual sets `scale_param`) (broadcast over
  * the points, as ParameterNode.forward does); eq_param_partials: [ppsci_epilogue_partial_rows(N), PPSCI_MAX_EPARAM]
  * receiving per-block sums of d(sum_k loss_k)/d(param) (NULL when Ubar is NULL); summed with ppsci_reduce_rows. */
 int ppsci_epilogue_params(const ppsci_epilogue_desc* e, int64_t n_points, const float* const* inputs_host,

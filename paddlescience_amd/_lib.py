@@ -82,7 +82,7 @@ class Instr(C.Structure):
 
 class Residual(C.Structure):
     _fields_ = [("value", C.c_int32), ("label", C.c_int32), ("weight", C.c_int32), ("area", C.c_int32),
-                ("scale", C.c_float), ("kind", C.c_int32)]
+                ("scale", C.c_float), ("kind", C.c_int32), ("scale_param", C.c_int32)]
 
 
 class EpilogueDesc(C.Structure):

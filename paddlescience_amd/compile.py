@@ -114,7 +114,7 @@ class CompiledConstraint:
                                causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None,
                                periodic=bool(getattr(loss, "periodic", False))))
         self._loss_rows = losses
-        self.low = graph.lower(outputs, losses, extra_outputs)
+        self.low = graph.lower(outputs, losses, extra_outputs, n_global=n_global)
         if getattr(loss, "periodic", False):
             if batch_size % 2:
                 raise ValueError(f"Length of output({batch_size}) should be even.")  # mse.py:326-329
@@ -158,6 +158,11 @@ class CompiledConstraint:
             from .equation.pde.base import EqParamStore
 
             self.fused.set_eq_params(EqParamStore.get())
+        if self.low.reductions:
+            if self.low.periodic or self.low.causal or self._row_slices:
+                raise NotImplementedError("batch reductions together with a periodic / causal loss or row-sliced outputs")
+            red = self.low.reductions
+            self.fused.set_reductions(red["p1"].build(), red["p3"].build(), red["k"])
         if self.low.periodic:
             self.fused.set_periodic(self.low.periodic)
         if self.low.causal:

@@ -328,7 +328,8 @@ extern "C" int ppsci_epilogue_losses(const ppsci_epilogue_desc* e, int64_t n_poi
   for (int k = 0; k < e->n_res; ++k) {
     const ppsci_residual& r = e->res[k];
     if (r.value < 0 || r.value >= e->n_instr || r.label >= e->n_aux || r.weight >= e->n_aux || r.area >= e->n_aux ||
-        r.kind < PPSCI_LOSS_MSE || r.kind > PPSCI_LOSS_ABSREL) {
+        r.kind < PPSCI_LOSS_MSE || r.kind > PPSCI_LOSS_LINEAR || r.scale_param < 0 || r.scale_param > PPSCI_MAX_EPARAM ||
+        (r.scale_param > 0 && !eq_params)) {
       ppsci_set_error("epilogue: bad residual %d", k);
       return PPSCI_E_INVALID;
     }

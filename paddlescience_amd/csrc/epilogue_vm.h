@@ -88,7 +88,7 @@ static inline int epi_fast_encode(const ppsci_epilogue_desc& e, unsigned* out, i
     }
   }
   for (int k = 0; k < e.n_res; ++k)
-    if (e.res[k].kind != PPSCI_LOSS_MSE) return -1;
+    if (e.res[k].kind != PPSCI_LOSS_MSE || e.res[k].scale_param != 0) return -1;
   int n = 0;
   for (int i = 0; i < e.n_instr; ++i) {
     const ppsci_instr& ins = e.prog[i];
@@ -295,12 +295,18 @@ __device__ __forceinline__ void epi_point(const EpiArgs& a, float* const vp, flo
       if (rs.area >= 0 && rs.kind != PPSCI_LOSS_ABSREL) w *= arel;
       const float diff = rv - lab;
       if (valid) {
+        // (scale_param: a multiplier that lives on the device -- the adjoint of a batch reduction, ppsci_hip.h)
+        const float tscale = rs.scale_param > 0 ? rs.scale * a.ep[PPSCI_MAX_EPARAM + rs.scale_param - 1] : rs.scale;
         if (rs.kind == PPSCI_LOSS_MSE) {
-          w *= rs.scale;
+          w *= tscale;
           lsum[k] += w * diff * diff;
           ap[(rs.value) * RS] += 2.f * w * diff;
+        } else if (rs.kind == PPSCI_LOSS_LINEAR) {
+          w *= tscale;
+          lsum[k] += w * diff;
+          ap[(rs.value) * RS] += w;
         } else {
-          float f = rs.scale * (rs.kind == PPSCI_LOSS_SQRTABS ? sqrtf(w) : w);
+          float f = tscale * (rs.kind == PPSCI_LOSS_SQRTABS ? sqrtf(w) : w);
           if (rs.kind == PPSCI_LOSS_ABSREL) f /= fabsf(lab);
           lsum[k] += f * fabsf(diff);
           ap[(rs.value) * RS] += diff > 0.f ? f : (diff < 0.f ? -f : 0.f);

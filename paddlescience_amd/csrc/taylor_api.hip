@@ -444,6 +444,11 @@ static int fill_step(StepArgs& a, const ppsci_mlp_desc* d, const ppsci_epilogue_
       ppsci_set_error("taylor_step: learnable equation parameters take the separate launches");
       return PPSCI_E_UNSUPPORTED;
     }
+  for (int k = 0; k < e->n_res; ++k)
+    if (e->res[k].kind == PPSCI_LOSS_LINEAR || e->res[k].scale_param != 0) {
+      ppsci_set_error("taylor_step: batch sums (PPSCI_LOSS_LINEAR / scale_param) take the separate launches");
+      return PPSCI_E_UNSUPPORTED;
+    }
   a.e.e = *e;
   epi_fill_loads(a.e);
   a.e.N = n_points;

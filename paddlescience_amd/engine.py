@@ -110,6 +110,38 @@ class FusedConstraint:
         self.eq_store = store
         self.eq_partials = torch.zeros((self.loss_rows, L.MAX_EPARAM), dtype=torch.float32, device=self.U.device)
 
+    def set_reductions(self, p1: L.EpilogueDesc, p3: L.EpilogueDesc, k: int) -> None:
+        """Batch reductions in the expressions (graph.Sym.mean / .sum, graph.lower): `p1` sums the k summands (LINEAR terms),
+        the residual program reads the sums from parameter slots 0..k-1, `p3` is the residual program + the k summands seeded
+        with dL/dR_k.  red_values = [R_0..7 | dL/dR_0..7] on the device; nothing of it ever visits the host."""
+        f32 = dict(dtype=torch.float32, device=self.U.device)
+        self.reductions = dict(p1=p1, p3=p3, k=k)
+        self.red_values = torch.zeros(2 * L.MAX_EPARAM, **f32)
+        self.red_partials = torch.zeros((self.loss_rows, L.MAX_EPARAM), **f32)
+        self._red_l1 = torch.zeros((self.loss_rows, k), **f32)
+        self._red_l3 = torch.zeros((self.loss_rows, max(1, p3.n_res)), **f32)
+        self._red_p3 = torch.zeros((self.loss_rows, L.MAX_EPARAM), **f32)  # (pass 3's own parameter adjoints: not used)
+
+    def _forward_reductions(self, train: bool) -> None:
+        """Three launches of the epilogue VM around two fixed-order row sums (see set_reductions); under data parallelism
+        the sums and their adjoints are all-reduced (SUM): a mean is over the GLOBAL batch, as the loss is."""
+        rd, k, n = self.reductions, self.reductions["k"], self.n
+        dist = torch.distributed
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        hp.epilogue(rd["p1"], n, self.inputs, self.U, self.aux, None, None, self._red_l1)
+        hp.reduce_rows(self._red_l1, self.loss_rows, k, self.red_values[:k], False)
+        if multi:
+            dist.all_reduce(self.red_values[:k], op=dist.ReduceOp.SUM)
+        hp.epilogue(self.edesc, n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None, self.loss_partials,
+                    self.red_values, self.red_partials if train else None)
+        hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)
+        if not train:
+            return
+        hp.reduce_rows(self.red_partials, self.loss_rows, L.MAX_EPARAM, self.red_values[L.MAX_EPARAM:], False)
+        if multi:
+            dist.all_reduce(self.red_values[L.MAX_EPARAM:], op=dist.ReduceOp.SUM)
+        hp.epilogue(rd["p3"], n, self.inputs, self.U, self.aux, None, self.Ubar, self._red_l3, self.red_values, self._red_p3)
+
     def set_causal(self, rows: Sequence[tuple], n_chunks: int, tol: float) -> None:
         """CausalMSELoss (mse.py:109-189): rows = (residual row, label aux, weight aux, area aux, factor aux)."""
         self.causal, self.n_chunks, self.tol = list(rows), n_chunks, tol
@@ -129,6 +161,8 @@ class FusedConstraint:
                 continue
             hp.taylor_fwd(nt["desc"], params[nt["off"]:nt["off"] + nt["layout"].n_params], nt["inputs"], nt["U"],
                           nt["stash"] if train else None, self.n)
+        if getattr(self, "reductions", None):
+            return self._forward_reductions(train)
         if getattr(self, "causal", None):
             # first pass: the per-point values only; then the causal factor of every key from its window means
             # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
@@ -205,7 +239,7 @@ class FusedConstraint:
                     self._step_ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.U.device)
             self._one_launch = ok
         return (ok and not getattr(self, "causal", None) and not getattr(self, "periodic", None)
-                and getattr(self, "eq_store", None) is None)
+                and getattr(self, "eq_store", None) is None and not getattr(self, "reductions", None))
 
     def one_launch_wins(self, max_points_single_wave: int) -> bool:
         """one_launch_ready() and the one-launch kernel is the faster path at this batch size: the fused tile kernel

@@ -80,4 +80,13 @@ def where(cond, x, y):
     return np.where(cond, x, y)
 
 
-__all__ = sorted(list(_TORCH) + ["maximum", "minimum", "pow", "atan2", "where"])
+def mean(x):
+    """paddle.mean(x) over the whole batch: one scalar, broadcast where it is used (traced: graph.Sym.mean)."""
+    return x.mean() if isinstance(x, (Sym, torch.Tensor)) else np.mean(x)
+
+
+def sum(x):  # noqa: A001
+    return x.sum() if isinstance(x, (Sym, torch.Tensor)) else np.sum(x)
+
+
+__all__ = sorted(list(_TORCH) + ["maximum", "minimum", "pow", "atan2", "where", "mean", "sum"])

@@ -210,6 +210,25 @@ class Sym:
             return Sym("rows", comp=(key.start or 0, key.stop), args=(self,))
         raise TypeError("a traced expression can only be indexed by a row x[k] or a contiguous row slice x[a:b]")
 
+    # ---- batch reductions (tensor.mean() / .sum() in a user expression: utils/expression.py:96-102 runs arbitrary tensor code)
+    def _reduce(self, op: str, axis, keepdim) -> "Sym":
+        if axis not in (None, 0, (0,), [0], (0, 1), [0, 1]):
+            raise NotImplementedError(f"{op}(axis={axis!r}) of a traced [N, 1] value: only the reduction over the batch")
+        if self.kind == "rows":
+            raise TypeError("a batch reduction of a row slice is not lowered (reduce the whole column)")
+        if self.kind == "reduce" or (op == "mean" and self.kind == "const"):
+            return self  # (already one scalar for the whole batch)
+        return Sym("reduce", op=op, args=(self,))
+
+    def mean(self, axis=None, keepdim=False):
+        """One scalar for the whole batch (broadcast back over the points wherever it is used).  Lowered as a two-pass
+        program (graph.lower): the sum is taken by a first launch and read as a parameter slot by the residual program;
+        its adjoint is carried back to every point by a third launch.  Over the GLOBAL batch under data parallelism."""
+        return self._reduce("mean", axis, keepdim)
+
+    def sum(self, axis=None, keepdim=False):  # noqa: A003
+        return self._reduce("sum", axis, keepdim)
+
     def sin(self): return apply("sin", self)
     def cos(self): return apply("cos", self)
     def tanh(self): return apply("tanh", self)
@@ -352,6 +371,9 @@ def concrete_values(s: "Sym", what: str = "value") -> np.ndarray:
     if s.kind == "rows":
         a, b = s.comp
         return concrete_values(s.args[0], what)[a:b]
+    if s.kind == "reduce":
+        v = concrete_values(s.args[0], what).astype(np.float32)
+        return np.asarray(v.mean(dtype=np.float32) if s.op == "mean" else v.sum(dtype=np.float32), dtype=np.float32).reshape(1)
     if s.kind == "op" and s.op in _NUMPY_OPS:
         with np.errstate(all="ignore"):
             return np.asarray(_NUMPY_OPS[s.op](*[concrete_values(a, what) for a in s.args]), dtype=np.float32)
@@ -457,6 +479,9 @@ def diff(e: Sym, var: str) -> Sym:
         return Sym.const(1.0 if e.name == var else 0.0)
     if k in ("const", "param"):
         return Sym.const(0.0)
+    if k == "reduce":
+        raise NotImplementedError(f"derivative of the batch reduction {e!r} w.r.t. the per-point variable {var!r}: differentiate "
+                                  "first, reduce afterwards")
     if k == "net":
         if var not in net_raw_vars(e.model):
             return Sym.const(0.0)
@@ -566,16 +591,31 @@ class Lowered:
         self.causal: List[tuple] = []
         self.periodic: List[tuple] = []
         self.param_slots: List[int] = []  # slots of the learnable equation parameters the program reads
+        self.reductions: Optional[dict] = None  # batch reductions: {"k": count, "p1": summand program, "p3": adjoint program}
         self.nets: List[tuple] = []  # (model, StreamSpec, first U row, input indices) per network of the constraint
 
 
-def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = ()) -> Lowered:
+def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequence[str] = (),
+          n_global: Optional[int] = None) -> Lowered:
     """outputs: name -> traced expression.  losses: dicts with keys
          key (output name), label (aux name or None), weight (aux name or None), area (aux name or None), scale.
        Residual row k of the epilogue corresponds to losses[k]; `extra_outputs` are appended as
        scale-0 residual rows so that eval / predict can read their values."""
     roots = list(outputs.values())
     nodes = _walk(roots)
+    # batch reductions (Sym.mean / Sym.sum): reduction k is read from parameter slot k by the residual program
+    reduces = [n for n in nodes if n.kind == "reduce"]
+    if reduces:
+        if any(n.kind == "param" for n in nodes):
+            raise NotImplementedError("batch reductions together with learnable equation parameters (both use the parameter slots)")
+        if len(reduces) > L.MAX_EPARAM:
+            raise NotImplementedError(f"more than {L.MAX_EPARAM} batch reductions in the expressions of one constraint")
+        if any(m.kind == "reduce" for r in reduces for m in _walk([r.args[0]])):
+            raise NotImplementedError("a batch reduction inside a batch reduction (e.g. a variance written with two means): "
+                                      "one level is lowered")
+        if any(r.op == "mean" for r in reduces) and not n_global:
+            raise NotImplementedError("mean() over the batch needs the global batch size")
+    red_slot = {id(r): k for k, r in enumerate(reduces)}
     models = {id(n.model): n.model for n in nodes if n.kind == "net"}  # ModelList members: in order of appearance
     model_list = list(models.values())
     model = model_list[0] if model_list else None
@@ -705,61 +745,68 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             else:
                 pval[id(n)] = pg.op(_UNARY_OPS[n.op], pval[id(n.args[0])])
 
-    for n in nodes:
-        if n.kind == "in":
-            if n.name in input_names:
-                val[id(n)] = prog.ld_in(input_names.index(n.name))
+    def emit(prog: hp.Program, nodes, val: Dict[int, int]) -> None:
+        """The residual program of `nodes` (in dependency order) into `prog`; val: node id -> value index."""
+        for n in nodes:
+            if n.kind == "in":
+                if n.name in input_names:
+                    val[id(n)] = prog.ld_in(input_names.index(n.name))
+                else:
+                    val[id(n)] = prog.ld_aux(aux_index(n.name))
+            elif n.kind == "aux":
+                val[id(n)] = prog.ld_in(input_names.index(n.name)) if n.name in input_names else prog.ld_aux(aux_index(n.name))
+            elif n.kind == "param":
+                val[id(n)] = prog.ld_param(n.comp)
+                param_slots.add(n.comp)
+            elif n.kind == "reduce":
+                val[id(n)] = prog.ld_param(red_slot[id(n)])
+            elif n.kind == "const":
+                val[id(n)] = prog.const(n.value)
+            elif n.kind == "net":
+                c = n.comp + row0[id(n.model)] // S  # rows of a member start at a multiple of S
+                if len(n.dirs) == 0:
+                    val[id(n)] = prog.ld_u(c * S)
+                elif len(n.dirs) == 1:
+                    val[id(n)] = prog.ld_u(c * S + 1 + dir_index[n.dirs[0]])
+                else:
+                    base = {2: 1 + n1p, 3: 1 + n1p + n2p, 4: 1 + n1p + n2p + n3p}[len(n.dirs)]
+                    vs = sorted(set(n.dirs))
+                    if len(vs) == 1:
+                        val[id(n)] = prog.ld_u(c * S + base + dir_index[vs[0]])
+                    elif len(n.dirs) == 2:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
+                        a, b = sorted(n.dirs)
+                        sab = prog.ld_u(c * S + base + dir_index[(a, b)])
+                        sa = prog.ld_u(c * S + base + dir_index[a])
+                        sb = prog.ld_u(c * S + base + dir_index[b])
+                        t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, sab, sa), sb)
+                        val[id(n)] = prog.op(L.OP_MUL, prog.const(0.5), t)
+                    elif len(n.dirs) == 3:  # u_aab = (D3_{a+b} - D3_{a-b} - 2 D3_b) / 6
+                        a, b = (vs[0], vs[1]) if n.dirs.count(vs[0]) == 2 else (vs[1], vs[0])
+                        lo, hi = sorted((a, b))
+                        sp_ = prog.ld_u(c * S + base + dir_index[(lo, hi)])
+                        sm_ = prog.ld_u(c * S + base + dir_index[(lo, hi, -1.0)])  # D3 along lo - hi = +- D3 along a - b
+                        sb = prog.ld_u(c * S + base + dir_index[b])
+                        t = prog.op(L.OP_SUB if a == lo else L.OP_ADD, sp_, sm_)
+                        t = prog.op(L.OP_SUB, t, prog.op(L.OP_MUL, prog.const(2.0), sb))
+                        val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 6.0), t)
+                    else:  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
+                        a, b = vs
+                        sp_ = prog.ld_u(c * S + base + dir_index[(a, b)])
+                        sm_ = prog.ld_u(c * S + base + dir_index[(a, b, -1.0)])
+                        sa = prog.ld_u(c * S + base + dir_index[a])
+                        sb = prog.ld_u(c * S + base + dir_index[b])
+                        two = prog.const(2.0)
+                        t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, prog.op(L.OP_ADD, sp_, sm_), prog.op(L.OP_MUL, two, sa)),
+                                    prog.op(L.OP_MUL, two, sb))
+                        val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 12.0), t)
             else:
-                val[id(n)] = prog.ld_aux(aux_index(n.name))
-        elif n.kind == "aux":
-            val[id(n)] = prog.ld_in(input_names.index(n.name)) if n.name in input_names else prog.ld_aux(aux_index(n.name))
-        elif n.kind == "param":
-            val[id(n)] = prog.ld_param(n.comp)
-            param_slots.add(n.comp)
-        elif n.kind == "const":
-            val[id(n)] = prog.const(n.value)
-        elif n.kind == "net":
-            c = n.comp + row0[id(n.model)] // S  # rows of a member start at a multiple of S
-            if len(n.dirs) == 0:
-                val[id(n)] = prog.ld_u(c * S)
-            elif len(n.dirs) == 1:
-                val[id(n)] = prog.ld_u(c * S + 1 + dir_index[n.dirs[0]])
-            else:
-                base = {2: 1 + n1p, 3: 1 + n1p + n2p, 4: 1 + n1p + n2p + n3p}[len(n.dirs)]
-                vs = sorted(set(n.dirs))
-                if len(vs) == 1:
-                    val[id(n)] = prog.ld_u(c * S + base + dir_index[vs[0]])
-                elif len(n.dirs) == 2:  # polarisation: u_ab = (D2_{a+b} - D2_a - D2_b) / 2
-                    a, b = sorted(n.dirs)
-                    sab = prog.ld_u(c * S + base + dir_index[(a, b)])
-                    sa = prog.ld_u(c * S + base + dir_index[a])
-                    sb = prog.ld_u(c * S + base + dir_index[b])
-                    t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, sab, sa), sb)
-                    val[id(n)] = prog.op(L.OP_MUL, prog.const(0.5), t)
-                elif len(n.dirs) == 3:  # u_aab = (D3_{a+b} - D3_{a-b} - 2 D3_b) / 6
-                    a, b = (vs[0], vs[1]) if n.dirs.count(vs[0]) == 2 else (vs[1], vs[0])
-                    lo, hi = sorted((a, b))
-                    sp_ = prog.ld_u(c * S + base + dir_index[(lo, hi)])
-                    sm_ = prog.ld_u(c * S + base + dir_index[(lo, hi, -1.0)])  # D3 along lo - hi = +- D3 along a - b
-                    sb = prog.ld_u(c * S + base + dir_index[b])
-                    t = prog.op(L.OP_SUB if a == lo else L.OP_ADD, sp_, sm_)
-                    t = prog.op(L.OP_SUB, t, prog.op(L.OP_MUL, prog.const(2.0), sb))
-                    val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 6.0), t)
-                else:  # u_aabb = (D4_{a+b} + D4_{a-b} - 2 D4_a - 2 D4_b) / 12
-                    a, b = vs
-                    sp_ = prog.ld_u(c * S + base + dir_index[(a, b)])
-                    sm_ = prog.ld_u(c * S + base + dir_index[(a, b, -1.0)])
-                    sa = prog.ld_u(c * S + base + dir_index[a])
-                    sb = prog.ld_u(c * S + base + dir_index[b])
-                    two = prog.const(2.0)
-                    t = prog.op(L.OP_SUB, prog.op(L.OP_SUB, prog.op(L.OP_ADD, sp_, sm_), prog.op(L.OP_MUL, two, sa)),
-                                prog.op(L.OP_MUL, two, sb))
-                    val[id(n)] = prog.op(L.OP_MUL, prog.const(1.0 / 12.0), t)
-        else:
-            if n.op in _BINARY_OPS:
-                val[id(n)] = prog.op(_BINARY_OPS[n.op], val[id(n.args[0])], val[id(n.args[1])])
-            else:
-                val[id(n)] = prog.op(_UNARY_OPS[n.op], val[id(n.args[0])])
+                if n.op in _BINARY_OPS:
+                    val[id(n)] = prog.op(_BINARY_OPS[n.op], val[id(n.args[0])], val[id(n.args[1])])
+                else:
+                    val[id(n)] = prog.op(_UNARY_OPS[n.op], val[id(n.args[0])])
+
+
+    emit(prog, nodes, val)
 
     loss_keys = []
     periodic = []  # (residual row, label aux) -- Periodic*Loss: the label row receives the partner half's values
@@ -787,6 +834,26 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     low.causal = causal
     low.periodic = periodic
     low.param_slots = sorted(param_slots)
+    if reduces:
+        # pass 1: the summands alone, one LINEAR term each (scale 1 / N_global for a mean): its "loss terms" ARE the reductions
+        p1 = hp.Program(rows, len(in_keys))
+        v1: Dict[int, int] = {}
+        emit(p1, _walk([r.args[0] for r in reduces]), v1)
+        coef = [1.0 / float(n_global) if r.op == "mean" else 1.0 for r in reduces]
+        for r, c in zip(reduces, coef):
+            p1.residual(v1[id(r.args[0])], -1, -1, -1, c, hp.LOSS_LINEAR)
+        # pass 3: the residual program again + one LINEAR term per summand whose seed is c_k x dL/dR_k (a device value, written
+        # by pass 2's block sums): with R held fixed, the gradient of  L(U, R) + sum_k Rbar_k c_k sum_p v_k(p)  w.r.t. U is
+        # the gradient of the reference's loss, in which R depends on every point
+        import copy
+
+        p3 = copy.deepcopy(prog)
+        if len(p3.res) + len(reduces) > L.MAX_RES:
+            raise NotImplementedError(f"{len(p3.res)} loss terms + {len(reduces)} batch reductions exceed the {L.MAX_RES} term "
+                                      "slots of one epilogue program")
+        for k, (r, c) in enumerate(zip(reduces, coef)):
+            p3.residual(val[id(r.args[0])], -1, -1, -1, c, hp.LOSS_LINEAR, scale_param=k + 1)
+        low.reductions = {"k": len(reduces), "p1": p1, "p3": p3}
     # ---- stream programs of the input transforms: <= MAX_RES output rows per program, rows in (feature, stream) order
     pre = {}
     for mid, blocks in pre_nets.items():

@@ -286,7 +286,7 @@ def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torc
 
 
 OPT_SGD, OPT_MOMENTUM, OPT_RMSPROP, OPT_ADAMW = 0, 1, 2, 3
-LOSS_MSE, LOSS_ABS, LOSS_SQRTABS, LOSS_ABSREL = 0, 1, 2, 3
+LOSS_MSE, LOSS_ABS, LOSS_SQRTABS, LOSS_ABSREL, LOSS_LINEAR = 0, 1, 2, 3, 4
 
 
 def optim_step(kind: int, params: torch.Tensor, grad: torch.Tensor, states: Sequence[Optional[torch.Tensor]],
@@ -413,13 +413,13 @@ class Program:
         return self._emit(op, a, b, 0.0)
 
     def residual(self, value: int, label: int = -1, weight: int = -1, area: int = -1, scale: float = 1.0,
-                 kind: int = 0) -> int:
+                 kind: int = 0, scale_param: int = 0) -> int:
         if len(self.res) >= L.MAX_RES:
             raise NotImplementedError(f"more than {L.MAX_RES} loss terms in one epilogue")
         for k in (label, weight, area):
             if k >= 0:
                 self.n_aux = max(self.n_aux, k + 1)
-        self.res.append((value, label, weight, area, float(scale), int(kind)))
+        self.res.append((value, label, weight, area, float(scale), int(kind), int(scale_param)))
         return len(self.res) - 1
 
     def build(self) -> L.EpilogueDesc:
@@ -428,7 +428,7 @@ class Program:
         e.n_streams, e.n_in, e.n_aux = self.n_streams, self.n_in, self.n_aux
         for i, (op, a, b, c) in enumerate(self.instrs):
             e.prog[i].op, e.prog[i].a, e.prog[i].b, e.prog[i].c = op, a, b, c
-        for k, (v, lab, w, ar, sc, kind) in enumerate(self.res):
+        for k, (v, lab, w, ar, sc, kind, sp) in enumerate(self.res):
             r = e.res[k]
-            r.value, r.label, r.weight, r.area, r.scale, r.kind = v, lab, w, ar, sc, kind
+            r.value, r.label, r.weight, r.area, r.scale, r.kind, r.scale_param = v, lab, w, ar, sc, kind, sp
         return e

@@ -45,8 +45,8 @@ def test_struct_sizes_match_header_constants():
     from paddlescience_amd import _lib as L
 
     assert ctypes.sizeof(L.MlpDesc) == 4 * 8 + 4 * L.MAX_IN + 4 * L.MAX_IN + 4 * L.MAX_DIRS * L.MAX_IN + 8 + 8  # + n3, n4
-    assert ctypes.sizeof(L.Instr) == 16 and ctypes.sizeof(L.Residual) == 24
-    assert ctypes.sizeof(L.EpilogueDesc) == 20 + 16 * L.MAX_PROG + 24 * L.MAX_RES
+    assert ctypes.sizeof(L.Instr) == 16 and ctypes.sizeof(L.Residual) == 28
+    assert ctypes.sizeof(L.EpilogueDesc) == 20 + 16 * L.MAX_PROG + 28 * L.MAX_RES
 
 
 def test_no_cpu_fallback():

@@ -213,3 +213,46 @@ def test_fused_step_without_optional_outputs(dev):
         outs.append((grad.cpu().numpy().copy(), loss.cpu().numpy().copy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.abs(outs[0][0]).max() > 0
+
+
+@pytest.mark.gpu
+def test_captured_step_splits_its_weights_on_every_replay(monkeypatch):
+    """the fused tile step reached through the replayed HIP graph (two constraints: no one-launch step) with two
+    forward_backward calls per parameter update (gradient accumulation, update_freq = 2).  The eager warm-up call and the
+    capturing call have no parameter write between them -- a capture that KEPT the fragments of that moment would replay the
+    tile kernel on stale weights after every optimizer step.  Must train exactly like the run without graphs."""
+    device.set_device(None)
+    d = device.get_device()
+    assert d.type == "cuda"
+    lay = hp.NetLayout(2, 3, 50, 1, "tanh")
+    flat = _weights(lay, 21)
+
+    def run(graph):
+        monkeypatch.setenv("PPSCI_HIP_GRAPH", "1" if graph else "0")
+        L.lib().ppsci_set_step_tail(3)
+        try:
+            params = torch.tensor(flat, device=d)
+            eng = Engine(lay, params)
+            assert eng.use_graph == graph
+            csts = [_constraint(d, "laplace", lay, 900, 100), _constraint(d, "value", lay, 90, 101)]
+            assert all(c.one_launch_ready() and c._step_kind == hp.STEP_FUSED_TILE for c in csts)
+            assert not eng.one_launch_ready(csts)  # two constraints: forward_backward goes through StepGraph
+            grads = []
+            for step in range(6):
+                eng.forward_backward(csts)   # first of the two accumulation passes (same parameters)
+                g = eng.grad.clone()
+                eng.forward_backward(csts)
+                eng.grad.add_(g)
+                eng.optimizer_step(1e-2)
+                grads.append(eng.grad.detach().cpu().numpy().copy())
+            torch.cuda.synchronize()
+            return params.detach().cpu().numpy(), grads
+        finally:
+            L.lib().ppsci_set_step_tail(-1)
+
+    p_graph, g_graph = run(True)
+    p_eager, g_eager = run(False)
+    assert rel(p_eager, flat) > 1e-4
+    for a, b in zip(g_graph, g_eager):
+        assert rel(a, b) < 1e-5, rel(a, b)  # (stale fragments: the gradients drift apart from the second update on)
+    assert rel(p_graph, p_eager) < 1e-5
