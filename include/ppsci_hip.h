@@ -216,6 +216,14 @@ int ppsci_epilogue(const ppsci_epilogue_desc* e, int64_t n_points, const float* 
                    const float* U, const float* const* aux_host, float* residual_out, float* Ubar,
                    float* loss_partials, void* stream);
 
+/* The constant linear map of a batch-coupled residual (ppsci/equation/ide/volterra.py:66-77: `paddle.mm(int_mat, u)` between
+ * per-point expressions).  M: [rows, cols] row-major on the device.
+ *   transpose = 0:  y[i] = alpha * sum_q M[i][q] x[q]                        (i < rows; rowscale must be NULL)
+ *   transpose = 1:  y[q] = alpha * sum_i M[i][q] x[i] * rowscale[i]          (q < cols; rowscale NULL = 1)
+ * Fixed summation order. */
+int ppsci_dense_matvec(int64_t rows, int64_t cols, const float* M, const float* x, const float* rowscale, float alpha,
+                       int transpose, float* y, void* stream);
+
 /* ppsci_epilogue for programs that read learnable equation parameters (PPSCI_OP_LD_PARAM; e.g. the damping and
  * stiffness exponents of equation/pde/viv.py:41-62): eq_params: [PPSCI_MAX_EPARAM] current values (+ a second block of
  * PPSCI_MAX_EPARAM term multipliers when a residual sets `scale_param`) (broadcast over

@@ -139,6 +139,8 @@ _SYMBOLS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_taylor_bwd_ws": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ppsci_dense_matvec": (C.c_int, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
+                                     C.c_void_p]),
     "ppsci_reduce_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "ppsci_taylor_step_workspace_bytes": (C.c_int64, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_int64]),
     "ppsci_taylor_step_kind": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(EpilogueDesc), C.c_int64]),

@@ -98,6 +98,19 @@ class CompiledConstraint:
                 self._row_slices[k] = a
                 outputs[k] = v.args[0]
         weight_keys = list(weight_keys) + [k for k in self._row_slices if k not in weight_keys]
+        # Batch-coupled outputs (graph.couple: Volterra's `lhs[:N] - int_mat @ u`): the residual exists on the first R rows of
+        # the batch only -- the label / weight columns of the reference have R rows (volterra_ide.py: the dataset transform grows
+        # the INPUT to N + N Q quadrature points) and the loss is a mean over R.  Here: columns padded to the batch with a zero
+        # weight behind row R (bind), the term scale taken for R samples.
+        self._coupled: Dict[str, int] = {k: v.comp[0] for k, v in outputs.items() if isinstance(v, Sym) and v.kind == "couple"}
+        for k, v in outputs.items():
+            if k in self._coupled:
+                if v.comp[1] != batch_size or n_global != batch_size:
+                    raise NotImplementedError(f"batch-coupled output {k!r}: its matrix has {v.comp[1]} columns for a batch of "
+                                              f"{batch_size} points" + (" (single rank only)" if n_global != batch_size else ""))
+                if k not in label_keys or loss is None or getattr(loss, "term_kind", 0) != 0:
+                    raise NotImplementedError(f"batch-coupled output {k!r} is lowered as an MSELoss term")
+        weight_keys = weight_keys + [k for k in self._coupled if k not in weight_keys]
         for k in label_keys:
             if k not in outputs:
                 # a label on a raw network output (expression.py: output_dict holds the model outputs too)
@@ -109,7 +122,7 @@ class CompiledConstraint:
         for k in label_keys:
             losses.append(dict(key=k, label=LABEL_PREFIX + k, weight=(WEIGHT_PREFIX + k) if k in weight_keys else None,
                                area="area" if "area" in input_keys else None,
-                               scale=loss.term_scale(k, n_global) if loss is not None else 0.0,
+                               scale=loss.term_scale(k, self._coupled.get(k, n_global)) if loss is not None else 0.0,
                                kind=getattr(loss, "term_kind", 0) if loss is not None else 0,
                                causal=(CAUSAL_PREFIX + k) if getattr(loss, "causal", None) else None,
                                periodic=bool(getattr(loss, "periodic", False))))
@@ -153,11 +166,18 @@ class CompiledConstraint:
         if not nets:
             raise NotImplementedError("a constraint that evaluates no network has nothing to train")
         self.fused = FusedConstraint(name, nets, self.low.streams, self.low.program.build(), inputs, aux,
-                                     self.low.loss_keys, want_residual=want_values or bool(self.low.causal) or bool(self.low.periodic))
+                                     self.low.loss_keys, want_residual=(want_values or bool(self.low.causal) or bool(self.low.periodic)
+                                                                        or bool(self.low.couplings)))
         if self.low.param_slots:
             from .equation.pde.base import EqParamStore
 
             self.fused.set_eq_params(EqParamStore.get())
+        if self.low.couplings:
+            if self.low.periodic or self.low.causal or self._row_slices:
+                raise NotImplementedError("batch couplings together with a periodic / causal loss or row-sliced outputs")
+            cpl = self.low.couplings
+            mats = [torch.as_tensor(graph._COUPLE_MATS[it["name"]]).to(dev) for it in cpl["items"]]
+            self.fused.set_couplings(cpl["items"], cpl["pv"].build(), cpl["p3"].build(), mats)
         if self.low.reductions:
             if self.low.periodic or self.low.causal or self._row_slices:
                 raise NotImplementedError("batch reductions together with a periodic / causal loss or row-sliced outputs")
@@ -174,6 +194,8 @@ class CompiledConstraint:
         names = list(self.low.input_names) + list(self.low.aux_names)
         if self._row_slices:
             label, weight = self._bind_row_slices(input, dict(label or {}), dict(weight or {}))
+        if self._coupled:
+            label, weight = self._bind_coupled(dict(label or {}), dict(weight or {}))
         srcs: List[object] = []
         for i, name in enumerate(names):
             if i < len(self.low.input_names):
@@ -186,7 +208,7 @@ class CompiledConstraint:
                     srcs.append(w)  # already the effective column
                     continue
                 srcs.append(self.loss.batch_weight(w) if hasattr(self.loss, "batch_weight") else w)
-            elif name.startswith(CAUSAL_PREFIX):
+            elif name.startswith(CAUSAL_PREFIX) or name.startswith((graph.COUPLE_RHS_PREFIX, graph.COUPLE_VBAR_PREFIX)):
                 srcs.append(None)  # written on the device every step (engine.FusedConstraint.forward)
             else:
                 srcs.append(input[name])
@@ -211,6 +233,28 @@ class CompiledConstraint:
         ev = torch.cuda.Event()
         ev.record()
         self._stage_done[k] = ev
+
+    def _bind_coupled(self, label, weight):
+        """Label / weight columns of batch-coupled outputs: R rows in the reference, padded to the batch with weight 0."""
+        n = self.batch_size
+
+        def host(a, rows):
+            a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+            a = np.asarray(a, dtype=np.float32).reshape(-1)
+            if a.size == 1:
+                a = np.full(rows, a[0], np.float32)
+            if a.size != rows:
+                raise ValueError(f"a batch-coupled output has {rows} residual rows, its label / weight column {a.size}")
+            return a
+
+        for k, rows in self._coupled.items():
+            lab = np.zeros(n, np.float32)
+            if k in label:
+                lab[:rows] = host(label[k], rows)
+            w = np.zeros(n, np.float32)
+            w[:rows] = host(weight[k], rows) if weight.get(k) is not None else 1.0
+            label[k], weight[k] = lab.reshape(n, 1), w.reshape(n, 1)
+        return label, weight
 
     def _bind_row_slices(self, input, label, weight):
         """Label / weight columns of the row-sliced outputs (see __init__) and the constant part of their loss terms."""

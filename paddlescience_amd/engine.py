@@ -142,6 +142,33 @@ class FusedConstraint:
             dist.all_reduce(self.red_values[L.MAX_EPARAM:], op=dist.ReduceOp.SUM)
         hp.epilogue(rd["p3"], n, self.inputs, self.U, self.aux, None, self.Ubar, self._red_l3, self.red_values, self._red_p3)
 
+    def set_couplings(self, items: Sequence[dict], pv: L.EpilogueDesc, p3: L.EpilogueDesc, matrices: Sequence[torch.Tensor]) -> None:
+        """Batch-coupled residuals lhs[:R] - M v (graph.couple; ppsci/equation/ide/volterra.py:66-77): `pv` evaluates every v into
+        a row of `_cv`, `p3` is the residual program + one LINEAR term per coupling on v with the per-point weight column vbar."""
+        f32 = dict(dtype=torch.float32, device=self.U.device)
+        assert self.resid is not None
+        self.couplings = dict(items=list(items), pv=pv, p3=p3, M=list(matrices))
+        self._cv = torch.zeros((len(items), self.n), **f32)
+        self._cl1 = torch.zeros((self.loss_rows, len(items)), **f32)
+        self._cl3 = torch.zeros((self.loss_rows, max(1, p3.n_res)), **f32)
+
+    def _forward_couplings(self, train: bool) -> None:
+        """values of v -> rhs = M v (aux column) -> residual program (loss, dL/dU with rhs held fixed, residual rows) ->
+        vbar = -M^T (2 scale w r) (aux column) -> residual program + the LINEAR terms on v: dL/dU complete."""
+        cp, n = self.couplings, self.n
+        hp.epilogue(cp["pv"], n, self.inputs, self.U, self.aux, self._cv, None, self._cl1)
+        for j, (it, M) in enumerate(zip(cp["items"], cp["M"])):
+            hp.dense_matvec(M, self._cv[j], self.aux[it["rhs_aux"]], 1.0, False)
+        hp.epilogue(self.edesc, n, self.inputs, self.U, self.aux, self.resid, self.Ubar if train else None, self.loss_partials)
+        hp.reduce_rows(self.loss_partials, self.loss_rows, max(1, self.edesc.n_res), self.loss_terms, False)
+        if not train:
+            return
+        for it, M in zip(cp["items"], cp["M"]):
+            scale = float(self.edesc.res[it["res_row"]].scale)
+            hp.dense_matvec(M, self.resid[it["res_row"]], self.aux[it["vbar_aux"]], -2.0 * scale, True,
+                            rowscale=self.aux[it["weight_aux"]])
+        hp.epilogue(cp["p3"], n, self.inputs, self.U, self.aux, None, self.Ubar, self._cl3)
+
     def set_causal(self, rows: Sequence[tuple], n_chunks: int, tol: float) -> None:
         """CausalMSELoss (mse.py:109-189): rows = (residual row, label aux, weight aux, area aux, factor aux)."""
         self.causal, self.n_chunks, self.tol = list(rows), n_chunks, tol
@@ -163,6 +190,8 @@ class FusedConstraint:
                           nt["stash"] if train else None, self.n)
         if getattr(self, "reductions", None):
             return self._forward_reductions(train)
+        if getattr(self, "couplings", None):
+            return self._forward_couplings(train)
         if getattr(self, "causal", None):
             # first pass: the per-point values only; then the causal factor of every key from its window means
             # (constants for the reverse sweep: `.detach()`, mse.py:174); the pass below then weights with them
@@ -239,7 +268,8 @@ class FusedConstraint:
                     self._step_ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.U.device)
             self._one_launch = ok
         return (ok and not getattr(self, "causal", None) and not getattr(self, "periodic", None)
-                and getattr(self, "eq_store", None) is None and not getattr(self, "reductions", None))
+                and getattr(self, "eq_store", None) is None and not getattr(self, "reductions", None)
+                and not getattr(self, "couplings", None))
 
     def one_launch_wins(self, max_points_single_wave: int) -> bool:
         """one_launch_ready() and the one-launch kernel is the faster path at this batch size: the fused tile kernel

@@ -381,6 +381,23 @@ def concrete_values(s: "Sym", what: str = "value") -> np.ndarray:
                     "changes every step -- data-dependent Python control flow on it cannot be lowered to the fused HIP path")
 
 
+# ---- batch coupling by a constant matrix ------------------------------------------------------------------------------
+# `lhs[:len(rhs)] - paddle.mm(int_mat, v)` (ppsci/equation/ide/volterra.py:66-77): rows i < R of the batch get the residual
+# lhs_i - sum_q M[i, q] v_q, the other rows (the quadrature points) carry no residual.  Only legal as a WHOLE output expression:
+# lower() turns it into a per-point program around two small matrix-vector launches (engine.FusedConstraint._forward_couplings).
+COUPLE_RHS_PREFIX, COUPLE_VBAR_PREFIX = "__couple_rhs__", "__couple_vbar__"
+_COUPLE_MATS: Dict[str, np.ndarray] = {}
+
+
+def couple(lhs, matrix, v) -> "Sym":
+    M = np.ascontiguousarray(np.asarray(matrix, dtype=np.float32))
+    if M.ndim != 2:
+        raise ValueError(f"couple(): a [rows, batch] matrix is needed, got shape {M.shape}")
+    name = f"couple{len(_COUPLE_MATS)}_{zlib.crc32(M.tobytes()):08x}"
+    _COUPLE_MATS[name] = M
+    return Sym("couple", name=name, comp=(int(M.shape[0]), int(M.shape[1])), args=(_lift(lhs), _lift(v)))
+
+
 def _lift(v) -> Sym:
     if isinstance(v, Sym):
         return v
@@ -400,6 +417,8 @@ def apply(op: str, *args: Sym) -> Sym:
     fp32 result), so the reference's operation order is preserved."""
     if any(a.kind == "rows" for a in args):
         raise TypeError("arithmetic on a row slice of the batch is not a per-point program")
+    if any(a.kind == "couple" for a in args):
+        raise TypeError("a batch-coupled residual (graph.couple) must be the whole output expression")
     if op in _BINARY_OPS:
         a, b = args
         if op == "add":
@@ -479,6 +498,8 @@ def diff(e: Sym, var: str) -> Sym:
         return Sym.const(1.0 if e.name == var else 0.0)
     if k in ("const", "param"):
         return Sym.const(0.0)
+    if k == "couple":
+        raise NotImplementedError("derivative of a batch-coupled residual w.r.t. a per-point variable")
     if k == "reduce":
         raise NotImplementedError(f"derivative of the batch reduction {e!r} w.r.t. the per-point variable {var!r}: differentiate "
                                   "first, reduce afterwards")
@@ -591,6 +612,7 @@ class Lowered:
         self.causal: List[tuple] = []
         self.periodic: List[tuple] = []
         self.param_slots: List[int] = []  # slots of the learnable equation parameters the program reads
+        self.couplings: Optional[dict] = None  # batch couplings: {"items": [...], "pv": value program, "p3": adjoint program}
         self.reductions: Optional[dict] = None  # batch reductions: {"k": count, "p1": summand program, "p3": adjoint program}
         self.nets: List[tuple] = []  # (model, StreamSpec, first U row, input indices) per network of the constraint
 
@@ -616,6 +638,12 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         if any(r.op == "mean" for r in reduces) and not n_global:
             raise NotImplementedError("mean() over the batch needs the global batch size")
     red_slot = {id(r): k for k, r in enumerate(reduces)}
+    couples = [n for n in nodes if n.kind == "couple"]
+    if couples:
+        if reduces:
+            raise NotImplementedError("batch couplings together with batch reductions")
+        if any(id(c) not in {id(r) for r in roots} for c in couples) or any(a.kind == "couple" for n in nodes for a in n.args):
+            raise NotImplementedError("a batch-coupled residual must be the whole output expression")
     models = {id(n.model): n.model for n in nodes if n.kind == "net"}  # ModelList members: in order of appearance
     model_list = list(models.values())
     model = model_list[0] if model_list else None
@@ -760,6 +788,8 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
                 param_slots.add(n.comp)
             elif n.kind == "reduce":
                 val[id(n)] = prog.ld_param(red_slot[id(n)])
+            elif n.kind == "couple":  # lhs - (M v): the product is an aux column written between two launches
+                val[id(n)] = prog.op(L.OP_SUB, val[id(n.args[0])], prog.ld_aux(aux_index(COUPLE_RHS_PREFIX + n.name)))
             elif n.kind == "const":
                 val[id(n)] = prog.const(n.value)
             elif n.kind == "net":
@@ -809,6 +839,7 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
     emit(prog, nodes, val)
 
     loss_keys = []
+    couple_rows: Dict[str, tuple] = {}  # coupling name -> (residual row, weight aux)
     periodic = []  # (residual row, label aux) -- Periodic*Loss: the label row receives the partner half's values
     causal = []  # (residual row, label aux, weight aux, area aux, causal-factor aux) -- CausalMSELoss
     for ls in losses:
@@ -824,6 +855,17 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
             ar = cw
         if ls.get("periodic"):
             periodic.append((len(loss_keys), lab))
+        if outputs[key].kind == "couple":
+            if ls.get("kind", 0) != 0 or ls.get("causal") or ls.get("periodic") or ar >= 0 or w < 0:
+                raise NotImplementedError("a batch-coupled residual is lowered under MSELoss (no area column), with its row mask "
+                                          "as the weight column")
+            couple_rows[outputs[key].name] = (len(loss_keys), w)
+            # the term's difference d = lhs - M v - label is formed BY THE PROGRAM (the residual row then holds d, which is what
+            # the transposed product of the reverse sweep needs: vbar = -M^T (2 scale w d))
+            if lab >= 0:
+                prog.residual(prog.op(L.OP_SUB, val[id(outputs[key])], prog.ld_aux(lab)), -1, w, ar, ls.get("scale", 1.0), 0)
+                loss_keys.append(key)
+                continue
         prog.residual(val[id(outputs[key])], lab, w, ar, ls.get("scale", 1.0), ls.get("kind", 0))
         loss_keys.append(key)
     for name in extra_outputs:
@@ -854,6 +896,33 @@ def lower(outputs: Dict[str, Sym], losses: Sequence[dict], extra_outputs: Sequen
         for k, (r, c) in enumerate(zip(reduces, coef)):
             p3.residual(val[id(r.args[0])], -1, -1, -1, c, hp.LOSS_LINEAR, scale_param=k + 1)
         low.reductions = {"k": len(reduces), "p1": p1, "p3": p3}
+    if couples:
+        import copy
+
+        if any(c.name not in couple_rows for c in couples):
+            raise NotImplementedError("a batch-coupled output needs a loss term (it has no values outside its rows)")
+        # value program: v of every coupling into a row of a [C, N] buffer (scale-0 terms: values only)
+        pv = hp.Program(rows, len(in_keys))
+        vv: Dict[int, int] = {}
+        emit(pv, _walk([c.args[1] for c in couples]), vv)
+        for c in couples:
+            pv.residual(vv[id(c.args[1])], -1, -1, -1, 0.0)
+        # adjoint program: the residual program + one LINEAR term per coupling on v, weighted per point by
+        # vbar = -M^T (2 scale w r) (an aux column written between the launches): with rhs held fixed, the gradient of
+        # L(U, rhs) + sum_q vbar_q v_q  w.r.t. U is the gradient of the reference's loss, in which rhs = M v(U)
+        p3 = copy.deepcopy(prog)
+        if len(p3.res) + len(couples) > L.MAX_RES:
+            raise NotImplementedError(f"{len(p3.res)} loss terms + {len(couples)} batch couplings exceed the {L.MAX_RES} term slots")
+        items = []
+        for c in couples:
+            vb = aux_index(COUPLE_VBAR_PREFIX + c.name)
+            p3.n_aux = max(p3.n_aux, vb + 1)
+            p3.residual(val[id(c.args[1])], -1, vb, -1, 1.0, hp.LOSS_LINEAR)
+            row, w = couple_rows[c.name]
+            items.append({"name": c.name, "rows": c.comp[0], "cols": c.comp[1], "res_row": row, "weight_aux": w,
+                          "rhs_aux": aux_names.index(COUPLE_RHS_PREFIX + c.name), "vbar_aux": vb})
+        low.aux_names = aux_names
+        low.couplings = {"items": items, "pv": pv, "p3": p3}
     # ---- stream programs of the input transforms: <= MAX_RES output rows per program, rows in (feature, stream) order
     pre = {}
     for mid, blocks in pre_nets.items():

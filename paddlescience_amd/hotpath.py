@@ -270,6 +270,17 @@ def note_param_write() -> None:
     _PARAM_WRITES[0] += 1
 
 
+def dense_matvec(M: torch.Tensor, x: torch.Tensor, y: torch.Tensor, alpha: float = 1.0, transpose: bool = False,
+                 rowscale: Optional[torch.Tensor] = None) -> None:
+    """ppsci_dense_matvec: y[:rows] = alpha M x (transpose=False) or y[:cols] = alpha M^T (x * rowscale) (transpose=True)."""
+    _require_device(y)
+    _chk_f32(M, x, y, rowscale)
+    rows, cols = M.shape
+    assert x.numel() >= (rows if transpose else cols) and y.numel() >= (cols if transpose else rows)
+    L.check(L.lib().ppsci_dense_matvec(rows, cols, _p(M), _p(x), _p(rowscale), float(alpha), 1 if transpose else 0, _p(y),
+                                       _stream_ptr(y)))
+
+
 def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor, accumulate: bool) -> None:
     _require_device(out)
     _chk_f32(partials, out)

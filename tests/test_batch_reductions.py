@@ -116,3 +116,39 @@ def test_what_is_refused_says_why(dev):
         lower({"bad": lambda d: jacobian(d["u"].mean() * d["x"], d["x"])})
     low = lower({"ok": lambda d: d["u"] * d["x"].mean()})  # (a reduction of an input column is still a reduction: 1 slot)
     assert low.reductions["k"] == 1
+
+
+def test_volterra_coupled_residual_matches_autograd(dev, tmp_path):
+    """ppsci.equation.Volterra (volterra.py:66-77: lhs[:N] - int_mat @ u on the batch [points | quadrature points]) through the
+    kernels: loss and parameter gradient against float64 autograd of the same expression."""
+    torch.manual_seed(2)
+    N, Q = 6, 5
+    model = ppsci.arch.MLP(("x",), ("u",), 2, 16, "tanh")
+    eq = ppsci.equation.Volterra(0.0, N, Q, lambda x, s: np.exp(s - x), lambda out: jacobian(out["u"], out["x"]) + out["u"])
+    x = np.linspace(0.3, 2.0, N, dtype=np.float32).reshape(-1, 1)
+    xq = np.concatenate([x, eq.get_quad_points(x).reshape(-1, 1)], axis=0).astype(np.float32)
+    lab = np.linspace(-0.2, 0.3, N, dtype=np.float32).reshape(-1, 1)
+    cfg = {"dataset": {"name": "IterableNamedArrayDataset", "input": {"x": xq}, "label": {"volterra": lab}},
+           "batch_size": len(xq), "iters_per_epoch": 1}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), eq.equations, name="EQ")
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    solver = ppsci.solver.Solver(model, {"EQ": cst}, str(tmp_path), opt, epochs=1, iters_per_epoch=1)
+    cc = solver._compiled["EQ"]
+    assert cc.low.couplings and cc.specialised_to  # (the matrix was built from the values of this batch)
+    solver.engine.forward_backward([cc.fused])
+    loss = cc.fused.losses()["volterra"]
+    grad = solver.engine.grad.detach().cpu().numpy().astype(np.float64)
+
+    ps, X, u = _ref_forward(model, {"x": xq})
+    lhs = _g(u, X["x"]) + u
+    M = torch.tensor(eq._get_int_matrix(xq).astype(np.float64))
+    r = lhs[:N] - M @ u - torch.tensor(lab.astype(np.float64))
+    total = (r * r).mean()
+    gref = np.concatenate([g.detach().numpy().ravel() for g in torch.autograd.grad(total, ps)])
+    assert abs(loss / float(total.detach()) - 1.0) < 2e-5, (loss, float(total.detach()))
+    assert rel(grad, gref) < 5e-5, rel(grad, gref)
+    # a few optimizer steps move the loss down (the whole step runs: Taylor forward, five small launches, reverse, Adam)
+    solver.epochs = 25
+    solver.train()
+    solver.engine.forward_backward([cc.fused])
+    assert cc.fused.losses()["volterra"] < loss

@@ -8,7 +8,8 @@ What lowers: arithmetic / elementwise functions of the inputs, the network outpu
 the inputs (mixed: u_ab, u_aabb), `paddle.where` on input columns, one-row slices, several networks side by side (ModelList).
 What does not (raises NotImplementedError / TypeError with the reason): derivatives of PRODUCTS of network outputs taken as a whole
 (`jacobian(rho * u, x)` -- lowers: the product rule is applied symbolically); a network fed by another network's output or
-derivatives (deephpms: `model_pde` takes u, u_x, u_xx as inputs); quadrature over the batch (Volterra); batch-wide reductions.
+derivatives (deephpms: `model_pde` takes u, u_x, u_xx as inputs).  Since round 6 also lowered: batch-wide reductions
+(`u.mean()`, tests/test_batch_reductions.py) and Volterra's quadrature over other points of the batch (graph.couple).
 """
 import numpy as np
 import pytest
@@ -31,15 +32,16 @@ def _mlp(inputs, outputs):
     return ppsci.arch.MLP(tuple(inputs), tuple(outputs), 2, 16, "tanh")
 
 
-def _lower(model, exprs, input_keys, label_keys=None):
+def _lower(model, exprs, input_keys, label_keys=None, batch=None):
     loss = ppsci.loss.MSELoss("mean")
-    outputs = cp.trace_exprs(model, tuple(input_keys), exprs, (), None, [])
+    outputs = cp.trace_exprs(model, tuple(input_keys), exprs, (), batch, [])
     label_keys = list(label_keys if label_keys is not None else exprs.keys())
     for k in label_keys:
         if k not in outputs:
             outputs[k] = graph.Sym.net(model, model.output_keys.index(k))
-    losses = [dict(key=k, label=LABEL_PREFIX + k, weight=None, area=None, scale=loss.term_scale(k, 100), kind=0, causal=None,
-                   periodic=False) for k in label_keys]
+    # (a batch-coupled output carries its row mask as the weight column: compile.CompiledConstraint adds it)
+    losses = [dict(key=k, label=LABEL_PREFIX + k, weight=(cp.WEIGHT_PREFIX + k) if outputs[k].kind == "couple" else None, area=None,
+                   scale=loss.term_scale(k, 100), kind=0, causal=None, periodic=False) for k in label_keys]
     low = graph.lower(outputs, losses, ())
     return low.program.build(), low.streams
 
@@ -153,10 +155,12 @@ def case_shock_wave():  # examples/shock_wave/shock_wave.py:45-59: derivatives o
     return m, {"continuity": continuity}, ("t", "x", "y")
 
 
-def case_volterra():  # examples/ide/volterra_ide.py:48-60: u' + u feeds a quadrature over OTHER points of the batch
+def case_volterra():  # examples/ide/volterra_ide.py:48-94: u' + u against a quadrature over OTHER points of the (fixed) batch
     m = _mlp(("x",), ("u",))
-    eq = ppsci.equation.Volterra(0.0, 20, 20, lambda x, s: np.exp(s - x), lambda out: jacobian(out["u"], out["x"]) + out["u"])
-    return m, eq.equations, ("x",)
+    eq = ppsci.equation.Volterra(0.0, 12, 20, lambda x, s: np.exp(s - x), lambda out: jacobian(out["u"], out["x"]) + out["u"])
+    x = np.linspace(0.0, 5.0, 12, dtype=np.float32).reshape(-1, 1)  # [points | their quadrature points]: the dataset transform
+    batch = {"x": np.concatenate([x, eq.get_quad_points(x).reshape(-1, 1)], axis=0)}
+    return m, eq.equations, ("x",), batch
 
 
 def case_deephpms():  # examples/deephpms/burgers.py:84-99: a second network takes (u, u_x, u_xx) of the first as its INPUTS
@@ -186,7 +190,7 @@ CASES = [
     ("bubble/bubble.py (pressure)", case_bubble_poisson, "lowers"),
     ("bubble/bubble.py (stream function)", case_bubble_streamfunction, "lowers"),
     ("shock_wave/shock_wave.py", case_shock_wave, "lowers"),
-    ("ide/volterra_ide.py", case_volterra, "raises"),  # (the quadrature couples a point to OTHER points of the batch: no equation class)
+    ("ide/volterra_ide.py", case_volterra, "lowers"),  # (a batch-coupled residual: per-point programs around two matrix-vector launches)
     ("deephpms/burgers.py (+ korteweg_de_vries, kuramoto_sivashinsky, navier_stokes, schrodinger: the same structure)", case_deephpms,
      "raises"),
 ]
@@ -194,8 +198,8 @@ CASES = [
 
 def _attempt(builder):
     try:
-        model, exprs, keys = builder()
-        ed, streams = _lower(model, exprs, keys)
+        model, exprs, keys, *batch = builder()
+        ed, streams = _lower(model, exprs, keys, batch=batch[0] if batch else None)
         return "lowers", f"{ed.n_instr} instructions, {ed.n_res} terms, streams n1={len(streams.dirs)} n2={streams.n2}"
     except (NotImplementedError, TypeError, ValueError, KeyError, AttributeError, AssertionError) as e:
         return "raises", f"{type(e).__name__}: {str(e)[:160]}"
@@ -215,10 +219,10 @@ def test_inventory_has_no_unexplained_raises(capsys):
         for ex, st, det in rows:
             print(f"  f1 sweep | {ex[:58]:58s} | {st:6s} | {det}")
     lowered = sum(1 for _, st, _ in rows if st == "lowers")
-    assert lowered == 12
+    assert lowered == 13
     for ex, st, det in rows:
-        if st == "raises":  # the two structural cases of the module docstring: nothing else may fail
-            assert ("Volterra" in det) or ("input transform" in det), (ex, det)
+        if st == "raises":  # the one structural case of the module docstring: nothing else may fail
+            assert "input transform" in det, (ex, det)
 
 
 def test_third_order_mixed_derivative_values(tmp_path):
