@@ -595,6 +595,13 @@ int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
                            0 = P.  3P with the three pointers P apart interleaves the networks' rows [n][3][P], so that ONE
                            ppsci_reduce_rows(n, 3P) sums all three */, void* stream);
 
+/* Gradient rows ppsci_modmlp_bwd / _bwd_batch write per network for n points: one per 16-point tile on the MFMA tile kernel
+ * (width and d_out multiples of 16, at most 64), one per point otherwise.  The caller allocates [rows][P] (or the interleaved
+ * [rows][3][P]) and sums `rows` rows. */
+int64_t ppsci_modmlp_bwd_rows(const ppsci_modmlp_desc* d, int64_t n_points);
+/* Testing knob: 0 keeps the per-point reverse kernel for every shape (A/B, tests); read by ppsci_modmlp_bwd_rows too. */
+void ppsci_set_modmlp_tile(int on);
+
 /* ---- losses on [rows][H][W] fields (rows = batch x channels) of the operator-learning path, value and adjoint
  * (csrc/field_loss.hip).  LpLoss / H1Loss of /root/reference/examples/neuraloperator/metric.py:69-412 (p = 2, d = 2;
  * central differences :36-55, wrapping around or one-sided at the ends under fix_x / fix_y) and MSELoss on fields

@@ -210,6 +210,8 @@ _SYMBOLS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_modmlp_param_count": (C.c_int64, [C.POINTER(ModMlpDesc)]),
+    "ppsci_modmlp_bwd_rows": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
+    "ppsci_set_modmlp_tile": (None, [C.c_int]),
     "ppsci_modmlp_stash_floats": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
     "ppsci_modmlp_fwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),

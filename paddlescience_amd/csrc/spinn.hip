@@ -336,6 +336,324 @@ __global__ void __launch_bounds__(MOD_BWD_BLOCK) modmlp_bwd_kernel(ModArgs a) {
   }
 }
 
+// ---- the reverse sweep of the branch nets, 16 points per workgroup on the matrix cores -------------------------------
+// modmlp_bwd_kernel above gives every POINT a workgroup: each one stages every weight matrix for itself and writes a full
+// gradient row of its own (Helmholtz3D, 3 x 128 points on 4 x 64 nets: 26 MB of per-point rows per step, summed again by the
+// next launch; 34 us of a 100 us step).  Here a workgroup owns a 16-point TILE of one branch, in the tile model of the
+// Taylor kernels (taylor_tile.h): wave w holds feature block w of every quantity as float4 registers per stream in the C/D
+// layout of v_mfma_f32_16x16x4_f32 (lane (g, c): features 16w + 4g + r, point c), so that
+//   obar_{l-1} = W_l zbar_l          A = W_l[16w + c][16jb + 4g + r] (one float4 load per block jb, straight from L2),
+//                                    B = zbar's block jb (k-step (jb, r): every lane supplies its own register r);
+//   gW_l      = o_{l-1} zbar_l^T     contraction over (stream, point): both operands read back TRANSPOSED from two LDS
+//                                    planes [stream][feature][point] (row stride 17), 12 MFMAs per 16 x 16 block;
+// and the activation / gate adjoints are elementwise on the registers.  Bias and first-layer gradients are sums over the
+// tile's points: 4 xor-shuffles inside a 16-lane row.  One gradient row per TILE (1/16 of the rows to write and to sum).
+// Needs width and rank to be multiples of 16, at most 64; other shapes keep the per-point kernel.
+#define MODT_BLOCK 256
+#define MODT_LD 17
+
+__device__ __forceinline__ float sp_sum16(float v) {  // over the 16 lanes c of a lane group g
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__device__ __forceinline__ void sp_act_streams4(int act, const f32x4 z[3], f32x4 a[3], f32x4& d1, f32x4& d2, f32x4& d3) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float zz[3] = {z[0][r], z[1][r], z[2][r]};
+    float aa[3], e1, e2, e3;
+    sp_act_streams(act, zz, aa, e1, e2, e3);
+    a[0][r] = aa[0]; a[1][r] = aa[1]; a[2][r] = aa[2];
+    d1[r] = e1; d2[r] = e2; d3[r] = e3;
+  }
+}
+
+__device__ __forceinline__ void sp_gate4(const f32x4 a[3], const f32x4 U[3], const f32x4 V[3], f32x4 o[3]) {
+  const f32x4 D0 = U[0] - V[0], D1 = U[1] - V[1], D2 = U[2] - V[2];
+  o[0] = V[0] + a[0] * D0;
+  o[1] = V[1] + a[1] * D0 + a[0] * D1;
+  o[2] = V[2] + a[2] * D0 + 2.f * a[1] * D1 + a[0] * D2;
+}
+
+__global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) {
+  PPSCI_DYN_SMEM(sh);  // To[3][H][MODT_LD] | Tz[3][H][MODT_LD]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int H = a.d.width, L = a.d.n_hidden, R = a.d.d_out, act = a.d.activation, NB = H / 16, RB = R / 16;
+  int tile = blockIdx.x, bi = 0;
+  while (bi + 1 < a.nbatch && tile >= (a.br[bi].N + 15) / 16) { tile -= (a.br[bi].N + 15) / 16; ++bi; }
+  const ModBranch& B = a.br[bi];
+  const int N = B.N, pt0 = tile * 16, pt = pt0 + c;
+  const bool valid = pt < N;
+  const int ptc = valid ? pt : N - 1;
+  const float x = B.x[ptc];
+  const float* P = B.params;
+  const float* st = B.stash + (long long)ptc * (L + 2) * 3 * H;
+  float* G = B.partials + (long long)tile * B.pstride;
+  float* To = sh;
+  float* Tz = sh + 3 * H * MODT_LD;
+  const bool active = wave < NB;          // this wave owns feature block `wave`
+  const int f4 = 16 * wave + 4 * g;       // its lane's first feature
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 U[3], V[3], zu[3], zv[3], du1 = zero4, du2 = zero4, du3 = zero4, dv1 = zero4, dv2 = zero4, dv3 = zero4;
+  f32x4 zl[3], al[3], ol[3], d1 = zero4, d2 = zero4, d3 = zero4, ob[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) U[s] = V[s] = zu[s] = zv[s] = zl[s] = al[s] = ol[s] = ob[s] = zero4;
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      zu[s] = *(const f32x4*)&st[(0 * 3 + s) * H + f4];
+      zv[s] = *(const f32x4*)&st[(1 * 3 + s) * H + f4];
+      zl[s] = *(const f32x4*)&st[((2 + L - 1) * 3 + s) * H + f4];
+    }
+    sp_act_streams4(act, zu, U, du1, du2, du3);
+    sp_act_streams4(act, zv, V, dv1, dv2, dv3);
+    sp_act_streams4(act, zl, al, d1, d2, d3);
+    sp_gate4(al, U, V, ol);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) To[(s * H + f4 + r) * MODT_LD + c] = ol[s][r];
+  }
+  __syncthreads();
+  // ---- last_fc:  gWL[k][r] = sum_{s,p} o_s[k][p] Fbar_s[r][p]   (blocks (kb, rb) over the waves)
+  for (int b = wave; b < NB * RB; b += MODT_BLOCK / 64) {
+    const int kb = b / RB, rb = b - kb * RB;
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pp = pt0 + 4 * t + g;
+        const float av = To[(s * H + 16 * kb + c) * MODT_LD + 4 * t + g];
+        const float bv = pp < N ? B.Fbar[((long long)s * N + pp) * R + 16 * rb + c] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[a.o.wl + (16 * kb + 4 * g + r) * R + 16 * rb + c] = acc[r];
+  }
+  for (int r = tid; r < R; r += MODT_BLOCK) {  // gbL[r] = sum_p Fbar_0[r][p]
+    float sum = 0.f;
+    for (int p = 0; p < 16; ++p)
+      if (pt0 + p < N) sum += B.Fbar[((long long)pt0 + p) * R + r];
+    G[a.o.bl + r] = sum;
+  }
+  // ---- obar_s[k][p] = sum_r WL[k][r] Fbar_s[r][p]   (this wave's feature block; k-step (rb, r))
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      f32x4 acc = zero4;
+      for (int rb = 0; rb < RB; ++rb) {
+        const f32x4 aw = *(const f32x4*)&P[a.o.wl + (16 * wave + c) * R + 16 * rb + 4 * g];
+        const f32x4 fb = valid ? *(const f32x4*)&B.Fbar[((long long)s * N + pt) * R + 16 * rb + 4 * g] : zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], fb[r], acc, 0, 0, 0);
+      }
+      ob[s] = acc;
+    }
+  }
+  f32x4 Ub[3] = {zero4, zero4, zero4}, Vb[3] = {zero4, zero4, zero4};
+  for (int l = L - 1; l >= 0; --l) {
+    f32x4 zb[3] = {zero4, zero4, zero4};
+    if (active) {
+      // adjoint of the gate  o = V + a (U - V)  and of the activation streams (the per-point kernel's formulas on float4)
+      const f32x4 D0 = U[0] - V[0], D1 = U[1] - V[1], D2 = U[2] - V[2];
+      const f32x4 ab2 = ob[2] * D0;
+      const f32x4 ab1 = ob[1] * D0 + 2.f * ob[2] * D1;
+      const f32x4 ab0 = ob[0] * D0 + ob[1] * D1 + ob[2] * D2;
+      const f32x4 Db0 = ob[0] * al[0] + ob[1] * al[1] + ob[2] * al[2];
+      const f32x4 Db1 = ob[1] * al[0] + 2.f * ob[2] * al[1];
+      const f32x4 Db2 = ob[2] * al[0];
+      Ub[0] += Db0; Ub[1] += Db1; Ub[2] += Db2;
+      Vb[0] += ob[0] - Db0; Vb[1] += ob[1] - Db1; Vb[2] += ob[2] - Db2;
+      zb[2] = d1 * ab2;
+      zb[1] = d1 * ab1 + 2.f * d2 * zl[1] * ab2;
+      zb[0] = d1 * ab0 + d2 * zl[1] * ab1 + (d3 * zl[1] * zl[1] + d2 * zl[2]) * ab2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sb = sp_sum16(zb[0][r]);  // bias gradient: the sum over the tile's points
+        if (c == 0) G[a.o.b[l] + f4 + r] = sb;
+      }
+      if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sw = sp_sum16(x * zb[0][r] + zb[1][r]);  // input streams (x, 1, 0)
+          if (c == 0) G[a.o.w[0] + f4 + r] = sw;
+        }
+      }
+    }
+    if (l == 0) break;
+    f32x4 zp[3] = {zero4, zero4, zero4}, ap[3] = {zero4, zero4, zero4}, op[3] = {zero4, zero4, zero4};
+    f32x4 p1 = zero4, p2 = zero4, p3 = zero4;
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) zp[s] = *(const f32x4*)&st[((2 + l - 1) * 3 + s) * H + f4];
+      sp_act_streams4(act, zp, ap, p1, p2, p3);
+      sp_gate4(ap, U, V, op);
+    }
+    __syncthreads();  // the previous readers of the two planes are done
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          To[(s * H + f4 + r) * MODT_LD + c] = op[s][r];
+          Tz[(s * H + f4 + r) * MODT_LD + c] = zb[s][r];
+        }
+    }
+    __syncthreads();
+    // gW_l[k][j] = sum_{s,p} o_prev_s[k][p] zbar_s[j][p]   (blocks (kb, jb) over the waves)
+    for (int b = wave; b < NB * NB; b += MODT_BLOCK / 64) {
+      const int kb = b / NB, jb = b - kb * NB;
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(To[(s * H + 16 * kb + c) * MODT_LD + 4 * t + g],
+                                                     Tz[(s * H + 16 * jb + c) * MODT_LD + 4 * t + g], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G[a.o.w[l] + (16 * kb + 4 * g + r) * H + 16 * jb + c] = acc[r];
+    }
+    // obar_prev_s[k][p] = sum_j W_l[k][j] zbar_s[j][p]   (this wave's block k; zbar of block jb from the plane)
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f32x4 acc = zero4;
+        for (int jb = 0; jb < NB; ++jb) {
+          const f32x4 aw = *(const f32x4*)&P[a.o.w[l] + (16 * wave + c) * H + 16 * jb + 4 * g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], Tz[(s * H + 16 * jb + 4 * g + r) * MODT_LD + c], acc, 0, 0, 0);
+        }
+        ob[s] = acc;
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { zl[s] = zp[s]; al[s] = ap[s]; }
+      d1 = p1; d2 = p2; d3 = p3;
+    }
+  }
+  // embeddings: U = act(zu), V = act(zv) with streams (x w + b, w, 0)
+  if (active) {
+    f32x4 t0 = du1 * Ub[0] + du2 * zu[1] * Ub[1] + (du3 * zu[1] * zu[1] + du2 * zu[2]) * Ub[2];
+    f32x4 t1 = du1 * Ub[1] + 2.f * du2 * zu[1] * Ub[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sb = sp_sum16(t0[r]), sw = sp_sum16(x * t0[r] + t1[r]);
+      if (c == 0) { G[a.o.bu + f4 + r] = sb; G[a.o.wu + f4 + r] = sw; }
+    }
+    t0 = dv1 * Vb[0] + dv2 * zv[1] * Vb[1] + (dv3 * zv[1] * zv[1] + dv2 * zv[2]) * Vb[2];
+    t1 = dv1 * Vb[1] + 2.f * dv2 * zv[1] * Vb[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sb = sp_sum16(t0[r]), sw = sp_sum16(x * t0[r] + t1[r]);
+      if (c == 0) { G[a.o.bv + f4 + r] = sb; G[a.o.wv + f4 + r] = sw; }
+    }
+  }
+}
+
+// The forward sweep in the same tile model: z_l = W_l^T o_{l-1} + b_l with the previous layer's gated output read back from
+// one LDS plane as the B operand (k-step (kb, r): feature 16kb + 4g + r of point c), A = W_l[16kb + 4g + r][16w + c] from L2.
+__global__ void __launch_bounds__(MODT_BLOCK) modmlp_fwd_tile_kernel(ModArgs a) {
+  PPSCI_DYN_SMEM(sh);  // To[3][H][MODT_LD]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int H = a.d.width, L = a.d.n_hidden, R = a.d.d_out, act = a.d.activation, NB = H / 16, RB = R / 16;
+  int tile = blockIdx.x, bi = 0;
+  while (bi + 1 < a.nbatch && tile >= (a.br[bi].N + 15) / 16) { tile -= (a.br[bi].N + 15) / 16; ++bi; }
+  const ModBranch& B = a.br[bi];
+  const int N = B.N, pt = tile * 16 + c;
+  const bool valid = pt < N;
+  const float x = B.x[valid ? pt : N - 1];
+  const float* P = B.params;
+  float* st = (B.stash && valid) ? B.stash + (long long)pt * (L + 2) * 3 * H : nullptr;
+  float* To = sh;
+  const bool active = wave < NB;
+  const int f4 = 16 * wave + 4 * g;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 U[3] = {zero4, zero4, zero4}, V[3] = {zero4, zero4, zero4}, o[3] = {zero4, zero4, zero4};
+  f32x4 e1, e2, e3;
+  if (active) {
+    f32x4 z[3];
+    const f32x4 wu = *(const f32x4*)&P[a.o.wu + f4], bu = *(const f32x4*)&P[a.o.bu + f4];
+    z[0] = x * wu + bu; z[1] = wu; z[2] = zero4;
+    if (st) { *(f32x4*)&st[0 * H + f4] = z[0]; *(f32x4*)&st[1 * H + f4] = z[1]; *(f32x4*)&st[2 * H + f4] = z[2]; }
+    sp_act_streams4(act, z, U, e1, e2, e3);
+    const f32x4 wv = *(const f32x4*)&P[a.o.wv + f4], bv = *(const f32x4*)&P[a.o.bv + f4];
+    z[0] = x * wv + bv; z[1] = wv; z[2] = zero4;
+    if (st) { *(f32x4*)&st[3 * H + f4] = z[0]; *(f32x4*)&st[4 * H + f4] = z[1]; *(f32x4*)&st[5 * H + f4] = z[2]; }
+    sp_act_streams4(act, z, V, e1, e2, e3);
+  }
+  for (int l = 0; l < L; ++l) {
+    f32x4 z[3] = {zero4, zero4, zero4};
+    if (l == 0) {
+      if (active) {
+        const f32x4 w0 = *(const f32x4*)&P[a.o.w[0] + f4], b0 = *(const f32x4*)&P[a.o.b[0] + f4];
+        z[0] = x * w0 + b0; z[1] = w0;
+      }
+    } else {
+      __syncthreads();  // the previous layer's readers are done
+      if (active) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) To[(s * H + f4 + r) * MODT_LD + c] = o[s][r];
+      }
+      __syncthreads();
+      if (active) {
+        z[0] = *(const f32x4*)&P[a.o.b[l] + f4];  // bias: every point (column) of the block gets b[feature]
+        for (int kb = 0; kb < NB; ++kb) {
+          float aw[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) aw[r] = P[a.o.w[l] + (16 * kb + 4 * g + r) * H + 16 * wave + c];
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              z[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], z[s], 0, 0, 0);
+        }
+      }
+    }
+    if (active) {
+      if (st) {
+        float* q = st + (2 + l) * 3 * H;
+        *(f32x4*)&q[f4] = z[0]; *(f32x4*)&q[H + f4] = z[1]; *(f32x4*)&q[2 * H + f4] = z[2];
+      }
+      f32x4 av[3];
+      sp_act_streams4(act, z, av, e1, e2, e3);
+      sp_gate4(av, U, V, o);
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) To[(s * H + f4 + r) * MODT_LD + c] = o[s][r];
+  }
+  __syncthreads();
+  // last_fc: F_s[r][p] = sum_k WL[k][r] o_s[k][p] (+ bl for the value stream): rank blocks over the waves
+  for (int rb = wave; rb < RB; rb += MODT_BLOCK / 64) {
+    f32x4 acc[3] = {*(const f32x4*)&P[a.o.bl + 16 * rb + 4 * g], zero4, zero4};
+    for (int kb = 0; kb < NB; ++kb) {
+      float aw[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) aw[r] = P[a.o.wl + (16 * kb + 4 * g + r) * R + 16 * rb + c];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], acc[s], 0, 0, 0);
+    }
+    if (valid) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) *(f32x4*)&B.F[((long long)s * N + pt) * R + 16 * rb + 4 * g] = acc[s];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ grid kernels
 struct GridArgs {
   ppsci_spinn_grid_desc d;
@@ -767,6 +1085,18 @@ extern "C" int64_t ppsci_modmlp_stash_floats(const ppsci_modmlp_desc* d, int64_t
 
 static int block_for(int H) { return ((H + 63) / 64) * 64; }
 
+// the reverse sweep by 16-point tiles (modmlp_bwd_tile_kernel): width and rank multiples of 16, at most 64
+static int g_mod_tile = 1;
+extern "C" void ppsci_set_modmlp_tile(int on) { g_mod_tile = on ? 1 : 0; }
+static bool mod_tiled(const ppsci_modmlp_desc* d) {
+  return g_mod_tile && d->width % 16 == 0 && d->width <= 64 && d->d_out % 16 == 0 && d->d_out <= 64;
+}
+
+extern "C" int64_t ppsci_modmlp_bwd_rows(const ppsci_modmlp_desc* d, int64_t n) {
+  if (mod_check(d) != PPSCI_OK || n < 1) return 0;
+  return mod_tiled(d) ? (n + 15) / 16 : n;
+}
+
 extern "C" int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
                                       const float* const* x, float* const* F, float* const* stash, void* stream) {
   if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || !F) {
@@ -788,7 +1118,13 @@ extern "C" int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
     a.br[b].N = (int)n[b];
     total += n[b];
   }
-  PPSCI_LAUNCH(modmlp_fwd_kernel, ModArgs, (int)total, block_for(d->width), 3 * d->width * sizeof(float), stream, a);
+  if (mod_tiled(d)) {
+    int tiles = 0;
+    for (int b = 0; b < nbatch; ++b) tiles += (int)((n[b] + 15) / 16);
+    PPSCI_LAUNCH(modmlp_fwd_tile_kernel, ModArgs, tiles, MODT_BLOCK, (size_t)3 * d->width * MODT_LD * sizeof(float), stream, a);
+  } else {
+    PPSCI_LAUNCH(modmlp_fwd_kernel, ModArgs, (int)total, block_for(d->width), 3 * d->width * sizeof(float), stream, a);
+  }
   int e = PPSCI_LAST_LAUNCH_ERROR();
   if (e != 0) { ppsci_set_error("modmlp_fwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   return PPSCI_OK;
@@ -822,6 +1158,14 @@ extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
     a.br[b].partials = grad_partials[b]; a.br[b].N = (int)n[b];
     a.br[b].pstride = partial_stride > 0 ? partial_stride : a.o.P;
     total += n[b];
+  }
+  if (mod_tiled(d)) {  // one workgroup per 16-point tile (MFMA), one gradient row per tile
+    int tiles = 0;
+    for (int b = 0; b < nbatch; ++b) tiles += (int)((n[b] + 15) / 16);
+    PPSCI_LAUNCH(modmlp_bwd_tile_kernel, ModArgs, tiles, MODT_BLOCK, (size_t)6 * d->width * MODT_LD * sizeof(float), stream, a);
+    int et = PPSCI_LAST_LAUNCH_ERROR();
+    if (et != 0) { ppsci_set_error("modmlp_bwd: launch failed (%d)", et); return PPSCI_E_LAUNCH; }
+    return PPSCI_OK;
   }
   const int wcols = (d->width > d->d_out ? d->width : d->d_out) + 1;
   PPSCI_LAUNCH(modmlp_bwd_kernel, ModArgs, (int)total, MOD_BWD_BLOCK,

@@ -46,12 +46,14 @@ class SpinnConstraint:
         self.stash = [torch.zeros(int(L.lib().ppsci_modmlp_stash_floats(C.byref(m.spec.desc), n)), **f32) for n in shape]
         # per-point gradient rows of the three branch nets: with equal point counts they interleave as [n][3][P], so that one
         # reduce_rows(n, 3P) call sums all three into the flat gradient (branch b's parameters are grad[bP:(b+1)P])
+        # (rows: one per 16-point tile on the MFMA tile kernel of the reverse sweep, one per point otherwise)
+        grows = [int(L.lib().ppsci_modmlp_bwd_rows(C.byref(m.spec.desc), n)) for n in shape]
         self.gjoint = len(set(shape)) == 1
         if self.gjoint:
-            self.gpart_all = torch.zeros((shape[0], 3 * P), **f32)
+            self.gpart_all = torch.zeros((grows[0], 3 * P), **f32)
             self.gpart = [self.gpart_all.view(-1)[b * P:] for b in range(3)]  # row 0 of branch b; rows are 3P apart
         else:
-            self.gpart = [torch.zeros((n, P), **f32) for n in shape]
+            self.gpart = [torch.zeros((r, P), **f32) for r in grows]
         total = nx * ny * nz
         self.label = torch.zeros(total, **f32)
         self.gadj = torch.zeros(total, **f32)

@@ -27,9 +27,9 @@ def _params_of(model, b):
                 wl=vals["last_fc.weight"], bl=vals["last_fc.bias"])
 
 
-def _build(tmp_path, shape=(7, 5, 6), act="tanh", r=4):
+def _build(tmp_path, shape=(7, 5, 6), act="tanh", r=4, hidden=16, layers=3):
     np.random.seed(111)
-    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), r=r, num_layers=3, hidden_size=16, activation=act)
+    model = ppsci.arch.SPINN(("x", "y", "z"), ("u",), r=r, num_layers=layers, hidden_size=hidden, activation=act)
     with torch.no_grad():  # non-zero biases so that every path is exercised
         model.flat_params.add_(torch.from_numpy(np.random.default_rng(5).uniform(-0.1, 0.1, model.flat_params.numel()).astype(np.float32)).to(model.flat_params.device))
     eq = ppsci.equation.Helmholtz(3, 1.0)
@@ -55,12 +55,17 @@ def _build(tmp_path, shape=(7, 5, 6), act="tanh", r=4):
     return solver, model, xs, uc, face
 
 
-@pytest.mark.parametrize("act,shape,r", [("tanh", (7, 5, 6), 4), ("sin", (7, 5, 6), 4), ("tanh", (18, 35, 21), 20),
-                                         ("tanh", (17, 9, 20), 40), ("tanh", (5, 6, 7), 70), ("tanh", (9, 9, 9), 8)])
-def test_spinn_helmholtz_losses_and_grads(tmp_path, act, shape, r):
+@pytest.mark.parametrize("act,shape,r,hidden,layers", [
+    ("tanh", (7, 5, 6), 4, 16, 3), ("sin", (7, 5, 6), 4, 16, 3), ("tanh", (18, 35, 21), 20, 16, 3), ("tanh", (17, 9, 20), 40, 16, 3),
+    ("tanh", (5, 6, 7), 70, 16, 3), ("tanh", (9, 9, 9), 8, 16, 3),
+    # width and rank multiples of 16: the reverse sweep of the branch nets by 16-point tiles on the matrix cores
+    # (modmlp_bwd_tile_kernel): ragged tiles, 1..4 feature blocks, 1..3 rank blocks, one hidden layer, a 1-point face
+    ("tanh", (18, 35, 21), 32, 32, 3), ("sin", (7, 5, 6), 16, 16, 1), ("tanh", (17, 33, 20), 48, 64, 4),
+    ("silu", (16, 16, 16), 32, 48, 2)])
+def test_spinn_helmholtz_losses_and_grads(tmp_path, act, shape, r, hidden, layers):
     """ranks 4 / 20 / 40 take the MFMA grid kernels with 4 / 8 / 16 k-steps (ragged row, column and rank tails); rank 70
     the scalar ones; equal point counts on the three axes take the joint gradient-row layout (one reduce for all branches)."""
-    solver, model, xs, uc, face = _build(tmp_path, shape=shape, act=act, r=r)
+    solver, model, xs, uc, face = _build(tmp_path, shape=shape, act=act, r=r, hidden=hidden, layers=layers)
     nets = [R.ModifiedMLP1(_params_of(model, b), act) for b in range(3)]
     tx = [torch.tensor(x.astype(np.float64), requires_grad=True) for x in xs]
     u, res = R.spinn_helmholtz(nets, tx, 1.0)
@@ -84,6 +89,29 @@ def test_spinn_helmholtz_losses_and_grads(tmp_path, act, shape, r):
     pred = solver.predict({"x": xs[0], "y": xs[1], "z": xs[2]}, batch_size=None, return_numpy=True)["u"]
     assert pred.shape == tuple(shape) + (1,)
     assert rel(pred[..., 0], u.detach().numpy()) < 5e-6
+
+
+def test_tile_and_point_kernels_of_the_reverse_sweep_agree(tmp_path):
+    """The same step with the per-point reverse kernel (ppsci_set_modmlp_tile(0)) and with the tile kernel: equal up to the
+    order of the sums."""
+    from paddlescience_amd import _lib as L
+
+    grads = []
+    for tile in (1, 0):
+        L.lib().ppsci_set_modmlp_tile(tile)
+        try:
+            solver, model, xs, uc, face = _build(tmp_path / f"t{tile}", shape=(19, 16, 33), r=32, hidden=64, layers=3)
+            csts = list(solver._compiled.values())
+            rows = int(L.lib().ppsci_modmlp_bwd_rows(model.spec.desc, 19))
+            assert rows == (2 if tile else 19)
+            for name, cc in solver._compiled.items():
+                inp, lab, _ = next(solver.constraint[name].data_iter)
+                cc.bind(inp, lab)
+            solver.engine.forward_backward(csts)
+            grads.append(solver.engine.grad.cpu().numpy().copy())
+        finally:
+            L.lib().ppsci_set_modmlp_tile(1)
+    assert rel(grads[0], grads[1]) < 2e-6
 
 
 def test_spinn_training_step_runs(tmp_path):

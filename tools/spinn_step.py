@@ -10,6 +10,10 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    if os.environ.get("PPSCI_MODMLP_TILE", "1") == "0":  # A/B: the per-point kernels of the branch nets
+        from paddlescience_amd import _lib as L
+
+        L.lib().ppsci_set_modmlp_tile(0)
     with tempfile.TemporaryDirectory() as tmp:
         r = bench.secondary_spinn(tmp, steps, 10)
     print(json.dumps({k: r[k] for k in ("value", "ms_per_step", "parity", "roofline") if k in r}))
