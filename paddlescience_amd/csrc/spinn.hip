@@ -402,6 +402,17 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
   f32x4 zl[3], al[3], ol[3], d1 = zero4, d2 = zero4, d3 = zero4, ob[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) U[s] = V[s] = zu[s] = zv[s] = zl[s] = al[s] = ol[s] = ob[s] = zero4;
+  // every operand of the last_fc stage is requested here, in front of the activation arithmetic: a tile is one workgroup's
+  // latency chain (24 workgroups for 3 x 128 points), a load waited for inside a loop costs a memory round trip per trip
+  f32x4 awl[4], fbl[3][4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const bool on = active && rb < RB;
+    awl[rb] = on ? *(const f32x4*)&P[a.o.wl + (16 * wave + c) * R + 16 * rb + 4 * g] : zero4;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      fbl[s][rb] = (on && valid) ? *(const f32x4*)&B.Fbar[((long long)s * N + pt) * R + 16 * rb + 4 * g] : zero4;
+  }
   if (active) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -423,15 +434,19 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
   for (int b = wave; b < NB * RB; b += MODT_BLOCK / 64) {
     const int kb = b / RB, rb = b - kb * RB;
     f32x4 acc = zero4;
+    float bv[3][4];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int pp = pt0 + 4 * t + g;
-        const float av = To[(s * H + 16 * kb + c) * MODT_LD + 4 * t + g];
-        const float bv = pp < N ? B.Fbar[((long long)s * N + pp) * R + 16 * rb + c] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        bv[s][t] = pp < N ? B.Fbar[((long long)s * N + pp) * R + 16 * rb + c] : 0.f;
       }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(To[(s * H + 16 * kb + c) * MODT_LD + 4 * t + g], bv[s][t], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) G[a.o.wl + (16 * kb + 4 * g + r) * R + 16 * rb + c] = acc[r];
   }
@@ -441,23 +456,33 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
       if (pt0 + p < N) sum += B.Fbar[((long long)pt0 + p) * R + r];
     G[a.o.bl + r] = sum;
   }
-  // ---- obar_s[k][p] = sum_r WL[k][r] Fbar_s[r][p]   (this wave's feature block; k-step (rb, r))
+  // ---- obar_s[k][p] = sum_r WL[k][r] Fbar_s[r][p]   (this wave's feature block; k-step (rb, r); operands requested above)
   if (active) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       f32x4 acc = zero4;
-      for (int rb = 0; rb < RB; ++rb) {
-        const f32x4 aw = *(const f32x4*)&P[a.o.wl + (16 * wave + c) * R + 16 * rb + 4 * g];
-        const f32x4 fb = valid ? *(const f32x4*)&B.Fbar[((long long)s * N + pt) * R + 16 * rb + 4 * g] : zero4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], fb[r], acc, 0, 0, 0);
-      }
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb < RB) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(awl[rb][r], fbl[s][rb][r], acc, 0, 0, 0);
+        }
       ob[s] = acc;
     }
   }
   f32x4 Ub[3] = {zero4, zero4, zero4}, Vb[3] = {zero4, zero4, zero4};
   for (int l = L - 1; l >= 0; --l) {
     f32x4 zb[3] = {zero4, zero4, zero4};
+    // this layer's operands from memory, requested in front of the pointwise arithmetic that hides them: the A fragments of
+    // obar_{l-1} = W_l zbar_l and the stash of layer l - 1
+    f32x4 aw[4], zp[3] = {zero4, zero4, zero4};
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+      aw[jb] = (active && l > 0 && jb < NB) ? *(const f32x4*)&P[a.o.w[l] + (16 * wave + c) * H + 16 * jb + 4 * g] : zero4;
+    if (active && l > 0) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) zp[s] = *(const f32x4*)&st[((2 + l - 1) * 3 + s) * H + f4];
+    }
     if (active) {
       // adjoint of the gate  o = V + a (U - V)  and of the activation streams (the per-point kernel's formulas on float4)
       const f32x4 D0 = U[0] - V[0], D1 = U[1] - V[1], D2 = U[2] - V[2];
@@ -486,11 +511,9 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
       }
     }
     if (l == 0) break;
-    f32x4 zp[3] = {zero4, zero4, zero4}, ap[3] = {zero4, zero4, zero4}, op[3] = {zero4, zero4, zero4};
+    f32x4 ap[3] = {zero4, zero4, zero4}, op[3] = {zero4, zero4, zero4};
     f32x4 p1 = zero4, p2 = zero4, p3 = zero4;
     if (active) {
-#pragma unroll
-      for (int s = 0; s < 3; ++s) zp[s] = *(const f32x4*)&st[((2 + l - 1) * 3 + s) * H + f4];
       sp_act_streams4(act, zp, ap, p1, p2, p3);
       sp_gate4(ap, U, V, op);
     }
@@ -523,12 +546,13 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         f32x4 acc = zero4;
-        for (int jb = 0; jb < NB; ++jb) {
-          const f32x4 aw = *(const f32x4*)&P[a.o.w[l] + (16 * wave + c) * H + 16 * jb + 4 * g];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], Tz[(s * H + 16 * jb + 4 * g + r) * MODT_LD + c], acc, 0, 0, 0);
-        }
+        for (int jb = 0; jb < 4; ++jb)
+          if (jb < NB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[jb][r], Tz[(s * H + 16 * jb + 4 * g + r) * MODT_LD + c], acc, 0, 0, 0);
+          }
         ob[s] = acc;
       }
 #pragma unroll
@@ -594,6 +618,15 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_fwd_tile_kernel(ModArgs a) 
         z[0] = x * w0 + b0; z[1] = w0;
       }
     } else {
+      // (the layer's weights are requested in front of the two barriers that hide their latency)
+      float aw[4][4];
+      f32x4 bl4 = zero4;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          aw[kb][r] = (active && kb < NB) ? P[a.o.w[l] + (16 * kb + 4 * g + r) * H + 16 * wave + c] : 0.f;
+      if (active) bl4 = *(const f32x4*)&P[a.o.b[l] + f4];
       __syncthreads();  // the previous layer's readers are done
       if (active) {
 #pragma unroll
@@ -603,17 +636,16 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_fwd_tile_kernel(ModArgs a) 
       }
       __syncthreads();
       if (active) {
-        z[0] = *(const f32x4*)&P[a.o.b[l] + f4];  // bias: every point (column) of the block gets b[feature]
-        for (int kb = 0; kb < NB; ++kb) {
-          float aw[4];
+        z[0] = bl4;  // bias: every point (column) of the block gets b[feature]
 #pragma unroll
-          for (int r = 0; r < 4; ++r) aw[r] = P[a.o.w[l] + (16 * kb + 4 * g + r) * H + 16 * wave + c];
+        for (int kb = 0; kb < 4; ++kb)
+          if (kb < NB) {
 #pragma unroll
-          for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              z[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], z[s], 0, 0, 0);
-        }
+              for (int r = 0; r < 4; ++r)
+                z[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[kb][r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], z[s], 0, 0, 0);
+          }
       }
     }
     if (active) {
@@ -637,16 +669,20 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_fwd_tile_kernel(ModArgs a) 
   // last_fc: F_s[r][p] = sum_k WL[k][r] o_s[k][p] (+ bl for the value stream): rank blocks over the waves
   for (int rb = wave; rb < RB; rb += MODT_BLOCK / 64) {
     f32x4 acc[3] = {*(const f32x4*)&P[a.o.bl + 16 * rb + 4 * g], zero4, zero4};
-    for (int kb = 0; kb < NB; ++kb) {
-      float aw[4];
+    float aw[4][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) aw[r] = P[a.o.wl + (16 * kb + 4 * g + r) * R + 16 * rb + c];
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int r = 0; r < 4; ++r) aw[kb][r] = kb < NB ? P[a.o.wl + (16 * kb + 4 * g + r) * R + 16 * rb + c] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], acc[s], 0, 0, 0);
-    }
+    for (int kb = 0; kb < 4; ++kb)
+      if (kb < NB) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[kb][r], To[(s * H + 16 * kb + 4 * g + r) * MODT_LD + c], acc[s], 0, 0, 0);
+      }
     if (valid) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) *(f32x4*)&B.F[((long long)s * N + pt) * R + 16 * rb + 4 * g] = acc[s];
