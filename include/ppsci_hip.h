@@ -599,8 +599,10 @@ int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* 
  * (width and d_out multiples of 16, at most 64), one per point otherwise.  The caller allocates [rows][P] (or the interleaved
  * [rows][3][P]) and sums `rows` rows. */
 int64_t ppsci_modmlp_bwd_rows(const ppsci_modmlp_desc* d, int64_t n_points);
-/* Testing knob: 0 keeps the per-point reverse kernel for every shape (A/B, tests); read by ppsci_modmlp_bwd_rows too. */
-void ppsci_set_modmlp_tile(int on);
+/* Which sweeps of the branch nets run by 16-point tiles where the shape allows: 0 none (per-point kernels), 1 (default) the
+ * reverse sweep, 2 both sweeps (the forward tile kernel is the slower one at 3 x 128 points; A/B, tests).  Read by
+ * ppsci_modmlp_bwd_rows too. */
+void ppsci_set_modmlp_tile(int mode);
 
 /* ---- losses on [rows][H][W] fields (rows = batch x channels) of the operator-learning path, value and adjoint
  * (csrc/field_loss.hip).  LpLoss / H1Loss of /root/reference/examples/neuraloperator/metric.py:69-412 (p = 2, d = 2;

@@ -1122,11 +1122,17 @@ extern "C" int64_t ppsci_modmlp_stash_floats(const ppsci_modmlp_desc* d, int64_t
 static int block_for(int H) { return ((H + 63) / 64) * 64; }
 
 // the reverse sweep by 16-point tiles (modmlp_bwd_tile_kernel): width and rank multiples of 16, at most 64
+// Measured on MI355X (Helmholtz3D, 3 x 128 points, 4 x 64 nets, rank 32; profiles/r06_spinn_*): reverse 30.6 us by tiles against
+// 34.2 us by points, forward 17.7 us by tiles against 12.7 us by points -- 24 workgroups of four waves are a longer latency
+// chain per layer than 384 of them, and only the reverse sweep has traffic to save (26 MB of per-point gradient rows).
+// Default 1: tiles in the reverse sweep only; 2: both sweeps; 0: neither.
 static int g_mod_tile = 1;
-extern "C" void ppsci_set_modmlp_tile(int on) { g_mod_tile = on ? 1 : 0; }
-static bool mod_tiled(const ppsci_modmlp_desc* d) {
-  return g_mod_tile && d->width % 16 == 0 && d->width <= 64 && d->d_out % 16 == 0 && d->d_out <= 64;
+extern "C" void ppsci_set_modmlp_tile(int mode) { g_mod_tile = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+static bool mod_tile_shape(const ppsci_modmlp_desc* d) {
+  return d->width % 16 == 0 && d->width <= 64 && d->d_out % 16 == 0 && d->d_out <= 64;
 }
+static bool mod_tiled(const ppsci_modmlp_desc* d) { return g_mod_tile >= 1 && mod_tile_shape(d); }      // reverse sweep
+static bool mod_tiled_fwd(const ppsci_modmlp_desc* d) { return g_mod_tile >= 2 && mod_tile_shape(d); }  // forward sweep
 
 extern "C" int64_t ppsci_modmlp_bwd_rows(const ppsci_modmlp_desc* d, int64_t n) {
   if (mod_check(d) != PPSCI_OK || n < 1) return 0;
@@ -1154,7 +1160,7 @@ extern "C" int ppsci_modmlp_fwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
     a.br[b].N = (int)n[b];
     total += n[b];
   }
-  if (mod_tiled(d)) {
+  if (mod_tiled_fwd(d)) {
     int tiles = 0;
     for (int b = 0; b < nbatch; ++b) tiles += (int)((n[b] + 15) / 16);
     PPSCI_LAUNCH(modmlp_fwd_tile_kernel, ModArgs, tiles, MODT_BLOCK, (size_t)3 * d->width * MODT_LD * sizeof(float), stream, a);

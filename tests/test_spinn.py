@@ -97,7 +97,7 @@ def test_tile_and_point_kernels_of_the_reverse_sweep_agree(tmp_path):
     from paddlescience_amd import _lib as L
 
     grads = []
-    for tile in (1, 0):
+    for tile in (1, 0, 2):
         L.lib().ppsci_set_modmlp_tile(tile)
         try:
             solver, model, xs, uc, face = _build(tmp_path / f"t{tile}", shape=(19, 16, 33), r=32, hidden=64, layers=3)
@@ -111,7 +111,7 @@ def test_tile_and_point_kernels_of_the_reverse_sweep_agree(tmp_path):
             grads.append(solver.engine.grad.cpu().numpy().copy())
         finally:
             L.lib().ppsci_set_modmlp_tile(1)
-    assert rel(grads[0], grads[1]) < 2e-6
+    assert rel(grads[0], grads[1]) < 2e-6 and rel(grads[2], grads[1]) < 2e-6
 
 
 def test_spinn_training_step_runs(tmp_path):
