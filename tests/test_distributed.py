@@ -9,6 +9,15 @@ import sys
 import numpy as np
 import pytest
 
+
+def _free_port() -> str:
+    """A loopback port nobody listens on right now (the suite runs on several pytest-xdist workers: fixed ports collide)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -19,7 +28,7 @@ def _run(outdir, world, reduction):
         cmd = [sys.executable, worker, outdir, reduction]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", "29533", worker, outdir, reduction]
+               "--master-addr", "127.0.0.1", "--master-port", _free_port(), worker, outdir, reduction]
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=600, stdout=subprocess.DEVNULL)
     return np.load(os.path.join(outdir, f"result_w{world}.npz"))
 
@@ -114,7 +123,7 @@ def test_iterable_dataset_refuses_world_size_gt_1(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     worker = os.path.join(ROOT, "tests", "dp_worker.py")
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29537", worker, d, "iterable"], check=True, env=env, cwd=ROOT, timeout=300,
+                    "--master-port", _free_port(), worker, d, "iterable"], check=True, env=env, cwd=ROOT, timeout=300,
                    stdout=subprocess.DEVNULL)
     for rank in (0, 1):
         r = json.load(open(os.path.join(d, f"iterable_w2_r{rank}.json")))
@@ -130,7 +139,7 @@ def test_ranks_must_agree_on_trace_time_branches(tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     worker = os.path.join(ROOT, "tests", "dp_worker.py")
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29541", worker, d, "branch"], check=True, env=env, cwd=ROOT, timeout=600, stdout=subprocess.DEVNULL)
+                    "--master-port", _free_port(), worker, d, "branch"], check=True, env=env, cwd=ROOT, timeout=600, stdout=subprocess.DEVNULL)
     for rank in (0, 1):
         r = json.load(open(os.path.join(d, f"branch_w2_r{rank}.json")))
         assert r["shard_independent"] == "trained"
