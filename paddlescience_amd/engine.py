@@ -492,6 +492,9 @@ class Engine:
         work = sum(c.work for c in constraints)
         if work > self.graph_max_work and max(c.n for c in constraints) > self.multi_stream_max_points:
             return self._forward_backward_eager(constraints)
+        if self.world > 1 and any(getattr(c, "reductions", None) for c in constraints):
+            # batch reductions all-reduce their sums BETWEEN the launches of a constraint: collectives stay out of captured graphs
+            return self._forward_backward_eager(constraints)
         self._step_graph.enabled = self.use_graph
         self._step_graph.run(tuple(id(c) for c in constraints), lambda: self._forward_backward_eager(constraints))
         self.use_graph = self._step_graph.enabled

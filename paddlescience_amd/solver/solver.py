@@ -254,6 +254,9 @@ class Solver:
             # of _check_trace_decisions: take part in it (it raises there as well), then raise the reason of this rank
             self._check_trace_decisions(name, None, f"{type(e).__name__}: {e}")
             raise NotImplementedError(f"constraint {name}: not lowerable to the fused HIP kernels ({type(e).__name__}: {e})") from e
+        if name in self._ragged and (cc.low.reductions or cc.low.couplings):
+            raise NotImplementedError(f"constraint {name}: batch reductions / couplings over ragged data-parallel shards (the sampler's "
+                                      "wrap-around duplicates would be counted twice); make the sample count a multiple of the ranks")
         if cc.specialised_to:
             logger.info(f"constraint {name}: traced for the values of its (fixed) batch: {', '.join(cc.specialised_to)}")
         self._check_trace_decisions(name, cc)

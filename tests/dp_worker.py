@@ -43,6 +43,29 @@ def build_solver(outdir, world_batch, reduction, steps, pirate=False, ragged=Fal
     return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
 
 
+def build_reduction_solver(outdir, world_batch, steps):
+    """A residual with batch reductions (graph.Sym.mean / .sum): under data parallelism the sums and their adjoints are
+    all-reduced between the launches, so that the mean is over the GLOBAL batch as in a one-rank run."""
+    import ppsci
+    from oracle import taylor_np as T
+    from ppsci.autodiff import jacobian
+    from tests.common import set_model_weights
+
+    model = ppsci.arch.MLP(("t", "x"), ("u",), 2, 16, "tanh")
+    set_model_weights(model, T.make_net(2, [16, 16], 1, seed=7, bias_scale=0.05))
+    N = world_batch
+    X = np.random.default_rng(3).uniform([0, -1], [1, 1], (N, 2)).astype(np.float32)
+    lab = np.random.default_rng(4).standard_normal((N, 1)).astype(np.float32) * 0.1
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"t": X[:, :1], "x": X[:, 1:]}, "label": {"r": lab}},
+           "batch_size": N // world, "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    # (no exact invariance in it: `u - u.mean()` would leave the last bias with a zero gradient, which Adam turns into +-lr noise)
+    exprs = {"r": lambda d: d["u"] * (1.0 + (d["u"] * d["u"]).mean()) + (jacobian(d["u"], d["x"]) * d["t"]).sum() / 50.0}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), exprs, name="EQ")
+    opt = ppsci.optimizer.Adam(learning_rate=1e-3)(model)
+    return ppsci.solver.Solver(model, {"EQ": cst}, outdir, opt, epochs=steps, iters_per_epoch=1, log_freq=1), model
+
+
 def build_viv_solver(outdir, world_batch, steps):
     """Factored layers (random_weight) + learnable equation parameters (Vibration): the kernel-layout gradient is
     all-reduced and pulled back, the equation-parameter gradient has its own all-reduce."""
@@ -141,6 +164,8 @@ def main():
         # Adam + fragments in one launch (engine.Engine.train_step, ppsci_taylor_step_plan_apply); four steps, so that the
         # fragments the apply kernel left behind are used (the weight split is skipped from the second step on)
         solver, model = build_solver(outdir, 64, "mean", 4, width=64)
+    elif reduction == "batchmean":
+        solver, model = build_reduction_solver(outdir, 64, 3)
     elif ragged:
         solver, model = build_solver(outdir, 67, reduction[len("ragged_"):], 2, ragged=True)
     else:

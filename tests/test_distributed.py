@@ -56,6 +56,16 @@ def test_ragged_shards_get_zero_weight_padding(tmp_path, reduction):
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5, atol=1e-6)
 
 
+def test_two_ranks_reproduce_single_rank_with_batch_reductions(tmp_path):
+    """`u.mean()` / `.sum()` inside the residual (three launches of the residual program, engine._forward_reductions): the sums and
+    their adjoints are all-reduced, so two ranks train what one rank trains."""
+    d = str(tmp_path)
+    one = _run(d, 1, "batchmean")
+    two = _run(d, 2, "batchmean")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-5, atol=1e-6)
+
+
 def test_two_ranks_reproduce_single_rank_piratenet(tmp_path):
     """PirateNet (layer-by-layer kernels, RWF, trainable Fourier kernel and alpha): the flat trainable-layout gradient is
     all-reduced like an MLP's."""
