@@ -47,9 +47,13 @@ def build(cfg):
                                            {"dataset": "IterableNamedArrayDataset", "total_size": cfg["eval_total"]},
                                            ppsci.loss.MSELoss(), evenly=True, metric={"MSE": ppsci.metric.MSE()}, name="L2Rel_Validator")
     opt = ppsci.optimizer.Adam(cfg["learning_rate"])(model)
+    # visualizer (euler_beam.py:88-100 of the reference): exact and predicted deflection over x as a scatter plot
+    visu_points = geom["interval"].sample_interior(cfg["eval_total"], evenly=True)
+    visualizer = {"visualize_u": ppsci.visualize.VisualizerScatter1D(
+        visu_points, ("x",), {"u_label": lambda d: u_solution(d), "u_pred": lambda d: d["u"]}, num_timestamps=1, prefix="result_u")}
     solver = ppsci.solver.Solver(model, {pde.name: pde, bc.name: bc}, cfg["output_dir"], opt, epochs=cfg["epochs"],
                                  iters_per_epoch=cfg["iters_per_epoch"], log_freq=cfg["log_freq"], equation=equation, geom=geom,
-                                 validator={val.name: val})
+                                 validator={val.name: val}, visualizer=visualizer)
     return solver
 
 
@@ -59,3 +63,4 @@ if __name__ == "__main__":
     solver = build(cfg)
     solver.train()
     solver.eval()
+    solver.visualize()

@@ -40,12 +40,17 @@ def main():
                                                   {"dataset": "IterableNamedArrayDataset", "total_size": n_total},
                                                   ppsci.loss.MSELoss(), evenly=True, metric={"MSE": ppsci.metric.MSE()},
                                                   with_initial=True, name="MSE_Metric")
+    # visualizer (laplace2d.py:95-104 of the reference): the prediction on the evenly sampled points as a .vtu point cloud
+    vis_points = geom["rect"].sample_interior(n_total, evenly=True)
+    visualizer = {"visualize_u": ppsci.visualize.VisualizerVtu(vis_points, {"u": lambda d: d["u"]}, num_timestamps=1,
+                                                               prefix="result_u")}
     solver = ppsci.solver.Solver(model, {pde.name: pde, bc.name: bc}, cfg["output_dir"], optimizer, epochs=cfg["epochs"],
                                  iters_per_epoch=cfg["iters_per_epoch"], eval_during_train=True, eval_freq=cfg["eval_freq"],
                                  log_freq=cfg["log_freq"], equation=equation, geom=geom,
-                                 validator={mse_metric.name: mse_metric})
+                                 validator={mse_metric.name: mse_metric}, visualizer=visualizer)
     solver.train()
     solver.eval()
+    solver.visualize()
 
 
 if __name__ == "__main__":
