@@ -572,9 +572,10 @@ def secondary_tfno(steps, warmup, B=16, H=64, W=64):
     cst.bind({"x": x}, {"y": y})
     eng = OperatorEngine(model)
 
-    def step():
-        eng.forward_backward([cst])
-        opt.step(model.flat_grad)
+    from paddlescience_amd.engine import step_with_adam
+
+    def step():  # (what Solver.train runs for this engine: the sums over the weight-gradient partials + Adam in one launch)
+        step_with_adam(eng, [cst], opt, model.flat_params)
 
     t = time_wall(step, steps, warmup)
     # the same step timed with HIP events on the launch stream (device-side duration of the replayed graph + Adam): the
@@ -634,9 +635,10 @@ def secondary_spinn(tmp, steps, warmup, nc=128):
     if PURE:  # profiling run: nothing but the timed steps
         solver, opt, cc, xs, uc = run(nc, True)
 
+        from paddlescience_amd.engine import step_with_adam
+
         def pure_step():
-            solver.engine.forward_backward([cc])
-            opt.step(solver.engine.grad)
+            step_with_adam(solver.engine, [cc], opt, model.flat_params)
 
         t = time_wall(pure_step, steps, warmup)
         return {"value": nc ** 3 / t, "ms_per_step": t * 1e3, "steps": steps}
@@ -663,9 +665,10 @@ def secondary_spinn(tmp, steps, warmup, nc=128):
                          f"{nc}^3 grid, the timed model's weights",
               "u_rel_l2": rel(pred[..., 0], uo.detach().numpy()), "loss_rel": abs(cc.loss() / lo - 1.0)}
 
-    def step():
-        solver.engine.forward_backward([cc])
-        opt.step(solver.engine.grad)
+    from paddlescience_amd.engine import step_with_adam
+
+    def step():  # (what Solver.train runs for this engine: gradient rows + loss rows summed and Adam applied in one launch)
+        step_with_adam(solver.engine, [cc], opt, model.flat_params)
 
     t = time_wall(step, steps, warmup)
     t_g = time_events(lambda: cc.forward(True))

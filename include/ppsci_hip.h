@@ -184,6 +184,15 @@ typedef struct {
   int32_t accumulate;
 } ppsci_reduce_seg;
 int ppsci_reduce_rows_multi(int nseg, const ppsci_reduce_seg* segs, void* stream);
+/* ppsci_reduce_rows_multi + ppsci_adam_step in ONE launch: the row reductions that end a backward pass (SPINN: the gradient
+ * rows of the branch nets and the loss rows; FNO: the partials of the 1x1 convolutions' weight gradients) and the update of
+ * the flat parameter buffer behind them.  A segment whose `out` lies inside grad[0 .. n) is a gradient segment (it must not
+ * accumulate, and no two of them may overlap): its sums are written to grad AND consumed by the update at once; other
+ * segments are plain reductions; parameters no segment writes are updated from grad as it stands.  Same arithmetic and
+ * summation order as the two calls it replaces. */
+int ppsci_reduce_rows_multi_adam(int nseg, const ppsci_reduce_seg* segs, int64_t n, float* params, float* grad, float* m,
+                                 float* v, float lr, float beta1, float beta2, float eps, int64_t step_t, float grad_scale,
+                                 void* stream);
 /* PPSCI_OK when the current HIP device is a gfx950 (the kernels' cross-workgroup reductions rely on its store / vmcnt
  * behaviour, and the code object holds no other ISA); PPSCI_E_UNSUPPORTED with the device's name otherwise.  The Python
  * host side calls it once when it loads the library on a machine with a GPU. */

@@ -109,6 +109,9 @@ _SYMBOLS = {
     "ppsci_check_device": (C.c_int, []),
     "ppsci_linear_multi": (C.c_int, [C.c_int, C.POINTER(LinearJob), C.c_int, C.c_void_p]),
     "ppsci_reduce_rows_multi": (C.c_int, [C.c_int, C.POINTER(ReduceSeg), C.c_void_p]),
+    "ppsci_reduce_rows_multi_adam": (C.c_int, [C.c_int, C.POINTER(ReduceSeg), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, C.c_float,
+                                               C.c_void_p]),
     "ppsci_release_fragments": (None, [C.c_void_p]),
     "ppsci_set_max_grid": (None, [C.c_int]),
     "ppsci_set_wide_min_nb": (None, [C.c_int]),

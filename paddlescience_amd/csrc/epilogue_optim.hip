@@ -505,6 +505,147 @@ extern "C" int ppsci_adam_step(int64_t n, float* params, const float* grad, floa
   return PPSCI_OK;
 }
 
+// ---- the row reductions that END a backward pass and the Adam update behind them, in ONE launch -------------------------
+// (SPINN: the per-tile gradient rows of the three branch nets + the loss rows; FNO: the per-chunk partials of every 1x1
+// convolution's weight gradient -- each was a ppsci_reduce_rows_multi launch followed by ppsci_adam_step, two launch-floor
+// kernels.)  A workgroup of the reduction part does exactly what reduce_rows_multi_kernel does; the thread that finishes a
+// column whose destination lies inside the gradient buffer applies the update of that parameter at once.  Parameters whose
+// gradient no segment writes (other kernels wrote it: spectral weights, norm parameters) are updated by the plain-Adam
+// workgroups behind the reduction part.  Every parameter must get its gradient from at most ONE segment.
+#define ADAM_MAX_PLAIN (RED_MAX_SEG + 1)
+struct ReduceAdamArgs {
+  ReduceMultiArgs r;
+  AdamArgs a;
+  long long goff[RED_MAX_SEG];               // segment s writes grad[goff[s] .. goff[s] + cols); -1: not a gradient (loss rows)
+  long long plain0[ADAM_MAX_PLAIN], plain1[ADAM_MAX_PLAIN];  // parameter ranges no segment covers
+  int pfirst[ADAM_MAX_PLAIN + 1];             // their workgroup ranges (relative to the first plain workgroup)
+  int nplain, wg_plain;                       // wg_plain: index of the first plain workgroup
+};
+
+__device__ __forceinline__ void ppsci_adam_one(const AdamArgs& a, long long j, float graw) {
+  const float g = a.grad_scale * graw;
+  const float m = a.beta1 * a.m[j] + (1.f - a.beta1) * g;
+  const float v = a.beta2 * a.v[j] + (1.f - a.beta2) * g * g;
+  a.m[j] = m;
+  a.v[j] = v;
+  a.p[j] = a.p[j] - a.lr_t * (m / (sqrtf(v) + a.eps_t));
+}
+
+__global__ void __launch_bounds__(256) reduce_rows_multi_adam_kernel(ReduceAdamArgs q) {
+  PPSCI_DYN_SMEM(red);
+  if ((int)blockIdx.x >= q.wg_plain) {  // plain Adam on an uncovered parameter range
+    const int wgp = (int)blockIdx.x - q.wg_plain;
+    int k = 0;
+    while (k + 1 < q.nplain && wgp >= q.pfirst[k + 1]) ++k;
+    const long long j = q.plain0[k] + (long long)(wgp - q.pfirst[k]) * 256 + threadIdx.x;
+    if (j < q.plain1[k]) ppsci_adam_one(q.a, j, q.a.g[j]);
+    return;
+  }
+  const ReduceMultiArgs& m = q.r;
+  int s = 0;
+  while (s + 1 < m.nseg && (int)blockIdx.x >= m.first[s + 1]) ++s;
+  const ReduceArgs& a = m.seg[s];
+  const int wg = (int)blockIdx.x - m.first[s];
+  const int groups = a.groups, cw = 256 / groups;
+  const int tc = threadIdx.x % cw, rg = threadIdx.x / cw;
+  const long long j = (long long)wg * cw + tc;
+  float v = 0.f;
+  if (j < a.cols) {
+#pragma unroll 8
+    for (long long r = rg; r < a.rows; r += groups) v += a.partials[r * a.cols + j];
+  }
+  red[rg * cw + tc] = v;
+  __syncthreads();
+  if (rg == 0 && j < a.cols) {
+    float t = red[tc];
+    for (int k = 1; k < groups; ++k) t += red[k * cw + tc];
+    if (a.accumulate) t += a.out[j];
+    a.out[j] = t;
+    if (q.goff[s] >= 0) ppsci_adam_one(q.a, q.goff[s] + j, t);
+  }
+}
+
+extern "C" int ppsci_reduce_rows_multi_adam(int nseg, const ppsci_reduce_seg* segs, int64_t n, float* params, float* grad,
+                                            float* mom, float* var, float lr, float beta1, float beta2, float eps,
+                                            int64_t step_t, float grad_scale, void* stream) {
+  if (nseg < 1 || nseg > RED_MAX_SEG || !segs || !params || !grad || !mom || !var || n <= 0 || step_t < 1) {
+    ppsci_set_error("reduce_rows_multi_adam: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  ReduceAdamArgs q;
+  memset(&q, 0, sizeof(q));
+  q.r.nseg = nseg;
+  int total = 0;
+  // gradient ranges of the segments (sorted below to find what they leave uncovered)
+  long long lo[RED_MAX_SEG], hi[RED_MAX_SEG];
+  int ncov = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const ppsci_reduce_seg& g = segs[s];
+    if (!g.partials || !g.out || g.rows < 1 || g.cols < 1) {
+      ppsci_set_error("reduce_rows_multi_adam: invalid segment %d", s);
+      return PPSCI_E_INVALID;
+    }
+    ReduceArgs a{(const float*)g.partials, (float*)g.out, g.rows, g.cols, g.accumulate, RED_GROUPS};
+    if (g.cols <= 8 && g.rows >= 512) a.groups = 256;
+    else if (g.rows >= 128 && g.cols <= 2048) a.groups = 32;
+    else if (g.rows >= 128 && g.cols <= 32768) a.groups = 16;
+    const int cw = 256 / a.groups;
+    q.r.seg[s] = a;
+    q.r.first[s] = total;
+    total += (int)((g.cols + cw - 1) / cw);
+    const float* o = (const float*)g.out;
+    if (o >= grad && o < grad + n) {
+      const long long off = o - grad;
+      if (off + g.cols > n || g.accumulate) {
+        ppsci_set_error("reduce_rows_multi_adam: gradient segment %d leaves the buffer or accumulates", s);
+        return PPSCI_E_INVALID;
+      }
+      q.goff[s] = off;
+      lo[ncov] = off;
+      hi[ncov] = off + g.cols;
+      ++ncov;
+    } else {
+      q.goff[s] = -1;
+    }
+  }
+  q.r.first[nseg] = total;
+  for (int i = 1; i < ncov; ++i)  // insertion sort by start
+    for (int k = i; k > 0 && lo[k] < lo[k - 1]; --k) {
+      const long long tl = lo[k], th = hi[k];
+      lo[k] = lo[k - 1]; hi[k] = hi[k - 1];
+      lo[k - 1] = tl; hi[k - 1] = th;
+    }
+  long long cur = 0;
+  int np = 0, wgp = 0;
+  for (int i = 0; i <= ncov; ++i) {
+    const long long end = i < ncov ? lo[i] : n;
+    if (i < ncov && lo[i] < cur) {
+      ppsci_set_error("reduce_rows_multi_adam: two segments write the same parameters");
+      return PPSCI_E_INVALID;
+    }
+    if (end > cur) {
+      q.plain0[np] = cur;
+      q.plain1[np] = end;
+      q.pfirst[np] = wgp;
+      wgp += (int)((end - cur + 255) / 256);
+      ++np;
+    }
+    if (i < ncov) cur = hi[i];
+  }
+  q.pfirst[np] = wgp;
+  q.nplain = np;
+  q.wg_plain = total;
+  const double b1t = pow((double)beta1, (double)step_t), b2t = pow((double)beta2, (double)step_t);
+  const double c2 = sqrt(1.0 - b2t);
+  q.a = AdamArgs{params, grad, mom, var, n, (float)(lr * c2 / (1.0 - b1t)), beta1, beta2, (float)(eps * c2), grad_scale};
+  PPSCI_LAUNCH(reduce_rows_multi_adam_kernel, ReduceAdamArgs, total + wgp, 256, 256 * sizeof(float), stream, q);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("reduce_rows_multi_adam: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}
+
 extern "C" int ppsci_optim_step(int kind, int64_t n, float* params, const float* grad, float* state1, float* state2,
                                 float* state3, const float* hyper, int flag, void* stream) {
   if (!params || !grad || !hyper || n <= 0 || kind < PPSCI_OPT_SGD || kind > PPSCI_OPT_ADAMW ||

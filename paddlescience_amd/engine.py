@@ -345,6 +345,28 @@ class StepGraph:
         self._graphs.clear()
 
 
+def step_with_adam(eng, constraints, opt, params: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """One training step of an engine whose backward pass ENDS in row reductions (spinn_engine.SpinnEngine: the gradient rows of
+    the branch nets + the loss rows; operator_engine.OperatorEngine: the partials of the 1x1 convolutions' weight gradients),
+    with a plain Adam (`opt`: optimizer._AdamState without clipping / decay) on one rank: forward + backward without those
+    reductions, then ONE launch that sums the rows and applies the update (hp.reduce_rows_multi_adam) -- instead of a
+    reduction launch followed by the optimizer's launch.  More reductions than one launch takes, or rows that accumulate over
+    several constraints: the reductions are flushed and the optimizer steps as usual."""
+    if os.environ.get("PPSCI_FUSED_REDUCE_ADAM", "1") == "0":  # (A/B measurements, tests)
+        eng.forward_backward(constraints)
+        opt.step(eng.grad, grad_scale)
+        return
+    segs = eng.forward_backward_deferred(constraints)
+    if segs is None or len(segs) > 16:
+        if segs is not None:
+            eng.flush_deferred(segs)
+        opt.step(eng.grad, grad_scale)
+        return
+    opt.t += 1
+    hp.reduce_rows_multi_adam(segs, params, eng.grad, opt.m, opt.v, opt.get_lr(), opt.t, opt.beta1, opt.beta2, opt.epsilon,
+                              grad_scale)
+
+
 def run_on_streams(streams: List["torch.cuda.Stream"], jobs) -> None:
     """Run independent launch sequences concurrently, one HIP stream each, forked from and joined back into the
     current stream (inside a capture: parallel branches of the graph)."""

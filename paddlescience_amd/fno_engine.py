@@ -103,7 +103,7 @@ class FnoNative:
 
     # ------------------------------------------------------------------ buffers
     def _switch(self, B: int, H: int, W: int) -> None:
-        keep = ("m", "shape", "_sets", "max_sets", "generation", "use_side", "_side")
+        keep = ("m", "shape", "_sets", "max_sets", "generation", "use_side", "_side", "defer_wgrad_sums")
         return self._switch_(B, H, W, keep)
 
     def _switch_(self, B: int, H: int, W: int, keep) -> None:
@@ -365,6 +365,8 @@ class FnoNative:
                 self._wsegs.append((part1.data_ptr(), w1.grad.view(-1).data_ptr(), chunks, ld1))
         return True
 
+    defer_wgrad_sums = False  # backward() leaves the partials of the weight gradients unsummed (self._wsegs) when set
+
     def _flush_wgrads(self) -> None:
         """ONE launch sums the per-chunk partials of every weight gradient of the pass (ppsci_reduce_rows_multi; up to 16
         segments per launch): eight reductions of ~5 us each were launch latency, not work."""
@@ -485,4 +487,5 @@ class FnoNative:
         else:
             self._wgrad(B, m.in_channels, Ch, P0, self.x_in, gx, lift[0].weight, lift[0].bias)
         self._join()  # every weight gradient's partial rows are complete
-        self._flush_wgrads()
+        if not self.defer_wgrad_sums:
+            self._flush_wgrads()  # (deferred: the caller sums them together with its Adam update, operator_engine)

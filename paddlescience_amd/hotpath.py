@@ -287,6 +287,21 @@ def reduce_rows(partials: torch.Tensor, rows: int, cols: int, out: torch.Tensor,
     L.check(L.lib().ppsci_reduce_rows(_p(partials), rows, cols, _p(out), 1 if accumulate else 0, _stream_ptr(out)))
 
 
+def reduce_rows_multi_adam(segs: Sequence[tuple], params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor,
+                           lr: float, step_t: int, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                           grad_scale: float = 1.0) -> None:
+    """ppsci_reduce_rows_multi_adam: segs = (source pointer, destination pointer, rows, cols) -- the row reductions that end a
+    backward pass and the Adam update of the flat parameter buffer in ONE launch (<= 16 segments)."""
+    _require_device(params)
+    _chk_f32(params, grad, m, v)
+    note_param_write()
+    arr = (L.ReduceSeg * len(segs))()
+    for k, (src, dst, rows, cols) in enumerate(segs):
+        arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src, dst, rows, cols, 0
+    L.check(L.lib().ppsci_reduce_rows_multi_adam(len(segs), arr, params.numel(), _p(params), _p(grad), _p(m), _p(v), lr, beta1,
+                                                 beta2, eps, step_t, grad_scale, _stream_ptr(params)))
+
+
 def adam_step(params: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step_t: int,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0) -> None:
     _require_device(params)

@@ -143,6 +143,26 @@ class OperatorEngine:
         key = tuple((id(c), c.version) for c in constraints) + (self.native.generation,)
         self._step_graph.run(key, lambda: self._forward_backward_eager(constraints))
 
+    def forward_backward_deferred(self, constraints: List[OperatorConstraint]):
+        """forward_backward with the sums over the weight-gradient partials left to the caller (one launch together with its
+        Adam update, hp.reduce_rows_multi_adam): returns them as (source, destination, rows, cols) pointers."""
+        self.native.defer_wgrad_sums = True
+        try:
+            key = tuple((id(c), c.version) for c in constraints) + (self.native.generation, "deferred")
+            self._step_graph.run(key, lambda: self._forward_backward_eager(constraints))
+        finally:
+            self.native.defer_wgrad_sums = False
+        # (a replayed graph does not run Python: the segment list of the capturing / eager pass stays valid -- same buffers)
+        segs = list(self.native._wsegs) if self.native._wsegs else self._deferred_segs
+        self._deferred_segs = segs
+        return segs
+
+    _deferred_segs = None
+
+    def flush_deferred(self, segs) -> None:
+        self.native._wsegs = list(segs)
+        self.native._flush_wgrads()
+
     def allreduce(self):
         if self.world > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)

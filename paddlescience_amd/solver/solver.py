@@ -327,6 +327,8 @@ class Solver:
                     self.optimizer.step(closure)
                 elif self._step_in_one_launch(eng_csts, gscale):
                     pass  # forward -> loss -> backward -> Adam of every constraint in one launch each (engine.step_one_launch)
+                elif self._reduce_and_adam_in_one_launch(eng_csts, gscale):
+                    pass  # (SPINN / FNO) the reductions that end the backward pass and the Adam update in one launch
                 else:
                     self._materialize()
                     self.engine.forward_backward(eng_csts)
@@ -501,6 +503,22 @@ class Solver:
                                                            eps=opt.epsilon, grad_scale=gscale, t=opt.t + 1)):
             return False
         opt.t += 1
+        return True
+
+    def _reduce_and_adam_in_one_launch(self, eng_csts, gscale: float) -> bool:
+        """Engines whose backward pass ends in row reductions (SPINN: gradient rows of the branch nets + loss rows; FNO: the
+        partials of the 1x1 convolutions' weight gradients): one rank, plain Adam, nothing between the gradient and the update
+        -- the sums and the update are ONE launch (hp.reduce_rows_multi_adam) instead of two.  False: nothing was done."""
+        opt, eng = self.optimizer, self.engine
+        if (self.world_size != 1 or not hasattr(eng, "forward_backward_deferred") or type(opt).__name__ != "_AdamState"
+                or opt.grad_clip is not None or opt.l2 != 0.0 or opt.eq_store is not None or self.update_freq > 1 or self._reparam
+                or getattr(self.loss_aggregator, "per_loss_grad", False) or os.environ.get("PPSCI_FUSED_REDUCE_ADAM", "1") == "0"
+                or opt.model.flat_params.data_ptr() != self.model.flat_params.data_ptr()):
+            return False
+        from ..engine import step_with_adam
+
+        self._materialize()
+        step_with_adam(eng, eng_csts, opt, self.model.flat_params, gscale)
         return True
 
     def _train_grad(self) -> torch.Tensor:

@@ -150,7 +150,37 @@ class SpinnEngine:
         self.multi_stream = os.environ.get("PPSCI_MULTI_STREAM", "1") != "0"
         self._streams: list = []
 
-    def _forward_backward_eager(self, constraints: Sequence[SpinnConstraint]):
+    def _segments(self, constraints: Sequence[SpinnConstraint]):
+        """The row reductions that end the step of ONE constraint, as (source, destination, rows, cols) pointers: the loss
+        rows and the gradient rows of the three branch nets."""
+        P = self.model.branch_params
+        c0 = constraints[0]
+        segs = [(c0.lpart.data_ptr(), c0.loss_term.data_ptr(), c0.lrows, 1)]
+        if c0.gjoint:
+            segs.append((c0.gpart_all.data_ptr(), self.grad.data_ptr(), c0.gpart_all.shape[0], 3 * P))
+        else:
+            segs += [(c0.gpart[b].data_ptr(), self.grad[b * P:(b + 1) * P].data_ptr(), c0.gpart[b].shape[0], P) for b in range(3)]
+        return segs
+
+    def forward_backward_deferred(self, constraints: Sequence[SpinnConstraint]):
+        """forward_backward WITHOUT the reduction launch behind it, for a caller that sums the rows and applies Adam in one
+        launch (hp.reduce_rows_multi_adam; solver.Solver._reduce_and_adam_in_one_launch): returns the pending reductions.
+        None: several constraints share the gradient (their rows accumulate: the reductions stay separate launches) -- the
+        step was run in full."""
+        if len(constraints) != 1:
+            self.forward_backward(constraints)
+            return None
+        key = tuple((id(c), c._version, float(c.desc.scale)) for c in constraints) + ("deferred",)
+        self._step_graph.run(key, lambda: self._forward_backward_eager(constraints, reduce=False))
+        return self._segments(constraints)
+
+    def flush_deferred(self, segs) -> None:
+        arr = (L.ReduceSeg * len(segs))()
+        for k, (src, dst, rows, cols) in enumerate(segs):
+            arr[k].partials, arr[k].out, arr[k].rows, arr[k].cols, arr[k].accumulate = src, dst, rows, cols, 0
+        L.check(L.lib().ppsci_reduce_rows_multi(len(segs), arr, _stream_ptr(self.grad)))
+
+    def _forward_backward_eager(self, constraints: Sequence[SpinnConstraint], reduce: bool = True):
         P = self.model.branch_params
         if self.multi_stream and len(constraints) > 1 and self.grad.is_cuda:
             # the PDE grid and the six boundary faces are independent until their gradients are summed
@@ -159,6 +189,8 @@ class SpinnEngine:
             for c in constraints:
                 c.forward(True, False)
                 c.backward()
+        if not reduce:
+            return
         # ONE launch (ppsci_reduce_rows_multi) sums every constraint's loss rows and the FIRST constraint's gradient rows -- segments
         # with different destinations; the other constraints' gradient rows are added behind it, one launch each, in order (they
         # share a destination).  Helmholtz3D's single PDE constraint: two launches (this one + Adam) instead of three.

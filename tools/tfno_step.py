@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ppsci  # noqa: E402
+from paddlescience_amd.engine import step_with_adam  # noqa: E402
 from paddlescience_amd.operator_engine import OperatorConstraint, OperatorEngine  # noqa: E402
 
 B, H, W = 16, 64, 64
@@ -22,9 +23,8 @@ cst.bind({"x": x}, {"y": y})
 eng = OperatorEngine(model)
 
 
-def step():
-    eng.forward_backward([cst])
-    opt.step(model.flat_grad)
+def step():  # what Solver.train runs: the sums over the weight-gradient partials + Adam in one launch (PPSCI_FUSED_REDUCE_ADAM=0: two)
+    step_with_adam(eng, [cst], opt, model.flat_params)
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
