@@ -128,15 +128,23 @@ struct AdamArgs {
   float lr_t, beta1, beta2, eps_t, grad_scale;
 };
 
+// The update of ONE parameter from its (raw) gradient.  Every multiply-add is written as an explicit fmaf in a fixed form: the
+// compiler is free to contract  beta1 * m + (1 - beta1) * g  either way, and it chose differently in adam_kernel and in
+// reduce_rows_multi_adam_kernel (seen on MI355X: the two paths differed by one ulp per step).  One inline function, one
+// rounding sequence, wherever this file applies Adam.
+__device__ __forceinline__ void ppsci_adam_one(const AdamArgs& a, long long j, float graw) {
+  const float g = a.grad_scale * graw;
+  const float m = __builtin_fmaf(a.beta1, a.m[j], (1.f - a.beta1) * g);
+  const float v = __builtin_fmaf(a.beta2, a.v[j], ((1.f - a.beta2) * g) * g);
+  a.m[j] = m;
+  a.v[j] = v;
+  a.p[j] = __builtin_fmaf(-a.lr_t, m / (sqrtf(v) + a.eps_t), a.p[j]);
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   if (j >= a.n) return;
-  const float g = a.grad_scale * a.g[j];
-  const float m = a.beta1 * a.m[j] + (1.f - a.beta1) * g;
-  const float v = a.beta2 * a.v[j] + (1.f - a.beta2) * g * g;
-  a.m[j] = m;
-  a.v[j] = v;
-  a.p[j] = a.p[j] - a.lr_t * (m / (sqrtf(v) + a.eps_t));
+  ppsci_adam_one(a, j, a.g[j]);
 }
 
 // SGD / Momentum / RMSProp / AdamW on the flat parameter buffer (paddle.optimizer semantics as wrapped by
@@ -521,15 +529,6 @@ struct ReduceAdamArgs {
   int pfirst[ADAM_MAX_PLAIN + 1];             // their workgroup ranges (relative to the first plain workgroup)
   int nplain, wg_plain;                       // wg_plain: index of the first plain workgroup
 };
-
-__device__ __forceinline__ void ppsci_adam_one(const AdamArgs& a, long long j, float graw) {
-  const float g = a.grad_scale * graw;
-  const float m = a.beta1 * a.m[j] + (1.f - a.beta1) * g;
-  const float v = a.beta2 * a.v[j] + (1.f - a.beta2) * g * g;
-  a.m[j] = m;
-  a.v[j] = v;
-  a.p[j] = a.p[j] - a.lr_t * (m / (sqrtf(v) + a.eps_t));
-}
 
 __global__ void __launch_bounds__(256) reduce_rows_multi_adam_kernel(ReduceAdamArgs q) {
   PPSCI_DYN_SMEM(red);
