@@ -697,6 +697,14 @@ int ppsci_spinn_grid_fwd(const ppsci_spinn_grid_desc* d, const float* Fx, const 
 int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_desc* d);
 int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
                          const float* gadj, float* scratch, float* Fbar_x, float* Fbar_y, float* Fbar_z, void* stream);
+/* ppsci_spinn_grid_bwd with its three Fbar pointers NULL (MFMA shapes only) leaves the per-group partials of dL/dF in `scratch`;
+ * ppsci_modmlp_bwd_batch_parts is the reverse sweep of the three branch nets (ppsci_modmlp_bwd_batch on the axes of `gd`) that
+ * sums them on load, in the order of the launch it saves.  _supported: 1 when both the tile kernel of the branch nets and the
+ * MFMA grid kernels apply (width and rank multiples of 16 up to 64, rank % 4 == 0), else 0: the caller keeps the two calls. */
+int ppsci_modmlp_bwd_parts_supported(const ppsci_modmlp_desc* d, const ppsci_spinn_grid_desc* gd);
+int ppsci_modmlp_bwd_batch_parts(const ppsci_modmlp_desc* d, const ppsci_spinn_grid_desc* gd, const float* const* params,
+                                 const float* const* x, const float* scratch, const float* const* stash,
+                                 float* const* grad_partials, int64_t partial_stride, void* stream);
 
 /* ---- data-parallel collectives on RCCL (csrc/comm.hip): the fused gradient all-reduce of solver/train.py:168-171 and
  * the evaluation gather of utils/misc.py, on the ONE flat gradient buffer -- so that a host without torch.distributed can

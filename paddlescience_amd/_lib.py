@@ -214,6 +214,10 @@ _SYMBOLS = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_modmlp_param_count": (C.c_int64, [C.POINTER(ModMlpDesc)]),
     "ppsci_modmlp_bwd_rows": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
+    "ppsci_modmlp_bwd_parts_supported": (C.c_int, [C.POINTER(ModMlpDesc), C.POINTER(SpinnGridDesc)]),
+    "ppsci_modmlp_bwd_batch_parts": (C.c_int, [C.POINTER(ModMlpDesc), C.POINTER(SpinnGridDesc), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.c_int64, C.c_void_p]),
     "ppsci_set_modmlp_tile": (None, [C.c_int]),
     "ppsci_modmlp_stash_floats": (C.c_int64, [C.POINTER(ModMlpDesc), C.c_int64]),
     "ppsci_modmlp_fwd": (C.c_int, [C.POINTER(ModMlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -87,6 +87,8 @@ struct ModBranch {     // one network (one SPINN axis) and its points
   float* partials;     // bwd out: [N][P], row stride `pstride` floats
   long long pstride;
   int N;
+  const float* fpart;  // tile kernel: dL/dF as the grid kernel's group partials [N][ngrp][2][R] (null: `Fbar` holds the sums)
+  int ngrp;
 };
 struct ModArgs {       // up to SP_MAXBATCH networks of the same shape in one launch: workgroup = (branch, point)
   ppsci_modmlp_desc d;
@@ -351,6 +353,7 @@ __global__ void __launch_bounds__(MOD_BWD_BLOCK) modmlp_bwd_kernel(ModArgs a) {
 // Needs width and rank to be multiples of 16, at most 64; other shapes keep the per-point kernel.
 #define MODT_BLOCK 256
 #define MODT_LD 17
+#define FSUM_PARTS 8  // spinn_fbar_sum_kernel's interleaved subsets of the group partials (its summation order is kept here)
 
 __device__ __forceinline__ float sp_sum16(float v) {  // over the 16 lanes c of a lane group g
   v += __shfl_xor(v, 1, 64);
@@ -394,9 +397,39 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
   float* G = B.partials + (long long)tile * B.pstride;
   float* To = sh;
   float* Tz = sh + 3 * H * MODT_LD;
+  float* Fb = Tz + 3 * H * MODT_LD;       // [3][16][R]: dL/dF of the tile's points
   const bool active = wave < NB;          // this wave owns feature block `wave`
   const int f4 = 16 * wave + 4 * g;       // its lane's first feature
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // dL/dF of the tile into LDS: either the finished sums, or -- B.fpart -- the grid kernel's per-group partials summed here
+  // in spinn_fbar_sum_kernel's order (FSUM_PARTS interleaved subsets, then the subsets in order): that launch is saved
+  for (int e = tid; e < 16 * 2 * R; e += MODT_BLOCK) {
+    const int p = e / (2 * R), col = e - p * 2 * R;
+    const int i = pt0 + p;
+    float tot = 0.f;
+    if (i < N) {
+      if (B.fpart != nullptr) {
+        const float* q = B.fpart + (long long)i * B.ngrp * 2 * R + col;
+        float part[FSUM_PARTS];
+#pragma unroll
+        for (int k = 0; k < FSUM_PARTS; ++k) {
+          float sk = 0.f;
+#pragma unroll 4
+          for (int gi = k; gi < B.ngrp; gi += FSUM_PARTS) sk += q[(long long)gi * 2 * R];
+          part[k] = sk;
+        }
+#pragma unroll
+        for (int k = 0; k < FSUM_PARTS; ++k) tot += part[k];
+      } else {
+        tot = B.Fbar[((long long)(col < R ? 0 : 2) * N + i) * R + (col < R ? col : col - R)];
+      }
+    }
+    Fb[((col < R ? 0 : 2) * 16 + p) * R + (col < R ? col : col - R)] = tot;
+  }
+  for (int e = tid; e < 16 * R; e += MODT_BLOCK) {  // the first-derivative stream
+    const int p = e / R, r = e - p * R;
+    Fb[(16 + p) * R + r] = (B.fpart == nullptr && pt0 + p < N) ? B.Fbar[((long long)N + pt0 + p) * R + r] : 0.f;
+  }
 
   f32x4 U[3], V[3], zu[3], zv[3], du1 = zero4, du2 = zero4, du3 = zero4, dv1 = zero4, dv2 = zero4, dv3 = zero4;
   f32x4 zl[3], al[3], ol[3], d1 = zero4, d2 = zero4, d3 = zero4, ob[3];
@@ -404,15 +437,10 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
   for (int s = 0; s < 3; ++s) U[s] = V[s] = zu[s] = zv[s] = zl[s] = al[s] = ol[s] = ob[s] = zero4;
   // every operand of the last_fc stage is requested here, in front of the activation arithmetic: a tile is one workgroup's
   // latency chain (24 workgroups for 3 x 128 points), a load waited for inside a loop costs a memory round trip per trip
-  f32x4 awl[4], fbl[3][4];
+  f32x4 awl[4];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {
-    const bool on = active && rb < RB;
-    awl[rb] = on ? *(const f32x4*)&P[a.o.wl + (16 * wave + c) * R + 16 * rb + 4 * g] : zero4;
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      fbl[s][rb] = (on && valid) ? *(const f32x4*)&B.Fbar[((long long)s * N + pt) * R + 16 * rb + 4 * g] : zero4;
-  }
+  for (int rb = 0; rb < 4; ++rb)
+    awl[rb] = (active && rb < RB) ? *(const f32x4*)&P[a.o.wl + (16 * wave + c) * R + 16 * rb + 4 * g] : zero4;
   if (active) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -439,8 +467,7 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int pp = pt0 + 4 * t + g;
-        bv[s][t] = pp < N ? B.Fbar[((long long)s * N + pp) * R + 16 * rb + c] : 0.f;
+        bv[s][t] = Fb[(s * 16 + 4 * t + g) * R + 16 * rb + c];  // (zero beyond the batch)
       }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -452,8 +479,7 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
   }
   for (int r = tid; r < R; r += MODT_BLOCK) {  // gbL[r] = sum_p Fbar_0[r][p]
     float sum = 0.f;
-    for (int p = 0; p < 16; ++p)
-      if (pt0 + p < N) sum += B.Fbar[((long long)pt0 + p) * R + r];
+    for (int p = 0; p < 16; ++p) sum += Fb[p * R + r];
     G[a.o.bl + r] = sum;
   }
   // ---- obar_s[k][p] = sum_r WL[k][r] Fbar_s[r][p]   (this wave's feature block; k-step (rb, r); operands requested above)
@@ -464,8 +490,9 @@ __global__ void __launch_bounds__(MODT_BLOCK) modmlp_bwd_tile_kernel(ModArgs a) 
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
         if (rb < RB) {
+          const f32x4 fb = *(const f32x4*)&Fb[(s * 16 + c) * R + 16 * rb + 4 * g];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(awl[rb][r], fbl[s][rb][r], acc, 0, 0, 0);
+          for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(awl[rb][r], fb[r], acc, 0, 0, 0);
         }
       ob[s] = acc;
     }
@@ -1066,7 +1093,6 @@ __global__ void __launch_bounds__(GRID_BLOCK) spinn_grid_bwd_mfma_kernel(GridArg
 // One workgroup per index i: thread = (column of the [2][R] partial row, one of FSUM_PARTS interleaved group
 // subsets); the subsets' sums are combined through LDS in a fixed order (the loads of one thread are independent:
 // one round of memory latency instead of one per group).
-#define FSUM_PARTS 8
 __global__ void __launch_bounds__(GRID_BLOCK) spinn_fbar_sum_kernel(GridArgs a) {
   PPSCI_DYN_SMEM(red);  // [FSUM_PARTS][2R]
   int bx = blockIdx.x, ngrp;
@@ -1177,11 +1203,21 @@ extern "C" int ppsci_modmlp_fwd(const ppsci_modmlp_desc* d, const float* params,
   return ppsci_modmlp_fwd_batch(d, 1, &params, &n, &x, &F, stash ? &stash : nullptr, stream);
 }
 
+static int modmlp_bwd_batch_impl(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
+                                 const float* const* x, const float* const* Fbar, const float* const* fpart, const int* ngrp,
+                                 const float* const* stash, float* const* grad_partials, int64_t partial_stride, void* stream);
+
 extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
                                       const float* const* x, const float* const* Fbar, const float* const* stash,
                                       float* const* grad_partials, int64_t partial_stride, void* stream) {
-  if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || !Fbar || !stash ||
-      !grad_partials) {
+  return modmlp_bwd_batch_impl(d, nbatch, params, n, x, Fbar, nullptr, nullptr, stash, grad_partials, partial_stride, stream);
+}
+
+static int modmlp_bwd_batch_impl(const ppsci_modmlp_desc* d, int nbatch, const float* const* params, const int64_t* n,
+                                 const float* const* x, const float* const* Fbar, const float* const* fpart, const int* ngrp,
+                                 const float* const* stash, float* const* grad_partials, int64_t partial_stride, void* stream) {
+  if (mod_check(d) != PPSCI_OK || nbatch < 1 || nbatch > SP_MAXBATCH || !params || !n || !x || (!Fbar && !fpart) || !stash ||
+      !grad_partials || (fpart && (!ngrp || !mod_tiled(d)))) {
     ppsci_set_error("modmlp_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -1192,11 +1228,12 @@ extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
   a.nbatch = nbatch;
   long long total = 0;
   for (int b = 0; b < nbatch; ++b) {
-    if (!params[b] || !x[b] || !Fbar[b] || !stash[b] || !grad_partials[b] || n[b] < 1) {
+    if (!params[b] || !x[b] || (fpart ? !fpart[b] || ngrp[b] < 1 : !Fbar[b]) || !stash[b] || !grad_partials[b] || n[b] < 1) {
       ppsci_set_error("modmlp_bwd: invalid argument (branch %d)", b);
       return PPSCI_E_INVALID;
     }
-    a.br[b].params = params[b]; a.br[b].x = x[b]; a.br[b].Fbar = Fbar[b]; a.br[b].stash = (float*)stash[b];
+    a.br[b].params = params[b]; a.br[b].x = x[b]; a.br[b].Fbar = fpart ? nullptr : Fbar[b]; a.br[b].stash = (float*)stash[b];
+    a.br[b].fpart = fpart ? fpart[b] : nullptr; a.br[b].ngrp = fpart ? ngrp[b] : 0;
     a.br[b].partials = grad_partials[b]; a.br[b].N = (int)n[b];
     a.br[b].pstride = partial_stride > 0 ? partial_stride : a.o.P;
     total += n[b];
@@ -1204,7 +1241,8 @@ extern "C" int ppsci_modmlp_bwd_batch(const ppsci_modmlp_desc* d, int nbatch, co
   if (mod_tiled(d)) {  // one workgroup per 16-point tile (MFMA), one gradient row per tile
     int tiles = 0;
     for (int b = 0; b < nbatch; ++b) tiles += (int)((n[b] + 15) / 16);
-    PPSCI_LAUNCH(modmlp_bwd_tile_kernel, ModArgs, tiles, MODT_BLOCK, (size_t)6 * d->width * MODT_LD * sizeof(float), stream, a);
+    PPSCI_LAUNCH(modmlp_bwd_tile_kernel, ModArgs, tiles, MODT_BLOCK,
+                 ((size_t)6 * d->width * MODT_LD + (size_t)48 * d->d_out) * sizeof(float), stream, a);
     int et = PPSCI_LAST_LAUNCH_ERROR();
     if (et != 0) { ppsci_set_error("modmlp_bwd: launch failed (%d)", et); return PPSCI_E_LAUNCH; }
     return PPSCI_OK;
@@ -1292,7 +1330,9 @@ extern "C" int64_t ppsci_spinn_grid_bwd_scratch_floats(const ppsci_spinn_grid_de
 extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float* Fx, const float* Fy, const float* Fz,
                                     const float* gadj, float* scratch, float* Fbar_x, float* Fbar_y, float* Fbar_z,
                                     void* stream) {
-  if (!d || !Fx || !Fy || !Fz || !gadj || !scratch || !Fbar_x || !Fbar_y || !Fbar_z || d->rank > GRID_BLOCK) {
+  const bool nosum = !Fbar_x && !Fbar_y && !Fbar_z;  // the group partials stay in `scratch` (ppsci_modmlp_bwd_batch_parts sums them)
+  if (!d || !Fx || !Fy || !Fz || !gadj || !scratch || (!nosum && (!Fbar_x || !Fbar_y || !Fbar_z)) || d->rank > GRID_BLOCK ||
+      (nosum && !grid_mfma(d))) {
     ppsci_set_error("spinn_grid_bwd: invalid argument");
     return PPSCI_E_INVALID;
   }
@@ -1344,6 +1384,7 @@ extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float*
     }
     int e = PPSCI_LAST_LAUNCH_ERROR();
     if (e != 0) { ppsci_set_error("spinn_grid_bwd: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
+    if (nosum) return PPSCI_OK;
     a.wg3[0] = d->n[0]; a.wg3[1] = d->n[1]; a.wg3[2] = d->n[2];
     PPSCI_LAUNCH(spinn_fbar_sum_kernel, GridArgs, nsum, GRID_BLOCK, (size_t)FSUM_PARTS * 2 * d->rank * sizeof(float), stream, a);
     e = PPSCI_LAST_LAUNCH_ERROR();
@@ -1382,4 +1423,30 @@ extern "C" int ppsci_spinn_grid_bwd(const ppsci_spinn_grid_desc* d, const float*
     if (e != 0) { ppsci_set_error("spinn_fbar_sum: launch failed (%d)", e); return PPSCI_E_LAUNCH; }
   }
   return PPSCI_OK;
+}
+
+// The reverse sweep of the three branch nets reading dL/dF as the group partials ppsci_spinn_grid_bwd left in `scratch` (called with
+// its three Fbar pointers NULL): the tile kernel sums them on load -- spinn_fbar_sum_kernel's launch is saved.
+extern "C" int ppsci_modmlp_bwd_parts_supported(const ppsci_modmlp_desc* d, const ppsci_spinn_grid_desc* gd) {
+  return (d && gd && mod_check(d) == PPSCI_OK && mod_tiled(d) && grid_mfma(gd) && gd->rank == d->d_out) ? 1 : 0;
+}
+
+extern "C" int ppsci_modmlp_bwd_batch_parts(const ppsci_modmlp_desc* d, const ppsci_spinn_grid_desc* gd, const float* const* params,
+                                            const float* const* x, const float* scratch, const float* const* stash,
+                                            float* const* grad_partials, int64_t partial_stride, void* stream) {
+  if (!ppsci_modmlp_bwd_parts_supported(d, gd) || !scratch) {
+    ppsci_set_error("modmlp_bwd_parts: unsupported shape (tile kernel + MFMA grid kernels only)");
+    return PPSCI_E_UNSUPPORTED;
+  }
+  const float* fpart[3];
+  int ngrp[3];
+  int64_t n[3];
+  long long off = 0;
+  for (int ax = 0; ax < 3; ++ax) {  // the layout ppsci_spinn_grid_bwd writes: one region per axis, [n_ax][groups][2][R]
+    ngrp[ax] = grid_bwd_groups(gd, ax);
+    fpart[ax] = scratch + off;
+    off += (long long)gd->n[ax] * ngrp[ax] * 2 * gd->rank;
+    n[ax] = gd->n[ax];
+  }
+  return modmlp_bwd_batch_impl(d, 3, params, n, x, nullptr, fpart, ngrp, stash, grad_partials, partial_stride, stream);
 }

@@ -127,10 +127,19 @@ class SpinnConstraint:
 
     def backward(self):
         m, lib = self.model, L.lib()
+        vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
+        if (os.environ.get("PPSCI_SPINN_PARTS", "1") != "0"
+                and lib.ppsci_modmlp_bwd_parts_supported(C.byref(m.spec.desc), C.byref(self.desc))):
+            # the grid kernel leaves its per-group partials of dL/dF in the scratch; the branch nets' tile kernel sums them on load
+            L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
+                                             _p(self.bscratch), None, None, None, _stream_ptr(self.gadj)))
+            L.check(lib.ppsci_modmlp_bwd_batch_parts(C.byref(m.spec.desc), C.byref(self.desc), vp([m.branch(b) for b in range(3)]),
+                                                     vp(self.x), _p(self.bscratch), vp(self.stash), vp(self.gpart),
+                                                     3 * m.branch_params if self.gjoint else 0, _stream_ptr(self.x[0])))
+            return
         L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
                                          _p(self.bscratch), _p(self.Fbar[0]), _p(self.Fbar[1]), _p(self.Fbar[2]),
                                          _stream_ptr(self.gadj)))
-        vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
         L.check(lib.ppsci_modmlp_bwd_batch(C.byref(m.spec.desc), 3, vp([m.branch(b) for b in range(3)]),
                                            (C.c_int64 * 3)(*[t.numel() for t in self.x]), vp(self.x), vp(self.Fbar),
                                            vp(self.stash), vp(self.gpart), 3 * m.branch_params if self.gjoint else 0,

@@ -114,6 +114,22 @@ def test_tile_and_point_kernels_of_the_reverse_sweep_agree(tmp_path):
     assert rel(grads[0], grads[1]) < 2e-6 and rel(grads[2], grads[1]) < 2e-6
 
 
+def test_group_partials_summed_by_the_branch_kernel_equal_the_sum_launch(tmp_path, monkeypatch):
+    """ppsci_spinn_grid_bwd without its partial-sum launch + ppsci_modmlp_bwd_batch_parts (the tile kernel sums the grid kernel's
+    per-group partials of dL/dF on load, in that launch's order): bit-identical gradients."""
+    grads = []
+    for parts in ("1", "0"):
+        monkeypatch.setenv("PPSCI_SPINN_PARTS", parts)
+        solver, model, xs, uc, face = _build(tmp_path / f"p{parts}", shape=(19, 16, 33), r=32, hidden=32, layers=2)
+        csts = list(solver._compiled.values())
+        for name, cc in solver._compiled.items():
+            inp, lab, _ = next(solver.constraint[name].data_iter)
+            cc.bind(inp, lab)
+        solver.engine.forward_backward(csts)
+        grads.append(solver.engine.grad.cpu().numpy().copy())
+    assert np.array_equal(grads[0], grads[1]) and np.abs(grads[0]).sum() > 0
+
+
 def test_spinn_training_step_runs(tmp_path):
     solver, model, *_ = _build(tmp_path)
     p0 = model.flat_params.clone()
