@@ -128,9 +128,12 @@ class SpinnConstraint:
     def backward(self):
         m, lib = self.model, L.lib()
         vp = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])  # noqa: E731
-        if (os.environ.get("PPSCI_SPINN_PARTS", "1") != "0"
+        if (os.environ.get("PPSCI_SPINN_PARTS", "0") == "1"
                 and lib.ppsci_modmlp_bwd_parts_supported(C.byref(m.spec.desc), C.byref(self.desc))):
-            # the grid kernel leaves its per-group partials of dL/dF in the scratch; the branch nets' tile kernel sums them on load
+            # the grid kernel leaves its per-group partials of dL/dF in the scratch; the branch nets' tile kernel sums them on load.
+            # OFF by default -- measured on MI355X (128^3, 3 x 128 points): 0.0983 ms per step with it, 0.0914 without: the 24
+            # tile workgroups read 128 KB of partials each in front of their latency chain, which costs more than the ~5 us launch
+            # of spinn_fbar_sum_kernel (384 workgroups) it saves.  Kept as a tested option for larger point counts.
             L.check(lib.ppsci_spinn_grid_bwd(C.byref(self.desc), _p(self.F[0]), _p(self.F[1]), _p(self.F[2]), _p(self.gadj),
                                              _p(self.bscratch), None, None, None, _stream_ptr(self.gadj)))
             L.check(lib.ppsci_modmlp_bwd_batch_parts(C.byref(m.spec.desc), C.byref(self.desc), vp([m.branch(b) for b in range(3)]),

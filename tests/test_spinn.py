@@ -118,7 +118,7 @@ def test_group_partials_summed_by_the_branch_kernel_equal_the_sum_launch(tmp_pat
     """ppsci_spinn_grid_bwd without its partial-sum launch + ppsci_modmlp_bwd_batch_parts (the tile kernel sums the grid kernel's
     per-group partials of dL/dF on load, in that launch's order): bit-identical gradients."""
     grads = []
-    for parts in ("1", "0"):
+    for parts in ("1", "0"):  # (off by default: slower at 3 x 128 points, spinn_engine.SpinnConstraint.backward)
         monkeypatch.setenv("PPSCI_SPINN_PARTS", parts)
         solver, model, xs, uc, face = _build(tmp_path / f"p{parts}", shape=(19, 16, 33), r=32, hidden=32, layers=2)
         csts = list(solver._compiled.values())

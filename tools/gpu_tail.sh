@@ -12,7 +12,7 @@ for i in 1 2; do
   done
 done
 for f in 1 0; do echo "fused=$f"; cat $O/spinn_$f.txt $O/tfno_$f.txt; done
-for i in 1 2; do PPSCI_SPINN_PARTS=0 timeout 300 python tools/spinn_step.py 300 >> $O/spinn_noparts.txt 2>> $O/err.log; done
-echo "parts=0 (the partial-sum launch kept)"; cat $O/spinn_noparts.txt
+for i in 1 2; do PPSCI_SPINN_PARTS=1 timeout 300 python tools/spinn_step.py 300 >> $O/spinn_parts.txt 2>> $O/err.log; done
+echo "parts=1 (the branch kernel sums the grid partials: slower at this size)"; cat $O/spinn_parts.txt
 bash tools/profile_bench.sh r06_spinn python /root/repo/tools/spinn_step.py 50 > $O/profile.log 2>&1
 find gpurun_out/prof_r06_spinn -name "*_kernel_trace.csv" -delete
