@@ -1,7 +1,8 @@
 // hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A tiny CPU SIMT emulator so that the *same* kernel
 // source that hipcc compiles for gfx950 (paddlescience_amd/csrc/*.hip) can be compiled for the
 // host (clang++ -DPPSCI_EMU) and executed lane-by-lane in this GPU-less container.  Every lane of
-// a workgroup is a ucontext fiber; __syncthreads / wave collectives (MFMA, shuffles) are fiber
+// a workgroup is a fiber (a private stack + a hand-written x86-64 context switch; glibc's swapcontext pays a signal-mask
+// system call per switch, which was a fifth of the suite's time); __syncthreads / wave collectives (MFMA, shuffles) are fiber
 // barriers.  The product never loads the emulator build: paddlescience_amd/_lib.py only accepts
 // a library whose ppsci_is_device_build() returns 1 unless a test injects one explicitly.
 //
@@ -10,7 +11,6 @@
 //   register r of lane l is element (row = 4*(l>>4) + r, col = l&15); the result is a k-ordered
 //   fmaf chain (bitwise the same as the hardware, per the guide).
 #pragma once
-#include <ucontext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -53,16 +53,34 @@ struct Wave {
   unsigned op = 0;  // collective counter (same in every lane of the wave)
 };
 
+// ---- context switch: callee-saved registers on the fiber's own stack, the stack pointer in Ctx
+struct Ctx {
+  void* sp = nullptr;
+};
+#if !defined(__x86_64__)
+#error "tests/emu/hip_emu.h: the fiber switch is written for x86-64 (System V ABI)"
+#endif
+__attribute__((naked, noinline)) static void emu_switch(Ctx* /*from: rdi*/, Ctx* /*to: rsi*/) {
+  __asm__ volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\t"
+      "movq (%rsi), %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+      "ret\n\t");
+}
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   bool done = false;
   unsigned tid = 0;
   unsigned wave_op = 0;
+  const Barrier* wait_bar = nullptr;  // blocked on this barrier until its generation moves on (the scheduler skips the fiber)
+  int wait_gen = 0;
 };
 
 struct State {
-  ucontext_t sched;
+  Ctx sched;
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
   Barrier block_bar;
@@ -80,7 +98,7 @@ inline State& st() {
 
 inline void yield() {
   State& s = st();
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  emu_switch(&s.fibers[s.cur].ctx, &s.sched);
 }
 
 inline void barrier_wait(Barrier& b) {
@@ -89,15 +107,31 @@ inline void barrier_wait(Barrier& b) {
     b.count = 0;
     b.gen++;
   } else {
+    Fiber& f = st().fibers[st().cur];
+    f.wait_bar = &b;
+    f.wait_gen = g;
     while (b.gen == g) yield();
+    f.wait_bar = nullptr;
   }
 }
 
-inline void trampoline() {
+static void trampoline() {
   State& s = st();
   s.entry(s.args);
   s.fibers[s.cur].done = true;
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  emu_switch(&s.fibers[s.cur].ctx, &s.sched);
+  __builtin_trap();  // a finished fiber is never resumed
+}
+
+// A fresh fiber: its stack holds what emu_switch pops -- six callee-saved registers, then `trampoline` as the return address, with
+// the stack pointer 8 below a 16-byte boundary at trampoline's entry, as the ABI has it behind a call.
+inline void fiber_reset(Fiber& f) {
+  uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+  void** sp = (void**)top;
+  *--sp = nullptr;                 // the "return address" of trampoline (it never returns)
+  *--sp = (void*)&trampoline;      // popped by emu_switch's ret
+  for (int k = 0; k < 6; ++k) *--sp = nullptr;
+  f.ctx.sp = sp;
 }
 
 // Runs `entry(args)` for every thread of every block of the grid (blocks sequentially).
@@ -134,19 +168,17 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t dyn_lds_bytes, void (*e
       f.done = false;
       f.tid = t;
       f.wave_op = 0;
-      getcontext(&f.ctx);
-      f.ctx.uc_stack.ss_sp = f.stack;
-      f.ctx.uc_stack.ss_size = kStack;
-      f.ctx.uc_link = nullptr;
-      makecontext(&f.ctx, (void (*)())trampoline, 0);
+      f.wait_bar = nullptr;
+      fiber_reset(f);
     }
     unsigned remaining = nthreads;
     while (remaining) {
       for (unsigned t = 0; t < nthreads; ++t) {
-        if (s.fibers[t].done) continue;
+        Fiber& f = s.fibers[t];
+        if (f.done || (f.wait_bar != nullptr && f.wait_bar->gen == f.wait_gen)) continue;  // finished, or still blocked
         s.cur = (int)t;
-        swapcontext(&s.sched, &s.fibers[t].ctx);
-        if (s.fibers[t].done) --remaining;
+        emu_switch(&s.sched, &f.ctx);
+        if (f.done) --remaining;
       }
     }
   }

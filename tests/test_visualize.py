@@ -1,0 +1,104 @@
+"""ppsci.visualize + Solver(visualizer=) / Solver.visualize() + string log levels (/root/reference/ppsci/visualize/*.py,
+solver/solver.py:713-727, solver/visu.py, utils/logger.py:84-85): the surface the reference's example scripts touch."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+import ppsci
+from ppsci.utils import logger
+from tests.common import make_dev_fixture
+
+dev = make_dev_fixture()
+
+
+def _vtu_arrays(path):
+    root = ET.parse(path).getroot()
+    piece = root.find("UnstructuredGrid/Piece")
+    n = int(piece.get("NumberOfPoints"))
+    pts = np.array(piece.find("Points/DataArray").text.split(), dtype=np.float64).reshape(n, 3)
+    data = {a.get("Name"): np.array(a.text.split(), dtype=np.float64) for a in piece.find("PointData")}
+    cells = {a.get("Name"): np.array(a.text.split(), dtype=np.int64) for a in piece.find("Cells")}
+    return n, pts, data, cells
+
+
+def test_vtu_writer_point_cloud(tmp_path):
+    d = {"x": np.array([[1.0], [2], [3], [4]]), "y": np.array([[2.0], [3], [4], [4]]), "t": np.zeros((4, 1)),
+         "u": np.array([[4.0], [5], [6], [4]]), "v": np.array([[5.0], [6], [7], [4]])}
+    ppsci.visualize.save_vtu_from_dict(str(tmp_path / "a" / "f.vtu"), d, ("t", "x", "y"), ("u", "v"))  # "t" is not a coordinate
+    n, pts, data, cells = _vtu_arrays(tmp_path / "a" / "f.vtu")
+    assert n == 4 and np.allclose(pts[:, 0], [1, 2, 3, 4]) and np.allclose(pts[:, 1], [2, 3, 4, 4]) and np.all(pts[:, 2] == 0)
+    assert np.allclose(data["u"], [4, 5, 6, 4]) and np.allclose(data["v"], [5, 6, 7, 4])
+    assert np.array_equal(cells["connectivity"], np.arange(4)) and np.array_equal(cells["offsets"], np.arange(1, 5))
+    assert np.all(cells["types"] == 1)  # VTK_VERTEX
+    # several timestamps: one file per time level, named like the reference's (vtu.py:93-99)
+    ppsci.visualize.save_vtu_from_dict(str(tmp_path / "b"), d, ("x", "y"), ("u",), num_timestamps=2)
+    assert sorted(os.listdir(tmp_path)) == ["a", "b_t-0.vtu", "b_t-1.vtu"]
+    assert _vtu_arrays(tmp_path / "b_t-1.vtu")[0] == 2
+    with pytest.raises(ValueError, match="2, 3 or 4"):
+        ppsci.visualize.save_vtu_from_dict(str(tmp_path / "c"), d, ("x",), ("u",))
+    ppsci.visualize.save_vtu_to_mesh(str(tmp_path / "m" / "p.vtu"), d, ("x", "y"), ("u",))
+    assert _vtu_arrays(tmp_path / "m" / "p.vtu")[0] == 4
+
+
+def test_build_visualizer_and_refusals():
+    pts = {"x": np.zeros((4, 1), np.float32), "y": np.zeros((4, 1), np.float32)}
+    vis = ppsci.visualize.build_visualizer([{"VisualizerVtu": {"input_dict": pts, "output_expr": {"u": lambda d: d["u"]},
+                                                               "prefix": "p"}}])
+    assert list(vis) == ["VisualizerVtu"] and vis["VisualizerVtu"].input_keys == ("x", "y") and vis["VisualizerVtu"].batch_size == 64
+    assert ppsci.visualize.build_visualizer(None) is None
+    with pytest.raises(NotImplementedError, match="out of scope"):
+        ppsci.visualize.VisualizerWeather(pts, {})
+    assert "input_keys: ('x', 'y')" in str(vis["VisualizerVtu"])
+    with pytest.raises(ValueError, match="unique"):
+        ppsci.visualize.build_visualizer([{"VisualizerVtu": {"input_dict": pts, "output_expr": {}}}] * 2)
+
+
+def test_solver_visualize_writes_under_output_dir(dev, tmp_path):
+    model = ppsci.arch.MLP(("x", "y"), ("u",), 2, 16)
+    pts = {"x": np.linspace(0, 1, 10, dtype=np.float32).reshape(-1, 1), "y": np.linspace(1, 2, 10, dtype=np.float32).reshape(-1, 1)}
+    line = {"x": pts["x"], "u_ref": np.sin(pts["x"])}
+    vis = {"cloud": ppsci.visualize.VisualizerVtu(pts, {"u": lambda d: d["u"], "twice": lambda d: 2.0 * d["u"]}, batch_size=4,
+                                                  prefix="cloud"),
+           "line": ppsci.visualize.VisualizerScatter1D({**line, "y": pts["y"]}, ("x",),
+                                                       {"u_pred": lambda d: d["u"], "u_ref": lambda d: d["u_ref"]}, prefix="line")}
+    solver = ppsci.solver.Solver(model, output_dir=str(tmp_path), visualizer=vis)
+    solver.visualize()
+    solver.visualize(3)
+    n, _, data, _ = _vtu_arrays(tmp_path / "visual" / "cloud.vtu")
+    pred = solver.predict(pts, return_numpy=True)["u"][:, 0]
+    assert n == 10 and np.allclose(data["u"], pred, rtol=1e-6, atol=1e-7) and np.allclose(data["twice"], 2 * pred, rtol=1e-6, atol=1e-7)
+    assert os.path.exists(tmp_path / "visual" / "epoch_3" / "cloud.vtu")
+    assert os.path.exists(tmp_path / "visual" / "line.png") or os.path.exists(tmp_path / "visual" / "line.npz")
+    with pytest.raises(ValueError):
+        ppsci.solver.Solver(model, output_dir=str(tmp_path)).visualize()
+
+
+def test_log_levels_by_name(tmp_path):
+    import logging
+
+    logger.init_logger("ppsci_lvl", str(tmp_path / "a.log"), "info")  # what every reference example calls
+    assert logging.getLogger("ppsci_lvl").level == logging.INFO
+    logger.init_logger("ppsci_lvl", None, "DEBUG")
+    assert logging.getLogger("ppsci_lvl").level == logging.DEBUG
+    logger.set_log_level("message")
+    assert logging.getLogger("ppsci_lvl").level == logger.MESSAGE
+    with pytest.raises(ValueError):
+        logger.init_logger("ppsci_lvl", None, "chatty")
+    logger.init_logger()
+
+
+def test_every_ppsci_submodule_is_the_native_module():
+    import importlib
+
+    for name in ("ppsci.visualize.vtu", "ppsci.utils.initializer", "ppsci.equation.ide.volterra", "ppsci.optimizer.lr_scheduler",
+                 "ppsci.data.dataset", "ppsci.loss.mtl", "ppsci.geometry.timedomain"):
+        alias = importlib.import_module(name)
+        native = importlib.import_module("paddlescience_amd." + name[len("ppsci."):])
+        assert alias is native, name
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("ppsci.no_such_module")
+    from ppsci.utils import logger as l2  # noqa: E402
+
+    assert l2 is logger
