@@ -474,6 +474,12 @@ int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows,
  * y + sbias[plane % C] and of its square (ppsci_fno_tail_fwd_ex with have_rows = 1 then skips its statistics pass). */
 int ppsci_dft2_kept_inv_stats(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
                               const float* sbias, int C, float* rows_out, void* stream);
+/* ppsci_spectral_conv2d_fwd_kept + ppsci_dft2_kept_inv (rows_out NULL) / ppsci_dft2_kept_inv_stats (rows_out: [B * c_out][4], sbias:
+ * [c_out]) in ONE launch: a workgroup contracts the kept modes of the output plane it then inverse-transforms -- y [B, c_out, H, W];
+ * `rows` as for ppsci_dft2_kept_inv.  The channel sum runs in three interleaved parts added in order (not the MFMA order of
+ * ppsci_spectral_conv2d_fwd_kept): results agree to fp32 rounding. */
+int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, int rows, const float* x_k, const float* w_re,
+                                   const float* w_im, float scale, float* y, const float* sbias, float* rows_out, void* stream);
 int ppsci_spectral_conv2d_fwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
                                    float* out_k, float scale, void* stream);
 int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,

@@ -483,6 +483,89 @@ __global__ void __launch_bounds__(256) dft2_kept_inv_kernel(DftArgs a) {
   }
 }
 
+// The forward spectral convolution and the inverse transform behind it in ONE launch: a workgroup owns an output plane
+// (b, o); it contracts that plane's kept modes itself,
+//     Z[m] = scale * sum_i x_k[b, i, m] * w[i, o, m]          (complex; fno_block.py:346-372 `_contract_dense_trick`)
+// -- 2 Ci loads of 2 mx my floats, coalesced along the modes, all requested before the first sum: one memory round trip --
+// and runs dft2_kept_inv_kernel's stages on it.  The contraction as its own launch (spectral_mode_kernel: 9.2 us at the
+// BASELINE shape for 11 MFLOP) was pure launch + gather latency in front of a 10.9 us inverse launch.
+#define SPECINV_SPLIT 3  // the channel sum in three interleaved parts per mode (256 threads for 84 modes), added in part order
+struct SpecInvArgs {
+  DftArgs d;
+  const float* x;   // [B, Ci, mx, my, 2]
+  const float* wr;  // [Ci, Co, mx, my]
+  const float* wi;
+  int Ci, Co;
+  float scale;
+};
+
+__global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
+  PPSCI_DYN_SMEM(smem);
+  const DftArgs& a = q.d;
+  float* tw = smem;
+  float* th = tw + 2 * a.W * a.my;
+  float* Z = th + 2 * a.H * a.mx;
+  float* T = Z + 2 * a.mx * a.my;
+  float* sred = T + 2 * a.H * a.my;            // 512 floats: the row sums' tree
+  float* Zp = sred + 512;                      // [SPECINV_SPLIT][mx my][2]: the parts of the channel sum
+  const int tid = threadIdx.x, P = a.H * a.W, nm = a.mx * a.my;
+  bool first = true;
+  for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
+    const int b = p / q.Co, o = p - b * q.Co;
+    if (first) dft_twiddles(a, tw);
+    first = false;
+    __syncthreads();  // (the previous plane's readers of Z / Zp are done)
+    for (int idx = tid; idx < SPECINV_SPLIT * nm; idx += 256) {
+      const int part = idx / nm, m = idx - part * nm;
+      float sr = 0.f, si = 0.f;
+#pragma unroll 4
+      for (int i = part; i < q.Ci; i += SPECINV_SPLIT) {
+        const float* xp = q.x + ((long long)b * q.Ci + i) * nm * 2 + 2 * m;
+        const long long wi_ = ((long long)i * q.Co + o) * nm + m;
+        const float xr = xp[0], xi = xp[1], wr = q.wr[wi_], wim = q.wi[wi_];
+        sr += xr * wr - xi * wim;
+        si += xr * wim + xi * wr;
+      }
+      Zp[(part * nm + m) * 2] = sr;
+      Zp[(part * nm + m) * 2 + 1] = si;
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * nm; e += 256) {
+      float z = Zp[e];
+#pragma unroll
+      for (int part = 1; part < SPECINV_SPLIT; ++part) z += Zp[part * nm * 2 + e];
+      Z[e] = q.scale * z;
+    }
+    __syncthreads();
+    float* y = a.dst + (long long)p * P;
+    const float sb = (a.rows_out && a.sbias) ? a.sbias[p % a.C] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    dft_inv_stages(a, tw, th, Z, T, [&](int hh, int w, float val) {
+      y[(long long)hh * a.W + w] = val;
+      const float u = val + sb;
+      s1 += u;
+      s2 += u * u;
+    });
+    if (a.rows_out) {
+      __syncthreads();
+      sred[tid] = s1;
+      sred[256 + tid] = s2;
+      __syncthreads();
+      for (int wd = 128; wd > 0; wd >>= 1) {
+        if (tid < wd) {
+          sred[tid] += sred[tid + wd];
+          sred[256 + tid] += sred[256 + tid + wd];
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        a.rows_out[(long long)p * 4 + 0] = sred[0];
+        a.rows_out[(long long)p * 4 + 1] = sred[256];
+      }
+    }
+  }
+}
+
 static long long dft_lds_bytes(int H, int W, int mx, int my, int inverse) {
   if (!inverse) return 4LL * dft_fwd_lds_floats(H, W, mx, my);
   return 4LL * (2LL * W * my + 2LL * H * mx + 2LL * mx * my + 2LL * H * my + 512);
@@ -607,3 +690,39 @@ extern "C" int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, cons
   return spectral_bwd(d, x_k, w_re, w_im, ghat_k, gx_k, gw_re, gw_im, wscale, w_full, stream, xscale, 0, 1);
 }
 
+
+// ppsci_spectral_conv2d_fwd_kept + ppsci_dft2_kept_inv[_stats] in one launch (spectral_inv_kernel): y [B * c_out planes of H x W].
+extern "C" int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, int rows, const float* x_k,
+                                              const float* w_re, const float* w_im, float scale, float* y, const float* sbias,
+                                              float* rows_out, void* stream) {
+  if (!d || !x_k || !w_re || !w_im || !y || (rows != 0 && rows != 1) || d->batch < 1 || d->c_in < 1 || d->c_out < 1 ||
+      !ppsci_dft2_kept_supported(H, W, d->modes_x, d->modes_y)) {
+    ppsci_set_error("spectral_conv2d_inv_kept: invalid argument or unsupported shape");
+    return PPSCI_E_INVALID;
+  }
+  const int mx = d->modes_x, my = d->modes_y, n = d->batch * d->c_out;
+  const float* tab = ppsci_dft_table(H, W, mx, my, rows);
+  if (!tab) {
+    ppsci_set_error("spectral_conv2d_inv_kept: cannot build the twiddle table");
+    return PPSCI_E_LAUNCH;
+  }
+  SpecInvArgs q;
+  q.d = DftArgs{nullptr, y, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, d->c_out};
+  q.x = x_k; q.wr = w_re; q.wi = w_im; q.Ci = d->c_in; q.Co = d->c_out; q.scale = scale;
+  const long long lds = dft_lds_bytes(H, W, mx, my, 1) + 4LL * SPECINV_SPLIT * 2 * mx * my;
+  if (lds + 4096 > 64 * 1024) {
+    ppsci_set_error("spectral_conv2d_inv_kept: %lld B of LDS", lds);
+    return PPSCI_E_UNSUPPORTED;
+  }
+  const int grid = n < 8 * PPSCI_NUM_CU ? n : 8 * PPSCI_NUM_CU;
+  if (PPSCI_SET_MAX_LDS(spectral_inv_kernel, (int)lds) != 0) {
+    ppsci_set_error("spectral_conv2d_inv_kept: cannot raise dynamic LDS to %lld B", lds);
+    return PPSCI_E_LAUNCH;
+  }
+  PPSCI_LAUNCH(spectral_inv_kernel, SpecInvArgs, grid, 256, (int)lds, stream, q);
+  if (PPSCI_LAST_LAUNCH_ERROR() != 0) {
+    ppsci_set_error("spectral_conv2d_inv_kept: launch failed");
+    return PPSCI_E_LAUNCH;
+  }
+  return PPSCI_OK;
+}

@@ -165,6 +165,8 @@ class FnoNative:
         self.kept = bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my)) and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1"
         # (the tanh stabilizer puts a pointwise function between a block's output and the next transform's input)
         self.fuse_dft = self.kept and m.fno_blocks.stabilizer != "tanh"
+        # the forward contraction inside the inverse transform's launch (PPSCI_FNO_FUSE_CONTRACT=0: two launches; A/B, tests)
+        self.fuse_contract = self.kept and os.environ.get("PPSCI_FNO_FUSE_CONTRACT", "1") != "0"
         sp = (B, Ch, mx, my, 2) if self.kept else (B, Ch, H, Wf, 2)
         self.xft = [torch.empty(sp, **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
         self.out_ft = torch.empty(sp, **f)  # (full spectrum: cleared + kept modes written every time, C2R destroys it)
@@ -249,13 +251,20 @@ class FnoNative:
                 mx, my = self.desc.modes_x, self.desc.modes_y
                 if not (self.fuse_dft and l > 0):
                     L.check(L.lib().ppsci_dft2_kept_fwd(B * Ch, H, W, mx, my, 0, _p(xl), _p(xft), st))
-                L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(self.desc), _p(xft), _p(conv.weight_real),
-                                                               _p(conv.weight_imag), _p(self.out_ft), self.inv_n, st))
-                if nrm is not None:
-                    L.check(L.lib().ppsci_dft2_kept_inv_stats(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), _p(conv.bias),
-                                                              Ch, _p(self.rows), st))
+                if self.fuse_contract:
+                    # contraction + inverse transform (+ the tail's row sums) in one launch: a workgroup contracts the kept modes
+                    # of the plane it then transforms (csrc/spectral_conv.hip spectral_inv_kernel)
+                    L.check(L.lib().ppsci_spectral_conv2d_inv_kept(
+                        C.byref(self.desc), H, W, 1, _p(xft), _p(conv.weight_real), _p(conv.weight_imag), self.inv_n, _p(v),
+                        _p(conv.bias) if nrm is not None else None, _p(self.rows) if nrm is not None else None, st))
                 else:
-                    L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
+                    L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(self.desc), _p(xft), _p(conv.weight_real),
+                                                                   _p(conv.weight_imag), _p(self.out_ft), self.inv_n, st))
+                    if nrm is not None:
+                        L.check(L.lib().ppsci_dft2_kept_inv_stats(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), _p(conv.bias),
+                                                                  Ch, _p(self.rows), st))
+                    else:
+                        L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 1, _p(self.out_ft), _p(v), st))
                 self._join()
                 L.check(L.lib().ppsci_fno_tail_fwd_ex(
                     B, Ch, P, 1 if nrm is not None else 0, 0 if last else 1, float(nrm.eps) if nrm is not None else 0.0, _p(v),
