@@ -121,7 +121,7 @@ def profile_info(stem, kernel_substr=None, ms_per_step=None, once_per_step=False
     """What the committed rocprofv3 summaries of config `stem` say (profiles/<round>_<stem>_{kernel_stats.csv,
     pmc_summary.json}, newest round; tools/profile_all.sh + tools/summarize_profile.py): the DOMINANT kernel of a step by
     total time, the HBM bytes of one step (sum over all kernels of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches
-    per step; a step = one `adam_kernel` launch) and, for `kernel_substr`, that kernel's own bytes per launch.  PMC
+    per step; a step = one launch of the kernel that applies Adam) and, for `kernel_substr`, that kernel's own bytes per launch.  PMC
     counters can only be read by rocprofv3 around a process, so these figures are QUOTED from the named files, not
     measured by this run."""
     import csv
@@ -141,7 +141,9 @@ def profile_info(stem, kernel_substr=None, ms_per_step=None, once_per_step=False
             top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
             out["dominant_kernel"] = {"name": top["Name"].split("(")[0][-70:], "share_of_kernel_time": float(top["TotalDurationNs"]) / tot,
                                       "avg_us": float(top["AverageNs"]) / 1e3}
-        nstep = next((v.get("launches_pmc_fetch") for k, v in pmc.items() if k.startswith("adam_kernel")), None)
+        # (a step = one launch of the kernel that applies the optimizer: adam_kernel, or the row reductions + Adam in one launch)
+        nstep = next((v.get("launches_pmc_fetch") for k, v in pmc.items()
+                      if k.startswith("adam_kernel") or k.startswith("reduce_rows_multi_adam_kernel")), None)
         if once_per_step:  # one-constraint PINN step: every kernel type runs once (forward, epilogue, reductions, reverse, Adam)
             nstep = 1
         if nstep:
