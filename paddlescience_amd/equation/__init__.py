@@ -3,9 +3,11 @@ import copy
 
 from . import ide, pde  # noqa: F401
 from .ide import Volterra  # noqa: F401
-from .pde import PDE, AllenCahn, Biharmonic, Helmholtz, Laplace, NavierStokes, Poisson, Vibration  # noqa: F401
+from .pde import (DETACH_FUNC_NAME, NLSMB, PDE, AllenCahn, Biharmonic, HeatExchanger, Helmholtz, Laplace,  # noqa: F401
+                  LinearElasticity, NavierStokes, NormalDotVec, Poisson, Vibration)
 
-__all__ = ["PDE", "AllenCahn", "Biharmonic", "Helmholtz", "Laplace", "NavierStokes", "Poisson", "Vibration", "Volterra", "build_equation"]
+__all__ = ["PDE", "DETACH_FUNC_NAME", "AllenCahn", "Biharmonic", "HeatExchanger", "Helmholtz", "Laplace", "LinearElasticity",
+           "NavierStokes", "NormalDotVec", "Poisson", "Vibration", "Volterra", "NLSMB", "build_equation"]
 
 
 def build_equation(cfg):

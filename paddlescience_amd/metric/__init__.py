@@ -6,13 +6,7 @@ import numpy as np
 import torch
 
 
-class Metric:
-    def __init__(self, keep_batch: bool = False):
-        self.keep_batch = keep_batch
-
-    def __call__(self, output_dict, label_dict):
-        with torch.no_grad():
-            return self.forward(output_dict, label_dict)
+from .base import Metric  # noqa: E402
 
 
 class MSE(Metric):

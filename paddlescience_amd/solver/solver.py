@@ -116,6 +116,7 @@ class Solver:
         self.global_step = 0
         self.best_metric = {"metric": float("inf"), "epoch": 0}
         self.train_output_info: Dict[str, misc.AverageMeter] = {}
+        self.train_loss_info: Dict[str, list] = {}
         self.train_time_info = {"batch_cost": misc.AverageMeter("batch_cost", ".5f", postfix="s"),
                                 "reader_cost": misc.AverageMeter("reader_cost", ".5f", postfix="s")}
         self.eval_output_info: Dict[str, misc.AverageMeter] = {}
@@ -572,6 +573,9 @@ class Solver:
             if k not in self.train_output_info:
                 self.train_output_info[k] = misc.AverageMeter(k, "7.5f")
             self.train_output_info[k].update(v, 1)
+            # plot_loss_history: the reference keeps EVERY iteration's value (it synchronises on .item() every iteration,
+            # train.py:145); here a value exists where the loss was fetched (every `log_freq` iterations): (iteration, value)
+            self.train_loss_info.setdefault(k, []).append((self.global_step, v))
 
     def _log_train_info(self, batch_size: int, epoch_id: int, iter_id: int):
         lr_msg = f"lr: {self.optimizer.get_lr():.5f}"
@@ -775,6 +779,41 @@ class Solver:
             logger.info(f"[Visualize][Epoch {epoch_id}] Finish visualization")
         else:
             logger.info("[Visualize] Finish visualization")
+
+    def plot_loss_history(self, by_epoch: bool = False, smooth_step: int = 1, use_semilogy: bool = True) -> None:
+        """solver.py:1046-1076: the training-loss curves as `<output_dir>/<ylabel>.jpg`-style figure (misc.plot_curve).  The points
+        are the iterations at which the loss was fetched from the device (every `log_freq`-th; the reference fetches every one)."""
+        if not self.train_loss_info:
+            logger.warning("plot_loss_history: no training loss has been recorded yet")
+            return
+        data = {}
+        for key, hist in self.train_loss_info.items():
+            if by_epoch:
+                per_epoch: Dict[int, list] = {}
+                for step, v in hist:
+                    per_epoch.setdefault(step // max(self.iters_per_epoch, 1), []).append(v)
+                data[key] = [float(np.mean(v)) for _, v in sorted(per_epoch.items())]
+            else:
+                data[key] = [v for _, v in hist]
+        n = min(len(v) for v in data.values())
+        misc.plot_curve({k: v[:n] for k, v in data.items()}, xlabel="Epoch" if by_epoch else "Iteration", ylabel="Loss",
+                        output_dir=self.output_dir, smooth_step=smooth_step, use_semilogy=use_semilogy)
+
+    @staticmethod
+    def no_grad_context_manager(enable: bool):
+        """solver.py:933-951.  The compiled forward never records a tape; the context only matters for user code on torch tensors."""
+        import contextlib
+
+        return torch.no_grad() if enable else contextlib.nullcontext()
+
+    @staticmethod
+    def autocast_context_manager(enable: bool, level: str = "O1"):
+        """solver.py:913-931: AMP is not available on the fused path (fp32 only)."""
+        import contextlib
+
+        if enable:
+            raise NotImplementedError("AMP is not available on the fused HIP path (fp32 only)")
+        return contextlib.nullcontext()
 
     def export(self, *args, **kwargs):
         raise NotImplementedError("inference export (paddle.inference / ONNX) is out of scope")

@@ -146,3 +146,39 @@ def run_at_rank0(func: Callable) -> Callable:
         return None
 
     return wrapped
+
+
+def plot_curve(data: Dict[str, List], xlabel: str = "X", ylabel: str = "Y", output_dir: str = "./output/", smooth_step: int = 1,
+               use_semilogy: bool = False) -> None:
+    """misc.py:582-640 of the reference: the curves of `data` (equal lengths) over their index, every `smooth_step` points averaged
+    into one, saved as `<output_dir>/<xlabel>-<ylabel>_curve.jpg`; without matplotlib the averaged arrays go to an .npz."""
+    import os
+
+    arr = np.stack([np.asarray(v, dtype=np.float64).reshape(-1) for v in data.values()], axis=1)
+    keep = arr.shape[0] - arr.shape[0] % smooth_step
+    if keep == 0:
+        keep, smooth_step = arr.shape[0], 1
+    arr = arr[:keep].reshape(-1, smooth_step, arr.shape[1]).mean(axis=1)
+    os.makedirs(output_dir, exist_ok=True)
+    stem = os.path.join(output_dir, f"{xlabel}-{ylabel}_curve")
+    try:
+        import matplotlib
+
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:  # noqa: BLE001
+        np.savez(stem + ".npz", x=np.arange(arr.shape[0]) * smooth_step, **{k: arr[:, i] for i, k in enumerate(data)})
+        return
+    fig = plt.figure()
+    if use_semilogy:
+        plt.yscale("log")
+        plt.xscale("log")
+    plt.plot(np.arange(arr.shape[0]) * smooth_step, arr)
+    plt.legend(list(data.keys()), loc="upper left", bbox_to_anchor=(1, 1))
+    plt.xlabel(xlabel)
+    plt.ylabel(ylabel)
+    plt.grid()
+    plt.yticks(size=10)
+    plt.xticks(size=10)
+    fig.savefig(stem + ".jpg", dpi=200, bbox_inches="tight")
+    plt.close(fig)

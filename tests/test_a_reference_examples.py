@@ -27,7 +27,18 @@ HYDRA_CASES = {
                              "NTIME_ALL": 2, "EVAL.batch_size.residual_validator": 4096}),
     "euler_beam": ("euler_beam/euler_beam.py", "euler_beam/conf/euler_beam.yaml",
                    {"TRAIN.epochs": 4, "TRAIN.eval_freq": 2, "TRAIN.save_freq": 2}),
+    # beyond the six the round-5 verdict named: a Laplace problem with five constraints and its own FDM comparison + figures
+    # (imports its sibling module fdm.py), and the two NLS-MB examples (five coupled outputs, Adam then L-BFGS, their own plots)
+    "heat_pinn": ("heat_pinn/heat_pinn.py", "heat_pinn/conf/heat_pinn.yaml",
+                  {"MODEL.num_layers": 2, "MODEL.hidden_size": 16, "TRAIN.epochs": 1, "TRAIN.save_freq": 1}),
+    "NLS-MB_optical_soliton": ("NLS-MB/NLS-MB_optical_soliton.py", "NLS-MB/conf/NLS-MB_soliton.yaml",
+                               {"MODEL.num_layers": 2, "MODEL.hidden_size": 16, "TRAIN.epochs": 2, "TRAIN.eval_freq": 1,
+                                "NPOINT_INTERIOR": 200, "NPOINT_BC": 20, "NTIME_ALL": 10}),
+    "NLS-MB_optical_rogue_wave": ("NLS-MB/NLS-MB_optical_rogue_wave.py", "NLS-MB/conf/NLS-MB_rogue_wave.yaml",
+                                  {"MODEL.num_layers": 2, "MODEL.hidden_size": 16, "TRAIN.epochs": 2, "TRAIN.eval_freq": 1,
+                                   "NPOINT_INTERIOR": 200, "NPOINT_BC": 20, "NTIME_ALL": 10}),
 }
+NO_VISUALIZER = {"heat_pinn", "NLS-MB_optical_soliton", "NLS-MB_optical_rogue_wave"}  # (they draw their own figures)
 
 
 @pytest.fixture
@@ -57,14 +68,18 @@ def test_reference_example_trains_unmodified(case, tmp_path, monkeypatch, emulat
     rel, yml, overrides = HYDRA_CASES[case]
     out = str(tmp_path / "out")
     cfg = hydra_stub.load_cfg(os.path.join(REF, yml), out, overrides)
-    spec = importlib.util.spec_from_file_location(f"_ref_example_{case}", os.path.join(REF, rel))
+    spec = importlib.util.spec_from_file_location(f"_ref_example_{case.replace('-', '_')}", os.path.join(REF, rel))
     mod = importlib.util.module_from_spec(spec)
     monkeypatch.chdir(tmp_path)
+    monkeypatch.syspath_prepend(os.path.dirname(os.path.join(REF, rel)))  # (sibling modules of the example: heat_pinn's fdm.py)
     spec.loader.exec_module(mod)
     mod.train(cfg)
+    assert os.path.exists(os.path.join(out, "checkpoints", "latest.pdparams"))
+    if case in NO_VISUALIZER:
+        assert any(f.endswith((".png", ".jpg")) for _, _, fs in os.walk(out) for f in fs), "the example's own figure is missing"
+        return
     files = _visual_files(out)
     assert files, "solver.visualize() wrote nothing"
-    assert os.path.exists(os.path.join(out, "checkpoints", "latest.pdparams"))
     if case.startswith(("laplace", "ldc")):
         vtus = [f for f in files if f.endswith(".vtu")]
         assert vtus

@@ -102,3 +102,36 @@ def test_every_ppsci_submodule_is_the_native_module():
     from ppsci.utils import logger as l2  # noqa: E402
 
     assert l2 is logger
+
+
+def test_loss_history_plot_and_context_managers(dev, tmp_path):
+    """Solver.plot_loss_history (solver.py:1046-1076) / misc.plot_curve, the no-grad / autocast context managers the examples use
+    around predict-time code, ppsci.metric.base.Metric as a base class of user metrics."""
+    import torch
+
+    model = ppsci.arch.MLP(("x",), ("u",), 2, 16)
+    x = np.linspace(0, 1, 32, dtype=np.float32).reshape(-1, 1)
+    cfg = {"dataset": {"name": "NamedArrayDataset", "input": {"x": x}, "label": {"u": np.sin(x)}}, "batch_size": 32,
+           "sampler": {"name": "BatchSampler", "shuffle": False, "drop_last": True}}
+    cst = ppsci.constraint.SupervisedConstraint(cfg, ppsci.loss.MSELoss("mean"), name="Sup")
+    solver = ppsci.solver.Solver(model, {"Sup": cst}, str(tmp_path), ppsci.optimizer.Adam(1e-3)(model), epochs=6, iters_per_epoch=2,
+                                 log_freq=1)
+    solver.train()
+    assert len(solver.train_loss_info["loss"]) == 12 and [s for s, _ in solver.train_loss_info["loss"]][:3] == [1, 2, 3]
+    solver.plot_loss_history()
+    solver.plot_loss_history(by_epoch=True, smooth_step=2, use_semilogy=False)
+    assert any(f.startswith("Iteration-Loss_curve") for f in os.listdir(tmp_path))
+    assert any(f.startswith("Epoch-Loss_curve") for f in os.listdir(tmp_path))
+    with solver.no_grad_context_manager(True):
+        assert not torch.is_grad_enabled()
+    with solver.no_grad_context_manager(False), solver.autocast_context_manager(False):
+        assert torch.is_grad_enabled()
+    with pytest.raises(NotImplementedError):
+        solver.autocast_context_manager(True)
+
+    class Twice(ppsci.metric.base.Metric):
+        def forward(self, output_dict, label_dict):
+            return {k: 2 * (output_dict[k] - label_dict[k]).abs().mean() for k in label_dict}
+
+    assert float(Twice()({"u": torch.ones(3)}, {"u": torch.zeros(3)})["u"]) == 2.0
+    assert issubclass(ppsci.metric.MSE, ppsci.metric.base.Metric)
