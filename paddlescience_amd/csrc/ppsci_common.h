@@ -10,8 +10,8 @@
 #define PPSCI_LAUNCH(KERNEL, ARGT, grid, block, lds, stream, args)                                   \
   do {                                                                                               \
     ARGT _a = (args);                                                                                \
-    emu::launch(emu_dim3{(unsigned)(grid)}, emu_dim3{(unsigned)(block)}, (size_t)(lds),              \
-                [](void* p) { KERNEL(*(ARGT*)p); }, &_a);                                            \
+    emu::launch_named(#KERNEL, emu_dim3{(unsigned)(grid)}, emu_dim3{(unsigned)(block)}, (size_t)(lds), \
+                      [](void* p) { KERNEL(*(ARGT*)p); }, &_a);                                      \
   } while (0)
 #define PPSCI_SET_MAX_LDS(KERNEL, bytes) (0)
 #define PPSCI_LAST_LAUNCH_ERROR() (0)

@@ -17,6 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <map>
+#include <string>
+#include <unistd.h>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -183,6 +187,34 @@ inline void launch(emu_dim3 grid, emu_dim3 block, size_t dyn_lds_bytes, void (*e
     }
   }
   s.cur = -1;
+}
+
+// PPSCI_EMU_PROFILE=<path prefix>: wall time per kernel name, written at exit to <prefix>.<pid> (which sources are worth an
+// optimised emulator build, tests/emu/build_emu.py HOT).
+struct Profile {
+  std::map<std::string, std::pair<double, long>> t;
+  const char* path = getenv("PPSCI_EMU_PROFILE");
+  ~Profile() {
+    if (!path || t.empty()) return;
+    std::string fn = std::string(path) + "." + std::to_string((long)getpid());
+    if (FILE* f = fopen(fn.c_str(), "w")) {
+      for (auto& kv : t) fprintf(f, "%.6f %ld %s\n", kv.second.first, kv.second.second, kv.first.c_str());
+      fclose(f);
+    }
+  }
+};
+inline Profile& profile() {
+  static Profile p;
+  return p;
+}
+inline void launch_named(const char* name, emu_dim3 grid, emu_dim3 block, size_t dyn_lds_bytes, void (*entry)(void*), void* args) {
+  Profile& p = profile();
+  if (!p.path) return launch(grid, block, dyn_lds_bytes, entry, args);
+  auto t0 = std::chrono::steady_clock::now();
+  launch(grid, block, dyn_lds_bytes, entry, args);
+  auto& e = p.t[name];
+  e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  e.second += 1;
 }
 
 struct TidProxy {
