@@ -560,6 +560,21 @@ int ppsci_pw_conv_wgrad(int B, int Ci, int Co, int P, const float* x, const floa
  * dst [n, hp, wp] at offset (oh, ow) with zeros around it; unpad == 1 copies that window of src [n, hp, wp] back into
  * dst [n, h, w].  Each is the other's backward. */
 int ppsci_pad2d(int n, int h, int w, int hp, int wp, int oh, int ow, int unpad, const float* src, float* dst, void* stream);
+/* ---- resolution changes of the U-shaped neural operator (csrc/uno.hip; /root/reference/ppsci/arch/unonet.py:246-289) ----
+ * ppsci_spectrum_resize: what irfftn(out_fft, s=(H2, W2)) does to a half spectrum laid out for an H x W grid before it transforms
+ * (fno_block.py:779-793): dst [n, H2, Wf2] complex = rows [0, H2) and columns [0, Wf2) of src [n, H, Wf] (Wf = W/2 + 1 of the
+ * respective grid), zeros where src has none.  With the sizes swapped it is the adjoint.  w_num, w_den > 0: column j is also
+ * multiplied by c_{w_num}(j) / c_{w_den}(j), where c_w(j) = 1 on the DC / Nyquist column of a real grid of width w and 2 elsewhere
+ * -- the Hermitian weights a real inverse transform applies.  On the way back through a resolution change (src = rfftn of dL/dy
+ * on the output grid, w_num = its width W2, w_den = the input grid's W) this leaves exactly the factor by which the weights of
+ * the two grids differ; 0, 0 = no scaling.
+ * ppsci_resample2d: y [n, H2, W2] (+)= Ah x Aw^T per plane, Ah [H2, H], Aw [W2, W] dense row-major -- F.interpolate(mode=
+ * "bicubic", align_corners=True) of fno_block.resample (:466-498) with the matrices of uno_engine.bicubic_matrix, its adjoint
+ * with their transposes.  A plane and the intermediate live in LDS: ppsci_resample2d_supported tells whether they fit. */
+int ppsci_spectrum_resize(int n, int H, int Wf, int H2, int Wf2, int w_num, int w_den, const float* src, float* dst, void* stream);
+int ppsci_resample2d_supported(int H, int W, int H2, int W2);
+int ppsci_resample2d(int n, int H, int W, int H2, int W2, const float* x, const float* Ah, const float* Aw, float* y,
+                     int accumulate, void* stream);
 int ppsci_fno_tail_fwd(int B, int C, int P, int norm, int gelu, float eps, const float* v, const float* sbias,
                        const float* gamma, const float* beta, const float* skip, float* rows, float* stats, float* t,
                        float* y, void* stream);

@@ -121,12 +121,12 @@ class OperatorEngine:
 
         self._step_graph = StepGraph(self.grad.is_cuda and os.environ.get("PPSCI_HIP_GRAPH", "1") != "0")
         # forward and backward on this framework's own kernels, no autograd graph of the network (fno_engine.py)
-        from . import fno_engine
+        from . import fno_engine, uno_engine
 
         why = fno_engine.supports(model)
-        if why is not None:
+        if why is not None and uno_engine.supports(model) is not None:
             raise NotImplementedError(f"operator engine: {why}")
-        self.native = model.native()
+        self.native = model.native()  # fno_engine.FnoNative / uno_engine.UnoNative
 
     def _forward_backward_eager(self, constraints: List[OperatorConstraint]):
         if len(constraints) != 1:
