@@ -468,6 +468,19 @@ int ppsci_spectral_conv2d_bwd_real_scaled(const ppsci_spectral_desc* d, const fl
  * otherwise use ppsci_fft2d_* with the full-spectrum entry points.
  * ppsci_spectral_conv2d_fwd_kept / _bwd_kept: ppsci_spectral_conv2d_fwd_scaled / _bwd_real_scaled on such spectra. */
 int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y);
+/* The pair between TWO grids (a UNO block that changes resolution, /root/reference/ppsci/arch/unonet.py:205-230): the kept modes
+ * sit where FactorizedSpectralConv leaves its products in a half spectrum laid out for the Hs x Ws grid of the block's INPUT
+ * (fno_block.py:721-777, the rows after its second fftshift), and irfftn(out_fft, s=(H, W)) (:779-793) reads rows [0, H) and
+ * columns [0, W/2 + 1) of that spectrum as frequencies of the H x W OUTPUT grid, dropping what lies beyond.
+ *   ppsci_dft2_kept_inv_from: y [n, H, W] = that irfftn of (Z [n, modes_x, modes_y] at the kept modes, zero elsewhere), unscaled;
+ *   ppsci_dft2_kept_fwd_from: the way back -- X = rfftn(x [n, H, W]) at the same (row, column) positions, zero for the dropped
+ *   modes, column q times c_W(q) / c_Ws(q) (c = 1 on the DC / Nyquist column of a real grid of that width, 2 elsewhere: where
+ *   the Hermitian weights of the two grids differ), so that ppsci_spectral_conv2d_bwd_kept with w_full = Ws and
+ *   ppsci_dft2_kept_inv on the Hs x Ws grid complete the adjoint.  modes_x <= Hs, modes_y <= Ws/2 + 1; they may exceed the
+ *   H x W spectrum.  ppsci_dft2_kept_from_supported: the LDS check for the H x W plane. */
+int ppsci_dft2_kept_from_supported(int H, int W, int modes_x, int modes_y);
+int ppsci_dft2_kept_fwd_from(int n, int H, int W, int modes_x, int modes_y, int Hs, int Ws, const float* x, float* X, void* stream);
+int ppsci_dft2_kept_inv_from(int n, int H, int W, int modes_x, int modes_y, int Hs, int Ws, const float* Z, float* y, void* stream);
 int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y, int rows, const float* x, float* X, void* stream);
 int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y, void* stream);
 /* ppsci_dft2_kept_inv that also leaves the first pass of the block tail behind: rows_out[plane][4] gets the sums of

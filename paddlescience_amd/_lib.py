@@ -203,6 +203,9 @@ _SYMBOLS = {
     "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "ppsci_pad2d": (C.c_int, [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_dft2_kept_from_supported": (C.c_int, [C.c_int] * 4),
+    "ppsci_dft2_kept_fwd_from": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_dft2_kept_inv_from": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_spectrum_resize": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_resample2d_supported": (C.c_int, [C.c_int] * 4),
     "ppsci_resample2d": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]),

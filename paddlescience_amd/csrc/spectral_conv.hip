@@ -583,14 +583,18 @@ extern "C" int ppsci_dft2_kept_supported(int H, int W, int modes_x, int modes_y)
 // Twiddle tables per (device, H, W, modes, rows): built on the host in double, uploaded at the first call (an eager one:
 // the engine captures HIP graphs from the second step on -- the same life cycle as a library FFT plan), kept for the process.
 static std::mutex g_dft_mutex;
-static std::map<std::tuple<int, int, int, int, int, int>, float*> g_dft_tabs;
-const float* ppsci_dft_table(int H, int W, int mx, int my, int rows) {
+static std::map<std::tuple<int, int, int, int, int, int, int, int, int>, float*> g_dft_tabs;
+// (Hs, Ws) > 0: the table of a RESOLUTION CHANGE (UNO, ppsci_dft2_kept_*_from) -- mode m stands in the row the reference's second
+// fftshift gives it in a spectrum laid out for an Hs x Ws grid; irfftn(s=(H, W)) reads that spectrum's rows [0, H) and columns
+// [0, W/2 + 1) as frequencies of the H x W grid and drops the rest (zero twiddles).  ratio: column q also carries
+// c_W(q) / c_Ws(q) (the forward direction = the way back through the change, see csrc/uno.hip).
+static const float* dft_table(int H, int W, int mx, int my, int rows, int Hs, int Ws, int ratio) {
   int dev = 0;
 #ifndef PPSCI_EMU
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
 #endif
   std::lock_guard<std::mutex> lock(g_dft_mutex);
-  const auto key = std::make_tuple(dev, H, W, mx, my, rows);
+  const auto key = std::make_tuple(dev, H, W, mx, my, rows, Hs, Ws, ratio);
   auto it = g_dft_tabs.find(key);
   if (it != g_dft_tabs.end()) return it->second;
   std::vector<float> t(2 * ((size_t)W * my + (size_t)H * mx));
@@ -598,17 +602,24 @@ const float* ppsci_dft_table(int H, int W, int mx, int my, int rows) {
   for (int w = 0; w < W; ++w)
     for (int q = 0; q < my; ++q) {
       const double ang = two_pi * (double)((long long)w * q % W) / (double)W;
-      t[2 * ((size_t)w * my + q)] = (float)cos(ang);
-      t[2 * ((size_t)w * my + q) + 1] = (float)sin(ang);
+      double f = 1.0;
+      if (Hs > 0) {
+        if (q > W / 2) f = 0.0;
+        else if (ratio) f = ((q == 0 || 2 * q == W) ? 1.0 : 2.0) / ((q == 0 || 2 * q == Ws) ? 1.0 : 2.0);
+      }
+      t[2 * ((size_t)w * my + q)] = (float)(f * cos(ang));
+      t[2 * ((size_t)w * my + q) + 1] = (float)(f * sin(ang));
     }
   float* th = t.data() + 2 * (size_t)W * my;
-  const int c0 = (H - mx) / 2, sh = rows ? H / 2 : H - H / 2;  // spec_row_out / spec_row_in
+  const int Hl = Hs > 0 ? Hs : H;  // the grid whose layout places the modes
+  const int c0 = (Hl - mx) / 2, sh = rows ? Hl / 2 : Hl - Hl / 2;  // spec_row_out / spec_row_in
   for (int h = 0; h < H; ++h)
     for (int m = 0; m < mx; ++m) {
-      const int k = (c0 + m + sh) % H;
+      const int k = (c0 + m + sh) % Hl;
+      const bool kept = k < H;
       const double ang = two_pi * (double)((long long)h * k % H) / (double)H;
-      th[2 * ((size_t)h * mx + m)] = (float)cos(ang);
-      th[2 * ((size_t)h * mx + m) + 1] = (float)sin(ang);
+      th[2 * ((size_t)h * mx + m)] = kept ? (float)cos(ang) : 0.f;
+      th[2 * ((size_t)h * mx + m) + 1] = kept ? (float)sin(ang) : 0.f;
     }
   float* devp = nullptr;
 #ifdef PPSCI_EMU
@@ -621,14 +632,23 @@ const float* ppsci_dft_table(int H, int W, int mx, int my, int rows) {
   g_dft_tabs[key] = devp;
   return devp;
 }
+const float* ppsci_dft_table(int H, int W, int mx, int my, int rows) { return dft_table(H, W, mx, my, rows, 0, 0, 0); }
+
+// the transforms between two grids: the mode counts belong to the OTHER grid and may exceed this one's spectrum
+extern "C" int ppsci_dft2_kept_from_supported(int H, int W, int modes_x, int modes_y) {
+  if (H < 2 || W < 2 || modes_x < 1 || modes_y < 1) return 0;
+  const long long fwd = dft_lds_bytes(H, W, modes_x, modes_y, 0), inv = dft_lds_bytes(H, W, modes_x, modes_y, 1);
+  return (fwd > inv ? fwd : inv) + 4096 <= 64 * 1024 ? 1 : 0;
+}
 
 static int dft_run(int n, int H, int W, int mx, int my, int rows, const float* src, float* dst, int inverse, void* stream,
-                   const float* sbias = nullptr, int C = 1, float* rows_out = nullptr) {
-  if (n < 1 || !src || !dst || (rows != 0 && rows != 1) || !ppsci_dft2_kept_supported(H, W, mx, my)) {
+                   const float* sbias = nullptr, int C = 1, float* rows_out = nullptr, int Hs = 0, int Ws = 0) {
+  if (n < 1 || !src || !dst || (rows != 0 && rows != 1) || (Hs > 0) != (Ws > 0) ||
+      !(Hs > 0 ? (mx <= Hs && my <= Ws / 2 + 1 && ppsci_dft2_kept_from_supported(H, W, mx, my)) : ppsci_dft2_kept_supported(H, W, mx, my))) {
     ppsci_set_error("dft2_kept: invalid argument or unsupported shape (%d planes of %d x %d, modes %d x %d)", n, H, W, mx, my);
     return PPSCI_E_INVALID;
   }
-  const float* tab = ppsci_dft_table(H, W, mx, my, rows);
+  const float* tab = dft_table(H, W, mx, my, rows, Hs, Ws, Hs > 0 && !inverse ? 1 : 0);
   if (!tab) {
     ppsci_set_error("dft2_kept: cannot build the twiddle table");
     return PPSCI_E_LAUNCH;
@@ -658,6 +678,23 @@ extern "C" int ppsci_dft2_kept_fwd(int n, int H, int W, int modes_x, int modes_y
 extern "C" int ppsci_dft2_kept_inv(int n, int H, int W, int modes_x, int modes_y, int rows, const float* Z, float* y,
                                    void* stream) {
   return dft_run(n, H, W, modes_x, modes_y, rows, Z, y, 1, stream);
+}
+
+extern "C" int ppsci_dft2_kept_fwd_from(int n, int H, int W, int modes_x, int modes_y, int Hs, int Ws, const float* x, float* X,
+                                        void* stream) {
+  if (Hs < 2 || Ws < 2) {
+    ppsci_set_error("dft2_kept_fwd_from: the source grid must be given");
+    return PPSCI_E_INVALID;
+  }
+  return dft_run(n, H, W, modes_x, modes_y, 1, x, X, 0, stream, nullptr, 1, nullptr, Hs, Ws);
+}
+extern "C" int ppsci_dft2_kept_inv_from(int n, int H, int W, int modes_x, int modes_y, int Hs, int Ws, const float* Z, float* y,
+                                        void* stream) {
+  if (Hs < 2 || Ws < 2) {
+    ppsci_set_error("dft2_kept_inv_from: the source grid must be given");
+    return PPSCI_E_INVALID;
+  }
+  return dft_run(n, H, W, modes_x, modes_y, 1, Z, y, 1, stream, nullptr, 1, nullptr, Hs, Ws);
 }
 
 // ppsci_dft2_kept_inv + the first pass of the block tail that consumes y: rows_out[plane][4] gets sum(y + sbias[plane % C])

@@ -24,6 +24,7 @@ Covered: 2-D, dense weights, GroupNorm(1 group) or no norm, linear or identity b
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -168,12 +169,19 @@ class UnoNative(FnoNative):
             # every norm gives the same product (fno_engine); between two grids they differ, and "backward" is what the reference does.
             scale = 1.0 / float(H2 * W2)
             src = m.horizontal_skips_map.get(i)
+            # the transforms on the kept modes only (two small DFTs per plane in LDS, csrc/spectral_conv.hip) when the planes of both
+            # grids fit; hipFFT on full spectra + ppsci_spectrum_resize otherwise (PPSCI_FNO_FULL_FFT=1 forces it: tests, timing)
+            kept = (bool(L.lib().ppsci_dft2_kept_supported(H, W, d.modes_x, d.modes_y))
+                    and bool(L.lib().ppsci_dft2_kept_from_supported(H2, W2, d.modes_x, d.modes_y))
+                    and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1")
+            nk = (d.modes_x, d.modes_y, 2)
             e = dict(
+                kept=kept, xk=torch.empty((B, ci) + nk, **f) if kept else None, zk=torch.empty((B, co) + nk, **f) if kept else None,
                 desc=d, scale=scale, hw=(H, W), hw2=(H2, W2), ci=ci, co=co, src=src, resized=(H, W) != (H2, W2),
                 xin=torch.empty((B, ci, P), **f) if src is not None else None,  # concat(previous output, U skip)
-                xft=torch.empty((B, ci, H, Wf, 2), **f),
-                out_ft=torch.empty((B, co, H, Wf, 2), **f),
-                out_ft2=torch.empty((B, co, H2, Wf2, 2), **f) if (H, W) != (H2, W2) else None,
+                xft=torch.empty((B, ci, H, Wf, 2), **f) if not kept else None,
+                out_ft=torch.empty((B, co, H, Wf, 2), **f) if not kept else None,
+                out_ft2=torch.empty((B, co, H2, Wf2, 2), **f) if (H, W) != (H2, W2) and not kept else None,
                 v=torch.empty((B, co, P2), **f), t=torch.empty((B, co, P2), **f), stats=torch.empty(4 * B, **f),
                 s_low=torch.empty((B, co, P), **f) if isinstance(blk.fno_skips[0], fno_arch.Conv1x1) else None,
                 s=torch.empty((B, co, P2), **f) if (H, W) != (H2, W2) else None,
@@ -245,14 +253,25 @@ class UnoNative(FnoNative):
             if e["rs"] is not None:
                 e["rs"].apply(B * co, sk, e["s"])
                 sk = e["s"]
-            L.check(L.lib().ppsci_fft2d_r2c(B * ci, H, W, _p(cur), _p(e["xft"]), st))
-            L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real),
-                                                             _p(conv.weight_imag), _p(e["out_ft"]), e["scale"], 1, st))
-            zf = e["out_ft"]
-            if e["resized"]:
-                L.check(L.lib().ppsci_spectrum_resize(B * co, H, W // 2 + 1, H2, W2 // 2 + 1, 0, 0, _p(zf), _p(e["out_ft2"]), st))
-                zf = e["out_ft2"]
-            L.check(L.lib().ppsci_fft2d_c2r(B * co, H2, W2, _p(zf), _p(e["v"]), st))
+            mx, my = e["desc"].modes_x, e["desc"].modes_y
+            if e["kept"] and not e["resized"]:  # contraction + inverse transform in one launch (as fno_engine)
+                L.check(L.lib().ppsci_dft2_kept_fwd(B * ci, H, W, mx, my, 0, _p(cur), _p(e["xk"]), st))
+                L.check(L.lib().ppsci_spectral_conv2d_inv_kept(C.byref(e["desc"]), H, W, 1, _p(e["xk"]), _p(conv.weight_real),
+                                                               _p(conv.weight_imag), e["scale"], _p(e["v"]), None, None, st))
+            elif e["kept"]:
+                L.check(L.lib().ppsci_dft2_kept_fwd(B * ci, H, W, mx, my, 0, _p(cur), _p(e["xk"]), st))
+                L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real),
+                                                               _p(conv.weight_imag), _p(e["zk"]), e["scale"], st))
+                L.check(L.lib().ppsci_dft2_kept_inv_from(B * co, H2, W2, mx, my, H, W, _p(e["zk"]), _p(e["v"]), st))
+            else:
+                L.check(L.lib().ppsci_fft2d_r2c(B * ci, H, W, _p(cur), _p(e["xft"]), st))
+                L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real),
+                                                                 _p(conv.weight_imag), _p(e["out_ft"]), e["scale"], 1, st))
+                zf = e["out_ft"]
+                if e["resized"]:
+                    L.check(L.lib().ppsci_spectrum_resize(B * co, H, W // 2 + 1, H2, W2 // 2 + 1, 0, 0, _p(zf), _p(e["out_ft2"]), st))
+                    zf = e["out_ft2"]
+                L.check(L.lib().ppsci_fft2d_c2r(B * co, H2, W2, _p(zf), _p(e["v"]), st))
             nrm = blk.norm[0] if blk.norm is not None else None
             L.check(L.lib().ppsci_fno_tail_fwd(
                 B, co, P2, 1 if nrm is not None else 0, 0, float(nrm.eps) if nrm is not None else 0.0, _p(e["v"]), _p(conv.bias),
@@ -327,18 +346,28 @@ class UnoNative(FnoNative):
                 hp.reduce_rows(gs.reshape(1, -1), 1, B * ci * P, gxin.view(-1), False)
             # spectral branch
             Wf, Wf2 = W // 2 + 1, W2 // 2 + 1
-            ghat = V(self.gf[0], B, co, H2, Wf2, 2)
-            L.check(L.lib().ppsci_fft2d_r2c(B * co, H2, W2, _p(gv), _p(ghat), st))
-            G = ghat
-            if e["resized"]:
-                G = V(self.gf[1], B, co, H, Wf, 2)
-                L.check(L.lib().ppsci_spectrum_resize(B * co, H2, Wf2, H, Wf, W2, W, _p(ghat), _p(G), st))
-            gx_ft = V(self.gf[2], B, ci, H, Wf, 2)
-            L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
-                C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real), _p(conv.weight_imag), _p(G), _p(gx_ft),
-                _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], 1, st))
             gsp = V(self.g[0], B, ci, P)
-            L.check(L.lib().ppsci_fft2d_c2r(B * ci, H, W, _p(gx_ft), _p(gsp), st))
+            if e["kept"]:
+                mx, my = e["desc"].modes_x, e["desc"].modes_y
+                ghat = V(self.gf[0], B, co, mx, my, 2)
+                L.check(L.lib().ppsci_dft2_kept_fwd_from(B * co, H2, W2, mx, my, H, W, _p(gv), _p(ghat), st))
+                gx_k = V(self.gf[2], B, ci, mx, my, 2)
+                L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
+                    C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real), _p(conv.weight_imag), _p(ghat), _p(gx_k),
+                    _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], st))
+                L.check(L.lib().ppsci_dft2_kept_inv(B * ci, H, W, mx, my, 0, _p(gx_k), _p(gsp), st))
+            else:
+                ghat = V(self.gf[0], B, co, H2, Wf2, 2)
+                L.check(L.lib().ppsci_fft2d_r2c(B * co, H2, W2, _p(gv), _p(ghat), st))
+                G = ghat
+                if e["resized"]:
+                    G = V(self.gf[1], B, co, H, Wf, 2)
+                    L.check(L.lib().ppsci_spectrum_resize(B * co, H2, Wf2, H, Wf, W2, W, _p(ghat), _p(G), st))
+                gx_ft = V(self.gf[2], B, ci, H, Wf, 2)
+                L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
+                    C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real), _p(conv.weight_imag), _p(G), _p(gx_ft),
+                    _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], 1, st))
+                L.check(L.lib().ppsci_fft2d_c2r(B * ci, H, W, _p(gx_ft), _p(gsp), st))
             hp.reduce_rows(gsp.view(1, -1), 1, B * ci * P, gxin.view(-1), True)  # gxin += gsp
             # the input was concat(previous output, U skip): split the gradient
             if e["src"] is not None:

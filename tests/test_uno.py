@@ -34,13 +34,18 @@ def _model(c):
     return model
 
 
+@pytest.mark.parametrize("full_fft", [False, True])
 @pytest.mark.parametrize("c", sorted(CASES))
-def test_native_path_reproduces_reference_uno(c, dev):
+def test_native_path_reproduces_reference_uno(c, dev, full_fft, monkeypatch):
+    """full_fft: library FFTs on whole spectra + ppsci_spectrum_resize (the path of planes too large for the kept-mode transforms);
+    otherwise the kept-mode transforms between the two grids of a block (ppsci_dft2_kept_*_from)."""
+    monkeypatch.setenv("PPSCI_FNO_FULL_FFT", "1" if full_fft else "0")
     model = _model(c)
     d = model.flat_params.device
     x = torch.as_tensor(G[f"{c}/x"].astype(np.float32)).to(d)
     eng = model.native()
     y = eng.forward(x)
+    assert all(e["kept"] != full_fft for e in eng.blk)
     assert tuple(y.shape) == G[f"{c}/y"].shape
     assert rel(y.cpu().numpy(), G[f"{c}/y"]) < 2e-5
     tgt = torch.as_tensor(G[f"{c}/target"].astype(np.float32)).to(d)
@@ -124,6 +129,43 @@ def test_spectrum_resize_is_the_crop_of_irfftn_and_its_way_back(sizes, dev):
     # Im of the DC / Nyquist columns of the OUTPUT grid never reaches y: autograd has 0 there, rfft(g) is real there as well
     assert rel(have.real.numpy(), want.real.numpy()) < 2e-5
     assert rel(have.imag.numpy(), want.imag.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("sizes", [(16, 16, 8, 8, 16, 16), (16, 16, 8, 8, 8, 8), (8, 8, 16, 16, 8, 8), (19, 19, 10, 10, 8, 8), (10, 10, 20, 20, 8, 8),
+                                   (12, 20, 18, 10, 6, 8), (20, 20, 19, 19, 16, 16)])
+def test_kept_mode_transforms_between_two_grids(sizes, dev):
+    """ppsci_dft2_kept_inv_from == irfftn(S, s=(H2, W2)) of the half spectrum S (laid out for H x W) that holds Z at the rows / columns
+    FactorizedSpectralConv writes to; ppsci_dft2_kept_fwd_from followed by the c_W weights == autograd through that irfftn."""
+    from paddlescience_amd import _lib as L
+    from paddlescience_amd.device import get_device
+    from paddlescience_amd.hotpath import _p, _stream_ptr
+
+    H, W, H2, W2, nmx, nmy = sizes
+    mx, my = nmx, nmy // 2 + 1
+    d = get_device()
+    rng = np.random.default_rng(sum(sizes))
+    n, Wf = 3, W // 2 + 1
+    Z = torch.as_tensor(rng.standard_normal((n, mx, my, 2)).astype(np.float32))
+    Zc = torch.view_as_complex(Z.double().contiguous()).requires_grad_(True)
+    S = torch.zeros((n, H, Wf), dtype=torch.complex128)
+    st = H - mx
+    sl = slice(st // 2, -st // 2) if st else slice(None)  # fno_block.py:747-757 on the shifted spectrum
+    S = torch.index_put(S, (torch.arange(n)[:, None, None], torch.arange(H)[sl][None, :, None], torch.arange(my)[None, None, :]), Zc)
+    S = torch.fft.fftshift(S, dim=-2)  # fno_block.py:788-789
+    y_ref = torch.fft.irfftn(S, s=(H2, W2), dim=(-2, -1), norm="forward")
+    y = torch.empty((n, H2, W2), dtype=torch.float32, device=d)
+    Zd = Z.to(d).contiguous()
+    L.check(L.lib().ppsci_dft2_kept_inv_from(n, H2, W2, mx, my, H, W, _p(Zd), _p(y), _stream_ptr(y)))
+    assert rel(y.cpu().numpy(), y_ref.detach().numpy()) < 2e-6
+    g = torch.as_tensor(rng.standard_normal((n, H2, W2)).astype(np.float32))
+    (gz,) = torch.autograd.grad((y_ref * g.double()).sum(), Zc)
+    gd = g.to(d).contiguous()
+    X = torch.empty((n, mx, my, 2), dtype=torch.float32, device=d)
+    L.check(L.lib().ppsci_dft2_kept_fwd_from(n, H2, W2, mx, my, H, W, _p(gd), _p(X), _stream_ptr(X)))
+    cW = torch.tensor([1.0 if (j == 0 or 2 * j == W) else 2.0 for j in range(my)], dtype=torch.float64)
+    have = torch.view_as_complex(X.cpu().double().contiguous()) * cW
+    assert rel(have.real.numpy(), gz.real.numpy()) < 2e-5
+    assert rel(have.imag.numpy(), gz.imag.numpy()) < 2e-5
 
 
 def test_unonet_trains_through_the_solver(dev, tmp_path):
