@@ -493,6 +493,14 @@ int ppsci_dft2_kept_inv_stats(int n, int H, int W, int modes_x, int modes_y, int
  * ppsci_spectral_conv2d_fwd_kept): results agree to fp32 rounding. */
 int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, int rows, const float* x_k, const float* w_re,
                                    const float* w_im, float scale, float* y, const float* sbias, float* rows_out, void* stream);
+/* ppsci_spectral_conv2d_inv_kept with (Hs, Ws) > 0: the inverse between two grids (ppsci_dft2_kept_inv_from; rows must be 1), and
+ * with conj_t != 0 the DATA GRADIENT of the contraction in the same form: x_k = the kept modes of dL/dy [B, c_out, modes], y
+ * [B * c_in planes of H x W] = the inverse transform of scale * x_k . conj(w)^T -- ppsci_spectral_conv2d_bwd_kept's gx_k and
+ * ppsci_dft2_kept_inv in one launch, the weights read along the modes (ppsci_spectral_conv2d_bwd_kept with gx_k = NULL then gives
+ * the weight gradients alone). */
+int ppsci_spectral_conv2d_inv_kept_ex(const ppsci_spectral_desc* d, int H, int W, int Hs, int Ws, int conj_t, int rows,
+                                      const float* x_k, const float* w_re, const float* w_im, float scale, float* y,
+                                      const float* sbias, float* rows_out, void* stream);
 int ppsci_spectral_conv2d_fwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,
                                    float* out_k, float scale, void* stream);
 int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, const float* x_k, const float* w_re, const float* w_im,

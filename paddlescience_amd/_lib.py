@@ -183,6 +183,8 @@ _SYMBOLS = {
     "ppsci_fno_tail_fwd_ex": (C.c_int, [C.c_int] * 5 + [C.c_float] + [C.c_void_p] * 9 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]),
     "ppsci_fno_tail_bwd_ex": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 13 + [C.c_int] * 4 + [C.c_void_p] * 3),
     "ppsci_spectral_conv2d_fwd_kept": (C.c_int, [C.POINTER(SpectralDesc)] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]),
+    "ppsci_spectral_conv2d_inv_kept_ex": (C.c_int, [C.POINTER(SpectralDesc)] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_spectral_conv2d_inv_kept": (C.c_int, [C.POINTER(SpectralDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_spectral_conv2d_bwd_kept": (C.c_int, [C.POINTER(SpectralDesc)] + [C.c_void_p] * 7 + [C.c_float, C.c_int, C.c_float,

@@ -497,6 +497,8 @@ struct SpecInvArgs {
   const float* wi;
   int Ci, Co;
   float scale;
+  int conj_t;  // 0: planes (b, o), Z = sum_i x[b, i] w[i, o]   (forward);   1: planes (b, i), Z = sum_o x[b, o] conj(w[i, o])
+               // (the data gradient: x = the kept modes of dL/dy) -- either way the weights are read along the modes
 };
 
 __global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
@@ -511,7 +513,8 @@ __global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
   const int tid = threadIdx.x, P = a.H * a.W, nm = a.mx * a.my;
   bool first = true;
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
-    const int b = p / q.Co, o = p - b * q.Co;
+    const int Cp = q.conj_t ? q.Ci : q.Co, Cs = q.conj_t ? q.Co : q.Ci;  // planes per sample / summed channels
+    const int b = p / Cp, o = p - b * Cp;
     if (first) dft_twiddles(a, tw);
     first = false;
     __syncthreads();  // (the previous plane's readers of Z / Zp are done)
@@ -519,10 +522,10 @@ __global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
       const int part = idx / nm, m = idx - part * nm;
       float sr = 0.f, si = 0.f;
 #pragma unroll 4
-      for (int i = part; i < q.Ci; i += SPECINV_SPLIT) {
-        const float* xp = q.x + ((long long)b * q.Ci + i) * nm * 2 + 2 * m;
-        const long long wi_ = ((long long)i * q.Co + o) * nm + m;
-        const float xr = xp[0], xi = xp[1], wr = q.wr[wi_], wim = q.wi[wi_];
+      for (int i = part; i < Cs; i += SPECINV_SPLIT) {
+        const float* xp = q.x + ((long long)b * Cs + i) * nm * 2 + 2 * m;
+        const long long wi_ = (q.conj_t ? (long long)o * q.Co + i : (long long)i * q.Co + o) * nm + m;
+        const float xr = xp[0], xi = xp[1], wr = q.wr[wi_], wim = q.conj_t ? -q.wi[wi_] : q.wi[wi_];
         sr += xr * wr - xi * wim;
         si += xr * wim + xi * wr;
       }
@@ -729,23 +732,27 @@ extern "C" int ppsci_spectral_conv2d_bwd_kept(const ppsci_spectral_desc* d, cons
 
 
 // ppsci_spectral_conv2d_fwd_kept + ppsci_dft2_kept_inv[_stats] in one launch (spectral_inv_kernel): y [B * c_out planes of H x W].
-extern "C" int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, int rows, const float* x_k,
-                                              const float* w_re, const float* w_im, float scale, float* y, const float* sbias,
-                                              float* rows_out, void* stream) {
+// _ex: (Hs, Ws) > 0 -- the inverse between two grids (ppsci_dft2_kept_inv_from); conj_t -- the data gradient: x_k = the kept modes of
+// dL/dy [B, c_out], y [B * c_in planes] = inverse transform of x_k . conj(w)^T (ppsci_spectral_conv2d_bwd_kept's gx_k + ppsci_dft2_kept_inv).
+extern "C" int ppsci_spectral_conv2d_inv_kept_ex(const ppsci_spectral_desc* d, int H, int W, int Hs, int Ws, int conj_t, int rows,
+                                                 const float* x_k, const float* w_re, const float* w_im, float scale, float* y,
+                                                 const float* sbias, float* rows_out, void* stream) {
   if (!d || !x_k || !w_re || !w_im || !y || (rows != 0 && rows != 1) || d->batch < 1 || d->c_in < 1 || d->c_out < 1 ||
-      !ppsci_dft2_kept_supported(H, W, d->modes_x, d->modes_y)) {
+      (Hs > 0) != (Ws > 0) || Hs < 0 ||
+      !(Hs > 0 ? (rows == 1 && d->modes_x <= Hs && d->modes_y <= Ws / 2 + 1 && ppsci_dft2_kept_from_supported(H, W, d->modes_x, d->modes_y))
+               : ppsci_dft2_kept_supported(H, W, d->modes_x, d->modes_y))) {
     ppsci_set_error("spectral_conv2d_inv_kept: invalid argument or unsupported shape");
     return PPSCI_E_INVALID;
   }
-  const int mx = d->modes_x, my = d->modes_y, n = d->batch * d->c_out;
-  const float* tab = ppsci_dft_table(H, W, mx, my, rows);
+  const int mx = d->modes_x, my = d->modes_y, n = d->batch * (conj_t ? d->c_in : d->c_out);
+  const float* tab = dft_table(H, W, mx, my, rows, Hs, Ws, 0);
   if (!tab) {
     ppsci_set_error("spectral_conv2d_inv_kept: cannot build the twiddle table");
     return PPSCI_E_LAUNCH;
   }
   SpecInvArgs q;
-  q.d = DftArgs{nullptr, y, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, d->c_out};
-  q.x = x_k; q.wr = w_re; q.wi = w_im; q.Ci = d->c_in; q.Co = d->c_out; q.scale = scale;
+  q.d = DftArgs{nullptr, y, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, conj_t ? d->c_in : d->c_out};
+  q.x = x_k; q.wr = w_re; q.wi = w_im; q.Ci = d->c_in; q.Co = d->c_out; q.scale = scale; q.conj_t = conj_t ? 1 : 0;
   const long long lds = dft_lds_bytes(H, W, mx, my, 1) + 4LL * SPECINV_SPLIT * 2 * mx * my;
   if (lds + 4096 > 64 * 1024) {
     ppsci_set_error("spectral_conv2d_inv_kept: %lld B of LDS", lds);
@@ -762,4 +769,9 @@ extern "C" int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int 
     return PPSCI_E_LAUNCH;
   }
   return PPSCI_OK;
+}
+extern "C" int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, int rows, const float* x_k,
+                                              const float* w_re, const float* w_im, float scale, float* y, const float* sbias,
+                                              float* rows_out, void* stream) {
+  return ppsci_spectral_conv2d_inv_kept_ex(d, H, W, 0, 0, 0, rows, x_k, w_re, w_im, scale, y, sbias, rows_out, stream);
 }

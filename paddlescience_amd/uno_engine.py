@@ -176,7 +176,7 @@ class UnoNative(FnoNative):
                     and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1")
             nk = (d.modes_x, d.modes_y, 2)
             e = dict(
-                kept=kept, xk=torch.empty((B, ci) + nk, **f) if kept else None, zk=torch.empty((B, co) + nk, **f) if kept else None,
+                kept=kept, xk=torch.empty((B, ci) + nk, **f) if kept else None,
                 desc=d, scale=scale, hw=(H, W), hw2=(H2, W2), ci=ci, co=co, src=src, resized=(H, W) != (H2, W2),
                 xin=torch.empty((B, ci, P), **f) if src is not None else None,  # concat(previous output, U skip)
                 xft=torch.empty((B, ci, H, Wf, 2), **f) if not kept else None,
@@ -254,15 +254,12 @@ class UnoNative(FnoNative):
                 e["rs"].apply(B * co, sk, e["s"])
                 sk = e["s"]
             mx, my = e["desc"].modes_x, e["desc"].modes_y
-            if e["kept"] and not e["resized"]:  # contraction + inverse transform in one launch (as fno_engine)
+            if e["kept"]:  # the kept modes of x, then contraction + inverse transform (onto the other grid, if it changes) in one launch
                 L.check(L.lib().ppsci_dft2_kept_fwd(B * ci, H, W, mx, my, 0, _p(cur), _p(e["xk"]), st))
-                L.check(L.lib().ppsci_spectral_conv2d_inv_kept(C.byref(e["desc"]), H, W, 1, _p(e["xk"]), _p(conv.weight_real),
-                                                               _p(conv.weight_imag), e["scale"], _p(e["v"]), None, None, st))
-            elif e["kept"]:
-                L.check(L.lib().ppsci_dft2_kept_fwd(B * ci, H, W, mx, my, 0, _p(cur), _p(e["xk"]), st))
-                L.check(L.lib().ppsci_spectral_conv2d_fwd_kept(C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real),
-                                                               _p(conv.weight_imag), _p(e["zk"]), e["scale"], st))
-                L.check(L.lib().ppsci_dft2_kept_inv_from(B * co, H2, W2, mx, my, H, W, _p(e["zk"]), _p(e["v"]), st))
+                hs, ws = (H, W) if e["resized"] else (0, 0)
+                L.check(L.lib().ppsci_spectral_conv2d_inv_kept_ex(C.byref(e["desc"]), H2, W2, hs, ws, 0, 1, _p(e["xk"]),
+                                                                  _p(conv.weight_real), _p(conv.weight_imag), e["scale"], _p(e["v"]),
+                                                                  None, None, st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * ci, H, W, _p(cur), _p(e["xft"]), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real),
@@ -351,11 +348,12 @@ class UnoNative(FnoNative):
                 mx, my = e["desc"].modes_x, e["desc"].modes_y
                 ghat = V(self.gf[0], B, co, mx, my, 2)
                 L.check(L.lib().ppsci_dft2_kept_fwd_from(B * co, H2, W2, mx, my, H, W, _p(gv), _p(ghat), st))
-                gx_k = V(self.gf[2], B, ci, mx, my, 2)
+                # weight gradients alone (threads along the modes), then the data gradient's contraction inside its inverse transform
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
-                    C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real), _p(conv.weight_imag), _p(ghat), _p(gx_k),
+                    C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real), _p(conv.weight_imag), _p(ghat), None,
                     _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], st))
-                L.check(L.lib().ppsci_dft2_kept_inv(B * ci, H, W, mx, my, 0, _p(gx_k), _p(gsp), st))
+                L.check(L.lib().ppsci_spectral_conv2d_inv_kept_ex(C.byref(e["desc"]), H, W, 0, 0, 1, 0, _p(ghat), _p(conv.weight_real),
+                                                                  _p(conv.weight_imag), e["scale"], _p(gsp), None, None, st))
             else:
                 ghat = V(self.gf[0], B, co, H2, Wf2, 2)
                 L.check(L.lib().ppsci_fft2d_r2c(B * co, H2, W2, _p(gv), _p(ghat), st))
