@@ -528,6 +528,61 @@ def strong_ns(tmp, world, rank, steps, warmup, barrier):
             "matrix_tflops_per_gpu": 6.0 * NS_PMAT * 5 * n_local / t / 1e12}
 
 
+def extra_uno(steps, warmup, B=16, R=16):
+    """The reference's UNO configuration (examples/neuraloperator/conf/uno_darcyflow_pretrain.yaml: in 3, hidden 64, lifting 256,
+    projection 64, five Fourier layers 32-64-64-64-32 with modes 16-8-8-8-16 and scalings 1, 0.5, 1, 2, 1, group_norm, domain padding
+    0.2, batch 16 at 16 x 16); one training step = forward + MSE + backward + fused Adam (uno_engine.UnoNative)."""
+    import ppsci
+
+    torch.manual_seed(0)
+    outs, modes = [32, 64, 64, 64, 32], [[16, 16], [8, 8], [8, 8], [8, 8], [16, 16]]
+    scal = [[1.0, 1.0], [0.5, 0.5], [1, 1], [2, 2], [1, 1]]
+    model = ppsci.arch.UNONet(("x",), ("y",), 3, 1, 64, 256, 64, n_layers=5, uno_out_channels=outs, uno_n_modes=modes,
+                              uno_scalings=scal, norm="group_norm", domain_padding=0.2, domain_padding_mode="one-sided")
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, R, R)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, R, R)).astype(np.float32)).cuda()
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    # parity (checker: the oracle's fp64 restatement of unonet.py, pinned by the reference-run tests/golden/uno.npz)
+    from oracle import ref_torch as Rf
+
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = Rf.uno_forward(x.cpu().double(), P, outs, modes, scal, None, "group_norm", domain_padding=0.2)
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    mse_loss = ppsci.loss.MSELoss("mean")
+    yh = nat.forward(x.contiguous())
+    lh, gy = mse_loss.value_and_grad(yh, y, "y")
+    yh = yh.clone()
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    gh = {n: p.grad.detach().cpu().numpy().copy() for n, p in torch.nn.Module.named_parameters(model)}
+    model.flat_grad.zero_()
+    parity = {"checker": "oracle/ref_torch.uno_forward fp64 (pinned by reference-run tests/golden/uno.npz), the whole timed batch, "
+                         "the timed model's weights",
+              "output_rel_l2": rel(yh.detach().cpu().numpy(), yo.detach().numpy()),
+              "grad_rel_l2": max(rel(gh[n], go[n].numpy()) for n in names),
+              "loss_rel": abs(float(lh["y"].detach()) / float(lo.detach()) - 1.0)}
+    from paddlescience_amd.engine import step_with_adam
+    from paddlescience_amd.operator_engine import OperatorConstraint, OperatorEngine
+
+    cst = OperatorConstraint("Sup", model, {"y": lambda d: d["y"]}, mse_loss, x.device, ["y"], B)
+    cst.bind({"x": x}, {"y": y})
+    eng = OperatorEngine(model)
+
+    def step():
+        step_with_adam(eng, [cst], opt, model.flat_params)
+
+    t = time_wall(step, steps, warmup)
+    t_ev = time_events(step, reps=steps)
+    return {"config": "extra: UNO Darcy (reference config): 16x16 grid padded to 19x19, batch 16, in 3, hidden 64, lifting 256, "
+                      "projection 64, layers 32-64-64-64-32 on grids 19/10/10/20/19, group_norm; forward + MSE + backward + Adam",
+            "value": B * R * R / t, "unit": "grid-points/s", "samples_per_s": B / t, "ms_per_step": t * 1e3, "steps": steps,
+            "ms_per_step_hip_events": t_ev * 1e3, "params": int(model.flat_params.numel()),
+            "native_forward_backward": type(eng.native).__name__, "parity": parity}
+
+
 def secondary_tfno(steps, warmup, B=16, H=64, W=64):
     """BASELINE configs[3] / SURVEY 8(d): TFNO2dNet in 3, hidden 32, lifting 256, projection 64, 4 layers, n_modes
     (12, 12), group_norm, fft_norm forward; one training step = forward + MSE + backward + fused Adam."""
@@ -1037,7 +1092,7 @@ def main():
             k, w = max(10, args.steps // 2), max(3, args.warmup // 2)
             sec = []
             for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),
-                       lambda: secondary_ns(tmp, k, w), lambda: secondary_ac256(tmp, k, w), lambda: secondary_tfno(k, w),
+                       lambda: secondary_ns(tmp, k, w), lambda: secondary_ac256(tmp, k, w), lambda: secondary_tfno(k, w), lambda: extra_uno(k, w),
                        lambda: secondary_spinn(tmp, k, w),
                        lambda: extra_piratenet(tmp, k, w), lambda: extra_cylinder2d(tmp, k, w),
                        lambda: extra_euler_beam(tmp)):

@@ -875,6 +875,73 @@ def fno_forward(x, P, n_layers, n_modes, norm=None, fft_norm="forward", eps=1e-5
     return mlp(x, "projection", 2)
 
 
+def uno_forward(x, P, out_channels, n_modes, scalings, skips_map=None, norm=None, eps=1e-5, domain_padding=None,
+                domain_padding_mode="one-sided"):
+    """UNONet.forward (/root/reference/ppsci/arch/unonet.py:246-289) on plain tensors; P named like paddlescience_amd.arch.uno.
+    Per layer (FNOBlocks with n_layers = 1: fno_block.py:1191-1210, no activation behind it)
+        x <- norm(SpectralConv_i(x) on the scaled grid) + bicubic(skip_i(x))
+    SpectralConv.forward (fno_block.py:707-796): rfftn, fftshift of the rows, the centred block of n_modes rows x n_modes//2+1 columns
+    times the weights, fftshift AGAIN, irfftn(s = the output grid) -- the crop / zero-pad at the end of both axes -- plus bias; the
+    transforms run with the norm "backward" whatever fft_norm is (FNOBlocks does not hand it on, :1099-1111).  The scaled grid is
+    round(size * factor) (:779-786), the last layer's the end-to-end grid (unonet.py:251-254, :273-274).  U skips: unonet.py:259-277."""
+    import torch.nn.functional as F
+
+    def conv1x1(x, w, b=None):
+        y = torch.einsum("oi,bihw->bohw", w[:, :, 0, 0], x)
+        return y if b is None else y + b.view(1, -1, 1, 1)
+
+    n = len(out_channels)
+    if skips_map is None:
+        skips_map = {n - i - 1: i for i in range(n // 2)}
+    x = conv1x1(F.gelu(conv1x1(x, P["lifting.fcs.0.weight"], P["lifting.fcs.0.bias"])), P["lifting.fcs.1.weight"], P["lifting.fcs.1.bias"])
+    H0, W0 = x.shape[-2:]
+    ph = pw = 0
+    if domain_padding is not None:
+        fr = [float(domain_padding)] * 2 if not isinstance(domain_padding, (list, tuple)) else [float(v) for v in domain_padding]
+        ph, pw = round(fr[0] * H0), round(fr[1] * W0)
+        sym = domain_padding_mode == "symmetric"
+        x = F.pad(x, [pw if sym else 0, pw, ph if sym else 0, ph])
+    e2e = [1.0, 1.0]
+    for sc in scalings:
+        e2e = [a * b for a, b in zip(e2e, sc)]
+    final = (int(round(x.shape[-2] * e2e[0])), int(round(x.shape[-1] * e2e[1])))
+    hs = {}
+    for i in range(n):
+        if i in skips_map:
+            t = hs[skips_map[i]]
+            if t.shape[-2:] != x.shape[-2:]:
+                t = F.interpolate(t, size=tuple(x.shape[-2:]), mode="bicubic", align_corners=True)
+            x = torch.cat([x, t], dim=1)
+        H, W = x.shape[-2:]
+        H2, W2 = final if i == n - 1 else (round(H * scalings[i][0]), round(W * scalings[i][1]))
+        pre = f"fno_blocks.{i}."
+        sk = conv1x1(x, P[pre + "fno_skips.0.weight"]) if pre + "fno_skips.0.weight" in P else x
+        if (H, W) != (H2, W2):
+            sk = F.interpolate(sk, size=(H2, W2), mode="bicubic", align_corners=True)
+        X = torch.fft.fftshift(torch.fft.rfftn(x, dim=(-2, -1), norm="backward"), dim=-2)
+        mx, my = n_modes[i][0], n_modes[i][1] // 2 + 1
+        w = torch.complex(P[pre + "convs.0.weight_real"], P[pre + "convs.0.weight_imag"])
+        st = H - min(H, mx)
+        rows = slice(st // 2, -st // 2) if st else slice(None)
+        out = torch.zeros(x.shape[0], w.shape[1], H, W // 2 + 1, dtype=X.dtype)
+        out[:, :, rows, :my] = torch.einsum("bihw,iohw->bohw", X[:, :, rows, :my], w)
+        out = torch.fft.fftshift(out, dim=-2)
+        y = torch.fft.irfftn(out, s=(H2, W2), dim=(-2, -1), norm="backward") + P[pre + "convs.0.bias"].view(1, -1, 1, 1)
+        if norm == "group_norm":
+            mu = y.mean(dim=(1, 2, 3), keepdim=True)
+            var = y.var(dim=(1, 2, 3), keepdim=True, unbiased=False)
+            y = (y - mu) / torch.sqrt(var + eps)
+            y = y * P[pre + "norm.0.weight"].view(1, -1, 1, 1) + P[pre + "norm.0.bias"].view(1, -1, 1, 1)
+        x = y + sk
+        if i in skips_map.values():
+            hs[i] = conv1x1(x, P[f"horizontal_skips.{i}.weight"])
+    if ph or pw:
+        oh, ow = (ph, pw) if domain_padding_mode == "symmetric" else (0, 0)
+        x = x[..., oh:oh + H0, ow:ow + W0]
+    return conv1x1(F.gelu(conv1x1(x, P["projection.fcs.0.weight"], P["projection.fcs.0.bias"])), P["projection.fcs.1.weight"],
+                   P["projection.fcs.1.bias"])
+
+
 def field_rel_error(x, y, order=0, p=2, spacing=(1.0, 1.0), fix=(False, False)):
     """Per-row relative error of /root/reference/examples/neuraloperator/metric.py on [B, C, H, W] tensors: LpLoss.rel
     (:148-160; order 0) and H1Loss.rel (:330-352; order 1: the squared norms of the central differences of :36-55 --

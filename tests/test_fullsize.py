@@ -237,6 +237,43 @@ def test_tfno_full_size_batch16_64x64(dev):
         assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 2e-5, n
 
 
+@pytest.mark.parametrize("res,full_fft", [(16, False), (16, True), (32, False), (64, False)])
+def test_uno_reference_config_full_size(dev, res, full_fft, monkeypatch):
+    """The reference's UNO configuration (conf/uno_darcyflow_pretrain.yaml: hidden 64, lifting 256, projection 64, layers
+    32-64-64-64-32, modes 16-8-8-8-16, scalings 1 / 0.5 / 1 / 2 / 1, GroupNorm, domain padding 0.2, batch 16) at its training
+    resolution 16, its second evaluation resolution 32 and at 64, against the fp64 oracle (oracle/ref_torch.uno_forward, pinned by
+    the reference-run tests/golden/uno.npz): output, loss, every gradient."""
+    if dev != "gpu":
+        pytest.skip("full sizes run on the GPU only")
+    import ppsci
+    from oracle import ref_torch as R
+
+    monkeypatch.setenv("PPSCI_FNO_FULL_FFT", "1" if full_fft else "0")
+    torch.manual_seed(0)
+    outs, modes = [32, 64, 64, 64, 32], [[16, 16], [8, 8], [8, 8], [8, 8], [16, 16]]
+    scal = [[1.0, 1.0], [0.5, 0.5], [1, 1], [2, 2], [1, 1]]
+    model = ppsci.arch.UNONet(("x",), ("y",), 3, 1, 64, 256, 64, n_layers=5, uno_out_channels=outs, uno_n_modes=modes,
+                              uno_scalings=scal, norm="group_norm", domain_padding=0.2, domain_padding_mode="one-sided")
+    B = 16 if res <= 32 else 4
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, res, res)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 1, res, res)).astype(np.float32)).cuda()
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.uno_forward(x.cpu().double(), P, outs, modes, scal, None, "group_norm", domain_padding=0.2)
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    yh = nat.forward(x)
+    assert all(e["kept"] != full_fft for e in nat.blk)
+    losses, gy = ppsci.loss.MSELoss("mean").value_and_grad(yh, y, "y")
+    assert K._rel(yh.cpu().numpy(), yo.detach().numpy()) < 5e-6
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    for n, p in torch.nn.Module.named_parameters(model):
+        assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 5e-5, n
+
+
 @pytest.mark.parametrize("padding,full_fft", [(0.078125, False), (0.078125, True), (0.1, False)])
 def test_tfno_64x64_with_the_yaml_domain_padding(dev, padding, full_fft, monkeypatch):
     """The padding the reference's TFNO yaml names (0.078125: 64 -> 69 x 69 planes, odd: element accesses, the double

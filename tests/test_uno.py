@@ -34,6 +34,23 @@ def _model(c):
     return model
 
 
+@pytest.mark.parametrize("c", sorted(CASES))
+def test_oracle_restatement_reproduces_the_reference_fixture(c):
+    """oracle/ref_torch.uno_forward (the checker of bench.py's UNO entry and of the full-size test) against the outputs and gradients
+    the REFERENCE's own unonet.py produced (tests/golden/uno.npz): fp64 round-off."""
+    from oracle import ref_torch as R
+
+    k = CASES[c]
+    P = {n[len(c) + 7:]: torch.tensor(G[n]).requires_grad_(True) for n in G.files if n.startswith(f"{c}/param/")}
+    y = R.uno_forward(torch.tensor(G[f"{c}/x"]), P, k["outs"], k["modes"], k["scal"], k["skips"], k["norm"], domain_padding=k["pad"],
+                      domain_padding_mode=k["pad_mode"])
+    assert rel(y.detach().numpy(), G[f"{c}/y"]) < 1e-12
+    loss = ((y - torch.tensor(G[f"{c}/target"])) ** 2).mean()
+    names = sorted(P)
+    for n, g in zip(names, torch.autograd.grad(loss, [P[n] for n in names])):
+        assert rel(g.numpy(), G[f"{c}/grad/{n}"]) < 1e-10, n
+
+
 @pytest.mark.parametrize("full_fft", [False, True])
 @pytest.mark.parametrize("c", sorted(CASES))
 def test_native_path_reproduces_reference_uno(c, dev, full_fft, monkeypatch):
