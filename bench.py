@@ -579,7 +579,7 @@ def extra_uno(steps, warmup, B=16, R=16):
     return {"config": "extra: UNO Darcy (reference config): 16x16 grid padded to 19x19, batch 16, in 3, hidden 64, lifting 256, "
                       "projection 64, layers 32-64-64-64-32 on grids 19/10/10/20/19, group_norm; forward + MSE + backward + Adam",
             "value": B * R * R / t, "unit": "grid-points/s", "samples_per_s": B / t, "ms_per_step": t * 1e3, "steps": steps,
-            "ms_per_step_hip_events": t_ev * 1e3, "params": int(model.flat_params.numel()),
+            "ms_per_step_hip_events": t_ev * 1e3, "params": int(model.flat_params.numel()), "roofline": step_hbm_roofline("uno", t),
             "native_forward_backward": type(eng.native).__name__, "parity": parity}
 
 
