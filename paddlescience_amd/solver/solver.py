@@ -87,6 +87,33 @@ class Solver:
                                                 or getattr(loss_aggregator, "per_loss_grad", False)):
             raise NotImplementedError("loss aggregators on the fused path: Sum, GradNorm, NTK")
         self.cfg = cfg
+        if cfg is not None and hasattr(cfg, "get") and cfg.get("TRAIN", None) is not None or (
+                cfg is not None and hasattr(cfg, "get") and cfg.get("output_dir", None) is not None):
+            # `Solver(model, constraint, ..., cfg=cfg)`: the run parameters come from the config, as in the reference
+            # (/root/reference/ppsci/solver/solver.py:165-168, _parse_params_from_cfg :1078-1116), with the defaults its config schema
+            # fills in (ppsci/utils/config.py TrainConfig / EvalConfig / SolverConfig)
+            def sub(name):
+                v = cfg.get(name, None)
+                return v if v is not None else {}
+
+            tr, ev = sub("TRAIN"), sub("EVAL")
+            if cfg.get("use_amp", False) or cfg.get("to_static", False):
+                raise NotImplementedError("AMP / to_static are not available on the fused HIP path (fp32 only)")
+            output_dir = cfg.get("output_dir", output_dir)
+            log_freq = cfg.get("log_freq", 20)
+            seed = cfg.get("seed", 42)
+            epochs = tr.get("epochs", epochs)
+            iters_per_epoch = tr.get("iters_per_epoch", 20)
+            update_freq = tr.get("update_freq", 1)
+            save_freq = tr.get("save_freq", 0)
+            eval_during_train = tr.get("eval_during_train", False)
+            start_eval_epoch = tr.get("start_eval_epoch", 1)
+            eval_freq = tr.get("eval_freq", 1)
+            checkpoint_path = tr.get("checkpoint_path", None)
+            compute_metric_by_batch = ev.get("compute_metric_by_batch", False)
+            eval_with_no_grad = ev.get("eval_with_no_grad", False)
+            mode = cfg.get("mode", "train")
+            pretrained_model_path = (tr if mode == "train" else ev if mode == "eval" else sub("INFER")).get("pretrained_model_path", None)
         self.model = model
         self.constraint = constraint
         self.output_dir = output_dir

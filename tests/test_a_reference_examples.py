@@ -38,6 +38,47 @@ HYDRA_CASES = {
                                   {"MODEL.num_layers": 2, "MODEL.hidden_size": 16, "TRAIN.epochs": 2, "TRAIN.eval_freq": 1,
                                    "NPOINT_INTERIOR": 200, "NPOINT_BC": 20, "NTIME_ALL": 10}),
 }
+
+
+def _cylinder_tables(tmp):
+    """The six CSV tables cylinder2d_unsteady_Re100.py reads (download_dataset.py fetches them; no network here), in the reference's
+    column naming, with synthetic content: four from examples/cylinder2d_unsteady.ensure_data, plus the probe series and the
+    evaluation cloud."""
+    from examples import cylinder2d_unsteady as mine
+
+    n_pde, n_in, n_out, nt = 40, 11, 5, 5
+    mine.ensure_data(dict(data_dir="./datasets", npoint_pde=n_pde, npoint_inlet_cylinder=n_in, npoint_outlet=n_out), np.random.default_rng(0))
+    rng = np.random.default_rng(1)
+    os.makedirs("datasets/probe", exist_ok=True)
+    t = np.repeat(np.linspace(1, 50, nt), 4)
+    xy = np.tile(rng.uniform(1, 5, (4, 2)), (nt, 1))
+    np.savetxt("datasets/probe/probe1_50.csv", np.stack([t, xy[:, 0], xy[:, 1], np.ones_like(t), np.zeros_like(t)], 1), delimiter=",",
+               header="t,Points:0,Points:1,U:0,U:1", comments="", fmt="%.8g")
+    dom = np.loadtxt("datasets/domain_train.csv", delimiter=",", skiprows=1)
+    ne = n_pde + n_in + n_out
+    pts = np.concatenate([dom, rng.uniform(-8, 8, (ne - len(dom), 2))])
+    np.savetxt("datasets/domain_eval.csv", np.stack([np.repeat(np.linspace(1, 50, nt), ne), np.tile(pts[:, 0], nt), np.tile(pts[:, 1], nt)], 1),
+               delimiter=",", header="t,x,y", comments="", fmt="%.8g")
+
+
+def _viv_mat(tmp):
+    """VIV_Training_Neta100.mat (columns t_f, eta, f) with a synthetic oscillation."""
+    import scipy.io
+
+    t = np.linspace(0, 10, 150)[:, None]
+    scipy.io.savemat("VIV_Training_Neta100.mat", {"t_f": t, "eta": 0.3 * np.sin(2 * t), "f": 0.1 * np.cos(2 * t)})
+
+
+# examples that read data files: written (synthetic, the reference's formats) into the working directory first
+HYDRA_CASES["cylinder2d_unsteady_Re100"] = (
+    "cylinder/2d_unsteady/cylinder2d_unsteady_Re100.py", "cylinder/2d_unsteady/conf/cylinder2d_unsteady_Re100.yaml",
+    {"NPOINT_PDE": 40, "NPOINT_INLET_CYLINDER": 11, "NPOINT_OUTLET": 5, "NUM_TIMESTAMPS": 5, "TRAIN_NUM_TIMESTAMPS": 3,
+     "TRAIN.epochs": 2, "TRAIN.eval_freq": 2, "MODEL.num_layers": 2, "MODEL.hidden_size": 16})
+# (this one hands its whole run configuration over as Solver(..., cfg=cfg): epochs, output_dir, frequencies come from the yaml)
+HYDRA_CASES["viv"] = ("fsi/viv.py", "fsi/conf/viv.yaml",
+                      {"TRAIN.epochs": 3, "TRAIN.eval_freq": 3, "TRAIN.save_freq": 3, "MODEL.num_layers": 2, "MODEL.hidden_size": 16,
+                       "TRAIN.batch_size": 50})
+PREPARE = {"cylinder2d_unsteady_Re100": _cylinder_tables, "viv": _viv_mat}
 NO_VISUALIZER = {"heat_pinn", "NLS-MB_optical_soliton", "NLS-MB_optical_rogue_wave"}  # (they draw their own figures)
 
 
@@ -72,9 +113,11 @@ def test_reference_example_trains_unmodified(case, tmp_path, monkeypatch, emulat
     mod = importlib.util.module_from_spec(spec)
     monkeypatch.chdir(tmp_path)
     monkeypatch.syspath_prepend(os.path.dirname(os.path.join(REF, rel)))  # (sibling modules of the example: heat_pinn's fdm.py)
+    if case in PREPARE:
+        PREPARE[case](tmp_path)
     spec.loader.exec_module(mod)
     mod.train(cfg)
-    assert os.path.exists(os.path.join(out, "checkpoints", "latest.pdparams"))
+    assert os.path.exists(os.path.join(out, "checkpoints", "latest.pdparams"))  # (viv: only if Solver(cfg=) took output_dir from cfg)
     if case in NO_VISUALIZER:
         assert any(f.endswith((".png", ".jpg")) for _, _, fs in os.walk(out) for f in fs), "the example's own figure is missing"
         return
