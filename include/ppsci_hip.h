@@ -497,7 +497,8 @@ int ppsci_spectral_conv2d_inv_kept(const ppsci_spectral_desc* d, int H, int W, i
  * with conj_t != 0 the DATA GRADIENT of the contraction in the same form: x_k = the kept modes of dL/dy [B, c_out, modes], y
  * [B * c_in planes of H x W] = the inverse transform of scale * x_k . conj(w)^T -- ppsci_spectral_conv2d_bwd_kept's gx_k and
  * ppsci_dft2_kept_inv in one launch, the weights read along the modes (ppsci_spectral_conv2d_bwd_kept with gx_k = NULL then gives
- * the weight gradients alone). */
+ * the weight gradients alone).  conj_t is a bit set: 1 = the data gradient as above, 2 = y += the result instead of y = (the
+ * spectral branch's share of dL/dx joining the skip branch's, which the caller has already written to y). */
 int ppsci_spectral_conv2d_inv_kept_ex(const ppsci_spectral_desc* d, int H, int W, int Hs, int Ws, int conj_t, int rows,
                                       const float* x_k, const float* w_re, const float* w_im, float scale, float* y,
                                       const float* sbias, float* rows_out, void* stream);

@@ -499,6 +499,7 @@ struct SpecInvArgs {
   float scale;
   int conj_t;  // 0: planes (b, o), Z = sum_i x[b, i] w[i, o]   (forward);   1: planes (b, i), Z = sum_o x[b, o] conj(w[i, o])
                // (the data gradient: x = the kept modes of dL/dy) -- either way the weights are read along the modes
+  int accumulate;  // y += instead of y = (the data gradient joining the skip branch's share of dL/dx, already in y)
 };
 
 __global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
@@ -544,7 +545,9 @@ __global__ void __launch_bounds__(256) spectral_inv_kernel(SpecInvArgs q) {
     const float sb = (a.rows_out && a.sbias) ? a.sbias[p % a.C] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     dft_inv_stages(a, tw, th, Z, T, [&](int hh, int w, float val) {
-      y[(long long)hh * a.W + w] = val;
+      float* yp = &y[(long long)hh * a.W + w];
+      if (q.accumulate) val += *yp;
+      *yp = val;
       const float u = val + sb;
       s1 += u;
       s2 += u * u;
@@ -744,15 +747,15 @@ extern "C" int ppsci_spectral_conv2d_inv_kept_ex(const ppsci_spectral_desc* d, i
     ppsci_set_error("spectral_conv2d_inv_kept: invalid argument or unsupported shape");
     return PPSCI_E_INVALID;
   }
-  const int mx = d->modes_x, my = d->modes_y, n = d->batch * (conj_t ? d->c_in : d->c_out);
+  const int mx = d->modes_x, my = d->modes_y, n = d->batch * ((conj_t & 1) ? d->c_in : d->c_out);
   const float* tab = dft_table(H, W, mx, my, rows, Hs, Ws, 0);
   if (!tab) {
     ppsci_set_error("spectral_conv2d_inv_kept: cannot build the twiddle table");
     return PPSCI_E_LAUNCH;
   }
   SpecInvArgs q;
-  q.d = DftArgs{nullptr, y, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, conj_t ? d->c_in : d->c_out};
-  q.x = x_k; q.wr = w_re; q.wi = w_im; q.Ci = d->c_in; q.Co = d->c_out; q.scale = scale; q.conj_t = conj_t ? 1 : 0;
+  q.d = DftArgs{nullptr, y, tab, n, H, W, mx, my, (H - mx) / 2, rows, sbias, rows_out, (conj_t & 1) ? d->c_in : d->c_out};
+  q.x = x_k; q.wr = w_re; q.wi = w_im; q.Ci = d->c_in; q.Co = d->c_out; q.scale = scale; q.conj_t = (conj_t & 1) ? 1 : 0; q.accumulate = (conj_t & 2) ? 1 : 0;
   const long long lds = dft_lds_bytes(H, W, mx, my, 1) + 4LL * SPECINV_SPLIT * 2 * mx * my;
   if (lds + 4096 > 64 * 1024) {
     ppsci_set_error("spectral_conv2d_inv_kept: %lld B of LDS", lds);

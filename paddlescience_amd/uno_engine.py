@@ -352,8 +352,9 @@ class UnoNative(FnoNative):
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_kept(
                     C.byref(e["desc"]), _p(e["xk"]), _p(conv.weight_real), _p(conv.weight_imag), _p(ghat), None,
                     _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], st))
-                L.check(L.lib().ppsci_spectral_conv2d_inv_kept_ex(C.byref(e["desc"]), H, W, 0, 0, 1, 0, _p(ghat), _p(conv.weight_real),
-                                                                  _p(conv.weight_imag), e["scale"], _p(gsp), None, None, st))
+                # (3 = conjugate + accumulate: gxin holds the skip branch's share already)
+                L.check(L.lib().ppsci_spectral_conv2d_inv_kept_ex(C.byref(e["desc"]), H, W, 0, 0, 3, 0, _p(ghat), _p(conv.weight_real),
+                                                                  _p(conv.weight_imag), e["scale"], _p(gxin), None, None, st))
             else:
                 ghat = V(self.gf[0], B, co, H2, Wf2, 2)
                 L.check(L.lib().ppsci_fft2d_r2c(B * co, H2, W2, _p(gv), _p(ghat), st))
@@ -366,7 +367,7 @@ class UnoNative(FnoNative):
                     C.byref(e["desc"]), _p(e["xft"]), _p(conv.weight_real), _p(conv.weight_imag), _p(G), _p(gx_ft),
                     _p(conv.weight_real.grad), _p(conv.weight_imag.grad), e["scale"], W, e["scale"], 1, st))
                 L.check(L.lib().ppsci_fft2d_c2r(B * ci, H, W, _p(gx_ft), _p(gsp), st))
-            hp.reduce_rows(gsp.view(1, -1), 1, B * ci * P, gxin.view(-1), True)  # gxin += gsp
+                hp.reduce_rows(gsp.view(1, -1), 1, B * ci * P, gxin.view(-1), True)  # gxin += gsp
             # the input was concat(previous output, U skip): split the gradient
             if e["src"] is not None:
                 se = self.blk[e["src"]]
