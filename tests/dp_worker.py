@@ -112,14 +112,19 @@ def main_viv(outdir):
         dist.destroy_process_group()
 
 
-def build_fno_solver(outdir, world_batch, steps):
-    """Operator-learning path: TFNO2dNet through torch autograd + the HIP spectral kernel, gradient averaged
-    over ranks (DataParallel semantics)."""
+def build_fno_solver(outdir, world_batch, steps, uno=False):
+    """Operator-learning path: TFNO2dNet (or UNONet) on the native executor, gradient averaged over ranks (DataParallel
+    semantics)."""
     import ppsci
 
     torch.manual_seed(5)
-    model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, hidden_channels=8, lifting_channels=16, projection_channels=16,
-                                 n_layers=2, norm="group_norm")
+    if uno:
+        model = ppsci.arch.UNONet(("x",), ("y",), 3, 1, 6, lifting_channels=8, projection_channels=8, n_layers=3,
+                                  uno_out_channels=[4, 6, 4], uno_n_modes=[[8, 8], [4, 4], [4, 4]],
+                                  uno_scalings=[[0.5, 0.5], [1, 1], [2, 2]], norm="group_norm")
+    else:
+        model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, hidden_channels=8, lifting_channels=16, projection_channels=16,
+                                     n_layers=2, norm="group_norm")
     rng = np.random.default_rng(9)
     x = rng.standard_normal((world_batch, 3, 8, 8)).astype(np.float32)
     y = rng.standard_normal((world_batch, 1, 8, 8)).astype(np.float32)
@@ -137,8 +142,8 @@ def build_fno_solver(outdir, world_batch, steps):
 
 def main():
     outdir, reduction = sys.argv[1], sys.argv[2]
-    if reduction == "fno":
-        return main_fno(outdir)
+    if reduction in ("fno", "uno"):
+        return main_fno(outdir, reduction == "uno")
     if reduction == "spinn":
         return main_spinn(outdir)
     if reduction == "viv":
@@ -335,7 +340,7 @@ def main_spinn(outdir):
         dist.destroy_process_group()
 
 
-def main_fno(outdir):
+def main_fno(outdir, uno=False):
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -344,7 +349,7 @@ def main_fno(outdir):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo")
-    solver, model, x = build_fno_solver(outdir, 4, 2)
+    solver, model, x = build_fno_solver(outdir, 4, 2, uno)
     solver.train()
     pred = solver.predict({"x": x}, return_numpy=True)
     if not dist.is_initialized() or dist.get_rank() == 0:

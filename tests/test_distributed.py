@@ -86,6 +86,16 @@ def test_two_ranks_reproduce_single_rank_fno(tmp_path):
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
 
 
+def test_two_ranks_reproduce_single_rank_uno(tmp_path):
+    """The same for UNONet (uno_engine.UnoNative: resolution-changing blocks, U skip) -- the executor is a sibling of the FNO one and
+    shares its data-parallel contract."""
+    d = str(tmp_path)
+    one = _run(d, 1, "uno")
+    two = _run(d, 2, "uno")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
+
+
 def test_two_ranks_reproduce_single_rank_spinn(tmp_path):
     """Separable path (SPINN / Helmholtz3D): x-axis slabs per rank, global-grid loss normalisation, SUM all-reduce."""
     d = str(tmp_path)
