@@ -620,6 +620,24 @@ int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* 
                           float* gv, float* ggamma, float* gbeta, float* gsbias, int H, int W, int modes_x, int modes_y,
                           float* ghat, const float* gout2_modes, void* stream);
 
+/* ---- spherical FNO (csrc/sht.hip; /root/reference/ppsci/arch/sfnonet.py on arch/paddle_harmonics/sht.py) -------------------
+ * The spherical-harmonic transform pair on n planes of H (colatitude) x W (longitude) points, L degrees x M orders (M <= W/2 + 1):
+ *   ppsci_sht_analysis : X [n, L, M] complex = sum_k leg[m][l][k] * (sum_j x[k][j] e^{-2 pi i j m / W})   RealSHT.forward, sht.py:118-150
+ *   ppsci_sht_synthesis: y [n, H, W] = sum_m Re( (sum_l leg[m][l][k] Z[l][m]) e^{+2 pi i j m / W} )      InverseRealSHT.forward, :216-232
+ * tw [W][M][2] = (cos, sin)(2 pi j m / W); leg [M][L][H] REAL -- quadrature weights and 2 pi / W for the forward transform, the
+ * Hermitian weights of irfft(n = W) for the inverse (paddlescience_amd/arch/sht_tables.py).  Each kernel on the OTHER transform's
+ * table is that transform's adjoint.  ppsci_sht_supported: the plane, its intermediate and the twiddles fit LDS.
+ * ppsci_sht_contract: the weights-per-degree contraction of SphericalConv (_contract_dense_trick(dhconv=True), sfnonet.py:45-74):
+ *   conj_t == 0: out [B, Co, L, M] = sum_i x[B, Ci, L, M] w[i, o, l];  conj_t != 0: out [B, Ci, L, M] = sum_o x[B, Co, L, M] conj(w[i, o, l]);
+ * ppsci_sht_contract_wgrad: gw[i, o, l] = sum_b sum_m conj(x[b, i, l, m]) g[b, o, l, m].  w_re / w_im [Ci, Co, L]. */
+int ppsci_sht_supported(int H, int W, int L, int M);
+int ppsci_sht_analysis(int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* x, float* X, void* stream);
+int ppsci_sht_synthesis(int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* Z, float* y, void* stream);
+int ppsci_sht_contract(int B, int Ci, int Co, int L, int M, const float* x, const float* w_re, const float* w_im, int conj_t,
+                       float* out, void* stream);
+int ppsci_sht_contract_wgrad(int B, int Ci, int Co, int L, int M, const float* x, const float* g, float* gw_re, float* gw_im,
+                             void* stream);
+
 /* ---- separable PINN (BASELINE config 5) --------------------------------------------------------------
  * Branch net = ppsci.arch.ModifiedMLP with ONE input (ppsci/arch/mlp.py:318-527) as SPINN builds it
  * (ppsci/arch/spinn.py:83-104).  Parameters flat in parameters() order: embed_u.W[1,H] embed_u.b embed_v.W

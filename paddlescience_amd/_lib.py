@@ -208,6 +208,11 @@ _SYMBOLS = {
     "ppsci_dft2_kept_from_supported": (C.c_int, [C.c_int] * 4),
     "ppsci_dft2_kept_fwd_from": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_dft2_kept_inv_from": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ppsci_sht_supported": (C.c_int, [C.c_int] * 4),
+    "ppsci_sht_analysis": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
+    "ppsci_sht_synthesis": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
+    "ppsci_sht_contract": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]),
+    "ppsci_sht_contract_wgrad": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
     "ppsci_spectrum_resize": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ppsci_resample2d_supported": (C.c_int, [C.c_int] * 4),
     "ppsci_resample2d": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]),

@@ -68,6 +68,23 @@ class SpectralConv2d(torch.nn.Module):
         self.bias = torch.nn.Parameter(std * torch.randn(out_channels, 1, 1)) if bias else None
 
 
+class SphericalConv2d(torch.nn.Module):
+    """Parameters of one layer of SphericalConv (/root/reference/ppsci/arch/sfnonet.py:183-360): complex weights PER DEGREE
+    `[Ci, Co, n_modes[0]]` (`weight_shape = (in, out, *n_modes[:-1])`, :268-276; the contraction runs with dhconv=True), bias
+    `[Co, 1, 1]`.  `n_modes` here = (degrees L, orders M) = (n_modes[0], n_modes[1] // 2), the `s=` of its sht call (:333-338)."""
+
+    def __init__(self, in_channels: int, out_channels: int, n_modes: Tuple[int, int], bias: bool = True,
+                 fft_norm: str = "backward", init_std: Optional[float] = None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.n_modes = (int(n_modes[0]), int(n_modes[1]) // 2)
+        std = (2 / (in_channels + out_channels)) ** 0.5 if init_std is None else init_std
+        shape = (in_channels, out_channels, self.n_modes[0])
+        self.weight_real = torch.nn.Parameter(torch.randn(shape) * std)
+        self.weight_imag = torch.nn.Parameter(torch.randn(shape) * std)
+        self.bias = torch.nn.Parameter(std * torch.randn(out_channels, 1, 1)) if bias else None
+
+
 class ChannelMLP(torch.nn.Module):
     """fno_block.MLP (fno_block.py:263-320): n_layers 1x1 convolutions with the non-linearity in between."""
 
@@ -89,8 +106,9 @@ class FNOBlocks(torch.nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, n_modes: Tuple[int, int], n_layers: int = 1,
                  non_linearity=gelu, stabilizer: Optional[str] = None, norm: Optional[str] = None,
-                 fno_skip: str = "linear", fft_norm: str = "forward"):
+                 fno_skip: str = "linear", fft_norm: str = "forward", conv_cls=None):
         super().__init__()
+        conv_cls = conv_cls or SpectralConv2d
         if in_channels != out_channels:
             raise NotImplementedError("FNOBlocks with in_channels != out_channels")
         if fno_skip not in ("linear", "identity"):
@@ -103,7 +121,7 @@ class FNOBlocks(torch.nn.Module):
             raise NotImplementedError("non_linearity: GELU is the activation fused into the kernels")
         self.n_layers, self.non_linearity, self.stabilizer = n_layers, non_linearity, stabilizer
         # FactorizedSpectralConv holds the weights of all layers; bias per layer (fno_block.py:652-663)
-        self.convs = torch.nn.ModuleList([SpectralConv2d(in_channels, out_channels, n_modes, bias=True, fft_norm=fft_norm)
+        self.convs = torch.nn.ModuleList([conv_cls(in_channels, out_channels, n_modes, bias=True, fft_norm=fft_norm)
                                           for _ in range(n_layers)])
         self.fno_skips = torch.nn.ModuleList([
             Conv1x1(in_channels, out_channels, bias=False) if fno_skip == "linear" else torch.nn.Identity()
@@ -120,6 +138,8 @@ class FNONet(base.Arch, torch.nn.Module):
     the data-parallel all-reduce and the fused Adam kernel act on a single tensor, as for the PINN path."""
 
     is_operator = True  # Solver: the operator engine (hand-written forward + backward, fno_engine.FnoNative)
+    _conv_cls = SpectralConv2d
+    spectral = "fft"  # the transform pair of the spectral branch: "fft" (rfftn / irfftn) or "sht" (SFNONet)
 
     def __init__(self, input_keys: Tuple[str, ...], output_keys: Tuple[str, ...], n_modes: Tuple[int, ...],
                  hidden_channels: int, in_channels: int = 3, out_channels: int = 1, lifting_channels: int = 256,
@@ -157,7 +177,7 @@ class FNONet(base.Arch, torch.nn.Module):
         self.n_modes, self.n_layers = tuple(n_modes), n_layers
         self.hidden_channels, self.in_channels, self.out_channels = hidden_channels, in_channels, out_channels
         self.fno_blocks = FNOBlocks(hidden_channels, hidden_channels, self.n_modes, n_layers, non_linearity, stabilizer,
-                                    norm, fno_skip, fft_norm)
+                                    norm, fno_skip, fft_norm, self._conv_cls)
         if lifting_channels:
             self.lifting = ChannelMLP(in_channels, hidden_channels, lifting_channels, 2)
         else:
@@ -265,6 +285,17 @@ class TFNO2dNet(FNONet):
                          factorization, rank, joint_factorization, implementation, domain_padding,
                          domain_padding_mode, fft_norm, patching_levels)
         self.n_modes_height, self.n_modes_width = n_modes_height, n_modes_width
+
+
+class SFNONet(FNONet):
+    """ppsci.arch.SFNONet (/root/reference/ppsci/arch/sfnonet.py:390-568): an FNONet -- same constructor, same lifting / blocks /
+    projection -- whose spectral convolution transforms with the spherical-harmonic pair of arch/paddle_harmonics (equiangular
+    colatitude grid, orthonormal harmonics: the defaults SphericalConv is built with, sfnonet.py:227-228) and holds its complex
+    weights per degree.  Input planes are [latitude (north to south), longitude]."""
+
+    _conv_cls = SphericalConv2d
+    spectral = "sht"
+    sht_grid, sht_norm = "equiangular", "ortho"
 
 
 class TFNO1dNet(FNONet):

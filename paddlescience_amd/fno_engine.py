@@ -160,14 +160,24 @@ class FnoNative:
         Wf = W // 2 + 1
         self.v = [torch.empty((B, Ch, P), **f) for _ in range(nl)]               # spectral outputs (irfftn results)
         mx, my = m.fno_blocks.convs[0].n_modes
+        # SFNONet: the spherical-harmonic pair instead of the FFT pair (csrc/sht.hip; tables per plane shape from arch/sht_tables.py)
+        self.sht = getattr(m, "spectral", "fft") == "sht"
+        if self.sht:
+            from .arch import sht_tables
+
+            if not L.lib().ppsci_sht_supported(H, W, mx, my):
+                raise NotImplementedError(f"SFNONet: a {H} x {W} plane with {mx} x {my} coefficients does not fit the transform kernels")
+            tw, ta, tb = sht_tables.tables(H, W, mx, my, m.sht_grid, m.sht_norm)
+            self.sht_tw, self.sht_a, self.sht_b = (torch.tensor(t, **f) for t in (tw, ta, tb))
         # the transforms on the kept modes only (two small DFTs per plane in LDS, spectra of mx x my numbers) when a plane
         # fits LDS; hipFFT on the full spectrum otherwise.  PPSCI_FNO_FULL_FFT=1 forces the library path (tests, timing)
-        self.kept = bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my)) and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1"
+        self.kept = (not self.sht and bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my))
+                     and os.environ.get("PPSCI_FNO_FULL_FFT", "0") != "1")
         # (the tanh stabilizer puts a pointwise function between a block's output and the next transform's input)
         self.fuse_dft = self.kept and m.fno_blocks.stabilizer != "tanh"
         # the forward contraction inside the inverse transform's launch (PPSCI_FNO_FUSE_CONTRACT=0: two launches; A/B, tests)
         self.fuse_contract = self.kept and os.environ.get("PPSCI_FNO_FUSE_CONTRACT", "1") != "0"
-        sp = (B, Ch, mx, my, 2) if self.kept else (B, Ch, H, Wf, 2)
+        sp = (B, Ch, mx, my, 2) if (self.kept or self.sht) else (B, Ch, H, Wf, 2)
         self.xft = [torch.empty(sp, **f) for _ in range(nl)]      # unscaled rfftn(x_l): kept for dL/dw
         self.out_ft = torch.empty(sp, **f)  # (full spectrum: cleared + kept modes written every time, C2R destroys it)
         self.gx_ft = torch.empty(sp, **f)
@@ -273,6 +283,12 @@ class FnoNative:
                     1 if nrm is not None else 0, H, W, mx, my,
                     _p(self.xft[l + 1]) if (self.fuse_dft and not last) else None, st))
                 continue
+            elif self.sht:  # sfnonet.py:333-354: sht -> weights per degree -> isht
+                mx, my = self.desc.modes_x, self.desc.modes_y
+                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a), _p(xl), _p(xft), st))
+                L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(xft), _p(conv.weight_real), _p(conv.weight_imag), 0,
+                                                   _p(self.out_ft), st))
+                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b), _p(self.out_ft), _p(v), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
@@ -460,6 +476,14 @@ class FnoNative:
                     continue
                 gx2_modes = None
                 L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 0, _p(self.gx_ft), _p(self.gsp), st))
+            elif self.sht:  # each transform's adjoint is the other kernel on its own table (csrc/sht.hip)
+                mx, my = self.desc.modes_x, self.desc.modes_y
+                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b), _p(self.gv), _p(self.ghat), st))
+                L.check(L.lib().ppsci_sht_contract_wgrad(B, Ch, Ch, mx, my, _p(self.xft[l]), _p(self.ghat), _p(conv.weight_real.grad),
+                                                         _p(conv.weight_imag.grad), st))
+                L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(self.ghat), _p(conv.weight_real), _p(conv.weight_imag), 1,
+                                                   _p(self.gx_ft), st))
+                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a), _p(self.gx_ft), _p(self.gsp), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(

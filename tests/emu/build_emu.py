@@ -10,7 +10,7 @@ EXTRA = os.environ.get("PPSCI_EMU_EXTRA_FLAGS", "").split()  # experiment builds
 OUT = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "_".join(f.lstrip("-D") for f in EXTRA) if EXTRA else ""))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["taylor_bwd_b_tanh.hip", "taylor_bwd_b_tanh_fourier.hip", "taylor_bwd_b_silu.hip", "taylor_bwd_b_sin.hip", "taylor_bwd_b_cos.hip", "taylor_bwd_b_sigmoid.hip", "taylor_bwd_b_gelu.hip", "taylor_bwd_b_relu.hip", "taylor_bwd_b_leaky_relu.hip", "taylor_bwd_b_elu.hip", "taylor_bwd_b_selu.hip", "taylor_bwd_b_identity.hip", "taylor_bwd_b_swish.hip", "taylor_bwd_b_stan.hip", "taylor_bwd_wx_tanh.hip", "taylor_bwd_wx_tanh_fourier.hip", "taylor_bwd_wx_silu.hip", "taylor_bwd_wx_sin.hip", "taylor_bwd_wx_cos.hip", "taylor_bwd_wx_sigmoid.hip", "taylor_bwd_wx_gelu.hip", "taylor_bwd_wx_relu.hip", "taylor_bwd_wx_leaky_relu.hip", "taylor_bwd_wx_elu.hip", "taylor_bwd_wx_selu.hip", "taylor_bwd_wx_identity.hip", "taylor_fwd_tanh.hip", "taylor_fwd_silu.hip", "taylor_fwd_sin.hip", "taylor_fwd_sigmoid.hip", "taylor_fwd_cos.hip", "taylor_fwd_gelu.hip", "taylor_fwd_swish.hip", "taylor_fwd_stan.hip", "taylor_bwd_swish.hip", "taylor_bwd_stan.hip", "taylor_fwd_tanh_fourier.hip", "taylor_bwd_tanh_fourier.hip", "reparam.hip", "taylor_bwd_tanh.hip",
-           "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_step_tanh.hip", "taylor_step_silu.hip", "taylor_step_sin.hip", "taylor_fused_tanh.hip", "taylor_fused_silu.hip", "taylor_fused_sin.hip", "taylor_fused_static_tanh.hip", "taylor_fused_static_silu.hip", "taylor_fused_static_sin.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "field_loss.hip", "fft.hip", "spinn.hip", "pirate.hip", "epilogue_optim.hip", "comm.hip", "coupling.hip", "uno.hip"]
+           "taylor_bwd_silu.hip", "taylor_bwd_sin.hip", "taylor_bwd_sigmoid.hip", "taylor_bwd_cos.hip", "taylor_bwd_gelu.hip", "taylor_fwd_relu.hip", "taylor_bwd_relu.hip", "taylor_fwd_leaky_relu.hip", "taylor_bwd_leaky_relu.hip", "taylor_fwd_elu.hip", "taylor_bwd_elu.hip", "taylor_fwd_selu.hip", "taylor_bwd_selu.hip", "taylor_fwd_identity.hip", "taylor_bwd_identity.hip", "taylor_step_tanh.hip", "taylor_step_silu.hip", "taylor_step_sin.hip", "taylor_fused_tanh.hip", "taylor_fused_silu.hip", "taylor_fused_sin.hip", "taylor_fused_static_tanh.hip", "taylor_fused_static_silu.hip", "taylor_fused_static_sin.hip", "taylor_api.hip", "wgrad_reduce.hip", "spectral_conv.hip", "fno.hip", "field_loss.hip", "fft.hip", "spinn.hip", "pirate.hip", "epilogue_optim.hip", "comm.hip", "coupling.hip", "uno.hip", "sht.hip"]
 # The four sources that carry 80 % of the suite's emulated time (PPSCI_EMU_PROFILE, hip_emu.h) are built -O1: 3x faster to run,
 # under a minute to compile next to the rest at -O0.
 HOT = {"taylor_fused_tanh.hip", "taylor_fwd_tanh.hip", "taylor_bwd_tanh.hip", "fno.hip"}

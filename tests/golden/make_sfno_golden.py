@@ -1,0 +1,147 @@
+"""Generates tests/golden/sfno.npz by executing the REFERENCE's own SFNO code (/root/reference/ppsci/arch/sfnonet.py: SphericalConv,
+SHT wrapper, SFNONet; arch/paddle_harmonics/{sht,legendre,quadrature}.py: RealSHT / InverseRealSHT with their tables; fno_block.py:
+FNOBlocks, MLP, skip) in this container, PaddlePaddle replaced by the torch-backed shim of make_fno_golden.py, in float64.
+
+    python tests/golden/make_sfno_golden.py
+
+Per case: explicit parameters (under the names of paddlescience_amd.arch.fno.SFNONet), the input batch, the network output and
+d(mean squared output error)/d(parameters) through the reference's graph; plus, per grid, the transform pair itself on a random plane
+(`sht/<nlat>x<nlon>_<L>x<M>/...`: x, RealSHT(x), InverseRealSHT(coefficients))."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _paddle_shim as S  # noqa: E402
+import make_fno_golden as G  # noqa: E402
+from sfno_cases import CASES  # noqa: E402
+
+D = torch.float64
+
+
+def install():
+    fno_block, _ = G.install_fno_shim()
+    paddle = sys.modules["paddle"]
+    nn = sys.modules["paddle.nn"]
+    np.math = __import__("math")  # (legendre.py:41 uses np.math.factorial in a helper)
+
+    class LayerDict(S.Layer):
+        def __init__(self, d=None):
+            super().__init__()
+            self._d = {}
+
+        def __setitem__(self, k, v):
+            self._d[k] = v
+            self._subs[k] = v
+
+        def __getitem__(self, k):
+            return self._d[k]
+
+    nn.LayerDict = LayerDict
+    fft = sys.modules["paddle.fft"]
+    fft.rfft = lambda x, n=None, axis=-1, norm="backward": torch.fft.rfft(x, n=n, dim=axis, norm=norm)
+    fft.irfft = lambda x, n=None, axis=-1, norm="backward": torch.fft.irfft(x, n=n, dim=axis, norm=norm)
+    paddle.as_real = torch.view_as_real
+    paddle.as_complex = lambda x: torch.view_as_complex(x.contiguous())
+    paddle.stack = lambda xs, axis=0: torch.stack(list(xs), dim=axis)
+    paddle.to_tensor = lambda v, dtype=None, **k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v, dtype=D if not (
+        isinstance(v, torch.Tensor) and v.is_complex()) else None)
+    paddle.float32 = D
+    torch.Tensor.astype = lambda self, dtype=None: self
+    S.Layer.astype = lambda self, dtype=None: self
+    sys.modules["omegaconf"].listconfig = types.SimpleNamespace(ListConfig=list)
+    sfnonet = importlib.import_module("ppsci.arch.sfnonet")
+    sht = importlib.import_module("ppsci.arch.paddle_harmonics.sht")
+    return fno_block, sfnonet, sht
+
+
+def shapes_of(c):
+    hid, L = c["hidden"], c["modes"][0]
+    out = c.get("out", 1)
+    sh = {"lifting.fcs.0.weight": (c["lift"], 3, 1, 1), "lifting.fcs.0.bias": (c["lift"],),
+          "lifting.fcs.1.weight": (hid, c["lift"], 1, 1), "lifting.fcs.1.bias": (hid,),
+          "projection.fcs.0.weight": (c["proj"], hid, 1, 1), "projection.fcs.0.bias": (c["proj"],),
+          "projection.fcs.1.weight": (out, c["proj"], 1, 1), "projection.fcs.1.bias": (out,)}
+    for i in range(c["layers"]):
+        sh[f"fno_blocks.convs.{i}.weight_real"] = (hid, hid, L)
+        sh[f"fno_blocks.convs.{i}.weight_imag"] = (hid, hid, L)
+        sh[f"fno_blocks.convs.{i}.bias"] = (hid, 1, 1)
+        sh[f"fno_blocks.fno_skips.{i}.weight"] = (hid, hid, 1, 1)
+        if c["norm"]:
+            sh[f"fno_blocks.norm.{i}.weight"] = (hid,)
+            sh[f"fno_blocks.norm.{i}.bias"] = (hid,)
+    return sh
+
+
+def main():
+    fno_block, sfnonet, sht = install()
+    out = {}
+    for cname, c in CASES.items():
+        rng = np.random.default_rng(len(cname) * 733)
+        nout = c.get("out", 1)
+        model = sfnonet.SFNONet(("x",), ("y",), c["modes"], c["hidden"], in_channels=3, out_channels=nout, lifting_channels=c["lift"],
+                                projection_channels=c["proj"], n_layers=c["layers"], norm=c["norm"])
+        shapes = shapes_of(c)
+        P = {}
+        for k, sh in shapes.items():
+            fan = max(1, int(np.prod(sh[1:])) if len(sh) > 1 else 1)
+            scale = 0.5 if k.endswith("bias") else (1.0 / np.sqrt(fan) if "weight_" not in k else (2.0 / (sh[0] + sh[1])) ** 0.5)
+            v = rng.standard_normal(sh) * scale
+            if ".norm." in k and k.endswith("weight"):
+                v = 1.0 + 0.2 * rng.standard_normal(sh)
+            P[k] = torch.tensor(v.astype(np.float32).astype(np.float64))
+        blocks = model.fno_blocks
+        leaves = {}
+        for name, mlp in (("lifting", model.lifting), ("projection", model.projection)):
+            for i, fc in enumerate(mlp.fcs):
+                leaves[f"{name}.fcs.{i}.weight"], leaves[f"{name}.fcs.{i}.bias"] = fc.weight, fc.bias
+        for i in range(c["layers"]):
+            leaves[f"fno_blocks.convs.{i}.weight_real"] = blocks.convs.weight[i].real
+            leaves[f"fno_blocks.convs.{i}.weight_imag"] = blocks.convs.weight[i].imag
+            leaves[f"fno_blocks.fno_skips.{i}.weight"] = blocks.fno_skips[i].weight
+            if c["norm"]:
+                leaves[f"fno_blocks.norm.{i}.weight"], leaves[f"fno_blocks.norm.{i}.bias"] = blocks.norm[i].weight, blocks.norm[i].bias
+        with torch.no_grad():
+            for k, leaf in leaves.items():
+                leaf.copy_(P[k])
+            for i in range(c["layers"]):
+                blocks.convs.bias[i].copy_(P[f"fno_blocks.convs.{i}.bias"])
+        B, H, W = c["B"], c["H"], c["W"]
+        x = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32).astype(np.float64))
+        tgt = torch.tensor(rng.standard_normal((B, nout, H, W)).astype(np.float32).astype(np.float64))
+        y = model({"x": x})["y"]
+        loss = ((y - tgt) ** 2).mean()
+        names = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[k] for k in names] + [blocks.convs.bias])
+        for k, g in zip(names, grads[:-1]):
+            out[f"{cname}/grad/{k}"] = g.numpy()
+        for i in range(c["layers"]):
+            out[f"{cname}/grad/fno_blocks.convs.{i}.bias"] = grads[-1][i].numpy()
+        for k, v in P.items():
+            out[f"{cname}/param/{k}"] = v.numpy()
+        out[f"{cname}/x"], out[f"{cname}/target"], out[f"{cname}/y"] = x.numpy(), tgt.numpy(), y.detach().numpy()
+        out[f"{cname}/loss"] = np.asarray(float(loss.detach()))
+        print(cname, "y", tuple(y.shape), "loss", float(loss.detach()))
+    # the transform pair by itself
+    for (H, W, L, M) in ((8, 16, 8, 4), (9, 14, 9, 6), (32, 64, 32, 16)):
+        rng = np.random.default_rng(H * W)
+        fwd = sht.RealSHT(nlat=H, nlon=W, lmax=L, mmax=M, grid="equiangular", norm="ortho")
+        inv = sht.InverseRealSHT(nlat=H, nlon=W, lmax=L, mmax=M, grid="equiangular", norm="ortho")
+        x = torch.tensor(rng.standard_normal((2, H, W)))
+        X = fwd(x)
+        Z = torch.complex(torch.tensor(rng.standard_normal((2, L, M))), torch.tensor(rng.standard_normal((2, L, M))))
+        key = f"sht/{H}x{W}_{L}x{M}"
+        out[f"{key}/x"], out[f"{key}/X"] = x.numpy(), torch.view_as_real(X).numpy()
+        out[f"{key}/Z"], out[f"{key}/y"] = torch.view_as_real(Z).numpy(), inv(Z).numpy()
+        print(key, "X", tuple(X.shape))
+    np.savez_compressed(os.path.join(HERE, "sfno.npz"), **out)
+    print("wrote", os.path.join(HERE, "sfno.npz"), len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -274,6 +274,38 @@ def test_uno_reference_config_full_size(dev, res, full_fft, monkeypatch):
         assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 5e-5, n
 
 
+@pytest.mark.parametrize("res", [(32, 64), (64, 128)])
+def test_sfno_reference_config_full_size(dev, res):
+    """The reference's SFNO configuration (conf/sfno_swe_pretrain.yaml: in 3, out 3, hidden 32, projection 64, 4 layers, n_modes
+    (32, 32) = 32 degrees x 16 orders, GroupNorm, batch 4) at its training grid 32 x 64 and its second evaluation grid 64 x 128, against
+    the fp64 oracle (oracle/ref_torch.sfno_forward, pinned by the reference-run tests/golden/sfno.npz): output, loss, every gradient."""
+    if dev != "gpu":
+        pytest.skip("full sizes run on the GPU only")
+    import ppsci
+    from oracle import ref_torch as R
+
+    torch.manual_seed(0)
+    model = ppsci.arch.SFNONet(("x",), ("y",), (32, 32), 32, in_channels=3, out_channels=3, lifting_channels=256, projection_channels=64,
+                               n_layers=4, norm="group_norm")
+    B = 4
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3) + res).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 3) + res).astype(np.float32)).cuda()
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = R.sfno_forward(x.cpu().double(), P, 4, (32, 32), "group_norm")
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    yh = nat.forward(x)
+    losses, gy = ppsci.loss.MSELoss("mean").value_and_grad(yh, y, "y")
+    assert K._rel(yh.cpu().numpy(), yo.detach().numpy()) < 5e-6
+    assert abs(float(losses["y"]) / float(lo) - 1.0) < 1e-5
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    for n, p in torch.nn.Module.named_parameters(model):
+        assert K._rel(p.grad.cpu().numpy(), go[n].numpy()) < 5e-5, n
+
+
 @pytest.mark.parametrize("padding,full_fft", [(0.078125, False), (0.078125, True), (0.1, False)])
 def test_tfno_64x64_with_the_yaml_domain_padding(dev, padding, full_fft, monkeypatch):
     """The padding the reference's TFNO yaml names (0.078125: 64 -> 69 x 69 planes, odd: element accesses, the double
