@@ -583,6 +583,59 @@ def extra_uno(steps, warmup, B=16, R=16):
             "native_forward_backward": type(eng.native).__name__, "parity": parity}
 
 
+def extra_sfno(steps, warmup, B=4, H=32, W=64):
+    """The reference's SFNO configuration (examples/neuraloperator/conf/sfno_swe_pretrain.yaml: in 3, out 3, hidden 32, lifting 256,
+    projection 64, 4 layers, n_modes (32, 32) = 32 degrees x 16 orders, group_norm, batch 4 on the 32 x 64 grid); one training step =
+    forward + MSE + backward + fused Adam (fno_engine.FnoNative with the transform pair of csrc/sht.hip)."""
+    import ppsci
+
+    torch.manual_seed(0)
+    model = ppsci.arch.SFNONet(("x",), ("y",), (32, 32), 32, in_channels=3, out_channels=3, lifting_channels=256,
+                               projection_channels=64, n_layers=4, norm="group_norm")
+    x = torch.as_tensor(np.random.default_rng(42).standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+    y = torch.as_tensor(np.random.default_rng(43).standard_normal((B, 3, H, W)).astype(np.float32)).cuda()
+    opt = ppsci.optimizer.Adam(1e-3)(model)
+    # parity (checker: the oracle's fp64 restatement of sfnonet.py / paddle_harmonics, pinned by the reference-run tests/golden/sfno.npz)
+    from oracle import ref_torch as Rf
+
+    P = {n: p.detach().cpu().double().requires_grad_(True) for n, p in torch.nn.Module.named_parameters(model)}
+    yo = Rf.sfno_forward(x.cpu().double(), P, 4, (32, 32), "group_norm")
+    lo = ((yo - y.cpu().double()) ** 2).mean()
+    names = sorted(P)
+    go = dict(zip(names, torch.autograd.grad(lo, [P[n] for n in names])))
+    nat = model.native()
+    mse_loss = ppsci.loss.MSELoss("mean")
+    yh = nat.forward(x.contiguous())
+    lh, gy = mse_loss.value_and_grad(yh, y, "y")
+    yh = yh.clone()
+    model.flat_grad.fill_(float("nan"))
+    nat.backward(gy)
+    gh = {n: p.grad.detach().cpu().numpy().copy() for n, p in torch.nn.Module.named_parameters(model)}
+    model.flat_grad.zero_()
+    parity = {"checker": "oracle/ref_torch.sfno_forward fp64 (pinned by reference-run tests/golden/sfno.npz), the whole timed batch, "
+                         "the timed model's weights",
+              "output_rel_l2": rel(yh.detach().cpu().numpy(), yo.detach().numpy()),
+              "grad_rel_l2": max(rel(gh[n], go[n].numpy()) for n in names),
+              "loss_rel": abs(float(lh["y"].detach()) / float(lo.detach()) - 1.0)}
+    from paddlescience_amd.engine import step_with_adam
+    from paddlescience_amd.operator_engine import OperatorConstraint, OperatorEngine
+
+    cst = OperatorConstraint("Sup", model, {"y": lambda d: d["y"]}, mse_loss, x.device, ["y"], B)
+    cst.bind({"x": x}, {"y": y})
+    eng = OperatorEngine(model)
+
+    def step():
+        step_with_adam(eng, [cst], opt, model.flat_params)
+
+    t = time_wall(step, steps, warmup)
+    t_ev = time_events(step, reps=steps)
+    return {"config": "extra: SFNO shallow-water shape (reference config): 32x64 lat-lon grid, batch 4, in 3, out 3, hidden 32, lifting "
+                      "256, projection 64, 4 layers, 32 degrees x 16 orders, group_norm; forward + MSE + backward + Adam",
+            "value": B * H * W / t, "unit": "grid-points/s", "samples_per_s": B / t, "ms_per_step": t * 1e3, "steps": steps,
+            "ms_per_step_hip_events": t_ev * 1e3, "params": int(model.flat_params.numel()), "roofline": step_hbm_roofline("sfno", t),
+            "native_forward_backward": type(eng.native).__name__, "parity": parity}
+
+
 def secondary_tfno(steps, warmup, B=16, H=64, W=64):
     """BASELINE configs[3] / SURVEY 8(d): TFNO2dNet in 3, hidden 32, lifting 256, projection 64, 4 layers, n_modes
     (12, 12), group_norm, fft_norm forward; one training step = forward + MSE + backward + fused Adam."""
@@ -1092,7 +1145,7 @@ def main():
             k, w = max(10, args.steps // 2), max(3, args.warmup // 2)
             sec = []
             for fn in (lambda: secondary_laplace(tmp, 4 * k, w, not args.no_cpu_baseline),
-                       lambda: secondary_ns(tmp, k, w), lambda: secondary_ac256(tmp, k, w), lambda: secondary_tfno(k, w), lambda: extra_uno(k, w),
+                       lambda: secondary_ns(tmp, k, w), lambda: secondary_ac256(tmp, k, w), lambda: secondary_tfno(k, w), lambda: extra_uno(k, w), lambda: extra_sfno(k, w),
                        lambda: secondary_spinn(tmp, k, w),
                        lambda: extra_piratenet(tmp, k, w), lambda: extra_cylinder2d(tmp, k, w),
                        lambda: extra_euler_beam(tmp)):

@@ -2,10 +2,11 @@ import copy
 
 from .array_dataset import ContinuousNamedArrayDataset, IterableNamedArrayDataset, NamedArrayDataset  # noqa: F401
 from .darcyflow_dataset import DarcyFlowDataset  # noqa: F401
+from .spherical_swe_dataset import SphericalSWEDataset  # noqa: F401
 from .file_dataset import (CSVDataset, IterableCSVDataset, IterableMatDataset, IterableNPZDataset, MatDataset,  # noqa: F401
                            NPZDataset)
 
-__all__ = ["NamedArrayDataset", "IterableNamedArrayDataset", "ContinuousNamedArrayDataset", "DarcyFlowDataset", "CSVDataset",
+__all__ = ["NamedArrayDataset", "IterableNamedArrayDataset", "ContinuousNamedArrayDataset", "DarcyFlowDataset", "SphericalSWEDataset", "CSVDataset",
            "IterableCSVDataset", "MatDataset", "IterableMatDataset", "NPZDataset", "IterableNPZDataset", "build_dataset"]
 
 

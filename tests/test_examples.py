@@ -22,6 +22,8 @@ TINY = {
                              "resample_every=1"],
     "tfno_darcyflow.py": ["epochs=1", "n_train=4", "n_test=2", "batch_size=2", "n_modes=4", "hidden_channels=8", "lifting_channels=8",
                           "projection_channels=8", "n_layers=1", "log_freq=1"],
+    "sfno_swe.py": ["epochs=1", "n_train=4", "n_test=2", "batch_size=2", "n_modes=8", "hidden_channels=6", "lifting_channels=8",
+                    "projection_channels=8", "n_layers=2", "log_freq=1"],
     "uno_darcyflow.py": ["epochs=1", "n_train=4", "n_test=2", "batch_size=2", "width=0.125", "modes=0.5", "lifting_channels=8",
                          "projection_channels=8", "log_freq=1"],
     "ldc_2d_sota.py": ["epochs=1,1", "Re=100,400", "iters_per_epoch=1", "hidden_size=16", "num_layers=2", "fourier_dim=8", "batch_pde=32",
@@ -37,7 +39,7 @@ def test_example_runs(script, tmp_path, monkeypatch):
     build_emu.inject()
     device.set_device("cpu")
     args = TINY[script] + [f"output_dir={tmp_path}/out"]
-    if script in ("cylinder2d_unsteady.py", "tfno_darcyflow.py", "uno_darcyflow.py"):
+    if script in ("cylinder2d_unsteady.py", "tfno_darcyflow.py", "uno_darcyflow.py", "sfno_swe.py"):
         args.append(f"data_dir={tmp_path}/data")
     monkeypatch.setattr(sys, "argv", [script] + args)
     try:
