@@ -624,7 +624,8 @@ int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* 
  * The spherical-harmonic transform pair on n planes of H (colatitude) x W (longitude) points, L degrees x M orders (M <= W/2 + 1):
  *   ppsci_sht_analysis : X [n, L, M] complex = sum_k leg[m][l][k] * (sum_j x[k][j] e^{-2 pi i j m / W})   RealSHT.forward, sht.py:118-150
  *   ppsci_sht_synthesis: y [n, H, W] = sum_m Re( (sum_l leg[m][l][k] Z[l][m]) e^{+2 pi i j m / W} )      InverseRealSHT.forward, :216-232
- * tw [W][M][2] = (cos, sin)(2 pi j m / W); leg [M][L][H] REAL -- quadrature weights and 2 pi / W for the forward transform, the
+ * tw [W][M][2] = (cos, sin)(2 pi j m / W); leg REAL, element (order m, degree l, latitude k) stored [H][L][M] for the analysis kernel
+ * and [L][H][M] for the synthesis kernel (consecutive threads read consecutive addresses) -- quadrature weights and 2 pi / W for the forward transform, the
  * Hermitian weights of irfft(n = W) for the inverse (paddlescience_amd/arch/sht_tables.py).  Each kernel on the OTHER transform's
  * table is that transform's adjoint.  ppsci_sht_supported: the plane, its intermediate and the twiddles fit LDS.
  * ppsci_sht_contract: the weights-per-degree contraction of SphericalConv (_contract_dense_trick(dhconv=True), sfnonet.py:45-74):

@@ -79,3 +79,9 @@ def tables(nlat: int, nlon: int, lmax: int, mmax: int, grid: str = "equiangular"
     ang = 2.0 * np.pi * ((j * m) % nlon) / nlon
     tw = np.stack([np.cos(ang), np.sin(ang)], axis=-1)
     return tw, A, B
+
+
+def kernel_layouts(T: np.ndarray):
+    """A table [m][l][k] in the two storage orders of csrc/sht.hip: ([k][l][m] for the analysis kernel, [l][k][m] for the synthesis
+    kernel) -- the threads of a wave then read consecutive addresses."""
+    return np.ascontiguousarray(T.transpose(2, 1, 0)), np.ascontiguousarray(T.transpose(1, 2, 0))

@@ -168,7 +168,10 @@ class FnoNative:
             if not L.lib().ppsci_sht_supported(H, W, mx, my):
                 raise NotImplementedError(f"SFNONet: a {H} x {W} plane with {mx} x {my} coefficients does not fit the transform kernels")
             tw, ta, tb = sht_tables.tables(H, W, mx, my, m.sht_grid, m.sht_norm)
-            self.sht_tw, self.sht_a, self.sht_b = (torch.tensor(t, **f) for t in (tw, ta, tb))
+            self.sht_tw = torch.tensor(tw, **f)
+            # (each table in the storage order of the kernel that reads it: forward AND as the other transform's adjoint)
+            (self.sht_a_an, self.sht_a_sy), (self.sht_b_an, self.sht_b_sy) = (
+                tuple(torch.tensor(t, **f) for t in sht_tables.kernel_layouts(T)) for T in (ta, tb))
         # the transforms on the kept modes only (two small DFTs per plane in LDS, spectra of mx x my numbers) when a plane
         # fits LDS; hipFFT on the full spectrum otherwise.  PPSCI_FNO_FULL_FFT=1 forces the library path (tests, timing)
         self.kept = (not self.sht and bool(L.lib().ppsci_dft2_kept_supported(H, W, mx, my))
@@ -285,10 +288,10 @@ class FnoNative:
                 continue
             elif self.sht:  # sfnonet.py:333-354: sht -> weights per degree -> isht
                 mx, my = self.desc.modes_x, self.desc.modes_y
-                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a), _p(xl), _p(xft), st))
+                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_an), _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(xft), _p(conv.weight_real), _p(conv.weight_imag), 0,
                                                    _p(self.out_ft), st))
-                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b), _p(self.out_ft), _p(v), st))
+                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_sy), _p(self.out_ft), _p(v), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
@@ -478,12 +481,12 @@ class FnoNative:
                 L.check(L.lib().ppsci_dft2_kept_inv(B * Ch, H, W, mx, my, 0, _p(self.gx_ft), _p(self.gsp), st))
             elif self.sht:  # each transform's adjoint is the other kernel on its own table (csrc/sht.hip)
                 mx, my = self.desc.modes_x, self.desc.modes_y
-                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b), _p(self.gv), _p(self.ghat), st))
+                L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_an), _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_sht_contract_wgrad(B, Ch, Ch, mx, my, _p(self.xft[l]), _p(self.ghat), _p(conv.weight_real.grad),
                                                          _p(conv.weight_imag.grad), st))
                 L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(self.ghat), _p(conv.weight_real), _p(conv.weight_imag), 1,
                                                    _p(self.gx_ft), st))
-                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a), _p(self.gx_ft), _p(self.gsp), st))
+                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_sy), _p(self.gx_ft), _p(self.gsp), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(
