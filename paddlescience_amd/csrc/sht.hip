@@ -27,6 +27,8 @@
 
 extern "C" void ppsci_set_error(const char* fmt, ...);
 
+#define SHT_BATCH 16
+
 struct ShtArgs {
   const float* src;
   float* dst;
@@ -71,10 +73,16 @@ __global__ void __launch_bounds__(256) sht_analysis_kernel(ShtArgs a) {
       const float* lg = a.leg + i;  // [k][l][m]: element (k, l, m) at k * L * M + i
       const int lm = a.L * a.M;
       float re = 0.f, im = 0.f;
-      for (int k = 0; k < a.H; ++k) {
-        const float w = lg[(long long)k * lm];
-        re += w * T[2 * (k * a.M + m)];
-        im += w * T[2 * (k * a.M + m) + 1];
+      for (int k0 = 0; k0 < a.H; k0 += SHT_BATCH) {  // SHT_BATCH table loads in flight (one per iteration: an L2 round trip each)
+        float w[SHT_BATCH];
+#pragma unroll
+        for (int u = 0; u < SHT_BATCH; ++u) w[u] = k0 + u < a.H ? lg[(long long)(k0 + u) * lm] : 0.f;
+#pragma unroll
+        for (int u = 0; u < SHT_BATCH; ++u) {
+          const int k = k0 + u < a.H ? k0 + u : 0;  // (w = 0 behind the end)
+          re += w[u] * T[2 * (k * a.M + m)];
+          im += w[u] * T[2 * (k * a.M + m) + 1];
+        }
       }
       X[2 * i] = re;
       X[2 * i + 1] = im;
@@ -99,10 +107,16 @@ __global__ void __launch_bounds__(256) sht_synthesis_kernel(ShtArgs a) {
       const float* lg = a.leg + i;  // [l][k][m]: element (l, k, m) at l * H * M + i
       const int hm = a.H * a.M;
       float re = 0.f, im = 0.f;
-      for (int l = 0; l < a.L; ++l) {
-        const float w = lg[(long long)l * hm];
-        re += w * Z[2 * (l * a.M + m)];
-        im += w * Z[2 * (l * a.M + m) + 1];
+      for (int l0 = 0; l0 < a.L; l0 += SHT_BATCH) {
+        float w[SHT_BATCH];
+#pragma unroll
+        for (int u = 0; u < SHT_BATCH; ++u) w[u] = l0 + u < a.L ? lg[(long long)(l0 + u) * hm] : 0.f;
+#pragma unroll
+        for (int u = 0; u < SHT_BATCH; ++u) {
+          const int l = l0 + u < a.L ? l0 + u : 0;
+          re += w[u] * Z[2 * (l * a.M + m)];
+          im += w[u] * Z[2 * (l * a.M + m) + 1];
+        }
       }
       T[2 * i] = re;
       T[2 * i + 1] = im;
