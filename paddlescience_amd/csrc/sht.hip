@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(256) sht_analysis_kernel(ShtArgs a) {
       const int k = i / a.M, m = i - k * a.M;
       const float* row = pl + k * a.W;
       float re = 0.f, im = 0.f;
+#pragma unroll 8
       for (int j = 0; j < a.W; ++j) {
         const float v = row[j];
         re += v * tw[2 * (j * a.M + m)];
@@ -123,13 +124,33 @@ __global__ void __launch_bounds__(256) sht_synthesis_kernel(ShtArgs a) {
     }
     __syncthreads();
     float* y = a.dst + (long long)p * a.H * a.W;
-    for (int i = tid; i < a.H * a.W; i += 256) {
-      const int k = i / a.W, j = i - k * a.W;
-      const float* t = T + 2 * k * a.M;
-      const float* e = tw + 2 * j * a.M;
-      float s = 0.f;
-      for (int m = 0; m < a.M; ++m) s += t[2 * m] * e[2 * m] - t[2 * m + 1] * e[2 * m + 1];
-      y[i] = s;
+    if (256 % a.W == 0 && a.M <= 16) {
+      // every output of this thread has the same longitude j = tid % W: its twiddles stay in registers, the T row of a latitude is
+      // read by all lanes of that latitude at one address (LDS broadcast)
+      const int j = tid % a.W;
+      float ec[16], es[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        ec[m] = m < a.M ? tw[2 * (j * a.M + m)] : 0.f;
+        es[m] = m < a.M ? tw[2 * (j * a.M + m) + 1] : 0.f;
+      }
+      for (int i = tid; i < a.H * a.W; i += 256) {
+        const float* t = T + 2 * (i / a.W) * a.M;
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+          if (m < a.M) s += t[2 * m] * ec[m] - t[2 * m + 1] * es[m];
+        y[i] = s;
+      }
+    } else {
+      for (int i = tid; i < a.H * a.W; i += 256) {
+        const int k = i / a.W, j = i - k * a.W;
+        const float* t = T + 2 * k * a.M;
+        const float* e = tw + 2 * j * a.M;
+        float s = 0.f;
+        for (int m = 0; m < a.M; ++m) s += t[2 * m] * e[2 * m] - t[2 * m + 1] * e[2 * m + 1];
+        y[i] = s;
+      }
     }
   }
 }
@@ -192,6 +213,7 @@ __global__ void __launch_bounds__(256) sht_contract_kernel(ShtConArgs a) {
   const int Cp = a.conj_t ? a.Ci : a.Co, Cs = a.conj_t ? a.Co : a.Ci;
   const int c = (int)(bc % Cp), b = (int)(bc / Cp);
   float sr = 0.f, si = 0.f;
+#pragma unroll 8
   for (int s = 0; s < Cs; ++s) {
     const float* xp = a.x + (((long long)b * Cs + s) * lm + pos) * 2;
     const long long wi_ = (a.conj_t ? (long long)c * a.Co + s : (long long)s * a.Co + c) * a.L + l;
@@ -224,6 +246,7 @@ __global__ void __launch_bounds__(256) sht_wgrad_kernel(ShtWArgs a) {
   for (int b = 0; b < a.B; ++b) {
     const float* xp = a.x + (((long long)b * a.Ci + i) * lm + (long long)l * a.M) * 2;
     const float* gp = a.g + (((long long)b * a.Co + o) * lm + (long long)l * a.M) * 2;
+#pragma unroll 8
     for (int m = 0; m < a.M; ++m) {
       const float xr = xp[2 * m], xi = xp[2 * m + 1], gr = gp[2 * m], gi = gp[2 * m + 1];
       sr += xr * gr + xi * gi;
