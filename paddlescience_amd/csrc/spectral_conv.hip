@@ -106,6 +106,7 @@ __device__ __forceinline__ void spec_wgrad_body(const SpecWArgs& a, long long t)
   const long long pix_x = a.compact ? (long long)mode * 2 : ((long long)spec_row_in(a.d, a.c0, mx) * a.d.wf + my) * 2;
   const long long pix_g = a.compact ? (long long)mode * 2 : ((long long)spec_row_out(a.d, a.c0, mx) * a.d.wf + my) * 2;
   float sr = 0.f, si = 0.f;
+#pragma unroll 8
   for (int b = 0; b < a.d.batch; ++b) {
     const float* xp = a.x + ((long long)b * a.d.c_in + i) * plane + pix_x;
     const float* gp = a.g + ((long long)b * a.d.c_out + o) * plane + pix_g;

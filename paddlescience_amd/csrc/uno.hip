@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) resample2d_kernel(ResampleArgs a) {
       const int o = i / a.W, w = i - o * a.W;
       const float* ar = a.Ah + (long long)o * a.H;
       float s = 0.f;
+#pragma unroll 8
       for (int h = 0; h < a.H; ++h) s += ar[h] * X[h * a.W + w];
       T[i] = s;
     }
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__(256) resample2d_kernel(ResampleArgs a) {
       const float* ar = a.Aw + (long long)q * a.W;
       const float* tr = T + o * a.W;
       float s = 0.f;
+#pragma unroll 8
       for (int w = 0; w < a.W; ++w) s += tr[w] * ar[w];
       yp[i] = a.accumulate ? yp[i] + s : s;
     }
