@@ -556,12 +556,14 @@ int ppsci_pw_conv_wgrad_v(int B, int Ci, int Co, int P, const float* x, const pp
 int ppsci_fno_proj_hidden_grad(int B, int C, int m, int P, const float* z2, const float* W2, const float* gy, float* out, void* stream);
 /* Weight + bias gradient of the FIRST convolution of the lifting MLP (x0 [B, K0, P] -> C1 channels -> GELU -> W1 [Ch, C1] -> the
  * blocks' input) from gx (+ gx2 when not NULL) = dL/d(lifting output) [B, Ch, P], without the hidden gradient GELU'(W0 x0 + b0) * (W1^T gx) in memory:
- * partial rows in the layout of ppsci_pw_conv_wgrad (ppsci_pw_conv_wgrad_chunks(B, P) rows; row = [C1 * K0] weights, then -- at
+ * partial rows in the layout of ppsci_pw_conv_wgrad (ppsci_fno_lift0_wgrad_chunks(B, P) rows; row = [C1 * K0] weights, then -- at
  * partials_b -- [C1] biases; ld_partials as there), summed by ppsci_reduce_rows.  K0 <= 4, Ch a multiple of 4, <= 64; otherwise
  * PPSCI_E_UNSUPPORTED (the caller keeps ppsci_pw_conv_v + ppsci_pw_conv_wgrad_v).  partials1 (or NULL; Ch <= 32): the SECOND
  * convolution's gradient from the same pass -- rows of [Ch * C1] weights + [Ch] biases, ld_partials1 floats apart -- i.e.
  * sum_p GELU(W0 x0 + b0)[c][p] gx[k][p] and sum_p gx[k][p] (instead of ppsci_pw_conv_wgrad_v with the virtual operand).  Reference: the backward of
  * /root/reference/ppsci/arch/fno_block.py MLP (lifting) under paddle autograd. */
+/* rows of `partials` / `partials1` that ppsci_fno_lift0_wgrad writes (its own pixel chunking, not ppsci_pw_conv_wgrad_chunks) */
+int64_t ppsci_fno_lift0_wgrad_chunks(int B, int P);
 int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0, const float* W1,
                           const float* gx, const float* gx2, float* partials, float* partials_b, int64_t ld_partials,
                           float* partials1, int64_t ld_partials1, void* stream);

@@ -202,6 +202,7 @@ _SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "ppsci_set_pw_pixels_per_lane": (None, [C.c_int]),
     "ppsci_pw_conv_wgrad_chunks": (C.c_int64, [C.c_int, C.c_int]),
+    "ppsci_fno_lift0_wgrad_chunks": (C.c_int64, [C.c_int, C.c_int]),
     "ppsci_pw_conv_wgrad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "ppsci_pad2d": (C.c_int, [C.c_int] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1584,6 +1584,22 @@ __global__ void __launch_bounds__(64 * LIFT0_WAVES) lift0_wgrad_kernel(Lift0Args
   }
 }
 
+// Pixels of one sample per workgroup.  A workgroup walks its chunk two 16-pixel tiles at a time (a chain of MFMA + pointwise + MFMA
+// per pair), so the launch takes as long as ONE chunk however many there are: 45 us with 256-pixel chunks for 65 536 pixels (256
+// workgroups) and 41 us for 8 192 pixels (32 workgroups, an eighth of the chip).  Small problems therefore take shorter chunks -- the
+// largest of 256 / 128 / 64 pixels that still gives 128 workgroups, 64 otherwise -- at the price of more partial rows for the one
+// reduction launch at the end of the backward pass; at 256 workgroups and more the 256-pixel chunk stays (measured on MI355X:
+// 128-pixel chunks at the TFNO shape 0.539 vs 0.533 ms per step, at the SFNO shape 0.522 vs 0.536).
+static int lift0_cpix(int B, int P) {
+  for (int c = 256; c > 64; c >>= 1)
+    if (P >= c && (long long)B * ((P + c - 1) / c) >= 128) return c;
+  return P >= 64 ? 64 : P;
+}
+extern "C" int64_t ppsci_fno_lift0_wgrad_chunks(int B, int P) {
+  const int cpix = lift0_cpix(B, P);
+  return (int64_t)B * ((P + cpix - 1) / cpix);
+}
+
 extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const float* x0, const float* W0, const float* b0,
                                      const float* W1, const float* gx, const float* gx2, float* partials, float* partials_b,
                                      int64_t ld_partials, float* partials1, int64_t ld_partials1, void* stream) {
@@ -1610,7 +1626,7 @@ extern "C" int ppsci_fno_lift0_wgrad(int B, int K0, int C1, int Ch, int P, const
   a.ldp = ld_partials ? ld_partials : (long long)C1 * K0;
   a.ldpb = ld_partials ? ld_partials : C1;
   a.B = B, a.K0 = K0, a.C1 = C1, a.Ch = Ch, a.P = P;
-  a.cpix = P >= PW_WGRAD_CPIX ? PW_WGRAD_CPIX : P;
+  a.cpix = lift0_cpix(B, P);
   a.chunks_per_b = (P + a.cpix - 1) / a.cpix;
   const int lds = ((Ch <= 32 ? 32 : 64) * (a.cpix + 17) + 4 * a.cpix + LIFT0_WAVES * 2 * 16 * 17) * 4;
   const int grid = B * a.chunks_per_b * ((C1 + 16 * LIFT0_WAVES - 1) / (16 * LIFT0_WAVES));

@@ -379,7 +379,7 @@ class FnoNative:
         if not both:
             self._wgrad(B, C1, Ch, P0, None, gx, w1, b1, xv=self.a1_virtual)
         with self._fork():
-            chunks = int(L.lib().ppsci_pw_conv_wgrad_chunks(B, P0))
+            chunks = int(L.lib().ppsci_fno_lift0_wgrad_chunks(B, P0))
             ld = C1 * K0 + C1
             part = self._partials(chunks * ld)
             ld1 = Ch * C1 + Ch
