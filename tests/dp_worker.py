@@ -112,7 +112,7 @@ def main_viv(outdir):
         dist.destroy_process_group()
 
 
-def build_fno_solver(outdir, world_batch, steps, uno=False):
+def build_fno_solver(outdir, world_batch, steps, uno=False, sfno=False):
     """Operator-learning path: TFNO2dNet (or UNONet) on the native executor, gradient averaged over ranks (DataParallel
     semantics)."""
     import ppsci
@@ -122,6 +122,9 @@ def build_fno_solver(outdir, world_batch, steps, uno=False):
         model = ppsci.arch.UNONet(("x",), ("y",), 3, 1, 6, lifting_channels=8, projection_channels=8, n_layers=3,
                                   uno_out_channels=[4, 6, 4], uno_n_modes=[[8, 8], [4, 4], [4, 4]],
                                   uno_scalings=[[0.5, 0.5], [1, 1], [2, 2]], norm="group_norm")
+    elif sfno:
+        model = ppsci.arch.SFNONet(("x",), ("y",), (8, 8), 6, in_channels=3, out_channels=1, lifting_channels=8, projection_channels=8,
+                                   n_layers=2, norm="group_norm")
     else:
         model = ppsci.arch.TFNO2dNet(("x",), ("y",), 4, 4, hidden_channels=8, lifting_channels=16, projection_channels=16,
                                      n_layers=2, norm="group_norm")
@@ -142,8 +145,8 @@ def build_fno_solver(outdir, world_batch, steps, uno=False):
 
 def main():
     outdir, reduction = sys.argv[1], sys.argv[2]
-    if reduction in ("fno", "uno"):
-        return main_fno(outdir, reduction == "uno")
+    if reduction in ("fno", "uno", "sfno"):
+        return main_fno(outdir, reduction == "uno", reduction == "sfno")
     if reduction == "spinn":
         return main_spinn(outdir)
     if reduction == "viv":
@@ -340,7 +343,7 @@ def main_spinn(outdir):
         dist.destroy_process_group()
 
 
-def main_fno(outdir, uno=False):
+def main_fno(outdir, uno=False, sfno=False):
     from paddlescience_amd import device
     from tests.emu import build_emu
 
@@ -349,7 +352,7 @@ def main_fno(outdir, uno=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo")
-    solver, model, x = build_fno_solver(outdir, 4, 2, uno)
+    solver, model, x = build_fno_solver(outdir, 4, 2, uno, sfno)
     solver.train()
     pred = solver.predict({"x": x}, return_numpy=True)
     if not dist.is_initialized() or dist.get_rank() == 0:

@@ -96,6 +96,15 @@ def test_two_ranks_reproduce_single_rank_uno(tmp_path):
     np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
 
 
+def test_two_ranks_reproduce_single_rank_sfno(tmp_path):
+    """... and for SFNONet (the FNO executor with the spherical-harmonic transform pair)."""
+    d = str(tmp_path)
+    one = _run(d, 1, "sfno")
+    two = _run(d, 2, "sfno")
+    np.testing.assert_allclose(two["params"], one["params"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(two["pred"], one["pred"], rtol=1e-4, atol=1e-5)
+
+
 def test_two_ranks_reproduce_single_rank_spinn(tmp_path):
     """Separable path (SPINN / Helmholtz3D): x-axis slabs per rank, global-grid loss normalisation, SUM all-reduce."""
     d = str(tmp_path)
