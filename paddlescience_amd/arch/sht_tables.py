@@ -16,7 +16,7 @@ the analysis kernel reading B, the adjoint of the analysis is the synthesis kern
 Pbar: fully normalised ("ortho": integral of |Y_l^m|^2 over the sphere = 1) with the Condon-Shortley phase, by the standard
 three-term recurrence in l started from the sectoral values (legendre.py:48-110).  Quadrature: "equiangular" = Clenshaw-Curtis on
 theta_k = k pi / (nlat - 1) (quadrature.py:88-121; the closed-form cosine series here instead of its FFT construction),
-"legendre-gauss" = numpy's Gauss-Legendre rule."""
+"legendre-gauss" = numpy's Gauss-Legendre rule, "lobatto" = Gauss-Lobatto from the roots of P'_{n-1}."""
 from __future__ import annotations
 
 import numpy as np
@@ -37,7 +37,12 @@ def quadrature(grid: str, nlat: int):
     if grid == "legendre-gauss":
         x, w = np.polynomial.legendre.leggauss(nlat)  # x ascending: theta descending -> reverse both (the rule is symmetric)
         return np.arccos(x)[::-1].copy(), w[::-1].copy()
-    raise NotImplementedError(f"SHT grid {grid!r} (built: 'equiangular', 'legendre-gauss')")
+    if grid == "lobatto":  # Gauss-Lobatto: the end points and the roots of P'_{n-1}; w = 2 / (n (n-1) P_{n-1}(x)^2)  (quadrature.py:45-85)
+        Pn = np.polynomial.legendre.Legendre.basis(nlat - 1)
+        x = np.concatenate(([-1.0], np.sort(Pn.deriv().roots().real), [1.0]))
+        w = 2.0 / (nlat * (nlat - 1) * Pn(x) ** 2)
+        return np.arccos(np.clip(x, -1.0, 1.0))[::-1].copy(), w[::-1].copy()
+    raise NotImplementedError(f"SHT grid {grid!r} (built: 'equiangular', 'legendre-gauss', 'lobatto')")
 
 
 def legendre(mmax: int, lmax: int, theta: np.ndarray) -> np.ndarray:

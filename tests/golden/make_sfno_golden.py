@@ -139,6 +139,16 @@ def main():
         out[f"{key}/x"], out[f"{key}/X"] = x.numpy(), torch.view_as_real(X).numpy()
         out[f"{key}/Z"], out[f"{key}/y"] = torch.view_as_real(Z).numpy(), inv(Z).numpy()
         print(key, "X", tuple(X.shape))
+    # the quadrature rules and the Legendre tables by themselves (numpy-only modules of the reference)
+    quad = importlib.import_module("ppsci.arch.paddle_harmonics.quadrature")
+    leg = importlib.import_module("ppsci.arch.paddle_harmonics.legendre")
+    for n in (9, 16, 33):
+        for grid, fn in (("equiangular", quad.clenshaw_curtiss_weights), ("legendre-gauss", quad.legendre_gauss_weights),
+                         ("lobatto", quad.lobatto_weights)):
+            cost, w = fn(n, -1, 1)
+            tq = np.flip(np.arccos(cost))  # as RealSHT.__init__ (sht.py:100-101)
+            out[f"quad/{grid}/{n}/theta"], out[f"quad/{grid}/{n}/w"] = tq, np.asarray(w)
+            out[f"quad/{grid}/{n}/pct"] = leg._precompute_legpoly(6, n - 1, tq)
     np.savez_compressed(os.path.join(HERE, "sfno.npz"), **out)
     print("wrote", os.path.join(HERE, "sfno.npz"), len(out), "arrays")
 

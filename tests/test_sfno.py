@@ -22,6 +22,19 @@ dev = make_dev_fixture()
 GRIDS = sorted({k.split("/")[1] for k in G.files if k.startswith("sht/")})
 
 
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss", "lobatto"])
+def test_quadrature_and_legendre_tables_are_the_references(grid):
+    """arch/sht_tables.py against the reference's quadrature.py / legendre.py run as they are (numpy-only): nodes, weights (the rules are
+    symmetric, so the reference's unflipped weights equal the flipped ones here) and the orthonormal associated Legendre functions."""
+    from paddlescience_amd.arch import sht_tables
+
+    for n in (9, 16, 33):
+        theta, w = sht_tables.quadrature(grid, n)
+        assert np.abs(theta - G[f"quad/{grid}/{n}/theta"]).max() < 1e-12
+        assert np.abs(w - G[f"quad/{grid}/{n}/w"]).max() < 1e-13
+        assert np.abs(sht_tables.legendre(6, n - 1, theta) - G[f"quad/{grid}/{n}/pct"]).max() < 1e-11
+
+
 def _tables(H, W, L, M, d):
     from paddlescience_amd.arch import sht_tables
 
