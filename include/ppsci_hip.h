@@ -636,6 +636,9 @@ int ppsci_fno_tail_bwd_ex(int B, int C, int P, int norm, int gelu, const float* 
 int ppsci_sht_supported(int H, int W, int L, int M);
 int ppsci_sht_analysis(int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* x, float* X, void* stream);
 int ppsci_sht_synthesis(int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* Z, float* y, void* stream);
+/* ppsci_sht_contract (conj_t as there) + ppsci_sht_synthesis in one launch; y [B * (conj_t ? Ci : Co) planes of H x W]; bit-identical to the two. */
+int ppsci_sht_synthesis_contract(int B, int Ci, int Co, int conj_t, int H, int W, int L, int M, const float* tw, const float* leg,
+                                 const float* x, const float* w_re, const float* w_im, float* y, void* stream);
 int ppsci_sht_contract(int B, int Ci, int Co, int L, int M, const float* x, const float* w_re, const float* w_im, int conj_t,
                        float* out, void* stream);
 int ppsci_sht_contract_wgrad(int B, int Ci, int Co, int L, int M, const float* x, const float* g, float* gw_re, float* gw_im,

@@ -212,6 +212,7 @@ _SYMBOLS = {
     "ppsci_sht_supported": (C.c_int, [C.c_int] * 4),
     "ppsci_sht_analysis": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
     "ppsci_sht_synthesis": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
+    "ppsci_sht_synthesis_contract": (C.c_int, [C.c_int] * 8 + [C.c_void_p] * 7),
     "ppsci_sht_contract": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]),
     "ppsci_sht_contract_wgrad": (C.c_int, [C.c_int] * 5 + [C.c_void_p] * 5),
     "ppsci_spectrum_resize": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p]),

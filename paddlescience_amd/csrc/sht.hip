@@ -35,6 +35,12 @@ struct ShtArgs {
   const float* tw;   // [W][M][2] (cos, sin)(2 pi j m / W)
   const float* leg;  // analysis: [H][L][M]; synthesis: [L][H][M]
   int n, H, W, L, M;
+  // synthesis only: the per-degree contraction in front of it (cx != null; src unused): plane p = (b, c),
+  // Z[l][m] = sum_s cx[b][s][l][m] * w[s][c][l]  (conj_t: * conj(w[c][s][l])) -- ppsci_sht_contract's sum, in its order
+  const float* cx;
+  const float* wr;
+  const float* wi;
+  int Ci, Co, conj_t;
 };
 
 static long long sht_lds_floats(int H, int W, int L, int M) {
@@ -99,9 +105,29 @@ __global__ void __launch_bounds__(256) sht_synthesis_kernel(ShtArgs a) {
   const int tid = threadIdx.x;
   for (int i = tid; i < 2 * a.W * a.M; i += 256) tw[i] = a.tw[i];
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
-    const float* z = a.src + (long long)p * a.L * a.M * 2;
     __syncthreads();
-    for (int i = tid; i < 2 * a.L * a.M; i += 256) Z[i] = z[i];
+    if (a.cx != nullptr) {
+      const int lm = a.L * a.M;
+      const int Cp = a.conj_t ? a.Ci : a.Co, Cs = a.conj_t ? a.Co : a.Ci;
+      const int b = p / Cp, c = p - b * Cp;
+      for (int i = tid; i < lm; i += 256) {
+        const int l = i / a.M;
+        float sr = 0.f, si = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < Cs; ++s) {
+          const float* xp = a.cx + (((long long)b * Cs + s) * lm + i) * 2;
+          const long long wi_ = (a.conj_t ? (long long)c * a.Co + s : (long long)s * a.Co + c) * a.L + l;
+          const float xr = xp[0], xi = xp[1], wr = a.wr[wi_], wim = a.conj_t ? -a.wi[wi_] : a.wi[wi_];
+          sr += xr * wr - xi * wim;
+          si += xr * wim + xi * wr;
+        }
+        Z[2 * i] = sr;
+        Z[2 * i + 1] = si;
+      }
+    } else {
+      const float* z = a.src + (long long)p * a.L * a.M * 2;
+      for (int i = tid; i < 2 * a.L * a.M; i += 256) Z[i] = z[i];
+    }
     __syncthreads();
     for (int i = tid; i < a.H * a.M; i += 256) {
       const int k = i / a.M, m = i - k * a.M;
@@ -161,12 +187,13 @@ extern "C" int ppsci_sht_supported(int H, int W, int L, int M) {
 }
 
 static int sht_run(int synthesis, int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* src, float* dst,
-                   void* stream) {
-  if (n < 1 || !tw || !leg || !src || !dst || !ppsci_sht_supported(H, W, L, M)) {
+                   void* stream, const float* cx = nullptr, const float* wr = nullptr, const float* wi = nullptr, int Ci = 0, int Co = 0,
+                   int conj_t = 0) {
+  if (n < 1 || !tw || !leg || (!src && !cx) || !dst || !ppsci_sht_supported(H, W, L, M)) {
     ppsci_set_error("sht: invalid argument or a %d x %d plane with %d x %d coefficients does not fit LDS", H, W, L, M);
     return PPSCI_E_INVALID;
   }
-  ShtArgs a{src, dst, tw, leg, n, H, W, L, M};
+  ShtArgs a{src, dst, tw, leg, n, H, W, L, M, cx, wr, wi, Ci, Co, conj_t};
   const int lds = (int)(4 * sht_lds_floats(H, W, L, M));
   const int grid = n < 8 * PPSCI_NUM_CU ? n : 8 * PPSCI_NUM_CU;
   int se;
@@ -191,6 +218,18 @@ extern "C" int ppsci_sht_analysis(int n, int H, int W, int L, int M, const float
 extern "C" int ppsci_sht_synthesis(int n, int H, int W, int L, int M, const float* tw, const float* leg, const float* Z, float* y,
                                    void* stream) {
   return sht_run(1, n, H, W, L, M, tw, leg, Z, y, stream);
+}
+
+// ppsci_sht_contract + ppsci_sht_synthesis in one launch: the workgroup that synthesises plane (b, c) contracts that plane's
+// coefficients itself (the same sum in the same order: bit-identical to the two launches)
+extern "C" int ppsci_sht_synthesis_contract(int B, int Ci, int Co, int conj_t, int H, int W, int L, int M, const float* tw,
+                                            const float* leg, const float* x, const float* w_re, const float* w_im, float* y,
+                                            void* stream) {
+  if (B < 1 || Ci < 1 || Co < 1 || !x || !w_re || !w_im) {
+    ppsci_set_error("sht_synthesis_contract: invalid argument");
+    return PPSCI_E_INVALID;
+  }
+  return sht_run(1, B * (conj_t ? Ci : Co), H, W, L, M, tw, leg, nullptr, y, stream, x, w_re, w_im, Ci, Co, conj_t ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------ contraction with weights per degree

@@ -289,9 +289,16 @@ class FnoNative:
             elif self.sht:  # sfnonet.py:333-354: sht -> weights per degree -> isht
                 mx, my = self.desc.modes_x, self.desc.modes_y
                 L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_an), _p(xl), _p(xft), st))
-                L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(xft), _p(conv.weight_real), _p(conv.weight_imag), 0,
-                                                   _p(self.out_ft), st))
-                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_sy), _p(self.out_ft), _p(v), st))
+                # PPSCI_SHT_FUSE_CONTRACT=1: the contraction inside the synthesis launch (bit-identical).  Measured on MI355X at the
+                # reference's shape: the synthesis grows 13.7 -> 23.6 us (128 plane-workgroups, each walking the 32 channels itself) for
+                # a 6.0 us launch saved -- 0.542 against 0.513 ms per step -- so it is OFF by default (kept as a tested knob)
+                if os.environ.get("PPSCI_SHT_FUSE_CONTRACT", "0") == "1":
+                    L.check(L.lib().ppsci_sht_synthesis_contract(B, Ch, Ch, 0, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_sy), _p(xft),
+                                                                 _p(conv.weight_real), _p(conv.weight_imag), _p(v), st))
+                else:
+                    L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(xft), _p(conv.weight_real), _p(conv.weight_imag), 0,
+                                                       _p(self.out_ft), st))
+                    L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_sy), _p(self.out_ft), _p(v), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(xl), _p(xft), st))
                 L.check(L.lib().ppsci_spectral_conv2d_fwd_scaled(C.byref(self.desc), _p(xft), _p(conv.weight_real),
@@ -484,9 +491,13 @@ class FnoNative:
                 L.check(L.lib().ppsci_sht_analysis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_b_an), _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_sht_contract_wgrad(B, Ch, Ch, mx, my, _p(self.xft[l]), _p(self.ghat), _p(conv.weight_real.grad),
                                                          _p(conv.weight_imag.grad), st))
-                L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(self.ghat), _p(conv.weight_real), _p(conv.weight_imag), 1,
-                                                   _p(self.gx_ft), st))
-                L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_sy), _p(self.gx_ft), _p(self.gsp), st))
+                if os.environ.get("PPSCI_SHT_FUSE_CONTRACT", "0") == "1":
+                    L.check(L.lib().ppsci_sht_synthesis_contract(B, Ch, Ch, 1, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_sy),
+                                                                 _p(self.ghat), _p(conv.weight_real), _p(conv.weight_imag), _p(self.gsp), st))
+                else:
+                    L.check(L.lib().ppsci_sht_contract(B, Ch, Ch, mx, my, _p(self.ghat), _p(conv.weight_real), _p(conv.weight_imag), 1,
+                                                       _p(self.gx_ft), st))
+                    L.check(L.lib().ppsci_sht_synthesis(B * Ch, H, W, mx, my, _p(self.sht_tw), _p(self.sht_a_sy), _p(self.gx_ft), _p(self.gsp), st))
             else:
                 L.check(L.lib().ppsci_fft2d_r2c(B * Ch, H, W, _p(self.gv), _p(self.ghat), st))
                 L.check(L.lib().ppsci_spectral_conv2d_bwd_real_scaled(

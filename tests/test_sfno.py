@@ -131,6 +131,23 @@ def test_native_path_reproduces_reference_sfno(c, dev):
     assert torch.equal(g1, model.flat_grad)
 
 
+def test_contraction_inside_the_synthesis_equals_the_two_launches(dev, monkeypatch):
+    """ppsci_sht_synthesis_contract (forward and as the data gradient) against ppsci_sht_contract + ppsci_sht_synthesis: the same sums in
+    the same order -- outputs and gradients bit-identical."""
+    c = sorted(CASES)[0]
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("PPSCI_SHT_FUSE_CONTRACT", fuse)
+        model = _model(c)
+        d = model.flat_params.device
+        x = torch.as_tensor(G[f"{c}/x"].astype(np.float32)).to(d)
+        eng = model.native()
+        y = eng.forward(x).clone()
+        eng.backward(torch.ones_like(y) / y.numel())
+        res.append((y.cpu().numpy(), model.flat_grad.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_sfnonet_trains_through_the_solver(dev, tmp_path):
     """SupervisedConstraint + Solver on an SFNONet at the reference example's grid (32 x 64), evaluated at 64 x 128 as its yaml does."""
     import ppsci
