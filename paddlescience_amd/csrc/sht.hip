@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256) sht_analysis_kernel(ShtArgs a) {
   }
 }
 
+template <bool CONTRACT>  // (its own instantiation: as a run-time branch the unused contraction cost the plain kernel 1.1 us per launch)
 __global__ void __launch_bounds__(256) sht_synthesis_kernel(ShtArgs a) {
   PPSCI_DYN_SMEM(smem);
   float* tw = smem;
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) sht_synthesis_kernel(ShtArgs a) {
   for (int i = tid; i < 2 * a.W * a.M; i += 256) tw[i] = a.tw[i];
   for (int p = blockIdx.x; p < a.n; p += gridDim.x) {
     __syncthreads();
-    if (a.cx != nullptr) {
+    if constexpr (CONTRACT) {
       const int lm = a.L * a.M;
       const int Cp = a.conj_t ? a.Ci : a.Co, Cs = a.conj_t ? a.Co : a.Ci;
       const int b = p / Cp, c = p - b * Cp;
@@ -197,9 +198,12 @@ static int sht_run(int synthesis, int n, int H, int W, int L, int M, const float
   const int lds = (int)(4 * sht_lds_floats(H, W, L, M));
   const int grid = n < 8 * PPSCI_NUM_CU ? n : 8 * PPSCI_NUM_CU;
   int se;
-  if (synthesis) {
-    se = PPSCI_SET_MAX_LDS(sht_synthesis_kernel, lds);
-    if (se == 0) PPSCI_LAUNCH(sht_synthesis_kernel, ShtArgs, grid, 256, lds, stream, a);
+  if (synthesis && cx != nullptr) {
+    se = PPSCI_SET_MAX_LDS(sht_synthesis_kernel<true>, lds);
+    if (se == 0) PPSCI_LAUNCH(sht_synthesis_kernel<true>, ShtArgs, grid, 256, lds, stream, a);
+  } else if (synthesis) {
+    se = PPSCI_SET_MAX_LDS(sht_synthesis_kernel<false>, lds);
+    if (se == 0) PPSCI_LAUNCH(sht_synthesis_kernel<false>, ShtArgs, grid, 256, lds, stream, a);
   } else {
     se = PPSCI_SET_MAX_LDS(sht_analysis_kernel, lds);
     if (se == 0) PPSCI_LAUNCH(sht_analysis_kernel, ShtArgs, grid, 256, lds, stream, a);
